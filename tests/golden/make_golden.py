@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING the reference's own numpy code.
+
+Run in the build container only (needs /root/reference; the GPU box never sees it):
+
+    python tests/golden/make_golden.py
+
+What is executed from the reference (nothing is copied -- only its *outputs* are stored):
+  * `Utilities/GaussJacobiQuadRule_V3.py`  -> Jacobi values, GLL nodes / weights
+  * the unbound methods `VPINN.Test_fcn / Test_fcnx / dTest_fcn` of the three drivers
+    (imported with `tensorflow` / `pyDOE` stubs; their `__main__` blocks do not run)
+  * the `__main__` *set-up* blocks of the three drivers (everything before `model = VPINN(`),
+    exec'd TF-free from the source file where it lies, with hyper-parameters pinned to the
+    BASELINE.json shapes -> grids, F_ext_total, boundary sets, test data.
+
+The TF1 graph itself (loss, tf.gradients, Adam) cannot run here (no tensorflow wheel,
+no network), so the loss/gradient/trajectory fixtures in `make_golden_oracle.py` come from
+the oracle restatement, not from the reference: that part of parity is UNPINNED upstream
+ and anchored only by the known-answer checks in tests/test_oracle.py.
+
+`pyDOE.lhs` is stubbed with `hp_vpinns_amd.sampling.lhs` (published classic-LHS algorithm);
+the sampled points are stored in the fixtures and treated as inputs.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REF, "Utilities"))
+
+from hp_vpinns_amd.sampling import lhs  # noqa: E402
+
+P1 = os.path.join(REF, "main/Poisson-1D/hp-VPINN-Poisson-1D.py")
+P2 = os.path.join(REF, "main/Poisson-2D/hp-VPINN-Poisson-2D.py")
+P3 = os.path.join(REF, "main/AdvDiff-Identification/hp-VPINN-AdvDiff-Identification.py")
+
+
+def _install_stubs():
+    tf = types.ModuleType("tensorflow")
+    tf.set_random_seed = lambda s: None
+    sys.modules["tensorflow"] = tf
+    pd = types.ModuleType("pyDOE")
+    pd.lhs = lhs
+    sys.modules["pyDOE"] = pd
+    import matplotlib
+    matplotlib.use("Agg")
+
+
+def _import(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class Pinned(dict):
+    """Namespace whose pinned names ignore re-assignment (hyper-parameter override)."""
+
+    def __init__(self, base, pinned):
+        super().__init__(base)
+        self._pinned = dict(pinned)
+        for k, v in pinned.items():
+            dict.__setitem__(self, k, v)
+
+    def __setitem__(self, k, v):
+        if k in self._pinned:
+            return
+        dict.__setitem__(self, k, v)
+
+
+def _main_setup_source(path, stop_marker="model = VPINN(", start_marker='if __name__ == "__main__":'):
+    lines = open(path).read().split("\n")
+    i0 = next(i for i, l in enumerate(lines) if l.startswith(start_marker))
+    i1 = next(i for i, l in enumerate(lines) if i > i0 and stop_marker in l)
+    return lines[i0 + 1:i1]
+
+
+def _exec_block(lines, ns, fname):
+    # the blocks contain column-0 comments, so dedent() cannot be used: keep the indentation
+    # and hang the block under an `if True:` instead.
+    src = "if True:\n" + "\n".join(lines) + "\n    pass\n"
+    exec(compile(src, fname, "exec"), ns)
+
+
+def gen_quadrature(out):
+    import GaussJacobiQuadRule_V3 as Q
+    d = {}
+    for q in (5, 10, 20, 80):
+        x, w = Q.GaussLobattoJacobiWeights(q, 0, 0)
+        d[f"gll_x_{q}"] = x
+        d[f"gll_w_{q}"] = w
+    xs = np.linspace(-1, 1, 41)
+    d["jac_x"] = xs
+    for (n, a, b) in [(0, 0, 0), (1, 0, 0), (2, 0, 0), (7, 0, 0), (61, 0, 0), (5, 1, 1),
+                      (60, 1, 1), (3, 2, 2), (59, 2, 2)]:
+        d[f"jac_{n}_{a}_{b}"] = Q.Jacobi(n, a, b, xs)
+    d["djac_6_0_0_2"] = Q.DJacobi(6, 0, 0, xs, 2)
+    gx, gw = Q.GaussJacobiWeights(7, 0, 0)
+    d["gj_x_7"], d["gj_w_7"] = gx, gw
+    np.savez_compressed(os.path.join(out, "quadrature.npz"), **d)
+
+
+def gen_testfcn(out, m1, m2, m3):
+    import GaussJacobiQuadRule_V3 as Q
+    d = {}
+    for (nt, q) in [(60, 80), (5, 10), (10, 20)]:
+        x = Q.GaussLobattoJacobiWeights(q, 0, 0)[0][:, None]
+        t = m1.VPINN.Test_fcn(None, nt, x)
+        d1, d2 = m1.VPINN.dTest_fcn(None, nt, x)
+        d[f"phi_{nt}_{q}"], d[f"dphi_{nt}_{q}"], d[f"d2phi_{nt}_{q}"] = t, d1, d2
+    # the 2-D / AdvDiff classes carry their own copies: check they agree on one shape
+    x = Q.GaussLobattoJacobiWeights(10, 0, 0)[0][:, None]
+    d["p2_phix_5_10"] = m2.VPINN.Test_fcnx(None, 5, x)
+    d["p2_phiy_5_10"] = m2.VPINN.Test_fcny(None, 5, x)
+    d["p2_dphi_5_10"], d["p2_d2phi_5_10"] = m2.VPINN.dTest_fcn(None, 5, x)
+    d["p3_phi_5_10"] = m3.VPINN.Test_fcn(None, 5, x)
+    d["p3_dphi_5_10"], d["p3_d2phi_5_10"] = m3.VPINN.dTest_fcn(None, 5, x)
+    xb = np.array([[-1.0], [1.0]])
+    d["dphi_edge_60"], d["d2phi_edge_60"] = m1.VPINN.dTest_fcn(None, 60, xb)
+    np.savez_compressed(os.path.join(out, "testfcn.npz"), **d)
+
+
+def gen_p1(out, tag, pinned):
+    np.random.seed(1234)
+    base = {"__name__": "p1_setup", "np": np, "lhs": lhs}
+    import GaussJacobiQuadRule_V3 as Q
+    base.update(Jacobi=Q.Jacobi, DJacobi=Q.DJacobi, GaussLobattoJacobiWeights=Q.GaussLobattoJacobiWeights,
+                GaussJacobiWeights=Q.GaussJacobiWeights)
+    ns = Pinned(base, pinned)
+    _exec_block(_main_setup_source(P1), ns, P1)
+    keep = dict(grid=ns["grid"], F_ext_total=ns["F_ext_total"], U_ext_total=ns["U_ext_total"],
+                X_quad_train=ns["X_quad_train"], W_quad_train=ns["W_quad_train"],
+                X_u_train=ns["X_u_train"], u_train=ns["u_train"],
+                X_f_train=ns["X_f_train"], f_train=ns["f_train"],
+                X_test=ns["X_test"], u_test=ns["u_test"],
+                N_testfcn=np.int64(ns["N_testfcn"]), N_Quad=np.int64(ns["N_Quad"]),
+                LR=np.float64(ns["LR"]), var_form=np.int64(ns["var_form"]),
+                lossb_weight=np.float64(ns["lossb_weight"]),
+                Net_layer=np.asarray(ns["Net_layer"], dtype=np.int64))
+    np.savez_compressed(os.path.join(out, f"poisson1d_{tag}.npz"), **keep)
+
+
+def gen_p2(out, tag, pinned, store_test=False):
+    np.random.seed(1234)
+    import GaussJacobiQuadRule_V3 as Q
+    base = {"__name__": "p2_setup", "np": np, "lhs": lhs, "Jacobi": Q.Jacobi, "DJacobi": Q.DJacobi,
+            "GaussLobattoJacobiWeights": Q.GaussLobattoJacobiWeights}
+    ns = Pinned(base, pinned)
+    _exec_block(_main_setup_source(P2), ns, P2)
+    keep = dict(grid_x=ns["grid_x"], grid_y=ns["grid_y"], F_ext_total=ns["F_ext_total"],
+                XY_quad_train=ns["XY_quad_train"], WXY_quad_train=ns["WXY_quad_train"],
+                X_u_train=ns["X_u_train"], u_train=ns["u_train"],
+                X_f_train=ns["X_f_train"], f_train=ns["f_train"],
+                N_test_x=np.asarray(ns["N_test_x"]), N_test_y=np.asarray(ns["N_test_y"]),
+                N_quad=np.int64(ns["N_quad"]), var_form=np.int64(ns["var_form"]),
+                Net_layer=np.asarray(ns["Net_layer"], dtype=np.int64),
+                X_test_shape=np.asarray(ns["X_test"].shape),
+                X_test_head=ns["X_test"][:500], u_test_head=ns["u_test"][:500],
+                u_test_sum=np.float64(ns["u_test"].sum()))
+    if store_test:
+        keep["X_test_sub"] = ns["X_test"][::37]
+        keep["u_test_sub"] = ns["u_test"][::37]
+    np.savez_compressed(os.path.join(out, f"poisson2d_{tag}.npz"), **keep)
+
+
+def gen_p3(out, tag, pinned, m3):
+    np.random.seed(1234)
+    import GaussJacobiQuadRule_V3 as Q
+    base = {k: getattr(m3, k) for k in ("LR", "Opt_Niter", "Opt_tresh", "var_form", "gamma", "epsilon",
+                                        "V", "T", "Net_layer", "N_el_x", "N_el_t", "N_test_x",
+                                        "N_test_t", "N_quad", "N_bound")}
+    base.update({"__name__": "p3_setup", "np": np, "lhs": lhs, "Jacobi": Q.Jacobi, "DJacobi": Q.DJacobi,
+                 "GaussLobattoJacobiWeights": Q.GaussLobattoJacobiWeights})
+    ns = Pinned(base, pinned)
+    lines = _main_setup_source(P3)
+    # P3:451 (np.asarray of the ragged test grid) raises under numpy 2.x because u_ext returns
+    # a (1,1) array for t != 0 and a scalar for t == 0 (P3:434-443); run the block in two
+    # pieces around it and evaluate the test grid point-wise instead.
+    i_a = next(i for i, l in enumerate(lines) if l.strip().startswith("delta_test = 0.01"))
+    i_b = next(i for i, l in enumerate(lines) if l.strip().startswith("#### Interior training points"))
+    _exec_block(lines[:i_a], ns, P3)
+    u_ext = ns["u_ext"]
+    xtest = np.linspace(-1, 1, 256)
+    ttest = np.arange(0, ns["T"] + 0.01, 0.01)
+    xs, ts = xtest[::8], ttest[::5]
+    ug = np.array([[float(np.ravel(u_ext(x, t))[0]) for x in xs] for t in ts])
+    XT_test = np.stack([np.tile(xtest, len(ttest)), np.repeat(ttest, len(xtest))], axis=1)
+    ns["XT_test"] = XT_test  # what P3:454-458 would produce (x fastest)
+    _exec_block(lines[i_b:], ns, P3)
+    keep = dict(grid_x=ns["grid_x"], grid_t=ns["grid_t"],
+                XT_u_train=ns["XT_u_train"], u_train=ns["u_train"], XT_f_train=ns["XT_f_train"],
+                T_quad=ns["T_quad"], WT_quad=ns["WT_quad"],
+                XT_quad_train=ns["XT_quad_train"][:2000], WXT_quad_train=ns["WXT_quad_train"][:2000],
+                N_test_x=np.asarray(ns["N_test_x"]), N_test_t=np.asarray(ns["N_test_t"]),
+                N_quad=np.int64(ns["N_quad"]), var_form=np.int64(ns["var_form"]),
+                V=np.float64(ns["V"]), epsilon_exact=np.float64(ns["epsilon"]), LR=np.float64(ns["LR"]),
+                Net_layer=np.asarray(ns["Net_layer"], dtype=np.int64),
+                uext_x=xs, uext_t=ts, uext_grid=ug)
+    np.savez_compressed(os.path.join(out, f"advdiff_{tag}.npz"), **keep)
+
+
+def main():
+    out = HERE
+    _install_stubs()
+    m1 = _import(P1, "ref_p1")
+    m2 = _import(P2, "ref_p2")
+    m3 = _import(P3, "ref_p3")
+    gen_quadrature(out)
+    gen_testfcn(out, m1, m2, m3)
+    L1 = [1, 20, 20, 20, 1]
+    gen_p1(out, "default", {})                                     # reference defaults (P1:231-240)
+    gen_p1(out, "cfg1", {"Net_layer": L1})                          # BASELINE config 1
+    gen_p1(out, "ne3", {"Net_layer": L1, "N_Element": 3})           # the published 3-element run
+    gen_p1(out, "cfg2", {"Net_layer": L1, "N_Element": 16})         # BASELINE config 2
+    gen_p1(out, "small", {"Net_layer": [1, 8, 8, 1], "N_Element": 4, "N_testfcn": 6, "N_Quad": 12})
+    L2 = [2, 20, 20, 20, 1]
+    gen_p2(out, "default", {}, store_test=True)                    # reference defaults (P2:279-288)
+    gen_p2(out, "cfg3", {"Net_layer": L2, "N_el_x": 8, "N_el_y": 8, "N_test_x": 8 * [5], "N_test_y": 8 * [5]})
+    gen_p2(out, "cfg4", {"Net_layer": L2, "N_el_x": 16, "N_el_y": 16, "N_test_x": 16 * [10],
+                          "N_test_y": 16 * [10], "N_quad": 20})
+    gen_p2(out, "small", {"Net_layer": [2, 8, 8, 1], "N_el_x": 3, "N_el_y": 2, "N_test_x": 3 * [4],
+                           "N_test_y": 2 * [3], "N_quad": 6, "N_bound": 10, "N_residual": 10})
+    gen_p3(out, "default", {}, m3)                                 # reference defaults (P3:31-54)
+    gen_p3(out, "cfg5", {"Net_layer": L2, "N_el_x": 8, "N_test_x": 8 * [5], "N_quad": 80}, m3)
+    gen_p3(out, "small", {"Net_layer": [2, 8, 8, 1], "N_el_x": 3, "N_el_t": 2, "N_test_x": 3 * [4],
+                           "N_test_t": 2 * [3], "N_quad": 6, "N_bound": 10}, m3)
+    for f in sorted(os.listdir(out)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(out, f)))
+
+
+if __name__ == "__main__":
+    main()
