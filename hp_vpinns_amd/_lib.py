@@ -1,0 +1,254 @@
+"""ctypes binding of libhpvpinn.so (include/hpvpinn.h).
+
+The library is the product: if it is missing, cannot be loaded, or reports no HIP device,
+every call raises -- there is no CPU fallback (the oracle under `oracle/` is test
+infrastructure and is never imported from here).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhpvpinn.so")
+
+HPV_MAX_LAYERS = 16
+PDE_POISSON1D, PDE_POISSON2D, PDE_ADVDIFF = 0, 1, 2
+ACT_TANH, ACT_SIN = 0, 1
+BACKEND_AUTO, BACKEND_GENERIC, BACKEND_MFMA = 0, 1, 2
+
+# every symbol include/hpvpinn.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "hpv_create", "hpv_destroy", "hpv_last_error", "hpv_set_stream", "hpv_set_quadrature",
+    "hpv_set_tables", "hpv_set_elements", "hpv_set_rhs", "hpv_set_data", "hpv_num_params",
+    "hpv_set_params", "hpv_get_params", "hpv_loss_and_grad", "hpv_step", "hpv_forward_backward",
+    "hpv_reduce_buffer", "hpv_apply_adam", "hpv_eval_loss", "hpv_read_loss", "hpv_sync",
+    "hpv_predict", "hpv_get_residuals", "hpv_backend_in_use", "hpv_enable_timing",
+    "hpv_kernel_time_ms", "hpv_bench_projection",
+]
+
+
+class HpvConfig(C.Structure):
+    _fields_ = [
+        ("pde", C.c_int), ("var_form", C.c_int), ("act", C.c_int), ("n_layers", C.c_int),
+        ("layers", C.c_int * HPV_MAX_LAYERS),
+        ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+        ("lossb_weight", C.c_double), ("V", C.c_double),
+        ("device", C.c_int), ("backend", C.c_int),
+    ]
+
+
+class HpvError(RuntimeError):
+    pass
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+
+
+def load():
+    """Load libhpvpinn.so (after torch, so that both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HpvError(f"{LIB_PATH} is missing: build it with hp_vpinns_amd/csrc/build.sh "
+                       "(or __graft_entry__.build()); there is no CPU fallback")
+    try:  # torch first: its bundled libamdhip64 (same soname) then serves both
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the single-GPU path
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    h = C.c_void_p
+    lib.hpv_create.argtypes = [C.POINTER(h), C.POINTER(HpvConfig)]
+    lib.hpv_destroy.argtypes = [h]
+    lib.hpv_destroy.restype = None
+    lib.hpv_last_error.argtypes = [h]
+    lib.hpv_last_error.restype = C.c_char_p
+    lib.hpv_set_stream.argtypes = [h, C.c_void_p]
+    lib.hpv_set_quadrature.argtypes = [h, _dp, _dp, C.c_int, _dp, _dp, C.c_int]
+    lib.hpv_set_tables.argtypes = [h, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, C.c_int, _dp]
+    lib.hpv_set_elements.argtypes = [h, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int]
+    lib.hpv_set_rhs.argtypes = [h, _dp, C.c_size_t]
+    lib.hpv_set_data.argtypes = [h, _dp, _dp, C.c_int]
+    lib.hpv_num_params.argtypes = [h]
+    lib.hpv_num_params.restype = C.c_size_t
+    lib.hpv_set_params.argtypes = [h, _dp, C.c_size_t]
+    lib.hpv_get_params.argtypes = [h, _dp, C.c_size_t]
+    lib.hpv_loss_and_grad.argtypes = [h, _dp, _dp]
+    lib.hpv_step.argtypes = [h, C.c_int, _dp]
+    lib.hpv_forward_backward.argtypes = [h]
+    lib.hpv_reduce_buffer.argtypes = [h, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.hpv_apply_adam.argtypes = [h]
+    lib.hpv_eval_loss.argtypes = [h]
+    lib.hpv_read_loss.argtypes = [h, _dp]
+    lib.hpv_sync.argtypes = [h]
+    lib.hpv_predict.argtypes = [h, _dp, C.c_int, _dp]
+    lib.hpv_get_residuals.argtypes = [h, _dp, C.c_size_t]
+    lib.hpv_backend_in_use.argtypes = [h]
+    lib.hpv_enable_timing.argtypes = [h, C.c_int]
+    lib.hpv_kernel_time_ms.argtypes = [h, C.c_int, _dp, C.POINTER(C.c_long)]
+    lib.hpv_bench_projection.argtypes = [h, C.c_long, C.c_int, _dp, _dp]
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _c(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Handle:
+    """Thin RAII wrapper over an `hpv_handle`; every method maps 1:1 onto a C entry point."""
+
+    def __init__(self, pde, var_form, act, layers, lr=1e-3, lossb_weight=1.0, V=1.0, device=0,
+                 backend=BACKEND_AUTO, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.lib = load()
+        cfg = HpvConfig()
+        cfg.pde, cfg.var_form, cfg.act = int(pde), int(var_form), int(act)
+        layers = [int(v) for v in layers]
+        if len(layers) > HPV_MAX_LAYERS:
+            raise HpvError("too many layers")
+        cfg.n_layers = len(layers)
+        for i, v in enumerate(layers):
+            cfg.layers[i] = v
+        cfg.lr, cfg.beta1, cfg.beta2, cfg.eps = lr, beta1, beta2, eps
+        cfg.lossb_weight, cfg.V = float(lossb_weight), float(V)
+        cfg.device, cfg.backend = int(device), int(backend)
+        self._h = C.c_void_p()
+        rc = self.lib.hpv_create(C.byref(self._h), C.byref(cfg))
+        if rc != 0:
+            msg = self.lib.hpv_last_error(None)
+            self._h = None
+            raise HpvError(f"hpv_create failed ({rc}): {msg.decode() if msg else ''}")
+        self.cfg = cfg
+        self.layers = layers
+        self._keep = []
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self.lib.hpv_last_error(self._h)
+            raise HpvError(f"libhpvpinn error {rc}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.hpv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- set-up -------------------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.hpv_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_quadrature(self, xi, wx, yi=None, wy=None):
+        xi, wx, yi, wy = _c(xi), _c(wx), _c(yi), _c(wy)
+        self._chk(self.lib.hpv_set_quadrature(self._h, _p(xi), _p(wx), xi.size, _p(yi), _p(wy),
+                                              1 if yi is None else yi.size))
+
+    def set_tables(self, tx, ty=None, edge_dphi=None):
+        """tx / ty: (3, ntest, q) arrays of phi, phi', phi''."""
+        tx = _c(tx)
+        ty = _c(ty)
+        ed = _c(edge_dphi)
+        a = [_p(tx[0]), _p(tx[1]), _p(tx[2]), tx.shape[1]]
+        b = [None, None, None, 1] if ty is None else [_p(ty[0]), _p(ty[1]), _p(ty[2]), ty.shape[1]]
+        self._chk(self.lib.hpv_set_tables(self._h, *a, *b, _p(ed)))
+
+    def set_elements(self, gridx, gridy=None, e_begin=0, e_end=None):
+        gx, gy = _c(gridx), _c(gridy)
+        nex = gx.size - 1
+        ney = 1 if gy is None else gy.size - 1
+        if e_end is None:
+            e_end = nex * ney
+        self._chk(self.lib.hpv_set_elements(self._h, _p(gx), nex, _p(gy), ney, int(e_begin), int(e_end)))
+
+    def set_rhs(self, F):
+        F = _c(F)
+        self._chk(self.lib.hpv_set_rhs(self._h, _p(F), 0 if F is None else F.size))
+
+    def set_data(self, X, u):
+        X, u = _c(X), _c(u)
+        n = 0 if X is None else X.shape[0]
+        self._chk(self.lib.hpv_set_data(self._h, _p(X), _p(u), n))
+
+    # ---- parameters ---------------------------------------------------------------------
+    def num_params(self):
+        return int(self.lib.hpv_num_params(self._h))
+
+    def set_params(self, theta):
+        theta = _c(theta).reshape(-1)
+        self._chk(self.lib.hpv_set_params(self._h, _p(theta), theta.size))
+
+    def get_params(self):
+        out = np.empty(self.num_params())
+        self._chk(self.lib.hpv_get_params(self._h, _p(out), out.size))
+        return out
+
+    # ---- compute ------------------------------------------------------------------------
+    def loss_and_grad(self, want_grad=True):
+        loss3 = np.empty(3)
+        g = np.empty(self.num_params()) if want_grad else None
+        self._chk(self.lib.hpv_loss_and_grad(self._h, _p(loss3), _p(g)))
+        return loss3, g
+
+    def step(self, n_iters, read_loss=True):
+        loss3 = np.empty(3) if read_loss else None
+        self._chk(self.lib.hpv_step(self._h, int(n_iters), _p(loss3)))
+        return loss3
+
+    def forward_backward(self):
+        self._chk(self.lib.hpv_forward_backward(self._h))
+
+    def reduce_buffer(self):
+        ptr, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.hpv_reduce_buffer(self._h, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def apply_adam(self):
+        self._chk(self.lib.hpv_apply_adam(self._h))
+
+    def eval_loss(self):
+        self._chk(self.lib.hpv_eval_loss(self._h))
+
+    def read_loss(self):
+        loss3 = np.empty(3)
+        self._chk(self.lib.hpv_read_loss(self._h, _p(loss3)))
+        return loss3
+
+    def sync(self):
+        self._chk(self.lib.hpv_sync(self._h))
+
+    def predict(self, X):
+        X = _c(X)
+        out = np.empty(X.shape[0])
+        self._chk(self.lib.hpv_predict(self._h, _p(X), X.shape[0], _p(out)))
+        return out
+
+    def residuals(self, n):
+        out = np.empty(n)
+        self._chk(self.lib.hpv_get_residuals(self._h, _p(out), out.size))
+        return out
+
+    def backend_in_use(self):
+        return int(self.lib.hpv_backend_in_use(self._h))
+
+    def enable_timing(self, on=True):
+        self._chk(self.lib.hpv_enable_timing(self._h, 1 if on else 0))
+
+    def kernel_time_ms(self, which):
+        ms, n = C.c_double(), C.c_long()
+        self._chk(self.lib.hpv_kernel_time_ms(self._h, int(which), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def bench_projection(self, n_elem, reps=10):
+        ms, by = C.c_double(), C.c_double()
+        self._chk(self.lib.hpv_bench_projection(self._h, int(n_elem), int(reps), C.byref(ms), C.byref(by)))
+        return ms.value, by.value

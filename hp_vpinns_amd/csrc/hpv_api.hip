@@ -1,0 +1,709 @@
+// C-ABI of libhpvpinn.so (include/hpvpinn.h): host orchestration of one hp-VPINN training
+// handle = one GPU's shard of elements + a replica of the network parameters.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hpv_internal.h"
+#include "hpv_mfma.h"
+
+namespace {
+
+std::string g_create_error;
+
+struct Batch {
+    long N = 0;
+    NetDesc nd{};
+    double* X = nullptr;     // [d][N]
+    double* ACT = nullptr;   // saved slots of every hidden layer
+    double* OUT = nullptr;   // [C][N]
+    double* GBAR = nullptr;  // [C][N]
+    double* GPART = nullptr; // [rows][P] partial parameter gradients
+    int rows = 0;
+    size_t act_doubles = 0;
+};
+
+struct TimerClass {
+    std::vector<hipEvent_t> ev;  // start/stop pairs
+    size_t used = 0;
+    double total_ms = 0.0;
+    long launches = 0;
+};
+
+}  // namespace
+
+struct hpv_ctx {
+    hpv_config cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int dim = 1;
+    int P = 0, Ptot = 0, has_eps = 0;
+    NetDesc nd_var{}, nd_val{};
+    ProjDesc pd{};
+    int backend = HPV_BACKEND_GENERIC;
+    // quadrature / tables (host copies + device weighted tables)
+    std::vector<double> xi, wx, yi, wy;
+    int qx = 0, qy = 1, ntx = 0, nty = 1;
+    double *d_wtx = nullptr, *d_wty = nullptr, *d_edge_dphi = nullptr;
+    bool have_quad = false, have_tables = false, have_elems = false, have_params = false;
+    // elements
+    int nex = 0, ney = 1, e_begin = 0, e_end = 0;
+    long n_elem = 0;
+    double *d_coef = nullptr, *d_edge_coef = nullptr, *d_F = nullptr, *d_R = nullptr, *d_loss_e = nullptr,
+           *d_deps_e = nullptr;
+    std::vector<double> F_all;
+    bool have_F = false;
+    Batch var, data, edge, pred;
+    double* d_udata = nullptr;
+    double* d_data_part = nullptr;
+    int n_data = 0;
+    // parameters / optimizer
+    double *d_theta = nullptr, *d_m = nullptr, *d_v = nullptr, *d_state = nullptr, *d_RB = nullptr;
+    // mfma path
+    HpvMfma* mfma = nullptr;
+    // timing
+    bool timing = false;
+    TimerClass timers[3];
+};
+
+namespace {
+
+int fail(hpv_ctx* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) return fail(h, -2, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int dalloc(hpv_ctx* h, T** p, size_t n) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (n == 0) return 0;
+    HIPCHK(h, hipMalloc((void**)p, n * sizeof(T)));
+    return 0;
+}
+
+int upload(hpv_ctx* h, double* dst, const double* src, size_t n) {
+    if (n == 0) return 0;
+    HIPCHK(h, hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+void free_batch(Batch& b) {
+    if (b.X) (void)hipFree(b.X);
+    if (b.ACT) (void)hipFree(b.ACT);
+    if (b.OUT) (void)hipFree(b.OUT);
+    if (b.GBAR) (void)hipFree(b.GBAR);
+    if (b.GPART) (void)hipFree(b.GPART);
+    b = Batch{};
+}
+
+// Build the network descriptor for a given tangent-channel selection.
+NetDesc make_netdesc(const hpv_config& c, int nT1, const int* t1dim, int nT2, const int* t2idx) {
+    NetDesc nd{};
+    nd.d = c.layers[0];
+    nd.nl = c.n_layers - 1;
+    int off = 0;
+    for (int l = 0; l < c.n_layers; ++l) nd.width[l] = c.layers[l];
+    for (int l = 0; l < nd.nl; ++l) {
+        nd.woff[l] = off; off += c.layers[l] * c.layers[l + 1];
+        nd.boff[l] = off; off += c.layers[l + 1];
+    }
+    nd.P = off;
+    nd.act = c.act;
+    nd.nT1 = nT1; nd.nT2 = nT2;
+    for (int i = 0; i < nT1; ++i) nd.t1dim[i] = t1dim[i];
+    for (int i = 0; i < nT2; ++i) nd.t2idx[i] = t2idx[i];
+    nd.C = 1 + nT1 + nT2;
+    nd.nslot = 2 + nT1 + nT2;
+    long a = 0;
+    for (int l = 0; l < nd.nl - 1; ++l) { nd.actoff[l] = a; a += (long)nd.nslot * c.layers[l + 1]; }
+    nd.actoff[nd.nl - 1] = a;  // total slots*width (per point)
+    return nd;
+}
+
+int alloc_batch(hpv_ctx* h, Batch& b, const NetDesc& nd, long N, bool need_bwd) {
+    free_batch(b);
+    b.N = N; b.nd = nd;
+    if (N == 0) return 0;
+    int rc;
+    if ((rc = dalloc(h, &b.X, (size_t)nd.d * N))) return rc;
+    if ((rc = dalloc(h, &b.OUT, (size_t)nd.C * N))) return rc;
+    if (need_bwd) {
+        b.act_doubles = (size_t)nd.actoff[nd.nl - 1] * N;
+        if ((rc = dalloc(h, &b.ACT, b.act_doubles))) return rc;
+        if ((rc = dalloc(h, &b.GBAR, (size_t)nd.C * N))) return rc;
+        b.rows = mlp_bwd_generic_rows(N);
+        if ((rc = dalloc(h, &b.GPART, (size_t)b.rows * nd.P))) return rc;
+    }
+    return 0;
+}
+
+// [n][d] row-major host points -> [d][n] device
+int upload_points(hpv_ctx* h, Batch& b, const double* X, long n, int d) {
+    std::vector<double> t((size_t)n * d);
+    for (long p = 0; p < n; ++p)
+        for (int c = 0; c < d; ++c) t[(size_t)c * n + p] = X[(size_t)p * d + c];
+    return upload(h, b.X, t.data(), t.size());
+}
+
+void tstart(hpv_ctx* h, int which) {
+    if (!h->timing) return;
+    TimerClass& t = h->timers[which];
+    if (t.used + 2 > t.ev.size()) {
+        size_t old = t.ev.size();
+        t.ev.resize(old + 512);
+        for (size_t i = old; i < t.ev.size(); ++i) (void)hipEventCreate(&t.ev[i]);
+    }
+    (void)hipEventRecord(t.ev[t.used], h->stream);
+}
+void tstop(hpv_ctx* h, int which) {
+    if (!h->timing) return;
+    TimerClass& t = h->timers[which];
+    (void)hipEventRecord(t.ev[t.used + 1], h->stream);
+    t.used += 2;
+    t.launches += 1;
+    if (t.used >= 4096) {  // flush
+        (void)hipStreamSynchronize(h->stream);
+        for (size_t i = 0; i < t.used; i += 2) { float ms = 0; (void)hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]); t.total_ms += ms; }
+        t.used = 0;
+    }
+}
+
+int check_ready(hpv_ctx* h) {
+    if (!h->have_quad) return fail(h, -3, "hpv_set_quadrature has not been called");
+    if (!h->have_tables) return fail(h, -3, "hpv_set_tables has not been called");
+    if (!h->have_elems) return fail(h, -3, "hpv_set_elements has not been called");
+    if (!h->have_params) return fail(h, -3, "hpv_set_params has not been called");
+    if (h->have_F && !h->d_F && h->n_elem > 0) return fail(h, -3, "internal: F not sliced");
+    return 0;
+}
+
+void run_fwd(hpv_ctx* h, Batch& b, int save_act) {
+    if (b.N == 0) return;
+    launch_mlp_fwd_generic(b.nd, h->d_theta, b.X, b.ACT, b.OUT, b.N, save_act, h->stream);
+}
+void run_bwd(hpv_ctx* h, Batch& b) {
+    if (b.N == 0) return;
+    launch_mlp_bwd_generic(b.nd, h->d_theta, b.X, b.ACT, b.GBAR, b.GPART, b.rows, b.N, h->stream);
+}
+
+int enqueue_pass(hpv_ctx* h, bool backward) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    const double* eps_ptr = h->has_eps ? h->d_theta + h->P : nullptr;
+    const bool use_mfma = h->mfma && h->backend == HPV_BACKEND_MFMA;
+    // --- variational term on this shard's quadrature batch ---
+    if (h->var.N > 0) {
+        tstart(h, 0);
+        if (use_mfma) hpv_mfma_forward(h->mfma, h->d_theta, h->var.X, h->var.OUT, backward ? 1 : 0, h->stream);
+        else run_fwd(h, h->var, backward ? 1 : 0);
+        tstop(h, 0);
+        if (h->pd.edge) run_fwd(h, h->edge, backward ? 1 : 0);
+        tstart(h, 1);
+        launch_project(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
+                       h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi,
+                       h->d_edge_coef, h->edge.GBAR, h->stream);
+        tstop(h, 1);
+        if (backward) {
+            tstart(h, 2);
+            if (use_mfma) hpv_mfma_backward(h->mfma, h->d_theta, h->var.X, h->var.GBAR, h->var.GPART, &h->var.rows, h->stream);
+            else run_bwd(h, h->var);
+            tstop(h, 2);
+            if (h->pd.edge) run_bwd(h, h->edge);
+        }
+    }
+    // --- boundary / data term ---
+    int ndp = 0;
+    if (h->n_data > 0) {
+        run_fwd(h, h->data, backward ? 1 : 0);
+        ndp = (h->n_data + 255) / 256; if (ndp > 64) ndp = 64;
+        launch_data_loss(h->data.OUT, h->d_udata, backward ? h->data.GBAR : nullptr,
+                         -2.0 * h->cfg.lossb_weight / (double)h->n_data, h->d_data_part, h->n_data, h->stream);
+        if (backward) run_bwd(h, h->data);
+    }
+    launch_finalize(backward && h->var.N > 0 ? h->var.GPART : nullptr, h->var.rows,
+                    backward && h->n_data > 0 ? h->data.GPART : nullptr, h->data.rows,
+                    backward && h->pd.edge && h->edge.N > 0 ? h->edge.GPART : nullptr, h->edge.rows, h->d_loss_e, h->n_elem,
+                    h->d_deps_e, h->d_data_part, ndp, h->cfg.lossb_weight, h->n_data, h->P, h->has_eps, h->d_RB,
+                    backward ? 1 : 0, h->stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, -2, "kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hpv_last_error(hpv_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int hpv_create(hpv_handle* out, const hpv_config* cfg) {
+    if (!out || !cfg) return fail(nullptr, -1, "null argument");
+    *out = nullptr;
+    if (cfg->n_layers < 2 || cfg->n_layers > HPV_MAX_LAYERS) return fail(nullptr, -1, "n_layers out of range");
+    const int dim = (cfg->pde == HPV_PDE_POISSON1D) ? 1 : 2;
+    if (cfg->pde < 0 || cfg->pde > 2) return fail(nullptr, -1, "unknown pde %d", cfg->pde);
+    if (cfg->layers[0] != dim) return fail(nullptr, -1, "layers[0]=%d but the problem is %d-D", cfg->layers[0], dim);
+    if (cfg->layers[cfg->n_layers - 1] != 1) return fail(nullptr, -1, "the network must have one output");
+    for (int l = 1; l < cfg->n_layers - 1; ++l)
+        if (cfg->layers[l] < 1 || cfg->layers[l] > HPV_MAXH) return fail(nullptr, -1, "hidden width %d not in 1..%d", cfg->layers[l], HPV_MAXH);
+    if (cfg->act != HPV_ACT_TANH && cfg->act != HPV_ACT_SIN) return fail(nullptr, -1, "unknown activation");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, -2, "no HIP device available");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, -1, "device %d out of range (%d devices)", cfg->device, ndev);
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, -2, "hipSetDevice failed");
+
+    hpv_ctx* h = new hpv_ctx();
+    h->cfg = *cfg;
+    h->dim = dim;
+    if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return fail(nullptr, -2, "hipStreamCreate failed"); }
+    h->own_stream = true;
+
+    // channel selection + integrand terms per (pde, var_form)
+    int t1[2] = {0, 1}, t2[2] = {0, 1};
+    ProjDesc& pd = h->pd;
+    pd = ProjDesc{};
+    int nT1 = 0, nT2 = 0;
+    const int vf = cfg->var_form;
+    auto term = [&](int dx, int dy, int eps_mult) -> TermDesc& {
+        TermDesc& t = pd.t[pd.nterms++];
+        t = TermDesc{}; t.dx = dx; t.dy = dy; t.eps_mult = eps_mult; return t;
+    };
+    if (cfg->pde == HPV_PDE_POISSON1D) {
+        if (vf == 1) { nT1 = 1; nT2 = 1; term(0, 0, 0).a0[2] = 1.0; }            // P1:83-84  -J int u'' phi
+        else if (vf == 2) { nT1 = 1; term(1, 0, 0).a0[1] = 1.0; }                // P1:86-87  int u' phi'
+        else if (vf == 3) { term(2, 0, 0).a0[0] = 1.0; pd.edge = 1; }            // P1:89-91
+        else { delete h; return fail(nullptr, -1, "Poisson-1D var_form must be 1, 2 or 3"); }
+    } else if (cfg->pde == HPV_PDE_POISSON2D) {
+        if (vf == 0) { nT1 = 2; nT2 = 2; TermDesc& t = term(0, 0, 0); t.a0[3] = 1.0; t.a0[4] = 1.0; }   // P2:93-96
+        else if (vf == 1) { nT1 = 2; term(1, 0, 0).a0[1] = 1.0; term(0, 1, 0).a0[2] = 1.0; }            // P2:98-105
+        else if (vf == 2) { term(2, 0, 0).a0[0] = 1.0; term(0, 2, 0).a0[0] = 1.0; }                     // P2:108-115
+        else { delete h; return fail(nullptr, -1, "Poisson-2D var_form must be 0, 1 or 2"); }
+    } else {
+        h->has_eps = 1;
+        if (vf == 0) {                                                           // P3:161-167
+            nT1 = 2; nT2 = 1;  // channels u, u_x, u_t, u_xx
+            TermDesc& t = term(0, 0, 0); t.a0[1] = cfg->V; t.a0[2] = 1.0; t.a1[3] = -1.0;
+        } else if (vf == 1) {                                                    // P3:169-174
+            nT1 = 2;
+            TermDesc& t = term(0, 0, 0); t.a0[1] = cfg->V; t.a0[2] = 1.0;
+            term(1, 0, 1).a0[1] = 1.0;
+        } else { delete h; return fail(nullptr, -1, "AdvDiff var_form must be 0 or 1"); }
+    }
+    h->nd_var = make_netdesc(*cfg, nT1, t1, nT2, t2);
+    h->nd_val = make_netdesc(*cfg, 0, t1, 0, t2);
+    pd.C = h->nd_var.C;
+    pd.has_eps = h->has_eps;
+    h->P = h->nd_var.P;
+    h->Ptot = h->P + h->has_eps;
+
+    int rc = 0;
+    rc |= dalloc(h, &h->d_theta, (size_t)h->Ptot);
+    rc |= dalloc(h, &h->d_m, (size_t)h->Ptot);
+    rc |= dalloc(h, &h->d_v, (size_t)h->Ptot);
+    rc |= dalloc(h, &h->d_state, 2);
+    rc |= dalloc(h, &h->d_RB, (size_t)h->Ptot + 4);
+    rc |= dalloc(h, &h->d_data_part, 64);
+    if (rc) { g_create_error = h->err; hpv_destroy(h); return -2; }
+    (void)hipMemset(h->d_RB, 0, ((size_t)h->Ptot + 4) * sizeof(double));
+    (void)hipMemset(h->d_data_part, 0, 64 * sizeof(double));
+    *out = h;
+    return 0;
+}
+
+void hpv_destroy(hpv_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->mfma) hpv_mfma_destroy(h->mfma);
+    free_batch(h->var); free_batch(h->data); free_batch(h->edge); free_batch(h->pred);
+    double* ptrs[] = {h->d_wtx, h->d_wty, h->d_edge_dphi, h->d_coef, h->d_edge_coef, h->d_F, h->d_R, h->d_loss_e,
+                      h->d_deps_e, h->d_udata, h->d_data_part, h->d_theta, h->d_m, h->d_v, h->d_state, h->d_RB};
+    for (double* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& t : h->timers) for (auto e : t.ev) (void)hipEventDestroy(e);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int hpv_set_stream(hpv_handle h, void* s) {
+    if (!h) return -1;
+    if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    h->stream = (hipStream_t)s;
+    h->own_stream = false;
+    return 0;
+}
+
+int hpv_set_quadrature(hpv_handle h, const double* xi, const double* wx, int qx, const double* yi, const double* wy, int qy) {
+    if (!h) return -1;
+    if (!xi || !wx || qx < 1) return fail(h, -1, "bad x quadrature");
+    if (h->dim == 1) { if (qy != 1) return fail(h, -1, "qy must be 1 for the 1-D problem"); }
+    else if (!yi || !wy || qy < 1) return fail(h, -1, "bad y quadrature");
+    h->xi.assign(xi, xi + qx); h->wx.assign(wx, wx + qx);
+    if (h->dim == 2) { h->yi.assign(yi, yi + qy); h->wy.assign(wy, wy + qy); }
+    else { h->yi.assign(1, 0.0); h->wy.assign(1, 1.0); }
+    h->qx = qx; h->qy = qy;
+    h->pd.qx = qx; h->pd.qy = qy;
+    h->have_quad = true;
+    h->have_tables = false;  // weighted tables depend on the weights
+    h->have_elems = false;
+    return 0;
+}
+
+int hpv_set_tables(hpv_handle h, const double* phix, const double* dphix, const double* d2phix, int ntx,
+                   const double* phiy, const double* dphiy, const double* d2phiy, int nty, const double* edge_dphi) {
+    if (!h) return -1;
+    if (!h->have_quad) return fail(h, -3, "call hpv_set_quadrature first");
+    if (!phix || !dphix || !d2phix || ntx < 1) return fail(h, -1, "bad x tables");
+    if (h->dim == 1) { if (nty != 1) return fail(h, -1, "nty must be 1 for the 1-D problem"); }
+    else if (!phiy || !dphiy || !d2phiy || nty < 1) return fail(h, -1, "bad y tables");
+    const int qx = h->qx, qy = h->qy;
+    std::vector<double> wtx((size_t)3 * ntx * qx), wty((size_t)3 * nty * qy);
+    const double* tx[3] = {phix, dphix, d2phix};
+    const double* ty[3] = {phiy, dphiy, d2phiy};
+    for (int d = 0; d < 3; ++d)
+        for (int r = 0; r < ntx; ++r)
+            for (int i = 0; i < qx; ++i) wtx[((size_t)d * ntx + r) * qx + i] = h->wx[i] * tx[d][(size_t)r * qx + i];
+    for (int d = 0; d < 3; ++d)
+        for (int k = 0; k < nty; ++k)
+            for (int j = 0; j < qy; ++j)
+                wty[((size_t)d * nty + k) * qy + j] = (h->dim == 1) ? 1.0 : h->wy[j] * ty[d][(size_t)k * qy + j];
+    int rc;
+    if ((rc = dalloc(h, &h->d_wtx, wtx.size()))) return rc;
+    if ((rc = dalloc(h, &h->d_wty, wty.size()))) return rc;
+    if ((rc = upload(h, h->d_wtx, wtx.data(), wtx.size()))) return rc;
+    if ((rc = upload(h, h->d_wty, wty.data(), wty.size()))) return rc;
+    if (h->pd.edge) {
+        if (!edge_dphi) return fail(h, -1, "var_form 3 needs edge_dphi");
+        if ((rc = dalloc(h, &h->d_edge_dphi, (size_t)2 * ntx))) return rc;
+        if ((rc = upload(h, h->d_edge_dphi, edge_dphi, (size_t)2 * ntx))) return rc;
+    }
+    h->ntx = ntx; h->nty = nty;
+    h->pd.ntx = ntx; h->pd.nty = nty;
+    if (hpv_proj_lds_bytes(h->pd) > 64 * 1024) return fail(h, -1, "element too large for the projection kernel's LDS (%zu B)", hpv_proj_lds_bytes(h->pd));
+    h->have_tables = true;
+    return 0;
+}
+
+int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* gridy, int ney, int e_begin, int e_end) {
+    if (!h) return -1;
+    if (!h->have_quad || !h->have_tables) return fail(h, -3, "call hpv_set_quadrature and hpv_set_tables first");
+    if (!gridx || nex < 1) return fail(h, -1, "bad x grid");
+    if (h->dim == 1) { if (ney != 1) return fail(h, -1, "ney must be 1 for the 1-D problem"); }
+    else if (!gridy || ney < 1) return fail(h, -1, "bad y grid");
+    const int ne_tot = nex * ney;
+    if (e_begin < 0 || e_end > ne_tot || e_begin > e_end) return fail(h, -1, "bad element range [%d,%d) of %d", e_begin, e_end, ne_tot);
+    h->nex = nex; h->ney = ney; h->e_begin = e_begin; h->e_end = e_end;
+    const long ne = e_end - e_begin;
+    h->n_elem = ne;
+    const int qx = h->qx, qy = h->qy, NQ = qx * qy;
+    const long N = ne * NQ;
+    int rc;
+    if ((rc = alloc_batch(h, h->var, h->nd_var, N, true))) return rc;
+    const int nterms = h->pd.nterms;
+    std::vector<double> X((size_t)h->dim * N), coef((size_t)nterms * ne), ecoef((size_t)ne), EX((size_t)2 * ne);
+    for (long le = 0; le < ne; ++le) {
+        const int e = e_begin + (int)le;
+        const int ex = e / ney, ey = e % ney;
+        const double gx0 = gridx[ex], gx1 = gridx[ex + 1];
+        double gy0 = 0, gy1 = 0;
+        if (h->dim == 2) { gy0 = gridy[ey]; gy1 = gridy[ey + 1]; }
+        // affine map of the reference nodes, same expression as P1:69 / P2:75-76 / P3:120-121
+        for (int j = 0; j < qy; ++j)
+            for (int i = 0; i < qx; ++i) {
+                const long p = le * NQ + (long)j * qx + i;
+                X[p] = gx0 + (gx1 - gx0) / 2 * (h->xi[i] + 1);
+                if (h->dim == 2) X[(size_t)N + p] = gy0 + (gy1 - gy0) / 2 * (h->yi[j] + 1);
+            }
+        const double Jx = (gx1 - gx0) / 2;
+        if (h->cfg.pde == HPV_PDE_POISSON1D) {
+            const double J = Jx;                                     // P1:71
+            if (h->cfg.var_form == 1) coef[le] = -J;
+            else if (h->cfg.var_form == 2) coef[le] = 1.0;
+            else { coef[le] = -1 / J; ecoef[le] = 1 / J; EX[2 * le] = gx0; EX[2 * le + 1] = gx1; }
+        } else if (h->cfg.pde == HPV_PDE_POISSON2D) {
+            const double Jy = (gy1 - gy0) / 2;
+            const double J = Jx * Jy;                                // P2:77-79
+            if (h->cfg.var_form == 0) coef[le] = J;
+            else if (h->cfg.var_form == 1) { coef[le] = -(J / Jx); coef[ne + le] = -(J / Jy); }
+            else { coef[le] = J; coef[ne + le] = J; }
+        } else {
+            const double J = (gy1 - gy0) / 2 * (gx1 - gx0) / 2;      // P3:115
+            if (h->cfg.var_form == 0) coef[le] = J;
+            else { coef[le] = J; coef[ne + le] = J / Jx; }
+        }
+    }
+    if ((rc = dalloc(h, &h->d_coef, coef.size()))) return rc;
+    if ((rc = dalloc(h, &h->d_R, (size_t)ne * h->ntx * h->nty))) return rc;
+    if ((rc = dalloc(h, &h->d_loss_e, (size_t)ne))) return rc;
+    if ((rc = dalloc(h, &h->d_deps_e, (size_t)ne))) return rc;
+    if (N > 0) {
+        if ((rc = upload(h, h->var.X, X.data(), X.size()))) return rc;
+        if ((rc = upload(h, h->d_coef, coef.data(), coef.size()))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->d_deps_e, 0, (size_t)ne * sizeof(double), h->stream));
+    }
+    if (h->pd.edge) {
+        if ((rc = alloc_batch(h, h->edge, h->nd_val, 2 * ne, true))) return rc;
+        if ((rc = dalloc(h, &h->d_edge_coef, (size_t)ne))) return rc;
+        if (ne > 0) {
+            if ((rc = upload(h, h->edge.X, EX.data(), EX.size()))) return rc;
+            if ((rc = upload(h, h->d_edge_coef, ecoef.data(), ecoef.size()))) return rc;
+        }
+    }
+    h->have_elems = true;
+    // (re)slice F if it was given before the elements
+    if (h->have_F) {
+        std::vector<double> F = h->F_all;
+        if ((rc = hpv_set_rhs(h, F.data(), F.size()))) return rc;
+    } else if (h->d_F) { (void)hipFree(h->d_F); h->d_F = nullptr; }
+    // the MFMA fast path (20-wide BASELINE networks)
+    if (h->mfma) { hpv_mfma_destroy(h->mfma); h->mfma = nullptr; }
+    h->backend = HPV_BACKEND_GENERIC;
+    if (h->cfg.backend != HPV_BACKEND_GENERIC && N > 0) {
+        std::string why;
+        h->mfma = hpv_mfma_create(h->nd_var, N, &why);
+        if (h->mfma) {
+            h->backend = HPV_BACKEND_MFMA;
+            // the MFMA path keeps its own activation store and partial-gradient rows
+            if (h->var.ACT) { (void)hipFree(h->var.ACT); h->var.ACT = nullptr; }
+            int rows = hpv_mfma_grad_rows(h->mfma);
+            if (rows > h->var.rows) { if ((rc = dalloc(h, &h->var.GPART, (size_t)rows * h->P))) return rc; }
+            h->var.rows = rows;
+        } else if (h->cfg.backend == HPV_BACKEND_MFMA) {
+            return fail(h, -4, "MFMA backend requested but not available for this shape: %s", why.c_str());
+        }
+    }
+    return 0;
+}
+
+int hpv_set_rhs(hpv_handle h, const double* F, size_t n) {
+    if (!h) return -1;
+    if (!F) { h->have_F = false; h->F_all.clear(); if (h->d_F) { (void)hipFree(h->d_F); h->d_F = nullptr; } return 0; }
+    if (h->have_elems) {
+        const size_t NR = (size_t)h->ntx * h->nty;
+        if (n != (size_t)h->nex * h->ney * NR) return fail(h, -1, "F has %zu entries, expected %zu", n, (size_t)h->nex * h->ney * NR);
+        int rc;
+        if ((rc = dalloc(h, &h->d_F, (size_t)h->n_elem * NR))) return rc;
+        if (h->n_elem > 0 && (rc = upload(h, h->d_F, F + (size_t)h->e_begin * NR, (size_t)h->n_elem * NR))) return rc;
+    }
+    if (F != h->F_all.data()) h->F_all.assign(F, F + n);
+    h->have_F = true;
+    return 0;
+}
+
+int hpv_set_data(hpv_handle h, const double* X, const double* u, int n) {
+    if (!h) return -1;
+    if (n < 0 || (n > 0 && (!X || !u))) return fail(h, -1, "bad data arguments");
+    int rc;
+    h->n_data = n;
+    if ((rc = alloc_batch(h, h->data, h->nd_val, n, true))) return rc;
+    if ((rc = dalloc(h, &h->d_udata, (size_t)n))) return rc;
+    if (n > 0) {
+        if ((rc = upload_points(h, h->data, X, n, h->dim))) return rc;
+        if ((rc = upload(h, h->d_udata, u, (size_t)n))) return rc;
+    }
+    return 0;
+}
+
+size_t hpv_num_params(hpv_handle h) { return h ? (size_t)h->Ptot : 0; }
+
+int hpv_set_params(hpv_handle h, const double* theta, size_t n) {
+    if (!h) return -1;
+    if (!theta || n != (size_t)h->Ptot) return fail(h, -1, "theta has %zu entries, expected %d", n, h->Ptot);
+    int rc;
+    if ((rc = upload(h, h->d_theta, theta, n))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->d_m, 0, n * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_v, 0, n * sizeof(double), h->stream));
+    const double st[2] = {h->cfg.beta1, h->cfg.beta2};
+    if ((rc = upload(h, h->d_state, st, 2))) return rc;
+    h->have_params = true;
+    return 0;
+}
+
+int hpv_get_params(hpv_handle h, double* theta, size_t n) {
+    if (!h) return -1;
+    if (!theta || n != (size_t)h->Ptot) return fail(h, -1, "theta buffer has %zu entries, expected %d", n, h->Ptot);
+    HIPCHK(h, hipMemcpyAsync(theta, h->d_theta, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int hpv_forward_backward(hpv_handle h) { return h ? enqueue_pass(h, true) : -1; }
+int hpv_eval_loss(hpv_handle h) { return h ? enqueue_pass(h, false) : -1; }
+
+int hpv_reduce_buffer(hpv_handle h, void** dev_ptr, size_t* n_doubles) {
+    if (!h || !dev_ptr || !n_doubles) return -1;
+    *dev_ptr = h->d_RB;
+    *n_doubles = (size_t)h->Ptot + 4;
+    return 0;
+}
+
+int hpv_apply_adam(hpv_handle h) {
+    if (!h) return -1;
+    launch_adam(h->d_theta, h->d_m, h->d_v, h->d_RB, h->d_state, h->Ptot, h->cfg.lr, h->cfg.beta1, h->cfg.beta2,
+                h->cfg.eps, h->stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, -2, "adam launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int hpv_sync(hpv_handle h) {
+    if (!h) return -1;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int hpv_read_loss(hpv_handle h, double* loss3) {
+    if (!h || !loss3) return -1;
+    double t[4];
+    HIPCHK(h, hipMemcpyAsync(t, h->d_RB + h->Ptot, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    loss3[0] = t[0] + t[1];
+    loss3[1] = (h->cfg.pde == HPV_PDE_ADVDIFF) ? t[1] : t[2];  // P3:184 folds the weight into lossb
+    loss3[2] = t[0];
+    return 0;
+}
+
+int hpv_loss_and_grad(hpv_handle h, double* loss3, double* grad) {
+    if (!h) return -1;
+    int rc = grad ? enqueue_pass(h, true) : enqueue_pass(h, false);
+    if (rc) return rc;
+    if (loss3 && (rc = hpv_read_loss(h, loss3))) return rc;
+    if (grad) {
+        HIPCHK(h, hipMemcpyAsync(grad, h->d_RB, (size_t)h->Ptot * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int hpv_step(hpv_handle h, int n_iters, double* loss3_after) {
+    if (!h) return -1;
+    int rc;
+    for (int it = 0; it < n_iters; ++it) {
+        if ((rc = enqueue_pass(h, true))) return rc;
+        if ((rc = hpv_apply_adam(h))) return rc;
+    }
+    if (loss3_after) {
+        if ((rc = enqueue_pass(h, false))) return rc;
+        if ((rc = hpv_read_loss(h, loss3_after))) return rc;
+    } else {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+int hpv_predict(hpv_handle h, const double* X, int n, double* u_out) {
+    if (!h) return -1;
+    if (!h->have_params) return fail(h, -3, "hpv_set_params has not been called");
+    if (n < 0 || (n > 0 && (!X || !u_out))) return fail(h, -1, "bad predict arguments");
+    if (n == 0) return 0;
+    int rc;
+    if (h->pred.N != n) { if ((rc = alloc_batch(h, h->pred, h->nd_val, n, false))) return rc; }
+    if ((rc = upload_points(h, h->pred, X, n, h->dim))) return rc;
+    launch_mlp_fwd_generic(h->pred.nd, h->d_theta, h->pred.X, nullptr, h->pred.OUT, n, 0, h->stream);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(u_out, h->pred.OUT, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int hpv_get_residuals(hpv_handle h, double* R, size_t n) {
+    if (!h || !R) return -1;
+    const size_t want = (size_t)h->n_elem * h->ntx * h->nty;
+    if (n != want) return fail(h, -1, "R buffer has %zu entries, expected %zu", n, want);
+    HIPCHK(h, hipMemcpyAsync(R, h->d_R, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int hpv_backend_in_use(hpv_handle h) { return h ? h->backend : -1; }
+
+int hpv_enable_timing(hpv_handle h, int on) {
+    if (!h) return -1;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->timing = on != 0;
+    for (auto& t : h->timers) { t.used = 0; t.total_ms = 0.0; t.launches = 0; }
+    return 0;
+}
+
+int hpv_kernel_time_ms(hpv_handle h, int which, double* avg_ms, long* launches) {
+    if (!h || which < 0 || which > 2) return -1;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    TimerClass& t = h->timers[which];
+    for (size_t i = 0; i < t.used; i += 2) { float ms = 0; (void)hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]); t.total_ms += ms; }
+    t.used = 0;
+    if (avg_ms) *avg_ms = t.launches ? t.total_ms / (double)t.launches : 0.0;
+    if (launches) *launches = t.launches;
+    return 0;
+}
+
+int hpv_bench_projection(hpv_handle h, long n_elem, int reps, double* avg_ms, double* bytes_per_launch) {
+    if (!h) return -1;
+    if (!h->have_quad || !h->have_tables) return fail(h, -3, "set quadrature and tables first");
+    if (n_elem < 1 || reps < 1) return fail(h, -1, "bad arguments");
+    const ProjDesc& pd = h->pd;
+    const long NQ = (long)pd.qx * pd.qy, NR = (long)pd.ntx * pd.nty, N = n_elem * NQ;
+    const int C = pd.C;
+    double *OUT = nullptr, *GB = nullptr, *R = nullptr, *F = nullptr, *coef = nullptr, *le = nullptr, *de = nullptr;
+    int rc = 0;
+    rc |= dalloc(h, &OUT, (size_t)C * N); rc |= dalloc(h, &GB, (size_t)C * N);
+    rc |= dalloc(h, &R, (size_t)n_elem * NR); rc |= dalloc(h, &F, (size_t)n_elem * NR);
+    rc |= dalloc(h, &coef, (size_t)pd.nterms * n_elem); rc |= dalloc(h, &le, (size_t)n_elem); rc |= dalloc(h, &de, (size_t)n_elem);
+    if (!rc) {
+        // deterministic pseudo-random fill on the host in chunks (seeded LCG -> uniform(-1,1))
+        std::vector<double> buf((size_t)1 << 20);
+        unsigned long long s = 1234;
+        auto fill = [&](double* dst, size_t n) {
+            for (size_t o = 0; o < n; o += buf.size()) {
+                size_t m = std::min(buf.size(), n - o);
+                for (size_t i = 0; i < m; ++i) { s = s * 6364136223846793005ULL + 1442695040888963407ULL; buf[i] = (double)(long long)(s >> 11) / 4503599627370496.0 - 1.0; }
+                (void)hipMemcpy(dst + o, buf.data(), m * sizeof(double), hipMemcpyHostToDevice);
+            }
+        };
+        fill(OUT, (size_t)C * N); fill(F, (size_t)n_elem * NR);
+        std::vector<double> c((size_t)pd.nterms * n_elem, 0.25);
+        (void)hipMemcpy(coef, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice);
+        const double* eps_ptr = h->has_eps ? h->d_theta + h->P : nullptr;
+        ProjDesc p2 = pd; p2.edge = 0;
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        auto go = [&]() {
+            if (h->mfma && h->backend == HPV_BACKEND_MFMA && hpv_mfma_has_projection(h->mfma))
+                hpv_mfma_project(h->mfma, p2, OUT, GB, R, F, coef, n_elem, h->d_wtx, h->d_wty, eps_ptr, le, de, N, n_elem, 1, h->stream);
+            else
+                launch_project(p2, OUT, GB, R, F, coef, n_elem, h->d_wtx, h->d_wty, eps_ptr, le, de, N, n_elem, 1, nullptr, nullptr, nullptr, nullptr, h->stream);
+        };
+        go();
+        (void)hipEventRecord(e0, h->stream);
+        for (int i = 0; i < reps; ++i) go();
+        (void)hipEventRecord(e1, h->stream);
+        (void)hipStreamSynchronize(h->stream);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (avg_ms) *avg_ms = ms / reps;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(h, -2, "projection bench failed: %s", hipGetErrorString(e));
+    }
+    // algorithmic bytes: read the integrated channels + F, write the adjoint channels + R
+    int cu = 0;
+    for (int ch = 0; ch < C; ++ch) { bool used = false; for (int t = 0; t < pd.nterms; ++t) if (pd.t[t].a0[ch] != 0.0 || pd.t[t].a1[ch] != 0.0) used = true; cu += used; }
+    if (bytes_per_launch) *bytes_per_launch = 8.0 * (2.0 * cu * (double)N + 2.0 * (double)n_elem * NR);
+    double* ptrs[] = {OUT, GB, R, F, coef, le, de};
+    for (double* p : ptrs) if (p) (void)hipFree(p);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// Internal descriptors shared by the host orchestration (hpv_api.hip) and the kernels.
+// Everything here is plain-old-data passed to kernels by value (kernarg segment).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/hpvpinn.h"
+
+#define HPV_MAXC 5    // value + up to 2 first tangents + up to 2 second tangents
+#define HPV_MAXH 64   // widest layer the generic kernels handle
+#define HPV_MAXT 2    // integrand terms per variational form
+
+// Network + Taylor-channel layout.  Channel order everywhere: [value | d/dc for c in T1 | d2/dc2 for c in T2].
+struct NetDesc {
+    int d;                       // input dimension (1 or 2)
+    int nl;                      // number of affine layers = n_layers - 1
+    int width[HPV_MAX_LAYERS];   // layer widths, width[0] = d, width[nl] = 1
+    int woff[HPV_MAX_LAYERS];    // offset of W_l (row-major [in][out]) in theta
+    int boff[HPV_MAX_LAYERS];    // offset of b_l in theta
+    int act;                     // HPV_ACT_*
+    int nT1, nT2;                // number of first / second tangent channels
+    int t1dim[2];                // input coordinate of each first tangent
+    int t2idx[2];                // index INTO the T1 list of each second tangent
+    int C;                       // 1 + nT1 + nT2
+    int nslot;                   // saved slots per hidden layer: A, A1, ZC[nT1], ZCC[nT2]
+    long actoff[HPV_MAX_LAYERS]; // hidden layer l block starts at actoff[l] * N doubles in ACT
+    int P;                       // number of network parameters (without epsilon)
+};
+
+// One integrand term: U[k][r] += mult * coef[e] * sum_q WTX[dx][r][i] WTY[dy][k][j] G[q],
+// G = sum_ch (a0[ch] + eps * a1[ch]) OUT[ch][q],  mult = eps if eps_mult else 1.
+struct TermDesc {
+    int dx, dy;      // derivative order (0,1,2) of the test-function table per direction
+    int eps_mult;    // the term carries the trainable epsilon as a factor (P3:171)
+    double a0[HPV_MAXC];
+    double a1[HPV_MAXC];
+};
+
+struct ProjDesc {
+    int nterms;
+    TermDesc t[HPV_MAXT];
+    int qx, qy, ntx, nty;
+    int C;
+    int has_eps;     // theta carries a trailing trainable epsilon
+    int edge;        // Poisson-1D var_form 3 boundary term (P1:90)
+};
+
+static inline size_t hpv_proj_lds_bytes(const ProjDesc& pd) {
+    size_t nq = (size_t)pd.qx * pd.qy, nr = (size_t)pd.ntx * pd.nty;
+    return (nq + (size_t)pd.qy * pd.ntx + nr + (size_t)pd.nterms * nr + (size_t)pd.nterms * pd.nty * pd.qx + 256) *
+           sizeof(double);
+}
+
+// ---- kernel launchers (kernels_generic.hip) ----
+void launch_mlp_fwd_generic(const NetDesc& nd, const double* theta, const double* X, double* ACT, double* OUT, long N,
+                            int save_act, hipStream_t s);
+void launch_mlp_bwd_generic(const NetDesc& nd, const double* theta, const double* X, const double* ACT,
+                            const double* GBAR, double* GPART, int rows, long N, hipStream_t s);
+int mlp_bwd_generic_rows(long N);
+void launch_project(const ProjDesc& pd, const double* OUT, double* GBAR, double* R, const double* F, const double* coef,
+                    long coef_stride, const double* wtx, const double* wty, const double* eps_ptr, double* loss_e,
+                    double* deps_e, long N, long n_elem, int do_adjoint, const double* edge_u, const double* edge_dphi,
+                    const double* edge_coef, double* edge_gbar, hipStream_t s);
+void launch_data_loss(const double* U, const double* Ud, double* GBAR, double scale_grad, double* part, int n,
+                      hipStream_t s);
+void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, int rows_b, const double* GPART_e,
+                     int rows_e, const double* loss_e, long n_elem, const double* deps_e, const double* data_part,
+                     int n_data_part, double lossb_weight, int n_data, int P, int has_eps, double* RB, int write_grad,
+                     hipStream_t s);
+void launch_adam(double* theta, double* m, double* v, const double* RB, double* state, int Ptot, double lr, double b1,
+                 double b2, double eps, hipStream_t s);

@@ -1,0 +1,19 @@
+// MFMA (v_mfma_f64_16x16x4_f64) fast path for the BASELINE-shaped networks; see kernels_mfma.hip.
+#pragma once
+#include <string>
+
+#include "hpv_internal.h"
+
+struct HpvMfma;
+
+// Returns nullptr (and a reason) when the network shape is not covered by the fast path.
+HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why);
+void hpv_mfma_destroy(HpvMfma* m);
+int hpv_mfma_grad_rows(HpvMfma* m);
+void hpv_mfma_forward(HpvMfma* m, const double* theta, const double* X, double* OUT, int save_act, hipStream_t s);
+void hpv_mfma_backward(HpvMfma* m, const double* theta, const double* X, const double* GBAR, double* GPART, int* rows,
+                       hipStream_t s);
+bool hpv_mfma_has_projection(HpvMfma* m);
+void hpv_mfma_project(HpvMfma* m, const ProjDesc& pd, const double* OUT, double* GBAR, double* R, const double* F,
+                      const double* coef, long coef_stride, const double* wtx, const double* wty, const double* eps_ptr,
+                      double* loss_e, double* deps_e, long N, long n_elem, int do_adjoint, hipStream_t s);

@@ -1,0 +1,537 @@
+// Generic (any layer widths <= HPV_MAXH, any variational form) fp64 kernels of the hp-VPINN
+// iteration for gfx950.  One thread per quadrature point for the network, one workgroup per
+// element for the projection.  These are the shape-agnostic path and the on-device cross-check
+// of the MFMA path (kernels_mfma.hip), which takes over for the 20-wide BASELINE networks.
+//
+// Maths (replaces tf.gradients at P1:144-148, P2:175-185, P3:236-245):
+//   hidden layer:  z = hW+b, z_c = h_c W, z_cc = h_cc W
+//                  h' = s(z), h'_c = s'(z) z_c, h'_cc = s''(z) z_c^2 + s'(z) z_cc
+//   reverse:       zb_cc = hb'_cc s',  zb_c = hb'_c s' + 2 hb'_cc s'' z_c,
+//                  zb   = hb' s' + sum_c [hb'_c s'' z_c + hb'_cc (s''' z_c^2 + s'' z_cc)]
+#include "hpv_internal.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+    return v;
+}
+
+// Block-wide sum of one double per thread (blockDim.x multiple of 64, <= 1024); result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) r += scratch[i];
+    }
+    return r;
+}
+
+__device__ __forceinline__ void act_eval(int act, double z, double& a, double& a1) {
+    if (act == HPV_ACT_TANH) {
+        a = tanh(z);
+        a1 = 1.0 - a * a;
+    } else {
+        sincos(z, &a, &a1);
+    }
+}
+// s'' and s''' from the saved (s, s').
+__device__ __forceinline__ void act_hi(int act, double a, double a1, double& a2, double& a3) {
+    if (act == HPV_ACT_TANH) {
+        a2 = -2.0 * a * a1;
+        a3 = -2.0 * a1 * (1.0 - 3.0 * a * a);
+    } else {
+        a2 = -a;
+        a3 = -a1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward Taylor-mode MLP: value + tangent channels at every point.  (P1:128-148)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_mlp_fwd_generic(NetDesc nd, const double* __restrict__ theta,
+                                                        const double* __restrict__ X, double* __restrict__ ACT,
+                                                        double* __restrict__ OUT, long N, int save_act) {
+    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const int C = nd.C, nT1 = nd.nT1, nT2 = nd.nT2;
+    double h[HPV_MAXC][HPV_MAXH];
+    double zn[HPV_MAXC][HPV_MAXH];
+    for (int j = 0; j < nd.d; ++j) {
+        h[0][j] = X[(long)j * N + p];
+        for (int a = 0; a < nT1; ++a) h[1 + a][j] = (nd.t1dim[a] == j) ? 1.0 : 0.0;
+        for (int b = 0; b < nT2; ++b) h[1 + nT1 + b][j] = 0.0;
+    }
+    const int nhid = nd.nl - 1;
+    for (int l = 0; l < nhid; ++l) {
+        const int in = nd.width[l], out = nd.width[l + 1];
+        const double* W = theta + nd.woff[l];
+        const double* B = theta + nd.boff[l];
+        for (int k = 0; k < out; ++k) {
+            for (int ch = 0; ch < C; ++ch) {
+                double acc = (ch == 0) ? B[k] : 0.0;
+                for (int j = 0; j < in; ++j) acc += h[ch][j] * W[j * out + k];
+                zn[ch][k] = acc;
+            }
+        }
+        double* base = ACT + nd.actoff[l] * N;
+        for (int k = 0; k < out; ++k) {
+            double a, a1, a2, a3;
+            act_eval(nd.act, zn[0][k], a, a1);
+            act_hi(nd.act, a, a1, a2, a3);
+            if (save_act) {
+                base[((long)0 * out + k) * N + p] = a;
+                base[((long)1 * out + k) * N + p] = a1;
+            }
+            h[0][k] = a;
+            for (int t = 0; t < nT1; ++t) {
+                double zc = zn[1 + t][k];
+                if (save_act) base[((long)(2 + t) * out + k) * N + p] = zc;
+                h[1 + t][k] = a1 * zc;
+            }
+            for (int b = 0; b < nT2; ++b) {
+                double zc = zn[1 + nd.t2idx[b]][k];
+                double zcc = zn[1 + nT1 + b][k];
+                if (save_act) base[((long)(2 + nT1 + b) * out + k) * N + p] = zcc;
+                h[1 + nT1 + b][k] = a2 * zc * zc + a1 * zcc;
+            }
+        }
+    }
+    {   // linear head (P1:135-137)
+        const int in = nd.width[nd.nl - 1];
+        const double* W = theta + nd.woff[nd.nl - 1];
+        const double* B = theta + nd.boff[nd.nl - 1];
+        for (int ch = 0; ch < C; ++ch) {
+            double acc = (ch == 0) ? B[0] : 0.0;
+            for (int j = 0; j < in; ++j) acc += h[ch][j] * W[j];
+            OUT[(long)ch * N + p] = acc;
+        }
+    }
+}
+
+void launch_mlp_fwd_generic(const NetDesc& nd, const double* theta, const double* X, double* ACT, double* OUT, long N,
+                            int save_act, hipStream_t s) {
+    if (N <= 0) return;
+    dim3 grid((unsigned)((N + 255) / 256));
+    hipLaunchKernelGGL(k_mlp_fwd_generic, grid, dim3(256), 0, s, nd, theta, X, ACT, OUT, N, save_act);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reverse pass through the Taylor-mode forward: dL/dW, dL/db from the output adjoints GBAR.
+// Each wave owns one row of GPART (zeroed by the host before launch); per parameter the wave
+// reduces its 64 points with shuffles and lane 0 accumulates -- deterministic, no atomics.
+// ------------------------------------------------------------------------------------------------
+#define BWD_BLOCK 256
+#define BWD_MAX_BLOCKS 1024
+
+int mlp_bwd_generic_rows(long N) {
+    long blocks = (N + BWD_BLOCK - 1) / BWD_BLOCK;
+    if (blocks > BWD_MAX_BLOCKS) blocks = BWD_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    return (int)(blocks * (BWD_BLOCK / WAVE));
+}
+
+__device__ __forceinline__ void load_layer_outputs(const NetDesc& nd, const double* ACT, int l, long N, long p, bool valid,
+                                                   double hin[HPV_MAXC][HPV_MAXH]) {
+    // outputs (h, h_c, h_cc) of hidden layer l recomputed from its saved slots
+    const int w = nd.width[l + 1], nT1 = nd.nT1, nT2 = nd.nT2;
+    const double* base = ACT + nd.actoff[l] * N;
+    for (int j = 0; j < w; ++j) {
+        double a = valid ? base[((long)0 * w + j) * N + p] : 0.0;
+        double a1 = valid ? base[((long)1 * w + j) * N + p] : 0.0;
+        double a2, a3;
+        act_hi(nd.act, a, a1, a2, a3);
+        hin[0][j] = a;
+        for (int t = 0; t < nT1; ++t) {
+            double zc = valid ? base[((long)(2 + t) * w + j) * N + p] : 0.0;
+            hin[1 + t][j] = a1 * zc;
+        }
+        for (int b = 0; b < nT2; ++b) {
+            double zc = valid ? base[((long)(2 + nd.t2idx[b]) * w + j) * N + p] : 0.0;
+            double zcc = valid ? base[((long)(2 + nT1 + b) * w + j) * N + p] : 0.0;
+            hin[1 + nT1 + b][j] = a2 * zc * zc + a1 * zcc;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BWD_BLOCK) k_mlp_bwd_generic(NetDesc nd, const double* __restrict__ theta,
+                                                              const double* __restrict__ X,
+                                                              const double* __restrict__ ACT,
+                                                              const double* __restrict__ GBAR,
+                                                              double* __restrict__ GPART, long N) {
+    const int lane = threadIdx.x & 63;
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nthreads = (long)gridDim.x * blockDim.x;
+    const long wave_global = tid >> 6;
+    double* row = GPART + wave_global * (long)nd.P;
+    const int C = nd.C, nT1 = nd.nT1, nT2 = nd.nT2;
+    const int nhid = nd.nl - 1;
+
+    double hbar[HPV_MAXC][HPV_MAXH];
+    double zbar[HPV_MAXC][HPV_MAXH];
+    double hin[HPV_MAXC][HPV_MAXH];
+
+    for (long p0 = wave_global * WAVE; p0 < N; p0 += nthreads) {
+        const long p = p0 + lane;
+        const bool valid = p < N;
+        double gb[HPV_MAXC];
+        for (int ch = 0; ch < C; ++ch) gb[ch] = valid ? GBAR[(long)ch * N + p] : 0.0;
+
+        // ---- linear head ----
+        {
+            const int in = nd.width[nd.nl - 1];
+            const double* W = theta + nd.woff[nd.nl - 1];
+            if (nhid > 0) {
+                load_layer_outputs(nd, ACT, nhid - 1, N, p, valid, hin);
+            } else {
+                for (int j = 0; j < in; ++j) {
+                    hin[0][j] = valid ? X[(long)j * N + p] : 0.0;
+                    for (int t = 0; t < nT1; ++t) hin[1 + t][j] = (valid && nd.t1dim[t] == j) ? 1.0 : 0.0;
+                    for (int b = 0; b < nT2; ++b) hin[1 + nT1 + b][j] = 0.0;
+                }
+            }
+            for (int j = 0; j < in; ++j) {
+                double v = 0.0;
+                for (int ch = 0; ch < C; ++ch) {
+                    v += hin[ch][j] * gb[ch];
+                    hbar[ch][j] = gb[ch] * W[j];
+                }
+                v = wave_sum(v);
+                if (lane == 0) row[nd.woff[nd.nl - 1] + j] += v;
+            }
+            double v = wave_sum(gb[0]);
+            if (lane == 0) row[nd.boff[nd.nl - 1]] += v;
+        }
+
+        // ---- hidden layers, last to first ----
+        for (int l = nhid - 1; l >= 0; --l) {
+            const int in = nd.width[l], out = nd.width[l + 1];
+            const double* W = theta + nd.woff[l];
+            const double* base = ACT + nd.actoff[l] * N;
+            for (int k = 0; k < out; ++k) {
+                double a = valid ? base[((long)0 * out + k) * N + p] : 0.0;
+                double a1 = valid ? base[((long)1 * out + k) * N + p] : 0.0;
+                double a2, a3;
+                act_hi(nd.act, a, a1, a2, a3);
+                double zc[2] = {0.0, 0.0};
+                for (int t = 0; t < nT1; ++t) zc[t] = valid ? base[((long)(2 + t) * out + k) * N + p] : 0.0;
+                double zb = hbar[0][k] * a1;
+                for (int t = 0; t < nT1; ++t) {
+                    zbar[1 + t][k] = hbar[1 + t][k] * a1;
+                    zb += hbar[1 + t][k] * a2 * zc[t];
+                }
+                for (int b = 0; b < nT2; ++b) {
+                    const int t = nd.t2idx[b];
+                    double zcc = valid ? base[((long)(2 + nT1 + b) * out + k) * N + p] : 0.0;
+                    double hb = hbar[1 + nT1 + b][k];
+                    zbar[1 + nT1 + b][k] = hb * a1;
+                    zbar[1 + t][k] += 2.0 * hb * a2 * zc[t];
+                    zb += hb * (a3 * zc[t] * zc[t] + a2 * zcc);
+                }
+                zbar[0][k] = valid ? zb : 0.0;
+            }
+            // inputs of this layer
+            if (l > 0) {
+                load_layer_outputs(nd, ACT, l - 1, N, p, valid, hin);
+            } else {
+                for (int j = 0; j < in; ++j) {
+                    hin[0][j] = valid ? X[(long)j * N + p] : 0.0;
+                    for (int t = 0; t < nT1; ++t) hin[1 + t][j] = (valid && nd.t1dim[t] == j) ? 1.0 : 0.0;
+                    for (int b = 0; b < nT2; ++b) hin[1 + nT1 + b][j] = 0.0;
+                }
+            }
+            for (int j = 0; j < in; ++j) {
+                for (int k = 0; k < out; ++k) {
+                    double v = 0.0;
+                    for (int ch = 0; ch < C; ++ch) v += hin[ch][j] * zbar[ch][k];
+                    v = wave_sum(v);
+                    if (lane == 0) row[nd.woff[l] + j * out + k] += v;
+                }
+            }
+            for (int k = 0; k < out; ++k) {
+                double v = wave_sum(zbar[0][k]);
+                if (lane == 0) row[nd.boff[l] + k] += v;
+            }
+            if (l > 0) {
+                for (int j = 0; j < in; ++j) {
+                    for (int ch = 0; ch < C; ++ch) {
+                        double acc = 0.0;
+                        for (int k = 0; k < out; ++k) acc += zbar[ch][k] * W[j * out + k];
+                        hin[ch][j] = acc;  // reuse hin as the new hbar
+                    }
+                }
+                for (int j = 0; j < in; ++j)
+                    for (int ch = 0; ch < C; ++ch) hbar[ch][j] = hin[ch][j];
+            }
+        }
+    }
+}
+
+void launch_mlp_bwd_generic(const NetDesc& nd, const double* theta, const double* X, const double* ACT,
+                            const double* GBAR, double* GPART, int rows, long N, hipStream_t s) {
+    if (N <= 0) return;
+    hipMemsetAsync(GPART, 0, (size_t)rows * nd.P * sizeof(double), s);
+    int blocks = rows / (BWD_BLOCK / WAVE);
+    hipLaunchKernelGGL(k_mlp_bwd_generic, dim3(blocks), dim3(BWD_BLOCK), 0, s, nd, theta, X, ACT, GBAR, GPART, N);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-element projection onto the test functions, residual, element loss and (optionally) the
+// adjoint back to the integrand channels.  One workgroup per element, sum-factorised
+// (x-contraction then y-contraction).  Replaces the Python-unrolled reduce chains of
+// P1:82-96, P2:91-120, P3:157-182.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_project(ProjDesc pd, const double* __restrict__ OUT, double* __restrict__ GBAR,
+                                                double* __restrict__ R, const double* __restrict__ F,
+                                                const double* __restrict__ coef, long coef_stride,
+                                                const double* __restrict__ wtx, const double* __restrict__ wty,
+                                                const double* __restrict__ eps_ptr, double* __restrict__ loss_e,
+                                                double* __restrict__ deps_e, long N, int do_adjoint,
+                                                const double* __restrict__ edge_u, const double* __restrict__ edge_dphi,
+                                                const double* __restrict__ edge_coef, double* __restrict__ edge_gbar) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const long e = blockIdx.x;
+    const int qx = pd.qx, qy = pd.qy, ntx = pd.ntx, nty = pd.nty;
+    const int NQ = qx * qy, NR = ntx * nty, nterms = pd.nterms, C = pd.C;
+    double* G = sm;
+    double* T = G + NQ;
+    double* U = T + qy * ntx;
+    double* Uraw = U + NR;
+    double* S = Uraw + nterms * NR;
+    double* red = S + nterms * nty * qx;
+    const long base = e * NQ;
+    const double eps = eps_ptr ? eps_ptr[0] : 0.0;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+
+    for (int idx = tid; idx < NR; idx += nthr) U[idx] = F ? -F[e * NR + idx] : 0.0;
+    __syncthreads();
+
+    for (int t = 0; t < nterms; ++t) {
+        const TermDesc& td = pd.t[t];
+        double alpha[HPV_MAXC];
+        for (int ch = 0; ch < C; ++ch) alpha[ch] = td.a0[ch] + eps * td.a1[ch];
+        for (int q = tid; q < NQ; q += nthr) {
+            double g = 0.0;
+            for (int ch = 0; ch < C; ++ch)
+                if (alpha[ch] != 0.0) g += alpha[ch] * OUT[(long)ch * N + base + q];
+            G[q] = g;
+        }
+        __syncthreads();
+        const double* ax = wtx + (long)td.dx * ntx * qx;
+        for (int idx = tid; idx < qy * ntx; idx += nthr) {
+            const int j = idx / ntx, r = idx - j * ntx;
+            double acc = 0.0;
+            for (int i = 0; i < qx; ++i) acc += ax[r * qx + i] * G[j * qx + i];
+            T[idx] = acc;
+        }
+        __syncthreads();
+        const double* by = wty + (long)td.dy * nty * qy;
+        const double c = coef[(long)t * coef_stride + e];
+        for (int idx = tid; idx < NR; idx += nthr) {
+            const int k = idx / ntx, r = idx - k * ntx;
+            double acc = 0.0;
+            for (int j = 0; j < qy; ++j) acc += by[k * qy + j] * T[j * ntx + r];
+            acc *= c;
+            Uraw[t * NR + idx] = acc;
+            U[idx] += td.eps_mult ? eps * acc : acc;
+        }
+        __syncthreads();
+    }
+    if (pd.edge) {  // P1:90: + 1/J [u(x_R) phi'_k(1) - u(x_L) phi'_k(-1)]
+        const double uL = edge_u[2 * e], uR = edge_u[2 * e + 1], ce = edge_coef[e];
+        for (int idx = tid; idx < NR; idx += nthr)
+            U[idx] += ce * (uR * edge_dphi[2 * idx + 1] - uL * edge_dphi[2 * idx]);
+        __syncthreads();
+    }
+    double sq = 0.0;
+    for (int idx = tid; idx < NR; idx += nthr) {
+        const double u = U[idx];
+        R[e * NR + idx] = u;
+        sq += u * u;
+    }
+    sq = block_sum(sq, red);
+    if (tid == 0) loss_e[e] = sq / (double)NR;  // reduce_mean(square(Res)) (P1:95)
+    if (!do_adjoint) return;
+
+    const double sc = 2.0 / (double)NR;
+    for (int t = 0; t < nterms; ++t) {
+        const double* ax = wtx + (long)pd.t[t].dx * ntx * qx;
+        for (int idx = tid; idx < nty * qx; idx += nthr) {
+            const int k = idx / qx, i = idx - k * qx;
+            double acc = 0.0;
+            for (int r = 0; r < ntx; ++r) acc += ax[r * qx + i] * U[k * ntx + r];
+            S[t * nty * qx + idx] = acc * sc;
+        }
+    }
+    __syncthreads();
+    double deps = 0.0;
+    for (int q = tid; q < NQ; q += nthr) {
+        const int j = q / qx, i = q - j * qx;
+        double gb[HPV_MAXC];
+        double o[HPV_MAXC];
+        for (int ch = 0; ch < C; ++ch) {
+            gb[ch] = 0.0;
+            o[ch] = OUT[(long)ch * N + base + q];
+        }
+        for (int t = 0; t < nterms; ++t) {
+            const TermDesc& td = pd.t[t];
+            const double* by = wty + (long)td.dy * nty * qy;
+            double gh = 0.0;
+            for (int k = 0; k < nty; ++k) gh += by[k * qy + j] * S[t * nty * qx + k * qx + i];
+            gh *= coef[(long)t * coef_stride + e];
+            const double m = td.eps_mult ? eps : 1.0;
+            double g1 = 0.0, gt = 0.0;
+            for (int ch = 0; ch < C; ++ch) {
+                const double al = td.a0[ch] + eps * td.a1[ch];
+                gb[ch] += al * (m * gh);
+                g1 += td.a1[ch] * o[ch];
+                gt += al * o[ch];
+            }
+            deps += gh * (m * g1 + (td.eps_mult ? gt : 0.0));
+        }
+        for (int ch = 0; ch < C; ++ch) GBAR[(long)ch * N + base + q] = gb[ch];
+    }
+    if (pd.edge) {
+        double sl = 0.0, sr = 0.0;
+        for (int idx = tid; idx < NR; idx += nthr) {
+            sl += U[idx] * edge_dphi[2 * idx];
+            sr += U[idx] * edge_dphi[2 * idx + 1];
+        }
+        sl = block_sum(sl, red);
+        sr = block_sum(sr, red);
+        if (tid == 0) {
+            edge_gbar[2 * e] = -edge_coef[e] * sc * sl;
+            edge_gbar[2 * e + 1] = edge_coef[e] * sc * sr;
+        }
+    }
+    if (pd.has_eps) {
+        deps = block_sum(deps, red);
+        if (tid == 0) deps_e[e] = deps;
+    }
+}
+
+void launch_project(const ProjDesc& pd, const double* OUT, double* GBAR, double* R, const double* F, const double* coef,
+                    long coef_stride, const double* wtx, const double* wty, const double* eps_ptr, double* loss_e,
+                    double* deps_e, long N, long n_elem, int do_adjoint, const double* edge_u, const double* edge_dphi,
+                    const double* edge_coef, double* edge_gbar, hipStream_t s) {
+    if (n_elem <= 0) return;
+    size_t lds = hpv_proj_lds_bytes(pd);
+    hipLaunchKernelGGL(k_project, dim3((unsigned)n_elem), dim3(256), lds, s, pd, OUT, GBAR, R, F, coef, coef_stride, wtx,
+                       wty, eps_ptr, loss_e, deps_e, N, do_adjoint, edge_u, edge_dphi, edge_coef, edge_gbar);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Boundary / data term: lossb = w * mean((u_d - u)^2)  (P1:98, P2:122, P3:184)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_data_loss(const double* __restrict__ U, const double* __restrict__ Ud,
+                                                  double* __restrict__ GBAR, double scale_grad,
+                                                  double* __restrict__ part, int n) {
+    __shared__ double red[16];
+    double sq = 0.0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        const double d = Ud[p] - U[p];
+        sq += d * d;
+        if (GBAR) GBAR[p] = scale_grad * d;
+    }
+    sq = block_sum(sq, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = sq;
+}
+
+void launch_data_loss(const double* U, const double* Ud, double* GBAR, double scale_grad, double* part, int n,
+                      hipStream_t s) {
+    if (n <= 0) return;
+    int blocks = (n + 255) / 256;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(k_data_loss, dim3(blocks), dim3(256), 0, s, U, Ud, GBAR, scale_grad, part, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Finalize: fixed-order sums of all partials into the packed reduce buffer
+//   RB = [grad (P) | (d eps) | lossv | w*lossb | mean-square of the data term | pad]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_finalize(const double* __restrict__ GPART_v, int rows_v,
+                                                 const double* __restrict__ GPART_b, int rows_b,
+                                                 const double* __restrict__ GPART_e, int rows_e,
+                                                 const double* __restrict__ loss_e, long n_elem,
+                                                 const double* __restrict__ deps_e,
+                                                 const double* __restrict__ data_part, int n_data_part,
+                                                 double lossb_weight, int n_data, int P, int has_eps,
+                                                 double* __restrict__ RB, int write_grad) {
+    __shared__ double red[16];
+    const int Ptot = P + (has_eps ? 1 : 0);
+    if (blockIdx.x < gridDim.x - 1) {
+        const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx < P && write_grad) {
+            double acc = 0.0;
+            if (GPART_v) for (int r = 0; r < rows_v; ++r) acc += GPART_v[(long)r * P + idx];
+            if (GPART_b) for (int r = 0; r < rows_b; ++r) acc += GPART_b[(long)r * P + idx];
+            if (GPART_e) for (int r = 0; r < rows_e; ++r) acc += GPART_e[(long)r * P + idx];
+            RB[idx] = acc;
+        }
+        return;
+    }
+    // last block: scalars
+    double lv = 0.0, de = 0.0;
+    for (long e = threadIdx.x; e < n_elem; e += blockDim.x) {
+        lv += loss_e[e];
+        if (has_eps && deps_e) de += deps_e[e];
+    }
+    lv = block_sum(lv, red);
+    de = block_sum(de, red);
+    if (threadIdx.x == 0) {
+        double sq = 0.0;
+        for (int i = 0; i < n_data_part; ++i) sq += data_part[i];
+        const double msq = n_data > 0 ? sq / (double)n_data : 0.0;
+        if (has_eps && write_grad) RB[P] = de;
+        RB[Ptot + 0] = lv;
+        RB[Ptot + 1] = lossb_weight * msq;
+        RB[Ptot + 2] = msq;
+        RB[Ptot + 3] = 0.0;
+    }
+}
+
+void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, int rows_b, const double* GPART_e,
+                     int rows_e, const double* loss_e, long n_elem, const double* deps_e, const double* data_part,
+                     int n_data_part, double lossb_weight, int n_data, int P, int has_eps, double* RB, int write_grad,
+                     hipStream_t s) {
+    int gblocks = (P + 255) / 256;
+    hipLaunchKernelGGL(k_finalize, dim3(gblocks + 1), dim3(256), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e, rows_e,
+                       loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB, write_grad);
+}
+
+// ------------------------------------------------------------------------------------------------
+// TF1 AdamOptimizer update (tf.train.AdamOptimizer(LR).minimize, P1:103-104):
+//   lr_t = lr sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+//   theta -= lr_t m / (sqrt(v) + eps)      -- eps OUTSIDE the bias correction, unlike torch.optim.Adam.
+// state = {beta1^t, beta2^t} kept as running products exactly like TF's beta*_power variables.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_adam(double* __restrict__ theta, double* __restrict__ m, double* __restrict__ v,
+                                              const double* __restrict__ g, double* __restrict__ state, int Ptot,
+                                              double lr, double b1, double b2, double eps) {
+    const double b1p = state[0], b2p = state[1];
+    const double lr_t = lr * sqrt(1.0 - b2p) / (1.0 - b1p);
+    for (int i = threadIdx.x; i < Ptot; i += blockDim.x) {
+        const double gi = g[i];
+        const double mi = b1 * m[i] + (1.0 - b1) * gi;
+        const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        theta[i] -= lr_t * mi / (sqrt(vi) + eps);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        state[0] = b1p * b1;
+        state[1] = b2p * b2;
+    }
+}
+
+void launch_adam(double* theta, double* m, double* v, const double* RB, double* state, int Ptot, double lr, double b1,
+                 double b2, double eps, hipStream_t s) {
+    hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, s, theta, m, v, RB, state, Ptot, lr, b1, b2, eps);
+}

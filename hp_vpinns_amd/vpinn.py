@@ -1,0 +1,327 @@
+"""The reference's `VPINN(...)` class surface on top of libhpvpinn.so.
+
+Three classes, one per reference driver, with the reference's positional constructor
+signatures, array layouts and `train` / `predict` semantics:
+
+  VPINN1D      <- main/Poisson-1D/hp-VPINN-Poisson-1D.py:30-224            (P1)
+  VPINN2D      <- main/Poisson-2D/hp-VPINN-Poisson-2D.py:27-257            (P2)
+  VPINNAdvDiff <- main/AdvDiff-Identification/...-Identification.py:58-341 (P3)
+
+Host work here is set-up only (tables, packing, sharding); every iteration -- MLP forward with
+its input derivatives, test-function projection, residual, gradients, Adam -- runs in the HIP
+library.  Module-level globals the reference classes read (`var_form`, `LR`, `lossb_weight`,
+`scheme`, `V`, `total_record`, `loss_his`) are keyword arguments with the reference defaults.
+"""
+import time
+
+import numpy as np
+
+from . import _lib
+from .dist import Reducer, dist_info, shard_range
+from .init import n_params, xavier_init
+from .testfcn import dTest_fcn, tables_1d
+
+
+def _tensor_rule(X_quad, W_quad):
+    """Recover the 1-D rules from the flattened tensor-product arrays of P2:355-360 (x fastest)."""
+    X_quad, W_quad = np.asarray(X_quad, dtype=np.float64), np.asarray(W_quad, dtype=np.float64)
+    nq = X_quad.shape[0]
+    q = int(round(np.sqrt(nq)))
+    if q * q != nq:
+        raise ValueError("X_quad is not a Q x Q tensor-product rule")
+    xi, yi = X_quad[:q, 0].copy(), X_quad[::q, 1].copy()
+    wx, wy = W_quad[:q, 0].copy(), W_quad[::q, 1].copy()
+    xx, yy = np.meshgrid(xi, yi)
+    wxx, wyy = np.meshgrid(wx, wy)
+    ok = (np.array_equal(xx.flatten(), X_quad[:, 0]) and np.array_equal(yy.flatten(), X_quad[:, 1])
+          and np.array_equal(wxx.flatten(), W_quad[:, 0]) and np.array_equal(wyy.flatten(), W_quad[:, 1]))
+    if not ok:
+        raise ValueError("quadrature arrays are not the x-fastest tensor product the reference builds (P2:355-360)")
+    return xi, wx, yi, wy
+
+
+def _uniform(lst, what):
+    vals = [int(v) for v in np.ravel(lst)]
+    if len(set(vals)) != 1:
+        raise ValueError(f"{what} must be the same in every element (the reference's F_ext_total "
+                         "reshape, P2:414, requires it too)")
+    return vals[0]
+
+
+def _next_chunk(it, nIter, every=10):
+    """Iterations `it .. it+n-1` run back to back on the device; `rec` says whether the last of
+    them is a recording iteration (it % every == 0, P1:210 / P3:314)."""
+    r = it if it % every == 0 else (it // every + 1) * every
+    if r < nIter:
+        return r - it + 1, True
+    return nIter - it, False
+
+
+class _VPINNBase:
+    """Common machinery: handle creation, sharding, the iteration loop pieces."""
+
+    _pde = None
+    _act = None
+    _n_extra = 0
+
+    def _create(self, layers, var_form, LR, lossb_weight, V, init_params, seed, backend, device):
+        self.layers = [int(v) for v in layers]
+        self.rank, self.world, local_rank = dist_info()
+        if device is None:
+            device = local_rank if self.world > 1 else 0
+        self.device = device
+        bk = {"auto": _lib.BACKEND_AUTO, "generic": _lib.BACKEND_GENERIC, "mfma": _lib.BACKEND_MFMA,
+              "hip": _lib.BACKEND_AUTO}[backend]
+        self.h = _lib.Handle(self._pde, var_form, self._act, self.layers, lr=LR, lossb_weight=lossb_weight,
+                             V=V, device=device, backend=bk)
+        if init_params is None:
+            init_params = xavier_init(self.layers, seed, extra=[1.0] * self._n_extra)
+        self._init_params = np.asarray(init_params, dtype=np.float64).reshape(-1).copy()
+        if self._init_params.size != n_params(self.layers, self._n_extra):
+            raise ValueError("init_params has the wrong length")
+        self._reducer = None
+        if self.world > 1:
+            import torch
+            torch.cuda.set_device(device)
+            self.h.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def _finish(self):
+        self.h.set_params(self._init_params)
+        if self.world > 1:
+            ptr, n = self.h.reduce_buffer()
+            self._reducer = Reducer(ptr, n, self.device)
+
+    # -- iteration pieces -----------------------------------------------------------------
+    def _step(self, n, read_loss):
+        """n Adam iterations; returns loss3 evaluated after the last update if read_loss."""
+        if self.world == 1:
+            return self.h.step(n, read_loss)
+        for _ in range(n):
+            self.h.forward_backward()
+            self._reducer.allreduce()
+            self.h.apply_adam()
+        if not read_loss:
+            return None
+        self.h.eval_loss()
+        self._reducer.allreduce()
+        return self.h.read_loss()
+
+    def loss_and_grad(self):
+        """({loss, lossb, lossv}, d loss / d theta) at the current parameters (global over ranks)."""
+        if self.world == 1:
+            return self.h.loss_and_grad(True)
+        self.h.forward_backward()
+        t = self._reducer.allreduce()
+        loss3 = self.h.read_loss()
+        return loss3, t[: self.h.num_params()].cpu().numpy()
+
+    def loss(self):
+        if self.world == 1:
+            return self.h.loss_and_grad(False)[0]
+        self.h.eval_loss()
+        self._reducer.allreduce()
+        return self.h.read_loss()
+
+    def get_params(self):
+        return self.h.get_params()
+
+    def set_params(self, theta):
+        self.h.set_params(theta)
+
+    def backend(self):
+        return {_lib.BACKEND_GENERIC: "generic", _lib.BACKEND_MFMA: "mfma"}[self.h.backend_in_use()]
+
+    def _predict(self, X):
+        X = np.asarray(X, dtype=np.float64)
+        return self.h.predict(X)[:, None]
+
+
+class VPINN1D(_VPINNBase):
+    """Poisson 1-D hp-VPINN (reference P1:30-224; constructor P1:31-32, call site P1:333-334)."""
+
+    _pde, _act = _lib.PDE_POISSON1D, _lib.ACT_SIN   # tf.sin, P1:134
+
+    def __init__(self, X_u_train, u_train, X_quad, W_quad, F_exact_total, grid, X_test, u_test, layers,
+                 X_f_train=None, f_train=None, *, var_form=1, lossb_weight=1, LR=0.001, init_params=None,
+                 seed=1234, backend="auto", device=None, total_record=None):
+        self.x, self.u = np.asarray(X_u_train, dtype=np.float64), np.asarray(u_train, dtype=np.float64)
+        self.xf, self.f = X_f_train, f_train
+        self.xquad, self.wquad = np.asarray(X_quad, dtype=np.float64), np.asarray(W_quad, dtype=np.float64)
+        self.xtest, self.utest = X_test, u_test
+        self.F_ext_total = np.asarray(F_exact_total, dtype=np.float64)
+        self.Nelement = self.F_ext_total.shape[0]          # P1:43
+        self.N_test = self.F_ext_total[0].shape[0]         # P1:44
+        self.grid = np.asarray(grid, dtype=np.float64)
+        self.var_form, self.LR, self.lossb_weight = var_form, LR, lossb_weight
+        self.total_record = [] if total_record is None else total_record
+        if self.grid.size != self.Nelement + 1:
+            raise ValueError("grid must have Nelement+1 entries")
+        self._create(layers, var_form, LR, lossb_weight, 1.0, init_params, seed, backend, device)
+        xi = self.xquad.reshape(-1)
+        self.h.set_quadrature(xi, self.wquad.reshape(-1))
+        edge = None
+        if var_form == 3:
+            d1b = dTest_fcn(self.N_test, np.array([-1.0, 1.0]))[0]     # (N_test, 2): phi'(-1), phi'(1)  (P1:79)
+            edge = np.ascontiguousarray(d1b)
+        self.h.set_tables(tables_1d(self.N_test, xi), None, edge)
+        eb, ee = shard_range(self.Nelement, self.rank, self.world)
+        self.h.set_elements(self.grid, None, eb, ee)
+        self.h.set_rhs(self.F_ext_total.reshape(-1))
+        if self.rank == 0:
+            self.h.set_data(self.x, self.u.reshape(-1))
+        self._finish()
+
+    def predict(self, x):                                   # P1:197-199
+        return self._predict(x)
+
+    def train(self, nIter, tresh):
+        """P1:201-224.  The loss is read back every 10 iterations, AFTER that iteration's update,
+        appended to `total_record` as [it, loss]; early exit when loss < tresh."""
+        start_time = time.time()
+        it = 0
+        while it < nIter:
+            n, rec = _next_chunk(it, nIter)
+            last = it + n - 1
+            loss3 = self._step(n, rec)
+            it += n
+            if rec:
+                loss_value, loss_valueb, loss_valuev = float(loss3[0]), float(loss3[1]), float(loss3[2])
+                self.total_record.append(np.array([last, loss_value]))
+                if loss_value < tresh:
+                    print('It: %d, Loss: %.3e' % (last, loss_value))
+                    break
+                if last % 100 == 0 and self.rank == 0:
+                    elapsed = time.time() - start_time
+                    print('It: %d, Lossb: %.3e, Lossv: %.3e, Time: %.2f' % (last, loss_valueb, loss_valuev, elapsed))
+                    start_time = time.time()
+        self.h.sync()
+
+
+class VPINN2D(_VPINNBase):
+    """Poisson 2-D hp-VPINN (reference P2:27-257; constructor P2:28-29, call site P2:430-431)."""
+
+    _pde, _act = _lib.PDE_POISSON2D, _lib.ACT_TANH   # tf.tanh, P2:165
+
+    def __init__(self, X_u_train, u_train, X_f_train, f_train, X_quad, W_quad, U_exact_total, F_exact_total,
+                 gridx, gridy, N_testfcn, X_test, u_test, layers, *, var_form=1, scheme="VPINNs", LR=0.001,
+                 lossb_weight=10, init_params=None, seed=1234, backend="auto", device=None, loss_his=None):
+        if scheme != "VPINNs":
+            raise NotImplementedError("scheme='PINNs' (strong-form branch, P2:128-129) is outside the hot path")
+        self.X_u_train = np.asarray(X_u_train, dtype=np.float64)
+        self.utrain = np.asarray(u_train, dtype=np.float64)
+        self.xf_train, self.ftrain = X_f_train, f_train
+        self.U_ext_total = U_exact_total                   # stored, never used (P2:47)
+        self.F_ext_total = np.asarray(F_exact_total, dtype=np.float64)
+        self.Nelementx, self.Nelementy = np.size(N_testfcn[0]), np.size(N_testfcn[1])   # P2:43-44
+        self.Ntestx = _uniform(N_testfcn[0], "N_test_x")
+        self.Ntesty = _uniform(N_testfcn[1], "N_test_y")
+        self.gridx, self.gridy = np.asarray(gridx, dtype=np.float64), np.asarray(gridy, dtype=np.float64)
+        self.X_test, self.utest = X_test, u_test
+        self.var_form = var_form
+        self.loss_his = [] if loss_his is None else loss_his
+        if self.F_ext_total.shape != (self.Nelementx, self.Nelementy, self.Ntesty, self.Ntestx):
+            raise ValueError(f"F_exact_total has shape {self.F_ext_total.shape}, expected "
+                             f"{(self.Nelementx, self.Nelementy, self.Ntesty, self.Ntestx)} (P2:414)")
+        self._create(layers, var_form, LR, lossb_weight, 1.0, init_params, seed, backend, device)
+        xi, wx, yi, wy = _tensor_rule(X_quad, W_quad)
+        self.h.set_quadrature(xi, wx, yi, wy)
+        self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntesty, yi))
+        eb, ee = shard_range(self.Nelementx * self.Nelementy, self.rank, self.world)
+        self.h.set_elements(self.gridx, self.gridy, eb, ee)
+        self.h.set_rhs(self.F_ext_total.reshape(-1))
+        if self.rank == 0:
+            self.h.set_data(self.X_u_train, self.utrain.reshape(-1))
+        self._finish()
+
+    def predict(self, X=None):                              # P2:255-257 (stored test grid)
+        return self._predict(self.X_test if X is None else X)
+
+    def train(self, nIter, record_every=1):
+        """P2:233-253: the loss is read back EVERY iteration (after the update) into `loss_his`.
+        `record_every=k` reads it every k-th iteration instead (the device then runs k iterations
+        back to back); the default 1 is the reference behaviour."""
+        start_time = time.time()
+        it = 0
+        while it < nIter:
+            n = min(record_every, nIter - it)
+            loss3 = self._step(n, True)
+            it += n
+            loss_value = float(loss3[0])
+            self.loss_his.append(loss_value)
+            if (it - 1) % 100 == 0 and self.rank == 0:
+                elapsed = time.time() - start_time
+                print('It: %d, Loss: %.3e, Time: %.2f' % (it - 1, loss_value, elapsed))
+                start_time = time.time()
+        self.h.sync()
+
+
+class VPINNAdvDiff(_VPINNBase):
+    """Advection-diffusion with trainable diffusion coefficient (reference P3:58-341;
+    constructor P3:60-61, call site P3:488-489)."""
+
+    _pde, _act = _lib.PDE_ADVDIFF, _lib.ACT_TANH   # tf.tanh, P3:226
+    _n_extra = 1                                   # epsilon, init 1.0 (P3:63)
+
+    def __init__(self, XT_u_train, u_train, XT_f_train, XT_quad, W_quad, T_quad, WT_quad, grid_x, grid_t,
+                 N_testfcn, XT_test, u_test, layers, lb=None, ub=None, *, var_form=0, LR=0.001, V=1.0,
+                 lossb_weight=10, init_params=None, seed=1234, backend="auto", device=None):
+        self.lb, self.ub = lb, ub
+        self.XT_u_train = np.asarray(XT_u_train, dtype=np.float64)
+        self.u = np.asarray(u_train, dtype=np.float64)
+        self.XT_f_train = XT_f_train
+        self.Nelementx, self.Nelementt = np.size(N_testfcn[0]), np.size(N_testfcn[1])
+        self.Ntestx = _uniform(N_testfcn[0], "N_test_x")
+        self.Ntestt = _uniform(N_testfcn[1], "N_test_t")
+        self.grid_x, self.grid_t = np.asarray(grid_x, dtype=np.float64), np.asarray(grid_t, dtype=np.float64)
+        self.XT_test, self.utest = XT_test, u_test
+        self.var_form, self.V = var_form, V
+        self._create(layers, var_form, LR, lossb_weight, V, init_params, seed, backend, device)
+        xi, wx, ti, wt = _tensor_rule(XT_quad, W_quad)
+        self.h.set_quadrature(xi, wx, ti, wt)
+        self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntestt, ti))
+        eb, ee = shard_range(self.Nelementx * self.Nelementt, self.rank, self.world)
+        self.h.set_elements(self.grid_x, self.grid_t, eb, ee)
+        self.h.set_rhs(None)                               # zero right-hand side (P3:180)
+        if self.rank == 0:
+            self.h.set_data(self.XT_u_train, self.u.reshape(-1))
+        self._finish()
+
+    @property
+    def epsilon(self):
+        return self.get_params()[-1:]
+
+    def predict(self, X=None):
+        return self._predict(self.XT_test if X is None else X)
+
+    def train(self, nIter, tresh):
+        """P3:291-341 -- returns (error_records, total_records, u_records, u_records_iterhis,
+        total_time_train) like the reference."""
+        total_time_train, min_loss = 0.0, 1e16
+        total_records, u_records_iterhis, u_records = [], [], None
+        loss_value, start_time = None, time.time()
+        it = 0
+        while it < nIter:
+            n, rec = _next_chunk(it, nIter)
+            last = it + n - 1
+            t0 = time.time()
+            loss3 = self._step(n, rec)
+            total_time_train += time.time() - t0
+            it += n
+            if rec:
+                loss_value = float(loss3[0])
+                epsilon_value = self.epsilon
+                total_records.append(np.array([last, loss_value, epsilon_value, 1], dtype=object))
+                if loss_value < tresh:
+                    print('It: %d, Loss: %.3e' % (last, loss_value))
+                    break
+                if last > 0.9 * nIter and loss_value < min_loss:
+                    min_loss = loss_value
+                    u_records = self.predict()
+                if last % 100 == 0 and self.rank == 0:
+                    elapsed = time.time() - start_time
+                    print('It: %d, Lossv: %.3e, Lossp: %.3e, Lossb: %.3e, Time: %.2f, epsilon: %.4f'
+                          % (last, loss3[2], 1, loss3[1], elapsed, float(epsilon_value[0])))
+                    start_time = time.time()
+        self.h.sync()
+        error_records = [loss_value, 1]
+        return error_records, total_records, u_records, u_records_iterhis, total_time_train

@@ -1,0 +1,130 @@
+/* hpvpinn.h -- C-ABI of libhpvpinn.so, the MI355X (gfx950) hp-VPINN training path.
+ *
+ * The reference (ehsankharazmi/hp-VPINNs) has no FFI / plugin interface: its boundary is the
+ * Python `class VPINN` of each driver script.  This header is the plain-C surface a binding of
+ * that class needs -- opaque handle, plain pointers and sizes, status codes; no torch types.
+ * Every entry point cites the reference lines whose work it replaces
+ * (P1 = main/Poisson-1D/hp-VPINN-Poisson-1D.py, P2 = main/Poisson-2D/hp-VPINN-Poisson-2D.py,
+ *  P3 = main/AdvDiff-Identification/hp-VPINN-AdvDiff-Identification.py).
+ *
+ * Conventions
+ *   - all floating point data is IEEE double (the reference is tf.float64 throughout);
+ *   - the caller owns every host buffer; the library copies on set_* and owns all device memory;
+ *   - return 0 = OK, negative = error (message via hpv_last_error); nothing is thread-safe per
+ *     handle, independent handles may live on different threads / processes (one per GPU);
+ *   - parameter packing: theta = [W0, b0, W1, b1, ..., (epsilon)], W_l row-major [in, out]
+ *     (row-vector convention H @ W + b of P1:128-138), epsilon only for HPV_PDE_ADVDIFF;
+ *   - element index e = ex * ney + ey (P2:69-70 loop order; F_ext_total[ex, ey] at P2:414);
+ *     quadrature index inside an element q = j * qx + i, x fastest (P2:362-365);
+ *   - residual entries of one element are [k (y / t index)][r (x index)] (P2:94-96).
+ */
+#ifndef HPVPINN_H
+#define HPVPINN_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPV_MAX_LAYERS 16
+
+enum { HPV_PDE_POISSON1D = 0, HPV_PDE_POISSON2D = 1, HPV_PDE_ADVDIFF = 2 };
+enum { HPV_ACT_TANH = 0, HPV_ACT_SIN = 1 };
+enum { HPV_BACKEND_AUTO = 0, HPV_BACKEND_GENERIC = 1, HPV_BACKEND_MFMA = 2 };
+
+typedef struct hpv_ctx* hpv_handle;
+
+typedef struct hpv_config {
+    int pde;                      /* HPV_PDE_*                                                        */
+    int var_form;                 /* P1:82-91 (1,2,3) / P2:93-115 (0,1,2) / P3:161-174 (0,1)           */
+    int act;                      /* HPV_ACT_SIN for P1:134, HPV_ACT_TANH for P2:165, P3:226          */
+    int n_layers;                 /* len(layers), e.g. 5 for [2,20,20,20,1]                           */
+    int layers[HPV_MAX_LAYERS];
+    double lr, beta1, beta2, eps; /* tf.train.AdamOptimizer(LR) defaults: 1e-3, 0.9, 0.999, 1e-8     */
+    double lossb_weight;          /* P1:100 (1), P2:127 (10), P3:184 (10)                             */
+    double V;                     /* advection speed, P3:43                                           */
+    int device;                   /* HIP device ordinal                                               */
+    int backend;                  /* HPV_BACKEND_*                                                    */
+} hpv_config;
+
+/* Construction = the graph-build part of VPINN.__init__ (P1:31-107, P2:28-136, P3:60-197). */
+int hpv_create(hpv_handle* out, const hpv_config* cfg);
+void hpv_destroy(hpv_handle h);
+const char* hpv_last_error(hpv_handle h); /* h may be NULL: last create() error */
+
+/* Run every kernel of this handle on an existing HIP stream (hipStream_t passed as void*), e.g.
+ * torch's current stream so that a torch.distributed collective orders after the kernels. */
+int hpv_set_stream(hpv_handle h, void* hip_stream);
+
+/* 1-D reference quadrature rule per direction: nodes xi in [-1,1] and weights (P1:312-316,
+ * P2:355-360, P3:395-400).  qy = 1 (and yi = wy = NULL) for the 1-D problem. */
+int hpv_set_quadrature(hpv_handle h, const double* xi, const double* wx, int qx,
+                       const double* yi, const double* wy, int qy);
+
+/* Test-function tables phi, phi', phi'' at the reference nodes, each [ntest][q] row-major
+ * (values of VPINN.Test_fcn / dTest_fcn, P1:157-183).  nty = 1, tables NULL in 1-D.
+ * edge_dphi = phi'_k(-1), phi'_k(+1) as [ntx][2], needed only by Poisson-1D var_form 3 (P1:79,90). */
+int hpv_set_tables(hpv_handle h, const double* phix, const double* dphix, const double* d2phix, int ntx,
+                   const double* phiy, const double* dphiy, const double* d2phiy, int nty,
+                   const double* edge_dphi);
+
+/* Element grids (P1:264-273, P2:370-376, P3:404-410) and the slice [e_begin, e_end) of flattened
+ * elements this handle (this GPU) owns -- the data-parallel shard.  The affine map of the
+ * reference nodes into each element (P1:69, P2:75-76, P3:120-121) is evaluated here. */
+int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* gridy, int ney,
+                     int e_begin, int e_end);
+
+/* Right-hand sides F_ext_total for ALL nex*ney elements, C-order [nex][ney][nty][ntx]
+ * (P1:294, P2:414); pass NULL for a zero right-hand side (P3:180). */
+int hpv_set_rhs(hpv_handle h, const double* F, size_t n);
+
+/* Boundary / data points of lossb (P1:98, P2:122, P3:184): X is [n][dim] row-major, u is [n].
+ * The term is weighted by cfg.lossb_weight.  n = 0 disables it (ranks other than 0). */
+int hpv_set_data(hpv_handle h, const double* X, const double* u, int n);
+
+size_t hpv_num_params(hpv_handle h);
+int hpv_set_params(hpv_handle h, const double* theta, size_t n); /* also resets Adam state (P1:107) */
+int hpv_get_params(hpv_handle h, double* theta, size_t n);
+
+/* loss3 = {loss, lossb (as the reference reports it), lossv} at the current parameters, and
+ * d loss / d theta (grad may be NULL).  Replaces the forward/backward graph of P1:64-104. */
+int hpv_loss_and_grad(hpv_handle h, double* loss3, double* grad_or_null);
+
+/* n_iters Adam iterations = n_iters x `sess.run(train_op_Adam)` (P1:208, P2:242, P3:309), all
+ * device-resident; loss3_after (may be NULL) is the loss evaluated AFTER the last update, which
+ * is what the reference records (P1:211, P2:243, P3:315). */
+int hpv_step(hpv_handle h, int n_iters, double* loss3_after);
+
+/* Pieces of hpv_step for the multi-GPU path (one process per GPU): enqueue forward + backward
+ * into the packed device buffer [grad (P) | lossv | lossb | pad] (all partial sums of this
+ * shard), let the caller all-reduce that buffer over RCCL, then apply the TF1 Adam update.
+ * hpv_reduce_buffer returns the device pointer and length (in doubles) of that buffer. */
+int hpv_forward_backward(hpv_handle h);
+int hpv_reduce_buffer(hpv_handle h, void** dev_ptr, size_t* n_doubles);
+int hpv_apply_adam(hpv_handle h);
+int hpv_eval_loss(hpv_handle h);            /* forward only -> same packed buffer slots [P], [P+1] */
+int hpv_read_loss(hpv_handle h, double* loss3); /* sync + copy {loss, lossb, lossv} from the buffer   */
+int hpv_sync(hpv_handle h);
+
+/* u at arbitrary points: VPINN.predict (P1:197-199, P2:255-257).  X is [n][dim] row-major. */
+int hpv_predict(hpv_handle h, const double* X, int n, double* u_out);
+
+/* Introspection for tests / benchmarks. */
+int hpv_get_residuals(hpv_handle h, double* R, size_t n);   /* R of the owned elements [ne][nty][ntx] */
+int hpv_backend_in_use(hpv_handle h);                       /* HPV_BACKEND_GENERIC or HPV_BACKEND_MFMA */
+/* Average device time (ms) per launch of kernel class `which` since the last reset, measured with
+ * hipEvents on the handle's stream when timing is enabled; which: 0 mlp_fwd, 1 project, 2 mlp_bwd. */
+int hpv_enable_timing(hpv_handle h, int on);
+int hpv_kernel_time_ms(hpv_handle h, int which, double* avg_ms, long* launches);
+
+/* Stand-alone launch of the per-element projection (residual + adjoint) kernel on synthetic
+ * integrand channels already resident on the device -- the HBM-roofline measurement of
+ * SURVEY.md section 8(d).  n_elem elements of the handle's (qx,qy,ntx,nty) shape; returns the
+ * average kernel time over `reps` launches. */
+int hpv_bench_projection(hpv_handle h, long n_elem, int reps, double* avg_ms, double* bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPVPINN_H */
