@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py -- variational-loss iterations/sec of the hp-VPINN hot path on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One step = one full training iteration of BASELINE.json config 4 (Poisson-2D, 16x16 elements,
+20x20 GLL points and 10x10 test functions per element, MLP [2,20,20,20,1] tanh, var_form 1):
+Taylor-mode MLP forward at all 102 400 quadrature points, per-element projection + residual,
+adjoint, reverse pass, boundary term (320 points), TF1 Adam update.  Inputs are synthetic of that
+shape (the driver's exact right-hand side, seeded boundary points, seeded Xavier init) and are
+resident in HBM before the timed region.  N>1 shards the 256 elements over the ranks (strong
+scaling: total work fixed) with one RCCL all-reduce of the packed gradient/loss buffer per step.
+
+Rank 0 prints ONE JSON line (see the contract in DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+CFG4 = dict(N_el_x=16, N_el_y=16, N_test_x=10, N_test_y=10, N_quad=20, N_bound=80, N_residual=100)
+LAYERS = [2, 20, 20, 20, 1]
+PEAK_FP64_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (datasheet; half the 157.3 TF FP32 rate of MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def gemm_flops_per_row(layers):
+    return 2 * sum(layers[l] * layers[l + 1] for l in range(len(layers) - 1))
+
+
+def cpu_baseline(setup, theta, iters):
+    """The oracle (reference-structured torch-fp64 restatement) timed on this host's cores."""
+    import torch
+    # tiny-op graphs get slower with many threads (128 threads: 26 s/iter vs 4 s/iter at 8 on the
+    # same box class), so the baseline is pinned to 8 threads -- stated in "cores"
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    from oracle.vpinn_oracle import OracleVPINN2D
+    s = setup
+    o = OracleVPINN2D(s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"],
+                      s["WXY_quad_train"], None, s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"],
+                      s["X_u_train"], s["u_train"], LAYERS, init_params=theta)
+    o.adam_step()  # warm-up (allocations, thread pool)
+    t0 = time.time()
+    for _ in range(iters):
+        o.adam_step()
+    dt = time.time() - t0
+    return {"value": iters / dt, "unit": "it/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "%d full iterations of the same config-4 workload, reference-structured oracle "
+                      "(per-element Python loop, one reduction per test-function pair, autograd double backward), "
+                      "host has %d logical cpus" % (iters, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--backend", default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-residual-roofline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--residual-elems", type=int, default=1 << 18)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    s = poisson2d.setup(**CFG4, with_test_grid=False)
+    theta = xavier_init(LAYERS, 1234)
+    model = poisson2d.build_model(s, LAYERS, var_form=1, init_params=theta, backend=args.backend, device=local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        model.h.sync()
+        torch.cuda.synchronize()
+
+    model._step(args.warmup, False)
+    barrier()
+    t0 = time.perf_counter()
+    model._step(args.steps, False)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel device times (hipEvents on the stream the kernels run on), untimed extra pass ----
+    nt = min(args.steps, 100)
+    model.h.enable_timing(True)
+    model._step(nt, False)
+    model.h.sync()
+    ktime = {name: model.h.kernel_time_ms(i)[0] for i, name in enumerate(("mlp_fwd", "project", "mlp_bwd"))}
+    model.h.enable_timing(False)
+    loss3 = model.loss()
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    N_local = (model.Nelementx * model.Nelementy * 400) // world  # points per rank
+    C, G = 3, gemm_flops_per_row(LAYERS)
+    flops = {"mlp_fwd": C * G * N_local, "mlp_bwd": 2 * C * G * N_local}
+    dom = max(("mlp_fwd", "mlp_bwd"), key=lambda k: ktime[k])
+    ach = flops[dom] / (ktime[dom] * 1e-3) / 1e12 if ktime[dom] > 0 else 0.0
+    out = {
+        "metric": "variational-loss iterations/sec", "value": args.steps / dt, "unit": "it/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "Poisson-2D hp-VPINN, 16x16 elements, 20x20 GLL quad/elem, 10x10 test fcns/elem, "
+                               "MLP [2,20,20,20,1] tanh, var_form 1, 320 boundary pts, TF1 Adam (BASELINE config 4)",
+                   "points": 102400, "residuals": 25600, "params": 921, "backend": model.backend(),
+                   "parallelism": "element-sharded dp%d" % world},
+        "loss_after": float(loss3[0]),
+        "kernel_ms": ktime,
+        "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                     "frac": ach / PEAK_FP64_TFLOPS, "traffic": None,
+                     "flops_per_launch": flops[dom], "avg_ms": ktime[dom]},
+    }
+    if world == 1 and not args.no_residual_roofline:
+        # the per-element projection (residual + adjoint) kernel on a batch larger than the 256 MB
+        # Infinity Cache: 2^18 elements of the config-4 element shape, random channels
+        ms, by = model.h.bench_projection(args.residual_elems, 5)
+        gbs = by / (ms * 1e-3) / 1e9
+        out["roofline_residual"] = {"kernel": "project (residual+adjoint)", "bound": "hbm", "achieved": gbs,
+                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                                    "bytes_per_launch": by, "avg_ms": ms, "n_elem": args.residual_elems}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(s, theta, args.cpu_iters)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,57 @@
+"""The C-ABI library loads, exports every symbol include/hpvpinn.h declares, and fails loudly
+(no CPU fallback) when there is no GPU.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "hpvpinn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hpv_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    from hp_vpinns_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_no_torch_types_in_the_abi():
+    src = open(os.path.join(ROOT, "include", "hpvpinn.h")).read()
+    assert "at::" not in src and "c10::" not in src and "#include <torch" not in src
+
+
+def test_create_fails_loudly_without_gpu_or_with_bad_config():
+    import torch
+    from hp_vpinns_amd import _lib
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.HpvError):
+            _lib.Handle(_lib.PDE_POISSON2D, 1, _lib.ACT_TANH, [2, 20, 20, 20, 1])
+    with pytest.raises(_lib.HpvError):          # wrong input width for a 2-D problem
+        _lib.Handle(_lib.PDE_POISSON2D, 1, _lib.ACT_TANH, [1, 20, 1])
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "hp_vpinns_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                s = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in s and "from oracle" not in s, f
+
+
+def test_missing_library_raises(tmp_path, monkeypatch):
+    from hp_vpinns_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.HpvError):
+        _lib.load()

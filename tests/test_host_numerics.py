@@ -1,0 +1,102 @@
+"""Host-side numerics (quadrature, test-function tables, drivers' set-up) against the golden
+fixtures produced by RUNNING the reference's numpy code (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+from cases import gold
+from hp_vpinns_amd import DJacobi, GaussJacobiWeights, GaussLobattoJacobiWeights, Jacobi, Test_fcn, dTest_fcn
+from hp_vpinns_amd.drivers import poisson1d, poisson2d
+from hp_vpinns_amd.testfcn import tables_1d
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-300), np.abs(a - b).max()
+
+
+@pytest.mark.parametrize("q", [5, 10, 20, 80])
+def test_gll_rule_matches_reference(q):
+    g = gold("quadrature")
+    x, w = GaussLobattoJacobiWeights(q, 0, 0)
+    _close(x, g[f"gll_x_{q}"], 1e-14)
+    _close(w, g[f"gll_w_{q}"], 1e-13)
+
+
+@pytest.mark.parametrize("q", [3, 10, 20, 80])
+def test_gll_analytic_properties(q):
+    x, w = GaussLobattoJacobiWeights(q, 0, 0)
+    assert abs(w.sum() - 2.0) < 1e-13                      # integrates constants
+    assert np.abs(x + x[::-1]).max() < 1e-15 and np.abs(w - w[::-1]).max() < 1e-13   # symmetry
+    assert x[0] == -1 and x[-1] == 1 and np.all(np.diff(x) > 0)
+    for deg in range(0, 2 * q - 2):                        # exact to degree 2Q-3
+        exact = 0.0 if deg % 2 else 2.0 / (deg + 1)
+        assert abs((w * x ** deg).sum() - exact) < 1e-12, deg
+
+
+def test_jacobi_matches_reference():
+    g = gold("quadrature")
+    xs = g["jac_x"]
+    for k in g.files:
+        if k.startswith("jac_") and k != "jac_x":
+            n, a, b = (int(v) for v in k.split("_")[1:])
+            _close(Jacobi(n, a, b, xs), g[k], 1e-13)
+    _close(DJacobi(6, 0, 0, xs, 2), g["djac_6_0_0_2"], 1e-13)
+    x, w = GaussJacobiWeights(7, 0, 0)
+    _close(x, g["gj_x_7"], 1e-14)
+    _close(w, g["gj_w_7"], 1e-13)
+
+
+@pytest.mark.parametrize("nt,q", [(60, 80), (5, 10), (10, 20)])
+def test_test_function_tables_match_reference(nt, q):
+    g = gold("testfcn")
+    x = GaussLobattoJacobiWeights(q, 0, 0)[0][:, None]
+    t = Test_fcn(nt, x)
+    d1, d2 = dTest_fcn(nt, x)
+    _close(t, g[f"phi_{nt}_{q}"], 1e-13)
+    _close(d1, g[f"dphi_{nt}_{q}"], 1e-12)
+    _close(d2, g[f"d2phi_{nt}_{q}"], 1e-12)
+    tab = tables_1d(nt, x[:, 0])
+    assert tab.shape == (3, nt, q)
+    _close(tab[0], g[f"phi_{nt}_{q}"][:, :, 0], 1e-13)
+
+
+def test_tables_same_in_all_three_reference_classes():
+    g = gold("testfcn")
+    for k in ("p2_phix_5_10", "p2_phiy_5_10", "p3_phi_5_10"):
+        _close(g[k], g["phi_5_10"], 1e-15)
+    _close(g["p2_dphi_5_10"], g["dphi_5_10"], 1e-15)
+    _close(g["p3_d2phi_5_10"], g["d2phi_5_10"], 1e-15)
+
+
+def test_test_functions_vanish_at_the_edges_and_edge_slopes():
+    g = gold("testfcn")
+    xb = np.array([[-1.0], [1.0]])
+    assert np.abs(Test_fcn(60, xb)).max() < 1e-12
+    d1, d2 = dTest_fcn(60, xb)
+    _close(d1, g["dphi_edge_60"], 1e-13)
+    _close(d2, g["d2phi_edge_60"], 1e-12)
+
+
+@pytest.mark.parametrize("tag,kw", [("cfg1", {}), ("ne3", dict(N_Element=3)), ("cfg2", dict(N_Element=16)),
+                                    ("small", dict(N_Element=4, N_testfcn=6, N_Quad=12))])
+def test_poisson1d_driver_setup_matches_reference(tag, kw):
+    g, s = gold("poisson1d_" + tag), poisson1d.setup(**kw)
+    for k in ("grid", "F_ext_total", "U_ext_total", "X_quad_train", "W_quad_train", "X_u_train", "u_train",
+              "X_f_train", "f_train", "X_test", "u_test"):
+        _close(s[k], g[k], 1e-12)
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("default", {}), ("cfg3", dict(N_el_x=8, N_el_y=8)),
+    ("cfg4", dict(N_el_x=16, N_el_y=16, N_test_x=10, N_test_y=10, N_quad=20)),
+    ("small", dict(N_el_x=3, N_el_y=2, N_test_x=4, N_test_y=3, N_quad=6, N_bound=10, N_residual=10))])
+def test_poisson2d_driver_setup_matches_reference(tag, kw):
+    g, s = gold("poisson2d_" + tag), poisson2d.setup(**kw)
+    for k in ("grid_x", "grid_y", "F_ext_total", "XY_quad_train", "WXY_quad_train", "X_u_train", "u_train",
+              "X_f_train", "f_train"):
+        _close(s[k], g[k], 1e-13)
+    assert tuple(g["X_test_shape"]) == s["X_test"].shape
+    _close(s["X_test"][:500], g["X_test_head"], 1e-15)
+    _close(s["u_test"][:500], g["u_test_head"], 1e-14)
+    assert abs(s["u_test"].sum() - g["u_test_sum"]) < 1e-9

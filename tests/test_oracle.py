@@ -1,0 +1,105 @@
+"""The CPU oracle itself: known answers, finite differences, TF1 Adam rule, recording semantics.
+(The TF1 graph cannot run here, so these are the anchors of the unpinned part -- see oracle header.)"""
+import numpy as np
+import pytest
+import torch
+
+from cases import gold, p1_args, p2_args, p3_args, theta0
+from oracle import vpinn_oracle as O
+
+
+def test_oracle_tables_match_reference_fixtures():
+    g = gold("testfcn")
+    x = O.GaussLobattoJacobiWeights(10, 0, 0)[0][:, None]
+    assert np.abs(O.Test_fcn(5, x) - g["phi_5_10"]).max() < 1e-14
+    d1, d2 = O.dTest_fcn(5, x)
+    assert np.abs(d1 - g["dphi_5_10"]).max() < 1e-13 and np.abs(d2 - g["d2phi_5_10"]).max() < 1e-12
+    q = gold("quadrature")
+    xs, ws = O.GaussLobattoJacobiWeights(80, 0, 0)
+    assert np.abs(xs - q["gll_x_80"]).max() == 0 and np.abs(ws - q["gll_w_80"]).max() == 0
+
+
+@pytest.mark.parametrize("tag,lv", [("poisson1d_cfg1", 290.4593764435546), ("poisson1d_ne3", 407.0420338281929)])
+def test_zero_network_loss_1d(tag, lv):
+    """loss(0) = sum_e mean(F_e^2) + lossb; the 3-element value 407.04+1 is the ~4e2 initial plateau of
+    the reference's published Results/loss.pdf."""
+    g = gold(tag)
+    a = p1_args(g)
+    o = O.OracleVPINN1D(*a, init_params=np.zeros(O.n_params(a[8])))
+    loss, lossb, lossv = (float(v) for v in o.loss_parts())
+    F = g["F_ext_total"]
+    assert abs(lossv - (F ** 2).mean(axis=(1, 2)).sum()) < 1e-9
+    assert abs(lossv - lv) < 1e-8 and abs(lossb - 1.0) < 1e-12 and abs(loss - lv - 1.0) < 1e-8
+
+
+def test_zero_network_loss_2d():
+    g = gold("poisson2d_default")
+    a = p2_args(g)
+    o = O.OracleVPINN2D(*a, init_params=np.zeros(O.n_params(a[13])))
+    loss, lossb, lossv = (float(v) for v in o.loss_parts())
+    assert abs(lossv - 60.15859233615944) < 1e-9 and abs(lossb - 0.24711041894014868) < 1e-12
+    assert abs(loss - (10 * lossb + lossv)) < 1e-12        # P2:127
+
+
+@pytest.mark.parametrize("kind,vf", [("1d", 1), ("1d", 2), ("1d", 3), ("2d", 0), ("2d", 1), ("2d", 2), ("adv", 0), ("adv", 1)])
+def test_gradient_vs_finite_differences(kind, vf):
+    if kind == "1d":
+        a = p1_args(gold("poisson1d_small")); o = O.OracleVPINN1D(*a, var_form=vf, init_params=theta0(a[8], 3))
+    elif kind == "2d":
+        a = p2_args(gold("poisson2d_small")); o = O.OracleVPINN2D(*a, var_form=vf, init_params=theta0(a[13], 3))
+    else:
+        a = p3_args(gold("advdiff_small")); o = O.OracleVPINNAdvDiff(*a, var_form=vf, init_params=theta0(a[12], 3, extra=[0.8]))
+    _, g = o.loss_and_grad()
+    th = o.get_params()
+    rng = np.random.default_rng(0)
+    idx = list(rng.choice(th.size, 6, replace=False)) + [th.size - 1]
+    for i in idx:
+        h = 1e-6 * max(1.0, abs(th[i]))
+        vals = []
+        for s in (+1, -1):
+            t = th.copy(); t[i] += s * h
+            o.theta = torch.tensor(t, requires_grad=True)
+            vals.append(float(o.loss_parts()[0]))
+        fd = (vals[0] - vals[1]) / (2 * h)
+        assert abs(fd - g[i]) < 1e-5 * max(1.0, abs(g[i])), (i, fd, g[i])
+
+
+def test_tf1_adam_rule():
+    """theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps): first step is lr*g/(|g|+eps*sqrt(1-b2)),
+    i.e. NOT torch.optim.Adam's eps placement."""
+    a = p1_args(gold("poisson1d_small"))
+    o = O.OracleVPINN1D(*a, init_params=theta0(a[8], 5))
+    th0 = o.get_params()
+    _, g = o.loss_and_grad()
+    o.adam_step()
+    lr_t = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    expect = th0 - lr_t * (0.1 * g) / (np.sqrt(0.001 * g * g) + 1e-8)
+    assert np.abs(o.get_params() - expect).max() < 1e-15
+    g2 = o.loss_and_grad()[1]
+    th1 = o.get_params()
+    o.adam_step()
+    m = 0.9 * 0.1 * g + 0.1 * g2
+    v = 0.999 * 0.001 * g * g + 0.001 * g2 * g2
+    lr_t = 1e-3 * np.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
+    assert np.abs(o.get_params() - (th1 - lr_t * m / (np.sqrt(v) + 1e-8))).max() < 1e-15
+
+
+def test_recording_semantics():
+    a = p1_args(gold("poisson1d_small"))
+    o = O.OracleVPINN1D(*a, init_params=theta0(a[8], 5))
+    rec = o.train(25, 0.0)
+    assert [int(r[0]) for r in rec] == [0, 10, 20]          # every 10 iterations (P1:210)
+    o2 = O.OracleVPINN1D(*a, init_params=theta0(a[8], 5))
+    o2.adam_step()
+    assert abs(float(o2.loss_parts()[0]) - rec[0][1]) < 1e-14   # recorded AFTER the update (P1:208-211)
+    a2 = p2_args(gold("poisson2d_small"))
+    o3 = O.OracleVPINN2D(*a2, init_params=theta0(a2[13], 5))
+    assert len(o3.train(4)) == 4                             # every iteration (P2:243-244)
+
+
+def test_advdiff_epsilon_moves_and_5tuple():
+    a = p3_args(gold("advdiff_small"))
+    o = O.OracleVPINNAdvDiff(*a, init_params=theta0(a[12], 5, extra=[1.0]))
+    out = o.train(12, 0.0)
+    assert len(out) == 5 and len(out[1]) == 2
+    assert float(o.get_params()[-1]) != 1.0
