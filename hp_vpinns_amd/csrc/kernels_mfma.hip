@@ -1,16 +1,583 @@
-// Placeholder until the MFMA kernels land: reports "not available" so the generic path runs.
+// MFMA fast path: Taylor-mode MLP forward / reverse for 20-wide hidden layers on gfx950 using
+// v_mfma_f64_16x16x4_f64.
+//
+// Formulation (everything "transposed" so layer outputs feed the next MFMA straight from registers):
+//   one wavefront owns a tile of 16 quadrature points.  For a hidden->hidden layer
+//       Z^T[out][pt] = W^T[out][in] * H^T[in][pt]          (M = out (20 -> 2 tiles of 16), K = in = 20 = 5 k-steps, N = 16 points)
+//   A operand (lane l: A[m = l&15][k = l>>4])  = W^T  -> per-lane constants held in registers,
+//   B operand (lane l: B[k = l>>4][n = l&15])  = H^T  -> lane holds neuron 4s+(l>>4), point l&15 for k-step s,
+//   D         (lane l, reg r: row (l>>4)+4r, col l&15) -> neuron 16t+4r+(l>>4), point l&15.
+//   D register (t,r) is exactly the B operand of k-step s = 4t+r of the next layer: no LDS, no shuffles.
+//   Each lane therefore carries 5 useful values per channel per layer (neurons 4s+q, s=0..4, q = l>>4)
+//   for point pt = l&15, and all activation math runs on full 64-lane VALU instructions.
+//   The reverse pass uses the same chaining for hbar_in^T = W * zbar^T; only the weight gradient
+//   dW[in][out] = sum_pt h_in[pt][in] zbar[pt][out] contracts over points, which needs the operands in the
+//   other orientation -> one small per-wave LDS transpose per channel and layer (cheap next to 64-cycle MFMAs).
+//
+// First layer (d -> 20) and linear head (20 -> 1) are VALU work (K = 1..2 and M = 1 are no MFMA shapes).
 #include "hpv_mfma.h"
 
-struct HpvMfma { int dummy; };
+typedef double v4d __attribute__((ext_vector_type(4)));
 
-HpvMfma* hpv_mfma_create(const NetDesc&, long, std::string* why) {
-    if (why) *why = "MFMA path not built yet";
-    return nullptr;
+#define MF_H 20
+#define MF_KS 5        // k-steps of 4 over the 20 inputs
+#define MF_LD 17       // padded leading dimension of the LDS transpose tiles
+#define MF_BLOCK 256
+#define MF_WAVES (MF_BLOCK / 64)
+
+struct MfmaArgs {
+    const double* theta;
+    const double* X;      // [d][N]
+    double* OUT;          // [C][N]
+    const double* GBAR;   // [C][N]
+    double* ACTS;         // [tile][layer][slot][5][64]
+    double* GPART;        // [block][P]
+    long N;
+    long ntiles;
+    int save_act;
+    int woff[HPV_MAX_LAYERS];
+    int boff[HPV_MAX_LAYERS];
+    int t1dim[2];
+    int t2idx[2];
+    int P;
+};
+
+struct HpvMfma {
+    NetDesc nd;
+    long N, ntiles;
+    int L;
+    int ns;            // saved slots per layer
+    double* ACTS = nullptr;
+    int fwd_blocks, bwd_blocks;
+    MfmaArgs base;
+    void (*fwd)(const MfmaArgs&, int, hipStream_t) = nullptr;
+    void (*bwd)(const MfmaArgs&, int, hipStream_t) = nullptr;
+};
+
+template <int ACT>
+__device__ __forceinline__ void act_fwd(double z, double& a, double& a1, double& a2) {
+    if constexpr (ACT == HPV_ACT_TANH) {
+        a = tanh(z);
+        a1 = 1.0 - a * a;
+        a2 = -2.0 * a * a1;
+    } else {
+        sincos(z, &a, &a1);
+        a2 = -a;
+    }
 }
-void hpv_mfma_destroy(HpvMfma* m) { delete m; }
-int hpv_mfma_grad_rows(HpvMfma*) { return 0; }
-void hpv_mfma_forward(HpvMfma*, const double*, const double*, double*, int, hipStream_t) {}
-void hpv_mfma_backward(HpvMfma*, const double*, const double*, const double*, double*, int*, hipStream_t) {}
+template <int ACT>
+__device__ __forceinline__ void act_saved(double a, double a1s, double& a1, double& a2, double& a3) {
+    if constexpr (ACT == HPV_ACT_TANH) {
+        a1 = 1.0 - a * a;
+        a2 = -2.0 * a * a1;
+        a3 = -2.0 * a1 * (1.0 - 3.0 * a * a);
+    } else {
+        a1 = a1s;
+        a2 = -a;
+        a3 = -a1s;
+    }
+}
+
+template <int ACT, int NT1, int NT2>
+struct SlotCount {
+    static constexpr int value = 1 + (ACT == HPV_ACT_SIN ? 1 : 0) + NT1 + NT2;
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int D, int NT1, int NT2, int ACT, int L>
+__global__ void __launch_bounds__(MF_BLOCK) k_fwd_mfma(MfmaArgs g) {
+    constexpr int C = 1 + NT1 + NT2;
+    constexpr int NS = SlotCount<ACT, NT1, NT2>::value;
+    constexpr int SA1 = 1;                                   // slot of A1 (sin only)
+    constexpr int SZC = 1 + (ACT == HPV_ACT_SIN ? 1 : 0);    // first ZC slot
+    constexpr int SZCC = SZC + NT1;
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, pt = lane & 15;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const double* __restrict__ th = g.theta;
+
+    // per-lane weight fragments
+    double w1[D][MF_KS], b1[MF_KS], wo[MF_KS];
+    double wT[L > 1 ? L - 1 : 1][2][MF_KS];
+    double bh[L > 1 ? L - 1 : 1][MF_KS];
+#pragma unroll
+    for (int s = 0; s < MF_KS; ++s) {
+        const int j = 4 * s + q;
+#pragma unroll
+        for (int c = 0; c < D; ++c) w1[c][s] = th[g.woff[0] + c * MF_H + j];
+        b1[s] = th[g.boff[0] + j];
+        wo[s] = th[g.woff[L] + j];
+    }
+#pragma unroll
+    for (int i = 1; i < L; ++i) {
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            bh[i - 1][s] = th[g.boff[i] + 4 * s + q];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int out = 16 * t + pt;
+                wT[i - 1][t][s] = (out < MF_H) ? th[g.woff[i] + (4 * s + q) * MF_H + out] : 0.0;
+            }
+        }
+    }
+    const double bo = th[g.boff[L]];
+
+    for (long tile = wave; tile < g.ntiles; tile += nwaves) {
+        const long p = tile * 16 + pt;
+        const bool valid = p < g.N;
+        double x[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) x[c] = valid ? g.X[(long)c * g.N + p] : 0.0;
+        double h[C][MF_KS];
+        double* sv = g.ACTS + (tile * L) * (long)(NS * MF_KS * 64) + lane;
+
+        // ---- layer 1 (VALU): z = b + x W, z_c = W[c,:], z_cc = 0 ----
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            double z = b1[s];
+#pragma unroll
+            for (int c = 0; c < D; ++c) z += x[c] * w1[c][s];
+            double a, a1, a2;
+            act_fwd<ACT>(z, a, a1, a2);
+            h[0][s] = a;
+            if (g.save_act) {
+                sv[(0 * MF_KS + s) * 64] = a;
+                if constexpr (ACT == HPV_ACT_SIN) sv[(SA1 * MF_KS + s) * 64] = a1;
+            }
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) h[1 + t][s] = a1 * w1[t < D ? t : 0][s];   // T1 = coordinates 0..NT1-1
+#pragma unroll
+            for (int b = 0; b < NT2; ++b) {
+                const double zc = w1[b < D ? b : 0][s];   // T2 = coordinates 0..NT2-1
+                h[1 + NT1 + b][s] = a2 * zc * zc;
+            }
+        }
+        // ---- hidden -> hidden layers (MFMA) ----
+#pragma unroll
+        for (int i = 1; i < L; ++i) {
+            v4d acc[C][2];
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+                if (ch == 0) {
+                    acc[0][0] = v4d{bh[i - 1][0], bh[i - 1][1], bh[i - 1][2], bh[i - 1][3]};
+                    acc[0][1] = v4d{bh[i - 1][4], 0.0, 0.0, 0.0};
+                } else {
+                    acc[ch][0] = v4d{0.0, 0.0, 0.0, 0.0};
+                    acc[ch][1] = v4d{0.0, 0.0, 0.0, 0.0};
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s)
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc[ch][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wT[i - 1][t][s], h[ch][s], acc[ch][t], 0, 0, 0);
+            double* svl = sv + (long)i * (NS * MF_KS * 64);
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                const int t = s >> 2, r = s & 3;
+                double a, a1, a2;
+                act_fwd<ACT>(acc[0][t][r], a, a1, a2);
+                h[0][s] = a;
+                if (g.save_act) {
+                    svl[(0 * MF_KS + s) * 64] = a;
+                    if constexpr (ACT == HPV_ACT_SIN) svl[(SA1 * MF_KS + s) * 64] = a1;
+                }
+                double zc[NT1 > 0 ? NT1 : 1];
+#pragma unroll
+                for (int u = 0; u < NT1; ++u) {
+                    zc[u] = acc[1 + u][t][r];
+                    if (g.save_act) svl[((SZC + u) * MF_KS + s) * 64] = zc[u];
+                    h[1 + u][s] = a1 * zc[u];
+                }
+#pragma unroll
+                for (int b = 0; b < NT2; ++b) {
+                    const double zcc = acc[1 + NT1 + b][t][r];
+                    const double z1 = zc[b < NT1 ? b : 0];
+                    if (g.save_act) svl[((SZCC + b) * MF_KS + s) * 64] = zcc;
+                    h[1 + NT1 + b][s] = a2 * z1 * z1 + a1 * zcc;
+                }
+            }
+        }
+        // ---- linear head (VALU + 2 cross-lane adds over the 4 neuron groups) ----
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            double v = 0.0;
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) v += h[ch][s] * wo[s];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (ch == 0) v += bo;
+            if (q == 0 && valid) g.OUT[(long)ch * g.N + p] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reverse
+// ------------------------------------------------------------------------------------------------
+template <int ACT, int NT1, int NT2>
+__device__ __forceinline__ void layer_outputs_from_saved(const double* svl, const int* t2idx, const double* zc1,
+                                                         bool first_layer, double hin[][MF_KS]) {
+    // (h, h_c, h_cc) of a hidden layer from its saved slots; for layer 1, z_c = W1[c,:] (zc1) and z_cc = 0
+    constexpr int SZC = 1 + (ACT == HPV_ACT_SIN ? 1 : 0);
+    constexpr int SZCC = SZC + NT1;
+#pragma unroll
+    for (int s = 0; s < MF_KS; ++s) {
+        const double a = svl[(0 * MF_KS + s) * 64];
+        double a1s = 0.0;
+        if constexpr (ACT == HPV_ACT_SIN) a1s = svl[(1 * MF_KS + s) * 64];
+        double a1, a2, a3;
+        act_saved<ACT>(a, a1s, a1, a2, a3);
+        hin[0][s] = a;
+        double zc[NT1 > 0 ? NT1 : 1];
+#pragma unroll
+        for (int u = 0; u < NT1; ++u) {
+            zc[u] = first_layer ? zc1[u * MF_KS + s] : svl[((SZC + u) * MF_KS + s) * 64];
+            hin[1 + u][s] = a1 * zc[u];
+        }
+#pragma unroll
+        for (int b = 0; b < NT2; ++b) {
+            const double zcc = first_layer ? 0.0 : svl[((SZCC + b) * MF_KS + s) * 64];
+            const double z1 = zc[b < NT1 ? b : 0];
+            hin[1 + NT1 + b][s] = a2 * z1 * z1 + a1 * zcc;
+        }
+    }
+}
+
+template <int D, int NT1, int NT2, int ACT, int L>
+__global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
+    constexpr int C = 1 + NT1 + NT2;
+    constexpr int NS = SlotCount<ACT, NT1, NT2>::value;
+    constexpr int SZC = 1 + (ACT == HPV_ACT_SIN ? 1 : 0);
+    constexpr int SZCC = SZC + NT1;
+    constexpr int LH = L > 1 ? L - 1 : 1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = lane >> 4, pt = lane & 15;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const double* __restrict__ th = g.theta;
+    double* TA = lds + wv * (2 * MF_H * MF_LD);   // per-wave transpose tiles
+    double* TB = TA + MF_H * MF_LD;
+
+    // per-lane weight fragments
+    double w1[D][MF_KS], wo[MF_KS];
+    double wN[LH][2][MF_KS];   // A operand of hbar_in^T = W zbar^T : W[in = 16t+pt][out = 4s+q]
+#pragma unroll
+    for (int s = 0; s < MF_KS; ++s) {
+        const int j = 4 * s + q;
+#pragma unroll
+        for (int c = 0; c < D; ++c) w1[c][s] = th[g.woff[0] + c * MF_H + j];
+        wo[s] = th[g.woff[L] + j];
+    }
+#pragma unroll
+    for (int i = 1; i < L; ++i)
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int in = 16 * t + pt;
+                wN[i - 1][t][s] = (in < MF_H) ? th[g.woff[i] + in * MF_H + 4 * s + q] : 0.0;
+            }
+    double zc1[(NT1 > 0 ? NT1 : 1) * MF_KS];   // z_c of layer 1 = W1[c,:]
+#pragma unroll
+    for (int u = 0; u < NT1; ++u)
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) zc1[u * MF_KS + s] = w1[u < D ? u : 0][s];
+
+    // gradient accumulators (per wave, over all its tiles)
+    v4d dWacc[LH][2][2];
+#pragma unroll
+    for (int i = 0; i < LH; ++i)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) dWacc[i][a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+    double db[L][MF_KS], dW1[D][MF_KS], dWo[MF_KS], dbo = 0.0;
+#pragma unroll
+    for (int s = 0; s < MF_KS; ++s) {
+        dWo[s] = 0.0;
+#pragma unroll
+        for (int i = 0; i < L; ++i) db[i][s] = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) dW1[c][s] = 0.0;
+    }
+
+    for (long tile = wave; tile < g.ntiles; tile += nwaves) {
+        const long p = tile * 16 + pt;
+        const bool valid = p < g.N;
+        double x[D], gb[C];
+#pragma unroll
+        for (int c = 0; c < D; ++c) x[c] = valid ? g.X[(long)c * g.N + p] : 0.0;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) gb[ch] = valid ? g.GBAR[(long)ch * g.N + p] : 0.0;
+        const double* sv = g.ACTS + (tile * L) * (long)(NS * MF_KS * 64) + lane;
+
+        double hin[C][MF_KS], hbar[C][MF_KS], zbar[C][MF_KS];
+        // ---- linear head ----
+        layer_outputs_from_saved<ACT, NT1, NT2>(sv + (long)(L - 1) * (NS * MF_KS * 64), g.t2idx, zc1, L == 1, hin);
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            double v = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+                v += hin[ch][s] * gb[ch];
+                hbar[ch][s] = gb[ch] * wo[s];
+            }
+            dWo[s] += v;
+        }
+        if (q == 0) dbo += gb[0];
+
+        // ---- hidden layers, last to first ----
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+            const double* svl = sv + (long)i * (NS * MF_KS * 64);
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                const double a = svl[(0 * MF_KS + s) * 64];
+                double a1s = 0.0;
+                if constexpr (ACT == HPV_ACT_SIN) a1s = svl[(1 * MF_KS + s) * 64];
+                double a1, a2, a3;
+                act_saved<ACT>(a, a1s, a1, a2, a3);
+                double zc[NT1 > 0 ? NT1 : 1];
+                double zb = hbar[0][s] * a1;
+#pragma unroll
+                for (int u = 0; u < NT1; ++u) {
+                    zc[u] = (i == 0) ? zc1[u * MF_KS + s] : svl[((SZC + u) * MF_KS + s) * 64];
+                    zbar[1 + u][s] = hbar[1 + u][s] * a1;
+                    zb += hbar[1 + u][s] * a2 * zc[u];
+                }
+#pragma unroll
+                for (int b = 0; b < NT2; ++b) {
+                    const int u = b < NT1 ? b : 0;
+                    const double zcc = (i == 0) ? 0.0 : svl[((SZCC + b) * MF_KS + s) * 64];
+                    const double hb = hbar[1 + NT1 + b][s];
+                    zbar[1 + NT1 + b][s] = hb * a1;
+                    zbar[1 + u][s] += 2.0 * hb * a2 * zc[u];
+                    zb += hb * (a3 * zc[u] * zc[u] + a2 * zcc);
+                }
+                zbar[0][s] = zb;
+                db[i][s] += zb;
+            }
+            if (i == 0) {
+                // dW1[c][j] += x_c zbar[j] + [c in T1] zbar_c[j]
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+#pragma unroll
+                    for (int c = 0; c < D; ++c) dW1[c][s] += x[c] * zbar[0][s];
+#pragma unroll
+                    for (int u = 0; u < NT1; ++u) dW1[u < D ? u : 0][s] += zbar[1 + u][s];
+                }
+            } else {
+                layer_outputs_from_saved<ACT, NT1, NT2>(sv + (long)(i - 1) * (NS * MF_KS * 64), g.t2idx, zc1, i == 1, hin);
+                // weight gradient: contraction over the 16 points of the tile (and over channels)
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s) {
+                        TA[(4 * s + q) * MF_LD + pt] = hin[ch][s];
+                        TB[(4 * s + q) * MF_LD + pt] = zbar[ch][s];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    double aF[2][4], bF[2][4];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const int row = 16 * t + pt;
+                            const bool ok = row < MF_H;
+                            aF[t][kk] = ok ? TA[row * MF_LD + 4 * kk + q] : 0.0;
+                            bF[t][kk] = ok ? TB[row * MF_LD + 4 * kk + q] : 0.0;
+                        }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                            for (int to = 0; to < 2; ++to)
+                                dWacc[i - 1][ti][to] =
+                                    __builtin_amdgcn_mfma_f64_16x16x4f64(aF[ti][kk], bF[to][kk], dWacc[i - 1][ti][to], 0, 0, 0);
+                }
+                // hbar_in^T = W zbar^T
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    v4d acc[2] = {v4d{0.0, 0.0, 0.0, 0.0}, v4d{0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wN[i - 1][t][s], zbar[ch][s], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s) hbar[ch][s] = acc[s >> 2][s & 3];
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: per-wave partials -> LDS -> one row per block ----
+    __syncthreads();
+    double* WP = lds + MF_WAVES * (2 * MF_H * MF_LD) + (long)wv * g.P;
+    for (int idx = lane; idx < g.P; idx += 64) WP[idx] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // hidden->hidden weight gradients: complete sums over this wave's points, D layout (row = in, col = out)
+#pragma unroll
+    for (int i = 1; i < L; ++i)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int to = 0; to < 2; ++to)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int in = 16 * ti + 4 * r + q, out = 16 * to + pt;
+                    if (in < MF_H && out < MF_H) WP[g.woff[i] + in * MF_H + out] = dWacc[i - 1][ti][to][r];
+                }
+    // per-lane partials: reduce over the 16 point lanes of each neuron group
+#pragma unroll
+    for (int s = 0; s < MF_KS; ++s) {
+        const int j = 4 * s + q;
+        double v[L + D + 1];
+#pragma unroll
+        for (int i = 0; i < L; ++i) v[i] = db[i][s];
+#pragma unroll
+        for (int c = 0; c < D; ++c) v[L + c] = dW1[c][s];
+        v[L + D] = dWo[s];
+#pragma unroll
+        for (int k = 0; k < L + D + 1; ++k) {
+            double t = v[k];
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 4, 64);
+            t += __shfl_xor(t, 8, 64);
+            v[k] = t;
+        }
+        if (pt == 0) {
+#pragma unroll
+            for (int i = 0; i < L; ++i) WP[g.boff[i] + j] = v[i];
+#pragma unroll
+            for (int c = 0; c < D; ++c) WP[g.woff[0] + c * MF_H + j] = v[L + c];
+            WP[g.woff[L] + j] = v[L + D];
+        }
+    }
+    {
+        double t = dbo;
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        if (lane == 0) WP[g.boff[L]] = t;
+    }
+    __syncthreads();
+    const double* W0 = lds + MF_WAVES * (2 * MF_H * MF_LD);
+    double* row = g.GPART + (long)blockIdx.x * g.P;
+    for (int idx = threadIdx.x; idx < g.P; idx += blockDim.x) {
+        double acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < MF_WAVES; ++w) acc += W0[(long)w * g.P + idx];
+        row[idx] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <int D, int NT1, int NT2, int ACT, int L>
+static void run_fwd(const MfmaArgs& a, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL((k_fwd_mfma<D, NT1, NT2, ACT, L>), dim3(blocks), dim3(MF_BLOCK), 0, s, a);
+}
+template <int D, int NT1, int NT2, int ACT, int L>
+static void run_bwd(const MfmaArgs& a, int blocks, hipStream_t s) {
+    size_t lds = ((size_t)MF_WAVES * 2 * MF_H * MF_LD + (size_t)MF_WAVES * a.P) * sizeof(double);
+    hipLaunchKernelGGL((k_bwd_mfma<D, NT1, NT2, ACT, L>), dim3(blocks), dim3(MF_BLOCK), lds, s, a);
+}
+
+template <int D, int NT1, int NT2, int ACT>
+static bool pick_L(HpvMfma* m, int L) {
+    switch (L) {
+        case 1: m->fwd = run_fwd<D, NT1, NT2, ACT, 1>; m->bwd = run_bwd<D, NT1, NT2, ACT, 1>; return true;
+        case 2: m->fwd = run_fwd<D, NT1, NT2, ACT, 2>; m->bwd = run_bwd<D, NT1, NT2, ACT, 2>; return true;
+        case 3: m->fwd = run_fwd<D, NT1, NT2, ACT, 3>; m->bwd = run_bwd<D, NT1, NT2, ACT, 3>; return true;
+        case 4: m->fwd = run_fwd<D, NT1, NT2, ACT, 4>; m->bwd = run_bwd<D, NT1, NT2, ACT, 4>; return true;
+        default: return false;
+    }
+}
+
+HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why) {
+    auto no = [&](const char* msg) -> HpvMfma* { if (why) *why = msg; return nullptr; };
+    const int L = nd.nl - 1;
+    if (L < 1 || L > 4) return no("1..4 hidden layers are covered");
+    for (int l = 1; l <= L; ++l)
+        if (nd.width[l] != MF_H) return no("all hidden layers must be 20 wide");
+    for (int u = 0; u < nd.nT1; ++u) if (nd.t1dim[u] != u) return no("tangent channels must be coordinates 0..nT1-1");
+    for (int b = 0; b < nd.nT2; ++b) if (nd.t2idx[b] != b) return no("second tangents must be coordinates 0..nT2-1");
+    HpvMfma* m = new HpvMfma();
+    m->nd = nd; m->N = N; m->L = L;
+    m->ntiles = (N + 15) / 16;
+    bool ok = false;
+    const int key = nd.d * 100 + nd.nT1 * 10 + nd.nT2;
+    if (nd.act == HPV_ACT_SIN) {
+        // Poisson-1D channel sets (P1:82-91)
+        if (key == 111) ok = pick_L<1, 1, 1, HPV_ACT_SIN>(m, L);
+        else if (key == 110) ok = pick_L<1, 1, 0, HPV_ACT_SIN>(m, L);
+        else if (key == 100) ok = pick_L<1, 0, 0, HPV_ACT_SIN>(m, L);
+        m->ns = 2 + nd.nT1 + nd.nT2;
+    } else {
+        // Poisson-2D (P2:93-115) and AdvDiff (P3:161-174) channel sets
+        if (key == 222) ok = pick_L<2, 2, 2, HPV_ACT_TANH>(m, L);
+        else if (key == 220) ok = pick_L<2, 2, 0, HPV_ACT_TANH>(m, L);
+        else if (key == 200) ok = pick_L<2, 0, 0, HPV_ACT_TANH>(m, L);
+        else if (key == 221) ok = pick_L<2, 2, 1, HPV_ACT_TANH>(m, L);
+        m->ns = 1 + nd.nT1 + nd.nT2;
+    }
+    if (!ok) { delete m; return no("channel set / activation combination not instantiated"); }
+    size_t bytes = (size_t)m->ntiles * L * m->ns * MF_KS * 64 * sizeof(double);
+    if (hipMalloc((void**)&m->ACTS, bytes) != hipSuccess) { delete m; return no("hipMalloc of the activation store failed"); }
+    (void)hipMemset(m->ACTS, 0, bytes);
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long tiles_per_block = MF_WAVES;
+    long want = (m->ntiles + tiles_per_block - 1) / tiles_per_block;
+    m->fwd_blocks = (int)std::min<long>(want, (long)cus * 4);   // up to 4 waves / SIMD
+    m->bwd_blocks = (int)std::min<long>(want, (long)cus * 2);   // up to 2 waves / SIMD (register heavy)
+    MfmaArgs& a = m->base;
+    a = MfmaArgs{};
+    a.N = N; a.ntiles = m->ntiles; a.ACTS = m->ACTS; a.P = nd.P;
+    for (int l = 0; l < nd.nl; ++l) { a.woff[l] = nd.woff[l]; a.boff[l] = nd.boff[l]; }
+    for (int i = 0; i < 2; ++i) { a.t1dim[i] = nd.t1dim[i]; a.t2idx[i] = nd.t2idx[i]; }
+    return m;
+}
+
+void hpv_mfma_destroy(HpvMfma* m) {
+    if (!m) return;
+    if (m->ACTS) (void)hipFree(m->ACTS);
+    delete m;
+}
+
+int hpv_mfma_grad_rows(HpvMfma* m) { return m->bwd_blocks; }
+
+void hpv_mfma_forward(HpvMfma* m, const double* theta, const double* X, double* OUT, int save_act, hipStream_t s) {
+    MfmaArgs a = m->base;
+    a.theta = theta; a.X = X; a.OUT = OUT; a.save_act = save_act;
+    m->fwd(a, m->fwd_blocks, s);
+}
+
+void hpv_mfma_backward(HpvMfma* m, const double* theta, const double* X, const double* GBAR, double* GPART, int* rows,
+                       hipStream_t s) {
+    MfmaArgs a = m->base;
+    a.theta = theta; a.X = X; a.GBAR = GBAR; a.GPART = GPART;
+    m->bwd(a, m->bwd_blocks, s);
+    if (rows) *rows = m->bwd_blocks;
+}
+
 bool hpv_mfma_has_projection(HpvMfma*) { return false; }
 void hpv_mfma_project(HpvMfma*, const ProjDesc&, const double*, double*, double*, const double*, const double*, long,
                       const double*, const double*, const double*, double*, double*, long, long, int, hipStream_t) {}

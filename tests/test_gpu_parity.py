@@ -146,3 +146,51 @@ def test_shard_invariance():
     assert rel(acc[:-2], gr) < 1e-12
     assert abs(acc[-2] - l3[2]) < 1e-12 * abs(l3[2])
     assert abs(acc[-2] + acc[-1] - l3[0]) < 1e-12 * abs(l3[0])
+
+
+# ---------------------------------------------------------------------------------------------------
+# MFMA fast path (20-wide hidden layers): every channel set the three problems use, 1..4 hidden layers,
+# point counts that are not a multiple of the 16-point MFMA tile.
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,vf", [("1d", 1), ("1d", 2), ("1d", 3), ("2d", 0), ("2d", 1), ("2d", 2), ("adv", 0), ("adv", 1)])
+def test_mfma_path_all_channel_sets(kind, vf):
+    if kind == "1d":
+        o, m = _pair_1d("poisson1d_small", vf, layers=[1, 20, 20, 20, 1], backend="mfma")
+    elif kind == "2d":
+        o, m = _pair_2d("poisson2d_small", vf, layers=[2, 20, 20, 20, 1], backend="mfma")
+    else:
+        o, m = _pair_adv("advdiff_small", vf, layers=[2, 20, 20, 20, 1], backend="mfma")
+    assert m.backend() == "mfma"
+    _check_loss_grad(o, m)
+    _check_traj(o, m, n=8)
+
+
+@pytest.mark.parametrize("nhid", [1, 2, 4])
+def test_mfma_path_depths(nhid):
+    o, m = _pair_2d("poisson2d_small", 1, layers=[2] + [20] * nhid + [1], backend="mfma")
+    assert m.backend() == "mfma"
+    _check_loss_grad(o, m)
+    o, m = _pair_1d("poisson1d_small", 1, layers=[1] + [20] * nhid + [1], backend="mfma")
+    _check_loss_grad(o, m)
+
+
+def test_mfma_equals_generic_on_device():
+    """Same inputs through both device paths (config-3 shape): loss/grad agree to rounding."""
+    from hp_vpinns_amd.vpinn import VPINN2D
+    g = gold("poisson2d_cfg3")
+    a = p2_args(g)
+    th = theta0(a[13], 12)
+    m1 = VPINN2D(*a, init_params=th, backend="generic")
+    m2 = VPINN2D(*a, init_params=th, backend="mfma")
+    assert (m1.backend(), m2.backend()) == ("generic", "mfma")
+    (l1, g1), (l2, g2) = m1.loss_and_grad(), m2.loss_and_grad()
+    assert rel(l2, l1) < 1e-12 and rel(g2, g1) < 1e-11
+    r1 = m1.h.residuals(64 * 25)
+    r2 = m2.h.residuals(64 * 25)
+    assert rel(r2, r1) < 1e-11
+
+
+def test_mfma_unavailable_shape_raises():
+    from hp_vpinns_amd import _lib
+    with pytest.raises(_lib.HpvError):
+        _pair_2d("poisson2d_small", 1, layers=[2, 8, 8, 1], backend="mfma")
