@@ -24,7 +24,7 @@ EXPORTS = [
     "hpv_set_params", "hpv_get_params", "hpv_loss_and_grad", "hpv_step", "hpv_forward_backward",
     "hpv_reduce_buffer", "hpv_apply_adam", "hpv_eval_loss", "hpv_read_loss", "hpv_sync",
     "hpv_predict", "hpv_get_residuals", "hpv_backend_in_use", "hpv_enable_timing",
-    "hpv_kernel_time_ms", "hpv_bench_projection",
+    "hpv_kernel_time_ms", "hpv_bench_projection", "hpv_debug_activation",
 ]
 
 
@@ -89,6 +89,7 @@ def load():
     lib.hpv_enable_timing.argtypes = [h, C.c_int]
     lib.hpv_kernel_time_ms.argtypes = [h, C.c_int, _dp, C.POINTER(C.c_long)]
     lib.hpv_bench_projection.argtypes = [h, C.c_long, C.c_int, _dp, _dp]
+    lib.hpv_debug_activation.argtypes = [h, _dp, C.c_int, _dp, _dp, _dp]
     _lib = lib
     return lib
 
@@ -247,6 +248,12 @@ class Handle:
         ms, n = C.c_double(), C.c_long()
         self._chk(self.lib.hpv_kernel_time_ms(self._h, int(which), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def debug_activation(self, x):
+        x = _c(x).reshape(-1)
+        a, a1, ref = np.empty_like(x), np.empty_like(x), np.empty_like(x)
+        self._chk(self.lib.hpv_debug_activation(self._h, _p(x), x.size, _p(a), _p(a1), _p(ref)))
+        return a, a1, ref
 
     def bench_projection(self, n_elem, reps=10):
         ms, by = C.c_double(), C.c_double()

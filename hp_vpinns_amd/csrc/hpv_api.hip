@@ -63,8 +63,10 @@ struct hpv_ctx {
     int n_data = 0;
     // parameters / optimizer
     double *d_theta = nullptr, *d_m = nullptr, *d_v = nullptr, *d_state = nullptr, *d_RB = nullptr;
-    // mfma path
+    // mfma path (one object per batch: quadrature points, boundary/data points, element edges)
     HpvMfma* mfma = nullptr;
+    HpvMfma* mfma_data = nullptr;
+    HpvMfma* mfma_edge = nullptr;
     // timing
     bool timing = false;
     TimerClass timers[3];
@@ -193,13 +195,29 @@ int check_ready(hpv_ctx* h) {
     return 0;
 }
 
-void run_fwd(hpv_ctx* h, Batch& b, int save_act) {
+void run_fwd(hpv_ctx* h, Batch& b, HpvMfma* m, int save_act) {
     if (b.N == 0) return;
-    launch_mlp_fwd_generic(b.nd, h->d_theta, b.X, b.ACT, b.OUT, b.N, save_act, h->stream);
+    if (m) hpv_mfma_forward(m, h->d_theta, b.X, b.OUT, save_act, h->stream);
+    else launch_mlp_fwd_generic(b.nd, h->d_theta, b.X, b.ACT, b.OUT, b.N, save_act, h->stream);
 }
-void run_bwd(hpv_ctx* h, Batch& b) {
+void run_bwd(hpv_ctx* h, Batch& b, HpvMfma* m) {
     if (b.N == 0) return;
-    launch_mlp_bwd_generic(b.nd, h->d_theta, b.X, b.ACT, b.GBAR, b.GPART, b.rows, b.N, h->stream);
+    if (m) hpv_mfma_backward(m, h->d_theta, b.X, b.GBAR, b.GPART, &b.rows, h->stream);
+    else launch_mlp_bwd_generic(b.nd, h->d_theta, b.X, b.ACT, b.GBAR, b.GPART, b.rows, b.N, h->stream);
+}
+
+// The small value-only batches (boundary/data points, element edges) ride the MFMA path too once the
+// quadrature batch does; their generic activation stores are dropped.
+int ensure_small_mfma(hpv_ctx* h, Batch& b, HpvMfma** m) {
+    if (*m || h->backend != HPV_BACKEND_MFMA || b.N == 0) return 0;
+    std::string why;
+    *m = hpv_mfma_create(b.nd, b.N, &why);
+    if (!*m) return 0;  // stays on the generic kernels
+    if (b.ACT) { (void)hipFree(b.ACT); b.ACT = nullptr; }
+    int rows = hpv_mfma_grad_rows(*m);
+    if (rows > b.rows) { int rc = dalloc(h, &b.GPART, (size_t)rows * h->P); if (rc) return rc; }
+    b.rows = rows;
+    return 0;
 }
 
 int enqueue_pass(hpv_ctx* h, bool backward) {
@@ -207,13 +225,15 @@ int enqueue_pass(hpv_ctx* h, bool backward) {
     if (rc) return rc;
     const double* eps_ptr = h->has_eps ? h->d_theta + h->P : nullptr;
     const bool use_mfma = h->mfma && h->backend == HPV_BACKEND_MFMA;
+    if ((rc = ensure_small_mfma(h, h->data, &h->mfma_data))) return rc;
+    if (h->pd.edge && (rc = ensure_small_mfma(h, h->edge, &h->mfma_edge))) return rc;
     // --- variational term on this shard's quadrature batch ---
     if (h->var.N > 0) {
         tstart(h, 0);
         if (use_mfma) hpv_mfma_forward(h->mfma, h->d_theta, h->var.X, h->var.OUT, backward ? 1 : 0, h->stream);
-        else run_fwd(h, h->var, backward ? 1 : 0);
+        else run_fwd(h, h->var, nullptr, backward ? 1 : 0);
         tstop(h, 0);
-        if (h->pd.edge) run_fwd(h, h->edge, backward ? 1 : 0);
+        if (h->pd.edge) run_fwd(h, h->edge, h->mfma_edge, backward ? 1 : 0);
         tstart(h, 1);
         launch_project(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
                        h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi,
@@ -222,19 +242,19 @@ int enqueue_pass(hpv_ctx* h, bool backward) {
         if (backward) {
             tstart(h, 2);
             if (use_mfma) hpv_mfma_backward(h->mfma, h->d_theta, h->var.X, h->var.GBAR, h->var.GPART, &h->var.rows, h->stream);
-            else run_bwd(h, h->var);
+            else run_bwd(h, h->var, nullptr);
             tstop(h, 2);
-            if (h->pd.edge) run_bwd(h, h->edge);
+            if (h->pd.edge) run_bwd(h, h->edge, h->mfma_edge);
         }
     }
     // --- boundary / data term ---
     int ndp = 0;
     if (h->n_data > 0) {
-        run_fwd(h, h->data, backward ? 1 : 0);
+        run_fwd(h, h->data, h->mfma_data, backward ? 1 : 0);
         ndp = (h->n_data + 255) / 256; if (ndp > 64) ndp = 64;
         launch_data_loss(h->data.OUT, h->d_udata, backward ? h->data.GBAR : nullptr,
                          -2.0 * h->cfg.lossb_weight / (double)h->n_data, h->d_data_part, h->n_data, h->stream);
-        if (backward) run_bwd(h, h->data);
+        if (backward) run_bwd(h, h->data, h->mfma_data);
     }
     launch_finalize(backward && h->var.N > 0 ? h->var.GPART : nullptr, h->var.rows,
                     backward && h->n_data > 0 ? h->data.GPART : nullptr, h->data.rows,
@@ -331,6 +351,8 @@ void hpv_destroy(hpv_handle h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->mfma) hpv_mfma_destroy(h->mfma);
+    if (h->mfma_data) hpv_mfma_destroy(h->mfma_data);
+    if (h->mfma_edge) hpv_mfma_destroy(h->mfma_edge);
     free_batch(h->var); free_batch(h->data); free_batch(h->edge); free_batch(h->pred);
     double* ptrs[] = {h->d_wtx, h->d_wty, h->d_edge_dphi, h->d_coef, h->d_edge_coef, h->d_F, h->d_R, h->d_loss_e,
                       h->d_deps_e, h->d_udata, h->d_data_part, h->d_theta, h->d_m, h->d_v, h->d_state, h->d_RB};
@@ -472,6 +494,7 @@ int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* g
     } else if (h->d_F) { (void)hipFree(h->d_F); h->d_F = nullptr; }
     // the MFMA fast path (20-wide BASELINE networks)
     if (h->mfma) { hpv_mfma_destroy(h->mfma); h->mfma = nullptr; }
+    if (h->mfma_edge) { hpv_mfma_destroy(h->mfma_edge); h->mfma_edge = nullptr; }
     h->backend = HPV_BACKEND_GENERIC;
     if (h->cfg.backend != HPV_BACKEND_GENERIC && N > 0) {
         std::string why;
@@ -510,6 +533,7 @@ int hpv_set_data(hpv_handle h, const double* X, const double* u, int n) {
     if (n < 0 || (n > 0 && (!X || !u))) return fail(h, -1, "bad data arguments");
     int rc;
     h->n_data = n;
+    if (h->mfma_data) { hpv_mfma_destroy(h->mfma_data); h->mfma_data = nullptr; }
     if ((rc = alloc_batch(h, h->data, h->nd_val, n, true))) return rc;
     if ((rc = dalloc(h, &h->d_udata, (size_t)n))) return rc;
     if (n > 0) {
@@ -631,6 +655,24 @@ int hpv_get_residuals(hpv_handle h, double* R, size_t n) {
 }
 
 int hpv_backend_in_use(hpv_handle h) { return h ? h->backend : -1; }
+
+int hpv_debug_activation(hpv_handle h, const double* x, int n, double* a, double* a1, double* ref) {
+    if (!h || !x || !a || !a1 || !ref || n < 1) return -1;
+    double* d = nullptr;
+    int rc = dalloc(h, &d, (size_t)4 * n);
+    if (rc) return rc;
+    rc = upload(h, d, x, (size_t)n);
+    if (!rc) {
+        launch_debug_act(h->cfg.act, d, n, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, h->stream);
+        hipError_t e = hipMemcpyAsync(a, d + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(a1, d + 2 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ref, d + 3 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, -2, "debug_activation failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    return rc;
+}
 
 int hpv_enable_timing(hpv_handle h, int on) {
     if (!h) return -1;

@@ -68,3 +68,4 @@ void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, i
                      hipStream_t s);
 void launch_adam(double* theta, double* m, double* v, const double* RB, double* state, int Ptot, double lr, double b1,
                  double b2, double eps, hipStream_t s);
+void launch_debug_act(int act, const double* x, int n, double* a, double* a1, double* ref, hipStream_t s);

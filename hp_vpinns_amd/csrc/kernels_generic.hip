@@ -9,6 +9,7 @@
 //   reverse:       zb_cc = hb'_cc s',  zb_c = hb'_c s' + 2 hb'_cc s'' z_c,
 //                  zb   = hb' s' + sum_c [hb'_c s'' z_c + hb'_cc (s''' z_c^2 + s'' z_cc)]
 #include "hpv_internal.h"
+#include "hpv_math.h"
 
 #define WAVE 64
 
@@ -35,7 +36,7 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 
 __device__ __forceinline__ void act_eval(int act, double z, double& a, double& a1) {
     if (act == HPV_ACT_TANH) {
-        a = tanh(z);
+        a = hpv_tanh(z);
         a1 = 1.0 - a * a;
     } else {
         sincos(z, &a, &a1);
@@ -455,24 +456,36 @@ void launch_data_loss(const double* U, const double* Ud, double* GBAR, double sc
 // Finalize: fixed-order sums of all partials into the packed reduce buffer
 //   RB = [grad (P) | (d eps) | lossv | w*lossb | mean-square of the data term | pad]
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_finalize(const double* __restrict__ GPART_v, int rows_v,
-                                                 const double* __restrict__ GPART_b, int rows_b,
-                                                 const double* __restrict__ GPART_e, int rows_e,
-                                                 const double* __restrict__ loss_e, long n_elem,
-                                                 const double* __restrict__ deps_e,
-                                                 const double* __restrict__ data_part, int n_data_part,
-                                                 double lossb_weight, int n_data, int P, int has_eps,
-                                                 double* __restrict__ RB, int write_grad) {
-    __shared__ double red[16];
+#define FIN_THREADS 1024
+#define FIN_PARTS (FIN_THREADS / 64)
+__global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restrict__ GPART_v, int rows_v,
+                                                         const double* __restrict__ GPART_b, int rows_b,
+                                                         const double* __restrict__ GPART_e, int rows_e,
+                                                         const double* __restrict__ loss_e, long n_elem,
+                                                         const double* __restrict__ deps_e,
+                                                         const double* __restrict__ data_part, int n_data_part,
+                                                         double lossb_weight, int n_data, int P, int has_eps,
+                                                         double* __restrict__ RB, int write_grad) {
+    __shared__ double red[FIN_PARTS * 64];
     const int Ptot = P + (has_eps ? 1 : 0);
     if (blockIdx.x < gridDim.x - 1) {
-        const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-        if (idx < P && write_grad) {
-            double acc = 0.0;
-            if (GPART_v) for (int r = 0; r < rows_v; ++r) acc += GPART_v[(long)r * P + idx];
-            if (GPART_b) for (int r = 0; r < rows_b; ++r) acc += GPART_b[(long)r * P + idx];
-            if (GPART_e) for (int r = 0; r < rows_e; ++r) acc += GPART_e[(long)r * P + idx];
-            RB[idx] = acc;
+        // 64 parameters per block; 16 row-groups summed in parallel then combined in a fixed order
+        if (!write_grad) return;
+        const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+        const int idx = blockIdx.x * 64 + c;
+        double acc = 0.0;
+        if (idx < P) {
+            if (GPART_v) for (int r = part; r < rows_v; r += FIN_PARTS) acc += GPART_v[(long)r * P + idx];
+            if (GPART_b) for (int r = part; r < rows_b; r += FIN_PARTS) acc += GPART_b[(long)r * P + idx];
+            if (GPART_e) for (int r = part; r < rows_e; r += FIN_PARTS) acc += GPART_e[(long)r * P + idx];
+        }
+        red[part * 64 + c] = acc;
+        __syncthreads();
+        if (part == 0 && idx < P) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < FIN_PARTS; ++k) t += red[k * 64 + c];
+            RB[idx] = t;
         }
         return;
     }
@@ -500,9 +513,10 @@ void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, i
                      int rows_e, const double* loss_e, long n_elem, const double* deps_e, const double* data_part,
                      int n_data_part, double lossb_weight, int n_data, int P, int has_eps, double* RB, int write_grad,
                      hipStream_t s) {
-    int gblocks = (P + 255) / 256;
-    hipLaunchKernelGGL(k_finalize, dim3(gblocks + 1), dim3(256), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e, rows_e,
-                       loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB, write_grad);
+    int gblocks = (P + 63) / 64;
+    hipLaunchKernelGGL(k_finalize, dim3(gblocks + 1), dim3(FIN_THREADS), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e,
+                       rows_e, loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB,
+                       write_grad);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -534,4 +548,21 @@ __global__ void __launch_bounds__(1024) k_adam(double* __restrict__ theta, doubl
 void launch_adam(double* theta, double* m, double* v, const double* RB, double* state, int Ptot, double lr, double b1,
                  double b2, double eps, hipStream_t s) {
     hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, s, theta, m, v, RB, state, Ptot, lr, b1, b2, eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Test hook: the device activation (value, derivative) and ocml's own, element-wise.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_debug_act(int act, const double* __restrict__ x, int n, double* __restrict__ a,
+                            double* __restrict__ a1, double* __restrict__ ref) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v, d;
+    act_eval(act, x[i], v, d);
+    a[i] = v;
+    a1[i] = d;
+    ref[i] = (act == HPV_ACT_TANH) ? tanh(x[i]) : sin(x[i]);
+}
+void launch_debug_act(int act, const double* x, int n, double* a, double* a1, double* ref, hipStream_t s) {
+    hipLaunchKernelGGL(k_debug_act, dim3((n + 255) / 256), dim3(256), 0, s, act, x, n, a, a1, ref);
 }

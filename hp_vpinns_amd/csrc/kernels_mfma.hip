@@ -16,6 +16,7 @@
 //
 // First layer (d -> 20) and linear head (20 -> 1) are VALU work (K = 1..2 and M = 1 are no MFMA shapes).
 #include "hpv_mfma.h"
+#include "hpv_math.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -52,12 +53,13 @@ struct HpvMfma {
     MfmaArgs base;
     void (*fwd)(const MfmaArgs&, int, hipStream_t) = nullptr;
     void (*bwd)(const MfmaArgs&, int, hipStream_t) = nullptr;
+    int occ_fwd = 1, occ_bwd = 1;   // resident 256-thread blocks per CU
 };
 
 template <int ACT>
 __device__ __forceinline__ void act_fwd(double z, double& a, double& a1, double& a2) {
     if constexpr (ACT == HPV_ACT_TANH) {
-        a = tanh(z);
+        a = hpv_tanh(z);
         a1 = 1.0 - a * a;
         a2 = -2.0 * a * a1;
     } else {
@@ -499,13 +501,25 @@ static void run_bwd(const MfmaArgs& a, int blocks, hipStream_t s) {
     hipLaunchKernelGGL((k_bwd_mfma<D, NT1, NT2, ACT, L>), dim3(blocks), dim3(MF_BLOCK), lds, s, a);
 }
 
+template <int D, int NT1, int NT2, int ACT, int L>
+static bool pick(HpvMfma* m) {
+    m->fwd = run_fwd<D, NT1, NT2, ACT, L>;
+    m->bwd = run_bwd<D, NT1, NT2, ACT, L>;
+    size_t lds = ((size_t)MF_WAVES * 2 * MF_H * MF_LD + (size_t)MF_WAVES * m->nd.P) * sizeof(double);
+    int of = 1, ob = 1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, k_fwd_mfma<D, NT1, NT2, ACT, L>, MF_BLOCK, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_bwd_mfma<D, NT1, NT2, ACT, L>, MF_BLOCK, lds);
+    m->occ_fwd = of > 0 ? of : 1;
+    m->occ_bwd = ob > 0 ? ob : 1;
+    return true;
+}
 template <int D, int NT1, int NT2, int ACT>
 static bool pick_L(HpvMfma* m, int L) {
     switch (L) {
-        case 1: m->fwd = run_fwd<D, NT1, NT2, ACT, 1>; m->bwd = run_bwd<D, NT1, NT2, ACT, 1>; return true;
-        case 2: m->fwd = run_fwd<D, NT1, NT2, ACT, 2>; m->bwd = run_bwd<D, NT1, NT2, ACT, 2>; return true;
-        case 3: m->fwd = run_fwd<D, NT1, NT2, ACT, 3>; m->bwd = run_bwd<D, NT1, NT2, ACT, 3>; return true;
-        case 4: m->fwd = run_fwd<D, NT1, NT2, ACT, 4>; m->bwd = run_bwd<D, NT1, NT2, ACT, 4>; return true;
+        case 1: return pick<D, NT1, NT2, ACT, 1>(m);
+        case 2: return pick<D, NT1, NT2, ACT, 2>(m);
+        case 3: return pick<D, NT1, NT2, ACT, 3>(m);
+        case 4: return pick<D, NT1, NT2, ACT, 4>(m);
         default: return false;
     }
 }
@@ -546,8 +560,10 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why) {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const long tiles_per_block = MF_WAVES;
     long want = (m->ntiles + tiles_per_block - 1) / tiles_per_block;
-    m->fwd_blocks = (int)std::min<long>(want, (long)cus * 4);   // up to 4 waves / SIMD
-    m->bwd_blocks = (int)std::min<long>(want, (long)cus * 2);   // up to 2 waves / SIMD (register heavy)
+    // persistent-style grids: exactly the number of blocks that are resident at once (the wave loops
+    // over its tiles), so weight fragments are loaded and gradient rows written once per resident wave
+    m->fwd_blocks = (int)std::min<long>(want, (long)cus * std::max(1, m->occ_fwd));
+    m->bwd_blocks = (int)std::min<long>(want, (long)cus * std::max(1, m->occ_bwd));
     MfmaArgs& a = m->base;
     a = MfmaArgs{};
     a.N = N; a.ntiles = m->ntiles; a.ACTS = m->ACTS; a.P = nd.P;

@@ -113,6 +113,9 @@ int hpv_predict(hpv_handle h, const double* X, int n, double* u_out);
 /* Introspection for tests / benchmarks. */
 int hpv_get_residuals(hpv_handle h, double* R, size_t n);   /* R of the owned elements [ne][nty][ntx] */
 int hpv_backend_in_use(hpv_handle h);                       /* HPV_BACKEND_GENERIC or HPV_BACKEND_MFMA */
+/* Test hook: the device activation s(x), s'(x) (cfg.act) and the ROCm math library's s(x) for the same
+ * inputs, so tests can bound the error of the hand-written fp64 tanh (replaces tf.tanh, P2:165). */
+int hpv_debug_activation(hpv_handle h, const double* x, int n, double* a, double* a1, double* ref);
 /* Average device time (ms) per launch of kernel class `which` since the last reset, measured with
  * hipEvents on the handle's stream when timing is enabled; which: 0 mlp_fwd, 1 project, 2 mlp_bwd. */
 int hpv_enable_timing(hpv_handle h, int on);

@@ -194,3 +194,17 @@ def test_mfma_unavailable_shape_raises():
     from hp_vpinns_amd import _lib
     with pytest.raises(_lib.HpvError):
         _pair_2d("poisson2d_small", 1, layers=[2, 8, 8, 1], backend="mfma")
+
+
+def test_device_tanh_accuracy():
+    """The hand-written fp64 tanh: <= 4e-16 absolute and relative error against the math library / numpy."""
+    from hp_vpinns_amd import _lib
+    h = _lib.Handle(_lib.PDE_POISSON2D, 1, _lib.ACT_TANH, [2, 20, 1])
+    x = np.concatenate([np.linspace(-8, 8, 40001), np.logspace(-14, 1.6, 3000), -np.logspace(-14, 1.6, 3000),
+                        [0.0, 40.0, -40.0, 1e3, -1e3, 1e300]])
+    a, a1, ref = h.debug_activation(x)
+    t = np.tanh(x)
+    assert np.abs(a - t).max() < 4e-16 and np.abs(ref - t).max() < 4e-16
+    nz = np.abs(t) > 0
+    assert (np.abs(a - t)[nz] / np.abs(t[nz])).max() < 6e-16
+    assert np.abs(a1 - (1 - t * t)).max() < 1e-15
