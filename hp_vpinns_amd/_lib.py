@@ -239,7 +239,10 @@ class Handle:
         return out
 
     def backend_in_use(self):
-        return int(self.lib.hpv_backend_in_use(self._h))
+        rc = int(self.lib.hpv_backend_in_use(self._h))
+        if rc < 0:
+            self._chk(rc)
+        return rc
 
     def enable_timing(self, on=True):
         self._chk(self.lib.hpv_enable_timing(self._h, 1 if on else 0))

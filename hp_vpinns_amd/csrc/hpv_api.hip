@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -58,6 +59,13 @@ struct hpv_ctx {
     std::vector<double> F_all;
     bool have_F = false;
     Batch var, data, edge, pred;
+    // host copies of the point sets; the device batches are (re)assembled lazily (assemble_batches)
+    std::vector<double> Xq_host;   // [dim][Nq] quadrature points of the owned elements
+    std::vector<double> Xd_host;   // [n_data][dim] boundary / data points
+    long Nq = 0;
+    bool batch_dirty = true;
+    bool merged = false;           // MFMA path: data points ride as extra tiles of the quadrature batch
+    long data_off = 0;             // first data point inside the merged batch
     double* d_udata = nullptr;
     double* d_data_part = nullptr;
     int n_data = 0;
@@ -70,6 +78,12 @@ struct hpv_ctx {
     // timing
     bool timing = false;
     TimerClass timers[3];
+    // whole-iteration hipGraph (forward + projection + backward || boundary branch -> finalize -> Adam)
+    hipStream_t stream2 = nullptr;       // side stream: the boundary/data branch runs beside the main branch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_active = false;            // true only while capturing
+    bool use_graph = true;
+    hipGraphExec_t g_step = nullptr;
 };
 
 namespace {
@@ -186,12 +200,62 @@ void tstop(hpv_ctx* h, int which) {
     }
 }
 
+// Build the device point batches from the host copies.  MFMA path: ONE batch = quadrature points (padded
+// to a 16-point tile) followed by the boundary/data points, so a single forward and a single reverse
+// launch serve both loss terms (the data points just carry zero adjoints on the tangent channels).
+// Generic path: separate batches.
+int assemble_batches(hpv_ctx* h) {
+    int rc;
+    const long N = h->Nq;
+    const int d = h->dim, nd = h->n_data;
+    if (h->mfma) { hpv_mfma_destroy(h->mfma); h->mfma = nullptr; }
+    if (h->mfma_data) { hpv_mfma_destroy(h->mfma_data); h->mfma_data = nullptr; }
+    h->backend = HPV_BACKEND_GENERIC;
+    h->merged = false;
+    if (h->cfg.backend != HPV_BACKEND_GENERIC && N > 0) {
+        const long Npad = (N + 15) / 16 * 16, Ntot = Npad + nd;
+        std::string why;
+        h->mfma = hpv_mfma_create(h->nd_var, Ntot, &why);
+        if (h->mfma) {
+            h->backend = HPV_BACKEND_MFMA;
+            h->merged = true;
+            h->data_off = Npad;
+            if ((rc = alloc_batch(h, h->var, h->nd_var, Ntot, true))) return rc;
+            if (h->var.ACT) { (void)hipFree(h->var.ACT); h->var.ACT = nullptr; }   // the MFMA path has its own store
+            const int rows = hpv_mfma_grad_rows(h->mfma);
+            if ((rc = dalloc(h, &h->var.GPART, (size_t)rows * h->P))) return rc;
+            h->var.rows = rows;
+            std::vector<double> X((size_t)d * Ntot, 0.0);
+            for (int c = 0; c < d; ++c) {
+                for (long p = 0; p < N; ++p) X[(size_t)c * Ntot + p] = h->Xq_host[(size_t)c * N + p];
+                for (int p = 0; p < nd; ++p) X[(size_t)c * Ntot + Npad + p] = h->Xd_host[(size_t)p * d + c];
+            }
+            if ((rc = upload(h, h->var.X, X.data(), X.size()))) return rc;
+            HIPCHK(h, hipMemsetAsync(h->var.GBAR, 0, (size_t)h->nd_var.C * Ntot * sizeof(double), h->stream));
+            HIPCHK(h, hipMemsetAsync(h->var.OUT, 0, (size_t)h->nd_var.C * Ntot * sizeof(double), h->stream));
+            free_batch(h->data);
+        } else if (h->cfg.backend == HPV_BACKEND_MFMA) {
+            return fail(h, -4, "MFMA backend requested but not available for this shape: %s", why.c_str());
+        }
+    }
+    if (!h->merged) {
+        if ((rc = alloc_batch(h, h->var, h->nd_var, N, true))) return rc;
+        if (N > 0 && (rc = upload(h, h->var.X, h->Xq_host.data(), h->Xq_host.size()))) return rc;
+        if ((rc = alloc_batch(h, h->data, h->nd_val, nd, true))) return rc;
+        if (nd > 0 && (rc = upload_points(h, h->data, h->Xd_host.data(), nd, d))) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->batch_dirty = false;
+    return 0;
+}
+
 int check_ready(hpv_ctx* h) {
     if (!h->have_quad) return fail(h, -3, "hpv_set_quadrature has not been called");
     if (!h->have_tables) return fail(h, -3, "hpv_set_tables has not been called");
     if (!h->have_elems) return fail(h, -3, "hpv_set_elements has not been called");
     if (!h->have_params) return fail(h, -3, "hpv_set_params has not been called");
     if (h->have_F && !h->d_F && h->n_elem > 0) return fail(h, -3, "internal: F not sliced");
+    if (h->batch_dirty) return assemble_batches(h);
     return 0;
 }
 
@@ -225,8 +289,16 @@ int enqueue_pass(hpv_ctx* h, bool backward) {
     if (rc) return rc;
     const double* eps_ptr = h->has_eps ? h->d_theta + h->P : nullptr;
     const bool use_mfma = h->mfma && h->backend == HPV_BACKEND_MFMA;
-    if ((rc = ensure_small_mfma(h, h->data, &h->mfma_data))) return rc;
-    if (h->pd.edge && (rc = ensure_small_mfma(h, h->edge, &h->mfma_edge))) return rc;
+    if (!h->side_active) {  // allocations are not allowed inside a stream capture
+        if ((rc = ensure_small_mfma(h, h->data, &h->mfma_data))) return rc;
+        if (h->pd.edge && (rc = ensure_small_mfma(h, h->edge, &h->mfma_edge))) return rc;
+    }
+    hipStream_t smain = h->stream;
+    const bool fork = h->side_active && !h->merged && h->n_data > 0;
+    if (fork) {
+        (void)hipEventRecord(h->ev_fork, smain);
+        (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
+    }
     // --- variational term on this shard's quadrature batch ---
     if (h->var.N > 0) {
         tstart(h, 0);
@@ -239,6 +311,9 @@ int enqueue_pass(hpv_ctx* h, bool backward) {
                        h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi,
                        h->d_edge_coef, h->edge.GBAR, h->stream);
         tstop(h, 1);
+        if (h->merged && h->n_data > 0)
+            launch_data_loss(h->var.OUT + h->data_off, h->d_udata, backward ? h->var.GBAR + h->data_off : nullptr,
+                             -2.0 * h->cfg.lossb_weight / (double)h->n_data, h->d_data_part, h->n_data, h->stream);
         if (backward) {
             tstart(h, 2);
             if (use_mfma) hpv_mfma_backward(h->mfma, h->d_theta, h->var.X, h->var.GBAR, h->var.GPART, &h->var.rows, h->stream);
@@ -249,20 +324,56 @@ int enqueue_pass(hpv_ctx* h, bool backward) {
     }
     // --- boundary / data term ---
     int ndp = 0;
-    if (h->n_data > 0) {
+    if (h->n_data > 0 && h->merged) {
+        // handled inside the quadrature batch (see assemble_batches); only the tiny loss kernel is separate
+        ndp = (h->n_data + 255) / 256; if (ndp > 64) ndp = 64;
+    } else if (h->n_data > 0) {
+        if (fork) h->stream = h->stream2;   // the launch helpers read h->stream
         run_fwd(h, h->data, h->mfma_data, backward ? 1 : 0);
         ndp = (h->n_data + 255) / 256; if (ndp > 64) ndp = 64;
         launch_data_loss(h->data.OUT, h->d_udata, backward ? h->data.GBAR : nullptr,
                          -2.0 * h->cfg.lossb_weight / (double)h->n_data, h->d_data_part, h->n_data, h->stream);
         if (backward) run_bwd(h, h->data, h->mfma_data);
+        h->stream = smain;
+    }
+    if (fork) {
+        (void)hipEventRecord(h->ev_join, h->stream2);
+        (void)hipStreamWaitEvent(smain, h->ev_join, 0);
     }
     launch_finalize(backward && h->var.N > 0 ? h->var.GPART : nullptr, h->var.rows,
-                    backward && h->n_data > 0 ? h->data.GPART : nullptr, h->data.rows,
+                    backward && h->n_data > 0 && !h->merged ? h->data.GPART : nullptr, h->data.rows,
                     backward && h->pd.edge && h->edge.N > 0 ? h->edge.GPART : nullptr, h->edge.rows, h->d_loss_e, h->n_elem,
                     h->d_deps_e, h->d_data_part, ndp, h->cfg.lossb_weight, h->n_data, h->P, h->has_eps, h->d_RB,
                     backward ? 1 : 0, h->stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, -2, "kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+void drop_graph(hpv_ctx* h) {
+    if (h->g_step) { (void)hipGraphExecDestroy(h->g_step); h->g_step = nullptr; }
+}
+
+// Capture one whole training iteration (incl. the Adam update) into an executable graph.
+int build_step_graph(hpv_ctx* h) {
+    int rc;
+    // one direct pass first: lazily created objects (small-batch MFMA stores) must exist before capture
+    if ((rc = ensure_small_mfma(h, h->data, &h->mfma_data))) return rc;
+    if (h->pd.edge && (rc = ensure_small_mfma(h, h->edge, &h->mfma_edge))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipGraph_t graph = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    h->side_active = true;
+    rc = enqueue_pass(h, true);
+    h->side_active = false;
+    if (!rc) launch_adam(h->d_theta, h->d_m, h->d_v, h->d_RB, h->d_state, h->Ptot, h->cfg.lr, h->cfg.beta1, h->cfg.beta2,
+                         h->cfg.eps, h->stream);
+    hipError_t e = hipStreamEndCapture(h->stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(h, -2, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&h->g_step, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { h->g_step = nullptr; return fail(h, -2, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
     return 0;
 }
 
@@ -293,6 +404,12 @@ int hpv_create(hpv_handle* out, const hpv_config* cfg) {
     h->dim = dim;
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return fail(nullptr, -2, "hipStreamCreate failed"); }
     h->own_stream = true;
+    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        delete h; return fail(nullptr, -2, "side stream / event creation failed");
+    }
+    { const char* ng = getenv("HPV_NO_GRAPH"); h->use_graph = !(ng && ng[0] == '1'); }
 
     // channel selection + integrand terms per (pde, var_form)
     int t1[2] = {0, 1}, t2[2] = {0, 1};
@@ -350,6 +467,10 @@ void hpv_destroy(hpv_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    drop_graph(h);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->mfma) hpv_mfma_destroy(h->mfma);
     if (h->mfma_data) hpv_mfma_destroy(h->mfma_data);
     if (h->mfma_edge) hpv_mfma_destroy(h->mfma_edge);
@@ -365,6 +486,7 @@ void hpv_destroy(hpv_handle h) {
 int hpv_set_stream(hpv_handle h, void* s) {
     if (!h) return -1;
     if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    drop_graph(h);
     h->stream = (hipStream_t)s;
     h->own_stream = false;
     return 0;
@@ -381,6 +503,7 @@ int hpv_set_quadrature(hpv_handle h, const double* xi, const double* wx, int qx,
     h->qx = qx; h->qy = qy;
     h->pd.qx = qx; h->pd.qy = qy;
     h->have_quad = true;
+    drop_graph(h);
     h->have_tables = false;  // weighted tables depend on the weights
     h->have_elems = false;
     return 0;
@@ -418,6 +541,7 @@ int hpv_set_tables(hpv_handle h, const double* phix, const double* dphix, const 
     h->pd.ntx = ntx; h->pd.nty = nty;
     if (hpv_proj_lds_bytes(h->pd) > 64 * 1024) return fail(h, -1, "element too large for the projection kernel's LDS (%zu B)", hpv_proj_lds_bytes(h->pd));
     h->have_tables = true;
+    drop_graph(h);
     return 0;
 }
 
@@ -435,7 +559,7 @@ int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* g
     const int qx = h->qx, qy = h->qy, NQ = qx * qy;
     const long N = ne * NQ;
     int rc;
-    if ((rc = alloc_batch(h, h->var, h->nd_var, N, true))) return rc;
+    h->Nq = N;
     const int nterms = h->pd.nterms;
     std::vector<double> X((size_t)h->dim * N), coef((size_t)nterms * ne), ecoef((size_t)ne), EX((size_t)2 * ne);
     for (long le = 0; le < ne; ++le) {
@@ -473,8 +597,9 @@ int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* g
     if ((rc = dalloc(h, &h->d_R, (size_t)ne * h->ntx * h->nty))) return rc;
     if ((rc = dalloc(h, &h->d_loss_e, (size_t)ne))) return rc;
     if ((rc = dalloc(h, &h->d_deps_e, (size_t)ne))) return rc;
+    h->Xq_host = X;
+    h->batch_dirty = true;
     if (N > 0) {
-        if ((rc = upload(h, h->var.X, X.data(), X.size()))) return rc;
         if ((rc = upload(h, h->d_coef, coef.data(), coef.size()))) return rc;
         HIPCHK(h, hipMemsetAsync(h->d_deps_e, 0, (size_t)ne * sizeof(double), h->stream));
     }
@@ -487,34 +612,19 @@ int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* g
         }
     }
     h->have_elems = true;
+    drop_graph(h);
     // (re)slice F if it was given before the elements
     if (h->have_F) {
         std::vector<double> F = h->F_all;
         if ((rc = hpv_set_rhs(h, F.data(), F.size()))) return rc;
     } else if (h->d_F) { (void)hipFree(h->d_F); h->d_F = nullptr; }
-    // the MFMA fast path (20-wide BASELINE networks)
-    if (h->mfma) { hpv_mfma_destroy(h->mfma); h->mfma = nullptr; }
     if (h->mfma_edge) { hpv_mfma_destroy(h->mfma_edge); h->mfma_edge = nullptr; }
-    h->backend = HPV_BACKEND_GENERIC;
-    if (h->cfg.backend != HPV_BACKEND_GENERIC && N > 0) {
-        std::string why;
-        h->mfma = hpv_mfma_create(h->nd_var, N, &why);
-        if (h->mfma) {
-            h->backend = HPV_BACKEND_MFMA;
-            // the MFMA path keeps its own activation store and partial-gradient rows
-            if (h->var.ACT) { (void)hipFree(h->var.ACT); h->var.ACT = nullptr; }
-            int rows = hpv_mfma_grad_rows(h->mfma);
-            if (rows > h->var.rows) { if ((rc = dalloc(h, &h->var.GPART, (size_t)rows * h->P))) return rc; }
-            h->var.rows = rows;
-        } else if (h->cfg.backend == HPV_BACKEND_MFMA) {
-            return fail(h, -4, "MFMA backend requested but not available for this shape: %s", why.c_str());
-        }
-    }
     return 0;
 }
 
 int hpv_set_rhs(hpv_handle h, const double* F, size_t n) {
     if (!h) return -1;
+    drop_graph(h);
     if (!F) { h->have_F = false; h->F_all.clear(); if (h->d_F) { (void)hipFree(h->d_F); h->d_F = nullptr; } return 0; }
     if (h->have_elems) {
         const size_t NR = (size_t)h->ntx * h->nty;
@@ -533,13 +643,11 @@ int hpv_set_data(hpv_handle h, const double* X, const double* u, int n) {
     if (n < 0 || (n > 0 && (!X || !u))) return fail(h, -1, "bad data arguments");
     int rc;
     h->n_data = n;
-    if (h->mfma_data) { hpv_mfma_destroy(h->mfma_data); h->mfma_data = nullptr; }
-    if ((rc = alloc_batch(h, h->data, h->nd_val, n, true))) return rc;
+    drop_graph(h);
+    h->Xd_host.assign(X, X + (size_t)n * h->dim);
+    h->batch_dirty = true;
     if ((rc = dalloc(h, &h->d_udata, (size_t)n))) return rc;
-    if (n > 0) {
-        if ((rc = upload_points(h, h->data, X, n, h->dim))) return rc;
-        if ((rc = upload(h, h->d_udata, u, (size_t)n))) return rc;
-    }
+    if (n > 0 && (rc = upload(h, h->d_udata, u, (size_t)n))) return rc;
     return 0;
 }
 
@@ -617,9 +725,15 @@ int hpv_loss_and_grad(hpv_handle h, double* loss3, double* grad) {
 int hpv_step(hpv_handle h, int n_iters, double* loss3_after) {
     if (!h) return -1;
     int rc;
-    for (int it = 0; it < n_iters; ++it) {
-        if ((rc = enqueue_pass(h, true))) return rc;
-        if ((rc = hpv_apply_adam(h))) return rc;
+    if (h->use_graph && h->own_stream && !h->timing && n_iters > 0) {
+        if ((rc = check_ready(h))) return rc;
+        if (!h->g_step && (rc = build_step_graph(h))) return rc;
+        for (int it = 0; it < n_iters; ++it) HIPCHK(h, hipGraphLaunch(h->g_step, h->stream));
+    } else {
+        for (int it = 0; it < n_iters; ++it) {
+            if ((rc = enqueue_pass(h, true))) return rc;
+            if ((rc = hpv_apply_adam(h))) return rc;
+        }
     }
     if (loss3_after) {
         if ((rc = enqueue_pass(h, false))) return rc;
@@ -654,7 +768,14 @@ int hpv_get_residuals(hpv_handle h, double* R, size_t n) {
     return 0;
 }
 
-int hpv_backend_in_use(hpv_handle h) { return h ? h->backend : -1; }
+int hpv_backend_in_use(hpv_handle h) {
+    if (!h) return -1;
+    if (h->have_quad && h->have_tables && h->have_elems && h->batch_dirty) {
+        int rc = assemble_batches(h);   // decides the backend; surfaces "MFMA not available" early
+        if (rc) return rc;
+    }
+    return h->backend;
+}
 
 int hpv_debug_activation(hpv_handle h, const double* x, int n, double* a, double* a1, double* ref) {
     if (!h || !x || !a || !a1 || !ref || n < 1) return -1;

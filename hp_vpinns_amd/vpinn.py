@@ -87,6 +87,7 @@ class _VPINNBase:
 
     def _finish(self):
         self.h.set_params(self._init_params)
+        self.h.backend_in_use()   # assembles the device batches; raises if a requested backend is unavailable
         if self.world > 1:
             ptr, n = self.h.reduce_buffer()
             self._reducer = Reducer(ptr, n, self.device)
