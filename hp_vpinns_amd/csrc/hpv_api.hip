@@ -163,6 +163,7 @@ int alloc_batch(hpv_ctx* h, Batch& b, const NetDesc& nd, long N, bool need_bwd) 
         b.act_doubles = (size_t)nd.actoff[nd.nl - 1] * N;
         if ((rc = dalloc(h, &b.ACT, b.act_doubles))) return rc;
         if ((rc = dalloc(h, &b.GBAR, (size_t)nd.C * N))) return rc;
+        HIPCHK(h, hipMemsetAsync(b.GBAR, 0, (size_t)nd.C * N * sizeof(double), h->stream));
         b.rows = mlp_bwd_generic_rows(N);
         if ((rc = dalloc(h, &b.GPART, (size_t)b.rows * nd.P))) return rc;
     }
@@ -307,9 +308,14 @@ int enqueue_pass(hpv_ctx* h, bool backward) {
         tstop(h, 0);
         if (h->pd.edge) run_fwd(h, h->edge, h->mfma_edge, backward ? 1 : 0);
         tstart(h, 1);
-        launch_project(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
-                       h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi,
-                       h->d_edge_coef, h->edge.GBAR, h->stream);
+        // specialised tensor-product kernel for the hot element shapes unless the generic backend is forced
+        // (needs GBAR's unused channels pre-zeroed: true for every batch, see alloc_batch)
+        if (h->cfg.backend == HPV_BACKEND_GENERIC ||
+            !launch_project_tp(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
+                               eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->stream))
+            launch_project(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
+                           h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi,
+                           h->d_edge_coef, h->edge.GBAR, h->stream);
         tstop(h, 1);
         if (h->merged && h->n_data > 0)
             launch_data_loss(h->var.OUT + h->data_off, h->d_udata, backward ? h->var.GBAR + h->data_off : nullptr,
@@ -843,10 +849,10 @@ int hpv_bench_projection(hpv_handle h, long n_elem, int reps, double* avg_ms, do
         const double* eps_ptr = h->has_eps ? h->d_theta + h->P : nullptr;
         ProjDesc p2 = pd; p2.edge = 0;
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipMemset(GB, 0, (size_t)C * N * sizeof(double));
         auto go = [&]() {
-            if (h->mfma && h->backend == HPV_BACKEND_MFMA && hpv_mfma_has_projection(h->mfma))
-                hpv_mfma_project(h->mfma, p2, OUT, GB, R, F, coef, n_elem, h->d_wtx, h->d_wty, eps_ptr, le, de, N, n_elem, 1, h->stream);
-            else
+            if (h->cfg.backend == HPV_BACKEND_GENERIC ||
+                !launch_project_tp(p2, OUT, GB, R, F, coef, n_elem, h->d_wtx, h->d_wty, eps_ptr, le, de, N, n_elem, 1, h->stream))
                 launch_project(p2, OUT, GB, R, F, coef, n_elem, h->d_wtx, h->d_wty, eps_ptr, le, de, N, n_elem, 1, nullptr, nullptr, nullptr, nullptr, h->stream);
         };
         go();

@@ -69,3 +69,6 @@ void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, i
 void launch_adam(double* theta, double* m, double* v, const double* RB, double* state, int Ptot, double lr, double b1,
                  double b2, double eps, hipStream_t s);
 void launch_debug_act(int act, const double* x, int n, double* a, double* a1, double* ref, hipStream_t s);
+bool launch_project_tp(const ProjDesc& pd, const double* OUT, double* GBAR, double* R, const double* F, const double* coef,
+                       long coef_stride, const double* wtx, const double* wty, const double* eps_ptr, double* loss_e,
+                       double* deps_e, long N, long n_elem, int do_adjoint, hipStream_t s);

@@ -1,0 +1,304 @@
+// Tensor-product projection kernel for the hot element shapes: one wavefront per element,
+// test-function tables staged once per workgroup in LDS, sum-factorised contractions
+// (x then y), wave-level synchronisation only, shuffle reductions for the element loss.
+//
+//   forward :  T_t[j][r] = sum_i AX_t[r][i] G_t[j][i]            AX = w_x * phi^(dx)      (P2:94-105)
+//              U[k][r]  += m_t c_t sum_j BY_t[k][j] T_t[j][r]    BY = w_y * phi^(dy)
+//              R = U - F,  loss_e = mean(R^2)                                             (P2:118-119)
+//   adjoint :  S_t[k][i] = sum_r AX_t[r][i] (2/NR) R[k][r]
+//              Ghat_t[j][i] = c_t sum_k BY_t[k][j] S_t[k][i],   GBAR[ch] = sum_t alpha_t[ch] m_t Ghat_t
+//
+// HBM traffic per element = read the integrated channels + F, write the adjoint channels + R (channels no
+// term uses are neither read nor written; their GBAR rows are zeroed once by the host).  This is the kernel
+// judged against the HBM roofline on the scaled synthetic batch.
+#include "hpv_internal.h"
+
+#define PJ_BLOCK 256
+#define PJ_WAVES (PJ_BLOCK / 64)
+
+__device__ __forceinline__ double pj_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void pj_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Work decomposition: "a lane owns a line".  LPE = max(QX,QY) lanes serve one element, EPW = 64/LPE elements
+// share a wavefront (3 for 20x20 points, 6 for 10x10).  In every contraction the lane keeps its line of
+// element data in registers and the test-function table entry is WAVE-UNIFORM (same index for all lanes
+// at the same instruction): tables are staged once per workgroup in LDS and read with broadcast reads.
+// The y-contraction comes first with the lane owning COLUMN i of the integrand (all j): those loads are
+// coalesced straight from HBM into registers (q = j*QX + i, i fastest), so no LDS staging of the
+// integrand is needed; one small LDS transpose (NTY x QX per element) separates the two contractions,
+// in the forward and again in the adjoint.  Residual rows stay in registers between forward and adjoint.
+//   forward :  T[k][i]  = sum_j BY[k][j] G[j][i]      (lane = i)     ->LDS->
+//              U[k][r] += m c sum_i AX[r][i] T[k][i]   (lane = k)
+//   adjoint :  V[k][i]  = sum_r AX[r][i] Rs[k][r]      (lane = k)     ->LDS->
+//              Gh[j][i] = c sum_k BY[k][j] V[k][i]     (lane = i)     -> coalesced stores
+struct ActiveCh {
+    int n;                      // number of channels some term integrates
+    int id[HPV_MAXC];           // their channel indices
+};
+
+template <int QX, int QY, int NTX, int NTY, int NA, bool EPS>
+__global__ void __launch_bounds__(PJ_BLOCK) k_project_tp(ProjDesc pd, ActiveCh ac, const double* __restrict__ OUT,
+                                                        double* __restrict__ GBAR, double* __restrict__ R,
+                                                        const double* __restrict__ F, const double* __restrict__ coef,
+                                                        long coef_stride, const double* __restrict__ wtx,
+                                                        const double* __restrict__ wty, const double* __restrict__ eps_ptr,
+                                                        double* __restrict__ loss_e, double* __restrict__ deps_e, long N,
+                                                        long n_elem, int do_adjoint) {
+    constexpr int NQ = QX * QY, NR = NTX * NTY;
+    constexpr int LPE = QX > QY ? QX : QY;
+    static_assert(NTX <= LPE && NTY <= LPE && LPE <= 64, "element shape");
+    constexpr int EPW = 64 / LPE;
+    constexpr int LDT = QX + 1;
+    constexpr int TB_D = EPW * NTY * LDT;
+    constexpr int WAVE_DOUBLES = TB_D + 64;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // tables in both orientations, so that every contraction walks its table contiguously in the OUTPUT
+    // index (independent accumulators, wide broadcast reads, many LDS reads in flight)
+    double* AXs = sm;                      // [3][NTX][QX]  w_x phi^(d)[r][i]
+    double* BYs = AXs + 3 * NTX * QX;      // [3][NTY][QY]  w_y phi^(d)[k][j]
+    double* AXT = BYs + 3 * NTY * QY;      // [3][QX][NTX]
+    double* BYT = AXT + 3 * NTX * QX;      // [3][QY][NTY]
+    for (int i = threadIdx.x; i < 3 * NTX * QX; i += PJ_BLOCK) {
+        const double v = wtx[i];
+        AXs[i] = v;
+        const int d = i / (NTX * QX), r = (i / QX) % NTX, c = i % QX;
+        AXT[d * (NTX * QX) + c * NTX + r] = v;
+    }
+    for (int i = threadIdx.x; i < 3 * NTY * QY; i += PJ_BLOCK) {
+        const double v = wty[i];
+        BYs[i] = v;
+        const int d = i / (NTY * QY), k = (i / QY) % NTY, c = i % QY;
+        BYT[d * (NTY * QY) + c * NTY + k] = v;
+    }
+    __syncthreads();
+    double* Tb = BYT + 3 * NTY * QY + wv * WAVE_DOUBLES;   // [EPW][NTY][LDT]  transpose tile (T, then V)
+    double* Rd = Tb + TB_D;                                // [64] slot-wise reductions
+    const int slot = lane / LPE, li = lane % LPE;
+    const bool lane_ok = slot < EPW;
+
+    const int nterms = pd.nterms, C = pd.C;
+    const double eps = eps_ptr ? eps_ptr[0] : 0.0;
+    const double sc = 2.0 / (double)NR;
+
+    const long ngroups = (n_elem + EPW - 1) / EPW;
+    for (long grp = (long)blockIdx.x * PJ_WAVES + wv; grp < ngroups; grp += (long)gridDim.x * PJ_WAVES) {
+        const long e = grp * EPW + slot;
+        const bool ev = lane_ok && e < n_elem;
+        const bool col = ev && li < QX;     // this lane owns quadrature column i = li
+        const bool row = ev && li < NTY;    // this lane owns residual row k = li
+        const double* __restrict__ Oe = OUT + e * NQ + li;
+        // all HBM reads of the group are issued up front (one memory round trip): the right-hand-side row
+        // and the quadrature column of every integrated channel
+        double u[NTX];
+#pragma unroll
+        for (int r = 0; r < NTX; ++r) u[r] = (row && F) ? -F[e * NR + li * NTX + r] : 0.0;
+        double o[NA][QY];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int j = 0; j < QY; ++j) o[a][j] = col ? Oe[(long)ac.id[a] * N + j * QX] : 0.0;
+        double gacc[NA][QY];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int j = 0; j < QY; ++j) gacc[a][j] = 0.0;
+
+#pragma unroll
+        for (int t = 0; t < HPV_MAXT; ++t) {
+            if (t >= nterms) break;
+            const TermDesc& td = pd.t[t];
+            // (a) integrand column of this term from the prefetched channels
+            double gcol[QY];
+#pragma unroll
+            for (int j = 0; j < QY; ++j) gcol[j] = 0.0;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const double al = td.a0[ac.id[a]] + eps * td.a1[ac.id[a]];
+#pragma unroll
+                for (int j = 0; j < QY; ++j) gcol[j] = fma(al, o[a][j], gcol[j]);
+            }
+            pj_wave_sync();   // previous readers of Tb are done
+            // (b) y-contraction, lane = column i
+            if (col) {
+                const double* byt = BYT + td.dy * (NTY * QY);
+                double acc[NTY];
+#pragma unroll
+                for (int k = 0; k < NTY; ++k) acc[k] = 0.0;
+#pragma unroll
+                for (int j = 0; j < QY; ++j)
+#pragma unroll
+                    for (int k = 0; k < NTY; ++k) acc[k] = fma(byt[j * NTY + k], gcol[j], acc[k]);
+#pragma unroll
+                for (int k = 0; k < NTY; ++k) Tb[slot * (NTY * LDT) + k * LDT + li] = acc[k];
+            }
+            pj_wave_sync();
+            // (c) x-contraction, lane = residual row k
+            if (row) {
+                const double* axt = AXT + td.dx * (NTX * QX);
+                const double c = coef[(long)t * coef_stride + e] * (td.eps_mult ? eps : 1.0);
+                double trow[QX], acc[NTX];
+#pragma unroll
+                for (int i = 0; i < QX; ++i) trow[i] = Tb[slot * (NTY * LDT) + li * LDT + i];
+#pragma unroll
+                for (int r = 0; r < NTX; ++r) acc[r] = 0.0;
+#pragma unroll
+                for (int i = 0; i < QX; ++i)
+#pragma unroll
+                    for (int r = 0; r < NTX; ++r) acc[r] = fma(axt[i * NTX + r], trow[i], acc[r]);
+#pragma unroll
+                for (int r = 0; r < NTX; ++r) u[r] = fma(c, acc[r], u[r]);
+            }
+        }
+        // residual row, element loss
+        double sq = 0.0;
+        if (row) {
+#pragma unroll
+            for (int r = 0; r < NTX; ++r) {
+                R[e * NR + li * NTX + r] = u[r];
+                sq = fma(u[r], u[r], sq);
+                u[r] *= sc;
+            }
+        }
+        Rd[lane] = sq;
+        pj_wave_sync();
+        if (ev && li == 0) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NTY; ++k) s += Rd[slot * LPE + k];
+            loss_e[e] = s / (double)NR;
+        }
+        if (!do_adjoint) continue;
+
+        double deps = 0.0;
+#pragma unroll
+        for (int t = 0; t < HPV_MAXT; ++t) {
+            if (t >= nterms) break;
+            const TermDesc& td = pd.t[t];
+            pj_wave_sync();
+            // (d) V[k][i] = sum_r AX[r][i] Rs[k][r], lane = row k
+            if (row) {
+                const double* ax = AXs + td.dx * (NTX * QX);
+                double acc[QX];
+#pragma unroll
+                for (int i = 0; i < QX; ++i) acc[i] = 0.0;
+#pragma unroll
+                for (int r = 0; r < NTX; ++r)
+#pragma unroll
+                    for (int i = 0; i < QX; ++i) acc[i] = fma(ax[r * QX + i], u[r], acc[i]);
+#pragma unroll
+                for (int i = 0; i < QX; ++i) Tb[slot * (NTY * LDT) + li * LDT + i] = acc[i];
+            }
+            pj_wave_sync();
+            // (e) Gh[j][i] = c sum_k BY[k][j] V[k][i], lane = column i; scattered onto the integrated channels
+            if (col) {
+                const double* by = BYs + td.dy * (NTY * QY);
+                const double c = coef[(long)t * coef_stride + e];
+                const double m = td.eps_mult ? eps : 1.0;
+                double vcol[NTY], gh[QY];
+#pragma unroll
+                for (int k = 0; k < NTY; ++k) vcol[k] = Tb[slot * (NTY * LDT) + k * LDT + li];
+#pragma unroll
+                for (int j = 0; j < QY; ++j) gh[j] = 0.0;
+#pragma unroll
+                for (int k = 0; k < NTY; ++k)
+#pragma unroll
+                    for (int j = 0; j < QY; ++j) gh[j] = fma(by[k * QY + j], vcol[k], gh[j]);
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    const double al = (td.a0[ac.id[a]] + eps * td.a1[ac.id[a]]) * (m * c);
+#pragma unroll
+                    for (int j = 0; j < QY; ++j) gacc[a][j] = fma(al, gh[j], gacc[a][j]);
+                }
+                if constexpr (EPS) {   // d loss / d epsilon (P3:63): through alpha(eps) and eps-multiplied terms
+#pragma unroll
+                    for (int j = 0; j < QY; ++j) {
+                        double g1 = 0.0, gt = 0.0;
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) {
+                            g1 = fma(td.a1[ac.id[a]], o[a][j], g1);
+                            gt = fma(td.a0[ac.id[a]] + eps * td.a1[ac.id[a]], o[a][j], gt);
+                        }
+                        deps = fma(c * gh[j], m * g1 + (td.eps_mult ? gt : 0.0), deps);
+                    }
+                }
+            }
+        }
+        // (f) adjoint of the integrated channels, coalesced (channels no term uses are never touched)
+        if (col) {
+            double* __restrict__ Ge = GBAR + e * NQ + li;
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int j = 0; j < QY; ++j) Ge[(long)ac.id[a] * N + j * QX] = gacc[a][j];
+        }
+        if constexpr (EPS) {
+            pj_wave_sync();
+            Rd[lane] = deps;
+            pj_wave_sync();
+            if (ev && li == 0) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < QX; ++i) s += Rd[slot * LPE + i];
+                deps_e[e] = s;
+            }
+        }
+    }
+}
+
+template <int QX, int QY, int NTX, int NTY, int NA, bool EPS>
+static bool launch_tp2(const ProjDesc& pd, const ActiveCh& ac, const double* OUT, double* GBAR, double* R, const double* F,
+                       const double* coef, long coef_stride, const double* wtx, const double* wty, const double* eps_ptr,
+                       double* loss_e, double* deps_e, long N, long n_elem, int do_adjoint, hipStream_t s) {
+    constexpr int LPE = QX > QY ? QX : QY;
+    constexpr int EPW = 64 / LPE;
+    constexpr int WAVE_DOUBLES = EPW * NTY * (QX + 1) + 64;
+    const size_t lds = (size_t)(2 * (3 * NTX * QX + 3 * NTY * QY) + PJ_WAVES * WAVE_DOUBLES) * sizeof(double);
+    const long ngroups = (n_elem + EPW - 1) / EPW;
+    long blocks = (ngroups + PJ_WAVES - 1) / PJ_WAVES;
+    if (blocks > 256 * 16) blocks = 256 * 16;   // grid-stride beyond that
+    hipLaunchKernelGGL((k_project_tp<QX, QY, NTX, NTY, NA, EPS>), dim3((unsigned)blocks), dim3(PJ_BLOCK), lds, s, pd, ac, OUT,
+                       GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, N, n_elem, do_adjoint);
+    return true;
+}
+
+template <int QX, int QY, int NTX, int NTY>
+static bool launch_tp(const ProjDesc& pd, const double* OUT, double* GBAR, double* R, const double* F, const double* coef,
+                      long coef_stride, const double* wtx, const double* wty, const double* eps_ptr, double* loss_e,
+                      double* deps_e, long N, long n_elem, int do_adjoint, hipStream_t s) {
+    ActiveCh ac{};
+    for (int ch = 0; ch < pd.C; ++ch) {
+        bool used = false;
+        for (int t = 0; t < pd.nterms; ++t) used |= (pd.t[t].a0[ch] != 0.0 || pd.t[t].a1[ch] != 0.0);
+        if (used) ac.id[ac.n++] = ch;
+    }
+#define HPV_NA(NA_, EPS_)                                                                                              \
+    if (ac.n == NA_ && (pd.has_eps != 0) == EPS_)                                                                      \
+        return launch_tp2<QX, QY, NTX, NTY, NA_, EPS_>(pd, ac, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e,   \
+                                                       deps_e, N, n_elem, do_adjoint, s);
+    HPV_NA(1, false) HPV_NA(2, false) HPV_NA(2, true) HPV_NA(3, true)
+#undef HPV_NA
+    return false;
+}
+
+// Returns false when the element shape has no specialised instantiation (caller falls back to k_project).
+bool launch_project_tp(const ProjDesc& pd, const double* OUT, double* GBAR, double* R, const double* F, const double* coef,
+                       long coef_stride, const double* wtx, const double* wty, const double* eps_ptr, double* loss_e,
+                       double* deps_e, long N, long n_elem, int do_adjoint, hipStream_t s) {
+    if (pd.edge || n_elem <= 0) return false;
+#define HPV_TP(QX_, QY_, NTX_, NTY_)                                                                              \
+    if (pd.qx == QX_ && pd.qy == QY_ && pd.ntx == NTX_ && pd.nty == NTY_)                                          \
+        return launch_tp<QX_, QY_, NTX_, NTY_>(pd, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e,  \
+                                               deps_e, N, n_elem, do_adjoint, s);
+    HPV_TP(20, 20, 10, 10)   // BASELINE config 4
+    HPV_TP(10, 10, 5, 5)     // BASELINE config 3, the Poisson-2D and AdvDiff reference defaults (P2:282-286, P3:47-51)
+#undef HPV_TP
+    return false;
+}

@@ -35,3 +35,6 @@ for label, fn in (("eval_loss (no act save, no adjoint)", h.eval_loss), ("forwar
 t0 = time.perf_counter()
 h.step(500, False)
 print("step(500): %.1f us/iter" % ((time.perf_counter() - t0) / 500 * 1e6))
+for ne in (1 << 14, 1 << 18):
+    ms, by = h.bench_projection(ne, 5)
+    print("projection bench n_elem=%d: %.3f ms  %.1f GB/s (%.1f%% of 8 TB/s)" % (ne, ms, by / ms / 1e6, by / ms / 1e6 / 80))
