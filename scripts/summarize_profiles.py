@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 outputs of scripts/gpu_round.sh into a markdown summary."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+out = sys.argv[1]
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")[:60]
+
+
+def stats(d):
+    f = glob.glob(os.path.join(out, d, "*kernel_stats.csv"))
+    if not f:
+        return
+    print(f"\n### rocprofv3 --kernel-trace --stats ({d})\n\n| kernel | calls | avg us | total % |\n|---|---|---|---|")
+    for r in csv.DictReader(open(f[0])):
+        print(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} |")
+
+
+def pmc(d):
+    f = glob.glob(os.path.join(out, d, "*counter_collection.csv"))
+    if not f:
+        return {}
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(f[0])):
+        k = short(r["Kernel_Name"])
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
+    return {k: {c: v / max(len(disp[k]), 1) for c, v in cs.items()} for k, cs in acc.items()}
+
+
+stats("stats")
+stats("stats_proj")
+for tagp, title in (("", "bench (config 4)"), ("_proj", "projection kernel, 2^18-element batch")):
+    fe, wr = pmc("pmc_fetch" + tagp), pmc("pmc_write" + tagp)
+    if fe or wr:
+        print(f"\n### HBM traffic per launch from PMC ({title})\n")
+        print("FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced "
+              "reads (MI355X_MICROARCH.md section HBM), so the corrected read bytes are 2 x FETCH_SIZE x 1024.\n")
+        print("| kernel | FETCH_SIZE KB | WRITE_SIZE KB | corrected HBM bytes (2*F+W)*1024 |\n|---|---|---|---|")
+        for k in sorted(set(fe) | set(wr)):
+            f_, w_ = fe.get(k, {}).get("FETCH_SIZE", 0.0), wr.get(k, {}).get("WRITE_SIZE", 0.0)
+            if f_ + w_ > 1.0:
+                print(f"| `{k}` | {f_:.0f} | {w_:.0f} | {(2 * f_ + w_) * 1024:.3e} |")
+sq = pmc("pmc_sq")
+if sq:
+    print("\n### SQ counters per launch (bench)\n")
+    cols = sorted({c for v in sq.values() for c in v})
+    print("| kernel | " + " | ".join(cols) + " |\n|---|" + "---|" * len(cols))
+    for k, v in sq.items():
+        if v.get("SQ_WAVE_CYCLES", 0) > 1e4:
+            print(f"| `{k}` | " + " | ".join(f"{v.get(c, 0):.3g}" for c in cols) + " |")

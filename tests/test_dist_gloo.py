@@ -1,0 +1,91 @@
+"""The N>1 path on CPU: world_size-2 `gloo` processes run the element sharding + packed all-reduce
+plumbing of hp_vpinns_amd.dist (the kernels' partial sums are stood in for by oracle partials, which
+is allowed for tests) and must reproduce the unsharded loss / gradient."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cases import gold, p2_args, theta0
+    from hp_vpinns_amd.dist import Reducer, dist_info, shard_range
+    from oracle.vpinn_oracle import OracleVPINN2D
+    assert dist_info()[:2] == (rank, world)
+    a = p2_args(gold("poisson2d_small"))
+    th = theta0(a[13], 21)
+    o = OracleVPINN2D(*a, init_params=th)
+    ne = o.Nelementx * o.Nelementy
+    o.e_range = shard_range(ne, rank, world)          # this rank's contiguous element block
+    o.use_data = rank == 0                            # boundary term lives on rank 0 only
+    (loss, lossb, lossv), g = o.loss_and_grad()
+    # packed buffer exactly as the library lays it out: [grad (P) | lossv | w*lossb | msq | pad]
+    buf = torch.tensor(np.concatenate([g, [lossv, loss - lossv, lossb, 0.0]]))
+    red = Reducer(tensor=buf)
+    assert red.active
+    out = red.allreduce().numpy().copy()
+    q.put((rank, o.e_range, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_everything():
+    from hp_vpinns_amd.dist import shard_range
+    for ne in (1, 2, 5, 6, 16, 256, 257):
+        for w in (1, 2, 3, 4, 8):
+            r = [shard_range(ne, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == ne
+            assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_world2_gloo_allreduce_matches_unsharded():
+    sys.path.insert(0, HERE)
+    from cases import gold, p2_args, rel, theta0
+    from oracle.vpinn_oracle import OracleVPINN2D
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a = p2_args(gold("poisson2d_small"))
+    o = OracleVPINN2D(*a, init_params=theta0(a[13], 21))
+    (loss, lossb, lossv), g = o.loss_and_grad()
+    ranges = sorted(r[1] for r in res)
+    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 6
+    for _, _, out in res:                         # every rank holds the same, complete sums
+        P = g.size
+        assert rel(out[:P], g) < 1e-12
+        assert abs(out[P] - lossv) < 1e-12 * abs(lossv)
+        assert abs(out[P] + out[P + 1] - loss) < 1e-12 * abs(loss)
+        assert abs(out[P + 2] - lossb) < 1e-14
+    assert np.array_equal(res[0][2], res[1][2])   # bitwise identical on both ranks -> replicas stay in sync

@@ -100,3 +100,19 @@ def test_poisson2d_driver_setup_matches_reference(tag, kw):
     _close(s["X_test"][:500], g["X_test_head"], 1e-15)
     _close(s["u_test"][:500], g["u_test_head"], 1e-14)
     assert abs(s["u_test"].sum() - g["u_test_sum"]) < 1e-9
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("default", {}), ("cfg5", dict(N_el_x=8, N_quad=80)),
+    ("small", dict(N_el_x=3, N_el_t=2, N_test_x=4, N_test_t=3, N_quad=6, N_bound=10))])
+def test_advdiff_driver_setup_matches_reference(tag, kw):
+    from hp_vpinns_amd.drivers import advdiff
+    g, s = gold("advdiff_" + tag), advdiff.setup(**kw, with_test_grid=False)
+    for k in ("grid_x", "grid_t", "XT_u_train", "u_train", "XT_f_train", "T_quad", "WT_quad"):
+        _close(s[k], g[k], 1e-13)
+    n = g["XT_quad_train"].shape[0]
+    _close(s["XT_quad_train"][:n], g["XT_quad_train"], 1e-14)
+    _close(s["WXT_quad_train"][:n], g["WXT_quad_train"], 1e-13)
+    X, T = np.meshgrid(g["uext_x"], g["uext_t"])
+    _close(advdiff.u_ext(X, T), g["uext_grid"], 1e-13)     # the 801-term Fourier series (P3:416-445)
+    assert abs(advdiff.epsilon - float(g["epsilon_exact"])) < 1e-16
