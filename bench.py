@@ -76,9 +76,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and os.environ.get("HPV_FORCE_DIST") == "1"):
+        # one process per GPU over RCCL; HPV_FORCE_DIST=1 under a 1-process torchrun exercises the same path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from hp_vpinns_amd.drivers import poisson2d

@@ -89,7 +89,7 @@ struct SlotCount {
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int D, int NT1, int NT2, int ACT, int L>
-__global__ void __launch_bounds__(MF_BLOCK) k_fwd_mfma(MfmaArgs g) {
+__global__ void __launch_bounds__(MF_BLOCK, 3) k_fwd_mfma(MfmaArgs g) {
     constexpr int C = 1 + NT1 + NT2;
     constexpr int NS = SlotCount<ACT, NT1, NT2>::value;
     constexpr int SA1 = 1;                                   // slot of A1 (sin only)
@@ -103,8 +103,6 @@ __global__ void __launch_bounds__(MF_BLOCK) k_fwd_mfma(MfmaArgs g) {
 
     // per-lane weight fragments
     double w1[D][MF_KS], b1[MF_KS], wo[MF_KS];
-    double wT[L > 1 ? L - 1 : 1][2][MF_KS];
-    double bh[L > 1 ? L - 1 : 1][MF_KS];
 #pragma unroll
     for (int s = 0; s < MF_KS; ++s) {
         const int j = 4 * s + q;
@@ -113,18 +111,21 @@ __global__ void __launch_bounds__(MF_BLOCK) k_fwd_mfma(MfmaArgs g) {
         b1[s] = th[g.boff[0] + j];
         wo[s] = th[g.woff[L] + j];
     }
-#pragma unroll
-    for (int i = 1; i < L; ++i) {
-#pragma unroll
-        for (int s = 0; s < MF_KS; ++s) {
-            bh[i - 1][s] = th[g.boff[i] + 4 * s + q];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int out = 16 * t + pt;
-                wT[i - 1][t][s] = (out < MF_H) ? th[g.woff[i] + (4 * s + q) * MF_H + out] : 0.0;
-            }
-        }
+    // A-operand fragments W^T[out = 16t+pt][in = 4s+q] and bias fragments of the hidden->hidden layers live in
+    // LDS, lane-major (conflict-free ds_read_b64), shared by the block's waves: frees ~60 VGPRs per wave
+    extern __shared__ __attribute__((aligned(16))) double fl[];
+    double* WT = fl;                                   // [(L-1)][2][MF_KS][64]
+    double* BH = fl + (L > 1 ? L - 1 : 0) * 2 * MF_KS * 64;   // [(L-1)][MF_KS][64]
+    for (int f = threadIdx.x; f < (L - 1) * 2 * MF_KS * 64; f += MF_BLOCK) {
+        const int ln = f & 63, s_ = (f >> 6) % MF_KS, t_ = (f / (64 * MF_KS)) & 1, i_ = f / (64 * MF_KS * 2) + 1;
+        const int out = 16 * t_ + (ln & 15);
+        WT[f] = (out < MF_H) ? th[g.woff[i_] + (4 * s_ + (ln >> 4)) * MF_H + out] : 0.0;
     }
+    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += MF_BLOCK) {
+        const int ln = f & 63, s_ = (f >> 6) % MF_KS, i_ = f / (64 * MF_KS) + 1;
+        BH[f] = th[g.boff[i_] + 4 * s_ + (ln >> 4)];
+    }
+    __syncthreads();
     const double bo = th[g.boff[L]];
 
     for (long tile = wave; tile < g.ntiles; tile += nwaves) {
@@ -135,6 +136,8 @@ __global__ void __launch_bounds__(MF_BLOCK) k_fwd_mfma(MfmaArgs g) {
         for (int c = 0; c < D; ++c) x[c] = valid ? g.X[(long)c * g.N + p] : 0.0;
         double h[C][MF_KS];
         double* sv = g.ACTS + (tile * L) * (long)(NS * MF_KS * 64) + lane;
+        int lofs = lane;                       // opaque per iteration: keeps the LDS fragment reads inside the
+        asm volatile("" : "+v"(lofs));         // loop instead of being hoisted into ~60 loop-invariant VGPRs
 
         // ---- layer 1 (VALU): z = b + x W, z_c = W[c,:], z_cc = 0 ----
 #pragma unroll
@@ -164,8 +167,9 @@ __global__ void __launch_bounds__(MF_BLOCK) k_fwd_mfma(MfmaArgs g) {
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) {
                 if (ch == 0) {
-                    acc[0][0] = v4d{bh[i - 1][0], bh[i - 1][1], bh[i - 1][2], bh[i - 1][3]};
-                    acc[0][1] = v4d{bh[i - 1][4], 0.0, 0.0, 0.0};
+                    const double* bhl = BH + (i - 1) * MF_KS * 64 + lofs;
+                    acc[0][0] = v4d{bhl[0], bhl[64], bhl[128], bhl[192]};
+                    acc[0][1] = v4d{bhl[256], 0.0, 0.0, 0.0};
                 } else {
                     acc[ch][0] = v4d{0.0, 0.0, 0.0, 0.0};
                     acc[ch][1] = v4d{0.0, 0.0, 0.0, 0.0};
@@ -177,7 +181,8 @@ __global__ void __launch_bounds__(MF_BLOCK) k_fwd_mfma(MfmaArgs g) {
                 for (int ch = 0; ch < C; ++ch)
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
-                        acc[ch][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wT[i - 1][t][s], h[ch][s], acc[ch][t], 0, 0, 0);
+                        acc[ch][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(WT[(((i - 1) * 2 + t) * MF_KS + s) * 64 + lofs], h[ch][s],
+                                                                          acc[ch][t], 0, 0, 0);
             double* svl = sv + (long)i * (NS * MF_KS * 64);
 #pragma unroll
             for (int s = 0; s < MF_KS; ++s) {
@@ -264,12 +269,16 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     const double* __restrict__ th = g.theta;
+    // LDS map: [region A: per-wave transpose tiles during the tile loop, per-wave gradient rows in the
+    //           epilogue] [region B: A-operand fragments of W for hbar_in^T = W zbar^T, lane-major]
+    constexpr int REGION_A = MF_WAVES * 2 * MF_H * MF_LD;
     double* TA = lds + wv * (2 * MF_H * MF_LD);   // per-wave transpose tiles
     double* TB = TA + MF_H * MF_LD;
+    const int regA = REGION_A > MF_WAVES * g.P ? REGION_A : MF_WAVES * g.P;
+    double* WN = lds + regA;                      // [(L-1)][2][MF_KS][64]
 
     // per-lane weight fragments
     double w1[D][MF_KS], wo[MF_KS];
-    double wN[LH][2][MF_KS];   // A operand of hbar_in^T = W zbar^T : W[in = 16t+pt][out = 4s+q]
 #pragma unroll
     for (int s = 0; s < MF_KS; ++s) {
         const int j = 4 * s + q;
@@ -277,15 +286,14 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
         for (int c = 0; c < D; ++c) w1[c][s] = th[g.woff[0] + c * MF_H + j];
         wo[s] = th[g.woff[L] + j];
     }
-#pragma unroll
-    for (int i = 1; i < L; ++i)
-#pragma unroll
-        for (int s = 0; s < MF_KS; ++s)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int in = 16 * t + pt;
-                wN[i - 1][t][s] = (in < MF_H) ? th[g.woff[i] + in * MF_H + 4 * s + q] : 0.0;
-            }
+    // A operand of hbar_in^T = W zbar^T : W[in = 16t+pt][out = 4s+q], kept in LDS (not registers) so that
+    // two waves per SIMD fit; every wave of the block reads the same lane-major fragments, conflict-free
+    for (int f = threadIdx.x; f < (L - 1) * 2 * MF_KS * 64; f += MF_BLOCK) {
+        const int ln = f & 63, s_ = (f >> 6) % MF_KS, t_ = (f / (64 * MF_KS)) & 1, i_ = f / (64 * MF_KS * 2) + 1;
+        const int in = 16 * t_ + (ln & 15);
+        WN[f] = (in < MF_H) ? th[g.woff[i_] + in * MF_H + 4 * s_ + (ln >> 4)] : 0.0;
+    }
+    __syncthreads();
     double zc1[(NT1 > 0 ? NT1 : 1) * MF_KS];   // z_c of layer 1 = W1[c,:]
 #pragma unroll
     for (int u = 0; u < NT1; ++u)
@@ -310,58 +318,96 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
         for (int c = 0; c < D; ++c) dW1[c][s] = 0.0;
     }
 
-    for (long tile = wave; tile < g.ntiles; tile += nwaves) {
+    // Saved slots of one hidden layer for this lane (5 neurons x (s, [cos], z_c.., z_cc..)).  Each layer's slots
+    // are loaded ONCE per tile and one layer AHEAD of their first use (the loads of layer i-1 are issued before
+    // the activation-backward of layer i), so the HBM/MALL latency hides behind a full layer of MFMA work
+    // even at one wave per SIMD.
+    struct Slots {
+        double a[MF_KS], a1s[MF_KS];
+        double zc[NT1 > 0 ? NT1 : 1][MF_KS];
+        double zcc[NT2 > 0 ? NT2 : 1][MF_KS];
+    };
+    auto load_slots = [&](const double* svl, bool first_layer, Slots& S) {
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            S.a[s] = svl[(0 * MF_KS + s) * 64];
+            if constexpr (ACT == HPV_ACT_SIN) S.a1s[s] = svl[(1 * MF_KS + s) * 64]; else S.a1s[s] = 0.0;
+#pragma unroll
+            for (int u = 0; u < NT1; ++u) S.zc[u][s] = first_layer ? zc1[u * MF_KS + s] : svl[((SZC + u) * MF_KS + s) * 64];
+#pragma unroll
+            for (int b = 0; b < NT2; ++b) S.zcc[b][s] = first_layer ? 0.0 : svl[((SZCC + b) * MF_KS + s) * 64];
+        }
+    };
+    auto outputs_of = [&](const Slots& S, int ch, double (&hv)[MF_KS]) {   // channel ch of the layer's outputs
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            double a1, a2, a3;
+            act_saved<ACT>(S.a[s], S.a1s[s], a1, a2, a3);
+            if (ch == 0) hv[s] = S.a[s];
+            else if (ch <= NT1) hv[s] = a1 * S.zc[(ch - 1) < NT1 ? (ch - 1) : 0][s];
+            else {
+                const int b = ch - 1 - NT1;
+                const double z1 = S.zc[b < NT1 ? b : 0][s];
+                hv[s] = a2 * z1 * z1 + a1 * S.zcc[b < NT2 ? b : 0][s];
+            }
+        }
+    };
+
+    // software pipeline across tiles: the inputs of the NEXT tile (adjoints, coordinates, last layer's slots)
+    // are requested while the first layer of the current tile is processed
+    auto load_tile_inputs = [&](long tile, double (&x)[D], double (&gb)[C], Slots& S) {
         const long p = tile * 16 + pt;
         const bool valid = p < g.N;
-        double x[D], gb[C];
 #pragma unroll
         for (int c = 0; c < D; ++c) x[c] = valid ? g.X[(long)c * g.N + p] : 0.0;
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) gb[ch] = valid ? g.GBAR[(long)ch * g.N + p] : 0.0;
+        load_slots(g.ACTS + (tile * L + (L - 1)) * (long)(NS * MF_KS * 64) + lane, L == 1, S);
+    };
+    double x[D], gb[C], nx[D], ngb[C];
+    Slots cur, nxt;
+    if (wave < g.ntiles) load_tile_inputs(wave, x, gb, cur);
+    for (long tile = wave; tile < g.ntiles; tile += nwaves) {
         const double* sv = g.ACTS + (tile * L) * (long)(NS * MF_KS * 64) + lane;
+        const bool have_next = tile + nwaves < g.ntiles;
 
-        double hin[C][MF_KS], hbar[C][MF_KS], zbar[C][MF_KS];
+        double hbar[C][MF_KS], zbar[C][MF_KS];
         // ---- linear head ----
-        layer_outputs_from_saved<ACT, NT1, NT2>(sv + (long)(L - 1) * (NS * MF_KS * 64), g.t2idx, zc1, L == 1, hin);
 #pragma unroll
-        for (int s = 0; s < MF_KS; ++s) {
-            double v = 0.0;
+        for (int ch = 0; ch < C; ++ch) {
+            double hv[MF_KS];
+            outputs_of(cur, ch, hv);
 #pragma unroll
-            for (int ch = 0; ch < C; ++ch) {
-                v += hin[ch][s] * gb[ch];
+            for (int s = 0; s < MF_KS; ++s) {
+                dWo[s] = fma(hv[s], gb[ch], dWo[s]);
                 hbar[ch][s] = gb[ch] * wo[s];
             }
-            dWo[s] += v;
         }
         if (q == 0) dbo += gb[0];
 
         // ---- hidden layers, last to first ----
 #pragma unroll
         for (int i = L - 1; i >= 0; --i) {
-            const double* svl = sv + (long)i * (NS * MF_KS * 64);
+            Slots prev;
+            if (i > 0) load_slots(sv + (long)(i - 1) * (NS * MF_KS * 64), i == 1, prev);   // one layer ahead
+            else if (have_next) load_tile_inputs(tile + nwaves, nx, ngb, nxt);             // one tile ahead
 #pragma unroll
             for (int s = 0; s < MF_KS; ++s) {
-                const double a = svl[(0 * MF_KS + s) * 64];
-                double a1s = 0.0;
-                if constexpr (ACT == HPV_ACT_SIN) a1s = svl[(1 * MF_KS + s) * 64];
                 double a1, a2, a3;
-                act_saved<ACT>(a, a1s, a1, a2, a3);
-                double zc[NT1 > 0 ? NT1 : 1];
+                act_saved<ACT>(cur.a[s], cur.a1s[s], a1, a2, a3);
                 double zb = hbar[0][s] * a1;
 #pragma unroll
                 for (int u = 0; u < NT1; ++u) {
-                    zc[u] = (i == 0) ? zc1[u * MF_KS + s] : svl[((SZC + u) * MF_KS + s) * 64];
                     zbar[1 + u][s] = hbar[1 + u][s] * a1;
-                    zb += hbar[1 + u][s] * a2 * zc[u];
+                    zb += hbar[1 + u][s] * a2 * cur.zc[u][s];
                 }
 #pragma unroll
                 for (int b = 0; b < NT2; ++b) {
                     const int u = b < NT1 ? b : 0;
-                    const double zcc = (i == 0) ? 0.0 : svl[((SZCC + b) * MF_KS + s) * 64];
                     const double hb = hbar[1 + NT1 + b][s];
                     zbar[1 + NT1 + b][s] = hb * a1;
-                    zbar[1 + u][s] += 2.0 * hb * a2 * zc[u];
-                    zb += hb * (a3 * zc[u] * zc[u] + a2 * zcc);
+                    zbar[1 + u][s] += 2.0 * hb * a2 * cur.zc[u][s];
+                    zb += hb * (a3 * cur.zc[u][s] * cur.zc[u][s] + a2 * cur.zcc[b][s]);
                 }
                 zbar[0][s] = zb;
                 db[i][s] += zb;
@@ -376,15 +422,16 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
                     for (int u = 0; u < NT1; ++u) dW1[u < D ? u : 0][s] += zbar[1 + u][s];
                 }
             } else {
-                layer_outputs_from_saved<ACT, NT1, NT2>(sv + (long)(i - 1) * (NS * MF_KS * 64), g.t2idx, zc1, i == 1, hin);
                 // weight gradient: contraction over the 16 points of the tile (and over channels)
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) {
+                    double hv[MF_KS];
+                    outputs_of(prev, ch, hv);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int s = 0; s < MF_KS; ++s) {
-                        TA[(4 * s + q) * MF_LD + pt] = hin[ch][s];
+                        TA[(4 * s + q) * MF_LD + pt] = hv[s];
                         TB[(4 * s + q) * MF_LD + pt] = zbar[ch][s];
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -416,17 +463,26 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
                     for (int s = 0; s < MF_KS; ++s)
 #pragma unroll
                         for (int t = 0; t < 2; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wN[i - 1][t][s], zbar[ch][s], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(WN[(((i - 1) * 2 + t) * MF_KS + s) * 64 + lane],
+                                                                          zbar[ch][s], acc[t], 0, 0, 0);
 #pragma unroll
                     for (int s = 0; s < MF_KS; ++s) hbar[ch][s] = acc[s >> 2][s & 3];
                 }
+                cur = prev;
             }
+        }
+        if (have_next) {
+            cur = nxt;
+#pragma unroll
+            for (int c = 0; c < D; ++c) x[c] = nx[c];
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) gb[ch] = ngb[ch];
         }
     }
 
     // ---- epilogue: per-wave partials -> LDS -> one row per block ----
     __syncthreads();
-    double* WP = lds + MF_WAVES * (2 * MF_H * MF_LD) + (long)wv * g.P;
+    double* WP = lds + (long)wv * g.P;   // region A is free now
     for (int idx = lane; idx < g.P; idx += 64) WP[idx] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -478,7 +534,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
         if (lane == 0) WP[g.boff[L]] = t;
     }
     __syncthreads();
-    const double* W0 = lds + MF_WAVES * (2 * MF_H * MF_LD);
+    const double* W0 = lds;
     double* row = g.GPART + (long)blockIdx.x * g.P;
     for (int idx = threadIdx.x; idx < g.P; idx += blockDim.x) {
         double acc = 0.0;
@@ -491,13 +547,20 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+static size_t fwd_lds_bytes(int L) { return (size_t)(L > 1 ? L - 1 : 0) * 3 * MF_KS * 64 * sizeof(double); }
+static size_t bwd_lds_bytes(int P, int L) {
+    size_t regA = (size_t)MF_WAVES * 2 * MF_H * MF_LD;
+    if ((size_t)MF_WAVES * P > regA) regA = (size_t)MF_WAVES * P;
+    return (regA + (size_t)(L > 1 ? L - 1 : 0) * 2 * MF_KS * 64) * sizeof(double);
+}
+
 template <int D, int NT1, int NT2, int ACT, int L>
 static void run_fwd(const MfmaArgs& a, int blocks, hipStream_t s) {
-    hipLaunchKernelGGL((k_fwd_mfma<D, NT1, NT2, ACT, L>), dim3(blocks), dim3(MF_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((k_fwd_mfma<D, NT1, NT2, ACT, L>), dim3(blocks), dim3(MF_BLOCK), fwd_lds_bytes(L), s, a);
 }
 template <int D, int NT1, int NT2, int ACT, int L>
 static void run_bwd(const MfmaArgs& a, int blocks, hipStream_t s) {
-    size_t lds = ((size_t)MF_WAVES * 2 * MF_H * MF_LD + (size_t)MF_WAVES * a.P) * sizeof(double);
+    size_t lds = bwd_lds_bytes(a.P, L);
     hipLaunchKernelGGL((k_bwd_mfma<D, NT1, NT2, ACT, L>), dim3(blocks), dim3(MF_BLOCK), lds, s, a);
 }
 
@@ -505,9 +568,9 @@ template <int D, int NT1, int NT2, int ACT, int L>
 static bool pick(HpvMfma* m) {
     m->fwd = run_fwd<D, NT1, NT2, ACT, L>;
     m->bwd = run_bwd<D, NT1, NT2, ACT, L>;
-    size_t lds = ((size_t)MF_WAVES * 2 * MF_H * MF_LD + (size_t)MF_WAVES * m->nd.P) * sizeof(double);
+    size_t lds = bwd_lds_bytes(m->nd.P, L);
     int of = 1, ob = 1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, k_fwd_mfma<D, NT1, NT2, ACT, L>, MF_BLOCK, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, k_fwd_mfma<D, NT1, NT2, ACT, L>, MF_BLOCK, fwd_lds_bytes(L));
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_bwd_mfma<D, NT1, NT2, ACT, L>, MF_BLOCK, lds);
     m->occ_fwd = of > 0 ? of : 1;
     m->occ_bwd = ob > 0 ? ob : 1;

@@ -12,6 +12,7 @@ its input derivatives, test-function projection, residual, gradients, Adam -- ru
 library.  Module-level globals the reference classes read (`var_form`, `LR`, `lossb_weight`,
 `scheme`, `V`, `total_record`, `loss_his`) are keyword arguments with the reference defaults.
 """
+import os
 import time
 
 import numpy as np
@@ -20,6 +21,14 @@ from . import _lib
 from .dist import Reducer, dist_info, shard_range
 from .init import n_params, xavier_init
 from .testfcn import dTest_fcn, tables_1d
+
+
+def _group_ready():
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+    except Exception:
+        return False
 
 
 def _tensor_rule(X_quad, W_quad):
@@ -67,8 +76,11 @@ class _VPINNBase:
     def _create(self, layers, var_form, LR, lossb_weight, V, init_params, seed, backend, device):
         self.layers = [int(v) for v in layers]
         self.rank, self.world, local_rank = dist_info()
+        # the collective code path is taken whenever a process group with >1 ranks exists; HPV_FORCE_DIST=1
+        # takes it with a 1-rank group too (lets a single-GPU box exercise exactly what N GPUs run)
+        self._dist = self.world > 1 or (os.environ.get("HPV_FORCE_DIST") == "1" and _group_ready())
         if device is None:
-            device = local_rank if self.world > 1 else 0
+            device = local_rank if self._dist else 0
         self.device = device
         bk = {"auto": _lib.BACKEND_AUTO, "generic": _lib.BACKEND_GENERIC, "mfma": _lib.BACKEND_MFMA,
               "hip": _lib.BACKEND_AUTO}[backend]
@@ -80,7 +92,7 @@ class _VPINNBase:
         if self._init_params.size != n_params(self.layers, self._n_extra):
             raise ValueError("init_params has the wrong length")
         self._reducer = None
-        if self.world > 1:
+        if self._dist:
             import torch
             torch.cuda.set_device(device)
             self.h.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -88,14 +100,14 @@ class _VPINNBase:
     def _finish(self):
         self.h.set_params(self._init_params)
         self.h.backend_in_use()   # assembles the device batches; raises if a requested backend is unavailable
-        if self.world > 1:
+        if self._dist:
             ptr, n = self.h.reduce_buffer()
-            self._reducer = Reducer(ptr, n, self.device)
+            self._reducer = Reducer(ptr, n, self.device, force=True)
 
     # -- iteration pieces -----------------------------------------------------------------
     def _step(self, n, read_loss):
         """n Adam iterations; returns loss3 evaluated after the last update if read_loss."""
-        if self.world == 1:
+        if not self._dist:
             return self.h.step(n, read_loss)
         for _ in range(n):
             self.h.forward_backward()
@@ -109,7 +121,7 @@ class _VPINNBase:
 
     def loss_and_grad(self):
         """({loss, lossb, lossv}, d loss / d theta) at the current parameters (global over ranks)."""
-        if self.world == 1:
+        if not self._dist:
             return self.h.loss_and_grad(True)
         self.h.forward_backward()
         t = self._reducer.allreduce()
@@ -117,7 +129,7 @@ class _VPINNBase:
         return loss3, t[: self.h.num_params()].cpu().numpy()
 
     def loss(self):
-        if self.world == 1:
+        if not self._dist:
             return self.h.loss_and_grad(False)[0]
         self.h.eval_loss()
         self._reducer.allreduce()

@@ -234,6 +234,16 @@ def test_reduce_buffer_is_a_zero_copy_torch_view():
         dist.all_reduce(t)
         torch.cuda.synchronize()
         assert np.array_equal(t.cpu().numpy(), v)
+        # the exact code path N GPUs run (forward_backward -> all_reduce -> apply_adam on torch's stream),
+        # forced on with a 1-rank RCCL group: must reproduce the single-process trajectory
+        os.environ["HPV_FORCE_DIST"] = "1"
+        try:
+            o2, m2 = _pair_2d("poisson2d_small", 1, layers=[2, 20, 20, 20, 1])
+            assert m2._dist and m2._reducer.active
+            _check_loss_grad(o2, m2)
+            _check_traj(o2, m2, n=6)
+        finally:
+            del os.environ["HPV_FORCE_DIST"]
     finally:
         dist.destroy_process_group()
 
