@@ -1,5 +1,6 @@
 // C-ABI of libhpvpinn.so (include/hpvpinn.h): host orchestration of one hp-VPINN training
 // handle = one GPU's shard of elements + a replica of the network parameters.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -235,6 +236,9 @@ int assemble_batches(hpv_ctx* h) {
             HIPCHK(h, hipMemsetAsync(h->var.GBAR, 0, (size_t)h->nd_var.C * Ntot * sizeof(double), h->stream));
             HIPCHK(h, hipMemsetAsync(h->var.OUT, 0, (size_t)h->nd_var.C * Ntot * sizeof(double), h->stream));
             free_batch(h->data);
+            const size_t nparts = (size_t)std::max(64, (nd + 15) / 16);
+            if ((rc = dalloc(h, &h->d_data_part, nparts))) return rc;
+            HIPCHK(h, hipMemsetAsync(h->d_data_part, 0, nparts * sizeof(double), h->stream));
         } else if (h->cfg.backend == HPV_BACKEND_MFMA) {
             return fail(h, -4, "MFMA backend requested but not available for this shape: %s", why.c_str());
         }
@@ -285,7 +289,13 @@ int ensure_small_mfma(hpv_ctx* h, Batch& b, HpvMfma** m) {
     return 0;
 }
 
-int enqueue_pass(hpv_ctx* h, bool backward) {
+AdamArgs adam_args(hpv_ctx* h) {
+    return AdamArgs{h->d_theta, h->d_m, h->d_v, h->d_state, h->cfg.lr, h->cfg.beta1, h->cfg.beta2, h->cfg.eps};
+}
+
+// One pass over both loss terms.  backward: also the reverse pass and the gradient reduction;
+// fuse_adam: the finalize kernel applies the TF1 Adam update itself (single-GPU training step).
+int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
     int rc = check_ready(h);
     if (rc) return rc;
     const double* eps_ptr = h->has_eps ? h->d_theta + h->P : nullptr;
@@ -303,7 +313,9 @@ int enqueue_pass(hpv_ctx* h, bool backward) {
     // --- variational term on this shard's quadrature batch ---
     if (h->var.N > 0) {
         tstart(h, 0);
-        if (use_mfma) hpv_mfma_forward(h->mfma, h->d_theta, h->var.X, h->var.OUT, backward ? 1 : 0, h->stream);
+        MfmaDataTerm dt{h->data_off, h->merged ? h->n_data : 0, h->d_udata, h->var.GBAR, h->d_data_part,
+                        h->n_data > 0 ? -2.0 * h->cfg.lossb_weight / (double)h->n_data : 0.0, backward ? 1 : 0};
+        if (use_mfma) hpv_mfma_forward(h->mfma, h->d_theta, h->var.X, h->var.OUT, backward ? 1 : 0, h->stream, &dt);
         else run_fwd(h, h->var, nullptr, backward ? 1 : 0);
         tstop(h, 0);
         if (h->pd.edge) run_fwd(h, h->edge, h->mfma_edge, backward ? 1 : 0);
@@ -317,9 +329,6 @@ int enqueue_pass(hpv_ctx* h, bool backward) {
                            h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi,
                            h->d_edge_coef, h->edge.GBAR, h->stream);
         tstop(h, 1);
-        if (h->merged && h->n_data > 0)
-            launch_data_loss(h->var.OUT + h->data_off, h->d_udata, backward ? h->var.GBAR + h->data_off : nullptr,
-                             -2.0 * h->cfg.lossb_weight / (double)h->n_data, h->d_data_part, h->n_data, h->stream);
         if (backward) {
             tstart(h, 2);
             if (use_mfma) hpv_mfma_backward(h->mfma, h->d_theta, h->var.X, h->var.GBAR, h->var.GPART, &h->var.rows, h->stream);
@@ -331,8 +340,8 @@ int enqueue_pass(hpv_ctx* h, bool backward) {
     // --- boundary / data term ---
     int ndp = 0;
     if (h->n_data > 0 && h->merged) {
-        // handled inside the quadrature batch (see assemble_batches); only the tiny loss kernel is separate
-        ndp = (h->n_data + 255) / 256; if (ndp > 64) ndp = 64;
+        // handled inside the quadrature batch by the forward kernel itself: one partial per 16-point data tile
+        ndp = (h->n_data + 15) / 16;
     } else if (h->n_data > 0) {
         if (fork) h->stream = h->stream2;   // the launch helpers read h->stream
         run_fwd(h, h->data, h->mfma_data, backward ? 1 : 0);
@@ -346,11 +355,12 @@ int enqueue_pass(hpv_ctx* h, bool backward) {
         (void)hipEventRecord(h->ev_join, h->stream2);
         (void)hipStreamWaitEvent(smain, h->ev_join, 0);
     }
+    const AdamArgs ad = adam_args(h);
     launch_finalize(backward && h->var.N > 0 ? h->var.GPART : nullptr, h->var.rows,
                     backward && h->n_data > 0 && !h->merged ? h->data.GPART : nullptr, h->data.rows,
                     backward && h->pd.edge && h->edge.N > 0 ? h->edge.GPART : nullptr, h->edge.rows, h->d_loss_e, h->n_elem,
                     h->d_deps_e, h->d_data_part, ndp, h->cfg.lossb_weight, h->n_data, h->P, h->has_eps, h->d_RB,
-                    backward ? 1 : 0, h->stream);
+                    backward ? 1 : 0, (backward && fuse_adam) ? &ad : nullptr, h->stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, -2, "kernel launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -370,10 +380,8 @@ int build_step_graph(hpv_ctx* h) {
     hipGraph_t graph = nullptr;
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     h->side_active = true;
-    rc = enqueue_pass(h, true);
+    rc = enqueue_pass(h, true, true);   // forward .. finalize with the Adam update fused in
     h->side_active = false;
-    if (!rc) launch_adam(h->d_theta, h->d_m, h->d_v, h->d_RB, h->d_state, h->Ptot, h->cfg.lr, h->cfg.beta1, h->cfg.beta2,
-                         h->cfg.eps, h->stream);
     hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) return fail(h, -2, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
@@ -459,7 +467,7 @@ int hpv_create(hpv_handle* out, const hpv_config* cfg) {
     rc |= dalloc(h, &h->d_theta, (size_t)h->Ptot);
     rc |= dalloc(h, &h->d_m, (size_t)h->Ptot);
     rc |= dalloc(h, &h->d_v, (size_t)h->Ptot);
-    rc |= dalloc(h, &h->d_state, 2);
+    rc |= dalloc(h, &h->d_state, (size_t)adam_state_doubles(h->P));
     rc |= dalloc(h, &h->d_RB, (size_t)h->Ptot + 4);
     rc |= dalloc(h, &h->d_data_part, 64);
     if (rc) { g_create_error = h->err; hpv_destroy(h); return -2; }
@@ -666,8 +674,9 @@ int hpv_set_params(hpv_handle h, const double* theta, size_t n) {
     if ((rc = upload(h, h->d_theta, theta, n))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_m, 0, n * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_v, 0, n * sizeof(double), h->stream));
-    const double st[2] = {h->cfg.beta1, h->cfg.beta2};
-    if ((rc = upload(h, h->d_state, st, 2))) return rc;
+    std::vector<double> st((size_t)adam_state_doubles(h->P));
+    for (size_t i = 0; i < st.size(); i += 2) { st[i] = h->cfg.beta1; st[i + 1] = h->cfg.beta2; }   // beta^1, every copy
+    if ((rc = upload(h, h->d_state, st.data(), st.size()))) return rc;
     h->have_params = true;
     return 0;
 }
@@ -692,8 +701,7 @@ int hpv_reduce_buffer(hpv_handle h, void** dev_ptr, size_t* n_doubles) {
 
 int hpv_apply_adam(hpv_handle h) {
     if (!h) return -1;
-    launch_adam(h->d_theta, h->d_m, h->d_v, h->d_RB, h->d_state, h->Ptot, h->cfg.lr, h->cfg.beta1, h->cfg.beta2,
-                h->cfg.eps, h->stream);
+    launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, -2, "adam launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -736,10 +744,8 @@ int hpv_step(hpv_handle h, int n_iters, double* loss3_after) {
         if (!h->g_step && (rc = build_step_graph(h))) return rc;
         for (int it = 0; it < n_iters; ++it) HIPCHK(h, hipGraphLaunch(h->g_step, h->stream));
     } else {
-        for (int it = 0; it < n_iters; ++it) {
-            if ((rc = enqueue_pass(h, true))) return rc;
-            if ((rc = hpv_apply_adam(h))) return rc;
-        }
+        for (int it = 0; it < n_iters; ++it)
+            if ((rc = enqueue_pass(h, true, true))) return rc;
     }
     if (loss3_after) {
         if ((rc = enqueue_pass(h, false))) return rc;

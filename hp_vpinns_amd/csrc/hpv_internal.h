@@ -50,6 +50,11 @@ static inline size_t hpv_proj_lds_bytes(const ProjDesc& pd) {
            sizeof(double);
 }
 
+struct AdamArgs {
+    double *theta, *m, *v, *state;   // theta == nullptr: no update
+    double lr, b1, b2, eps;
+};
+
 // ---- kernel launchers (kernels_generic.hip) ----
 void launch_mlp_fwd_generic(const NetDesc& nd, const double* theta, const double* X, double* ACT, double* OUT, long N,
                             int save_act, hipStream_t s);
@@ -65,9 +70,9 @@ void launch_data_loss(const double* U, const double* Ud, double* GBAR, double sc
 void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, int rows_b, const double* GPART_e,
                      int rows_e, const double* loss_e, long n_elem, const double* deps_e, const double* data_part,
                      int n_data_part, double lossb_weight, int n_data, int P, int has_eps, double* RB, int write_grad,
-                     hipStream_t s);
-void launch_adam(double* theta, double* m, double* v, const double* RB, double* state, int Ptot, double lr, double b1,
-                 double b2, double eps, hipStream_t s);
+                     const AdamArgs* fused_adam, hipStream_t s);
+void launch_adam(const AdamArgs& ad, const double* RB, int P, int Ptot, hipStream_t s);
+int adam_state_doubles(int P);
 void launch_debug_act(int act, const double* x, int n, double* a, double* a1, double* ref, hipStream_t s);
 bool launch_project_tp(const ProjDesc& pd, const double* OUT, double* GBAR, double* R, const double* F, const double* coef,
                        long coef_stride, const double* wtx, const double* wty, const double* eps_ptr, double* loss_e,

@@ -10,7 +10,18 @@ struct HpvMfma;
 HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why);
 void hpv_mfma_destroy(HpvMfma* m);
 int hpv_mfma_grad_rows(HpvMfma* m);
-void hpv_mfma_forward(HpvMfma* m, const double* theta, const double* X, double* OUT, int save_act, hipStream_t s);
+// Boundary/data term evaluated inside the forward kernel for the data tiles of a merged batch.
+struct MfmaDataTerm {
+    long data_off;        // first data point (multiple of 16)
+    int n_data;
+    const double* ud;
+    double* gbar0;
+    double* data_part;    // one partial per data tile
+    double scale;         // -2 w / n_data
+    int write_gbar;
+};
+void hpv_mfma_forward(HpvMfma* m, const double* theta, const double* X, double* OUT, int save_act, hipStream_t s,
+                      const MfmaDataTerm* dt = nullptr);
 void hpv_mfma_backward(HpvMfma* m, const double* theta, const double* X, const double* GBAR, double* GPART, int* rows,
                        hipStream_t s);
 bool hpv_mfma_has_projection(HpvMfma* m);

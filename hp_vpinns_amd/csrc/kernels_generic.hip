@@ -456,6 +456,20 @@ void launch_data_loss(const double* U, const double* Ud, double* GBAR, double sc
 // Finalize: fixed-order sums of all partials into the packed reduce buffer
 //   RB = [grad (P) | (d eps) | lossv | w*lossb | mean-square of the data term | pad]
 // ------------------------------------------------------------------------------------------------
+// TF1 AdamOptimizer rule (tf.train.AdamOptimizer(LR).minimize, P1:103-104), one parameter:
+//   lr_t = lr sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; theta -= lr_t m/(sqrt(v)+eps)
+// (eps OUTSIDE the bias correction, unlike torch.optim.Adam).  b1^t, b2^t are running products like TF's
+// beta*_power variables; they are kept REPLICATED -- state[0..1] for the scalar block / k_adam and one copy per
+// gradient block of the fused finalize+Adam kernel -- so that no block reads a value another block updates.
+__device__ __forceinline__ void adam_update(const AdamArgs& ad, int i, double g, double b1p, double b2p) {
+    const double lr_t = ad.lr * sqrt(1.0 - b2p) / (1.0 - b1p);
+    const double mi = ad.b1 * ad.m[i] + (1.0 - ad.b1) * g;
+    const double vi = ad.b2 * ad.v[i] + (1.0 - ad.b2) * g * g;
+    ad.m[i] = mi;
+    ad.v[i] = vi;
+    ad.theta[i] -= lr_t * mi / (sqrt(vi) + ad.eps);
+}
+
 #define FIN_THREADS 1024
 #define FIN_PARTS (FIN_THREADS / 64)
 __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restrict__ GPART_v, int rows_v,
@@ -465,7 +479,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
                                                          const double* __restrict__ deps_e,
                                                          const double* __restrict__ data_part, int n_data_part,
                                                          double lossb_weight, int n_data, int P, int has_eps,
-                                                         double* __restrict__ RB, int write_grad) {
+                                                         double* __restrict__ RB, int write_grad, AdamArgs ad) {
     __shared__ double red[FIN_PARTS * 64];
     const int Ptot = P + (has_eps ? 1 : 0);
     if (blockIdx.x < gridDim.x - 1) {
@@ -486,6 +500,14 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
 #pragma unroll
             for (int k = 0; k < FIN_PARTS; ++k) t += red[k * 64 + c];
             RB[idx] = t;
+            if (ad.theta) adam_update(ad, idx, t, ad.state[2 * (blockIdx.x + 1)], ad.state[2 * (blockIdx.x + 1) + 1]);
+        }
+        if (ad.theta) {   // this block's private copy of the running beta powers (no cross-block race)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                ad.state[2 * (blockIdx.x + 1)] *= ad.b1;
+                ad.state[2 * (blockIdx.x + 1) + 1] *= ad.b2;
+            }
         }
         return;
     }
@@ -495,13 +517,18 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
         lv += loss_e[e];
         if (has_eps && deps_e) de += deps_e[e];
     }
+    double sq = 0.0;
+    for (int i = threadIdx.x; i < n_data_part; i += blockDim.x) sq += data_part[i];
     lv = block_sum(lv, red);
     de = block_sum(de, red);
+    sq = block_sum(sq, red);
     if (threadIdx.x == 0) {
-        double sq = 0.0;
-        for (int i = 0; i < n_data_part; ++i) sq += data_part[i];
         const double msq = n_data > 0 ? sq / (double)n_data : 0.0;
-        if (has_eps && write_grad) RB[P] = de;
+        if (has_eps && write_grad) {
+            RB[P] = de;
+            if (ad.theta) adam_update(ad, P, de, ad.state[0], ad.state[1]);   // the trainable epsilon (P3:63)
+        }
+        if (ad.theta) { ad.state[0] *= ad.b1; ad.state[1] *= ad.b2; }
         RB[Ptot + 0] = lv;
         RB[Ptot + 1] = lossb_weight * msq;
         RB[Ptot + 2] = msq;
@@ -512,12 +539,15 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
 void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, int rows_b, const double* GPART_e,
                      int rows_e, const double* loss_e, long n_elem, const double* deps_e, const double* data_part,
                      int n_data_part, double lossb_weight, int n_data, int P, int has_eps, double* RB, int write_grad,
-                     hipStream_t s) {
+                     const AdamArgs* fused_adam, hipStream_t s) {
     int gblocks = (P + 63) / 64;
+    AdamArgs ad{};
+    if (fused_adam && write_grad) ad = *fused_adam;
     hipLaunchKernelGGL(k_finalize, dim3(gblocks + 1), dim3(FIN_THREADS), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e,
                        rows_e, loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB,
-                       write_grad);
+                       write_grad, ad);
 }
+int adam_state_doubles(int P) { return 2 * ((P + 63) / 64 + 1); }
 
 // ------------------------------------------------------------------------------------------------
 // TF1 AdamOptimizer update (tf.train.AdamOptimizer(LR).minimize, P1:103-104):
@@ -525,29 +555,18 @@ void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, i
 //   theta -= lr_t m / (sqrt(v) + eps)      -- eps OUTSIDE the bias correction, unlike torch.optim.Adam.
 // state = {beta1^t, beta2^t} kept as running products exactly like TF's beta*_power variables.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_adam(double* __restrict__ theta, double* __restrict__ m, double* __restrict__ v,
-                                              const double* __restrict__ g, double* __restrict__ state, int Ptot,
-                                              double lr, double b1, double b2, double eps) {
-    const double b1p = state[0], b2p = state[1];
-    const double lr_t = lr * sqrt(1.0 - b2p) / (1.0 - b1p);
-    for (int i = threadIdx.x; i < Ptot; i += blockDim.x) {
-        const double gi = g[i];
-        const double mi = b1 * m[i] + (1.0 - b1) * gi;
-        const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        theta[i] -= lr_t * mi / (sqrt(vi) + eps);
-    }
+__global__ void __launch_bounds__(1024) k_adam(AdamArgs ad, const double* __restrict__ g, int Ptot, int ncopies) {
+    const double b1p = ad.state[0], b2p = ad.state[1];
+    for (int i = threadIdx.x; i < Ptot; i += blockDim.x) adam_update(ad, i, g[i], b1p, b2p);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        state[0] = b1p * b1;
-        state[1] = b2p * b2;
+    for (int c = threadIdx.x; c < ncopies; c += blockDim.x) {   // advance every replicated copy
+        ad.state[2 * c] *= ad.b1;
+        ad.state[2 * c + 1] *= ad.b2;
     }
 }
 
-void launch_adam(double* theta, double* m, double* v, const double* RB, double* state, int Ptot, double lr, double b1,
-                 double b2, double eps, hipStream_t s) {
-    hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, s, theta, m, v, RB, state, Ptot, lr, b1, b2, eps);
+void launch_adam(const AdamArgs& ad, const double* RB, int P, int Ptot, hipStream_t s) {
+    hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, s, ad, RB, Ptot, adam_state_doubles(P) / 2);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -41,6 +41,13 @@ struct MfmaArgs {
     int t1dim[2];
     int t2idx[2];
     int P;
+    // boundary/data term folded into the forward kernel (tiles at and beyond data_off; -1: none)
+    long data_off;
+    const double* ud;     // [n_data] target values
+    double* gbar0;        // adjoint row of the value channel (written when data_write_gbar)
+    double* data_part;    // [data tiles] partial sums of (u_d - u)^2
+    double data_scale;    // -2 w / n_data
+    int data_write_gbar;
 };
 
 struct HpvMfma {
@@ -220,6 +227,20 @@ __global__ void __launch_bounds__(MF_BLOCK, 3) k_fwd_mfma(MfmaArgs g) {
             v += __shfl_xor(v, 32, 64);
             if (ch == 0) v += bo;
             if (q == 0 && valid) g.OUT[(long)ch * g.N + p] = v;
+            if (ch == 0 && g.data_off >= 0 && tile * 16 >= g.data_off) {
+                // lossb = w mean((u_d - u)^2) (P1:98, P2:122, P3:184): adjoint + per-tile partial sum, no extra launch
+                double dd = 0.0;
+                if (q == 0 && valid) {
+                    dd = g.ud[p - g.data_off] - v;
+                    if (g.data_write_gbar) g.gbar0[p] = g.data_scale * dd;
+                }
+                double sq = dd * dd;
+                sq += __shfl_xor(sq, 1, 64);
+                sq += __shfl_xor(sq, 2, 64);
+                sq += __shfl_xor(sq, 4, 64);
+                sq += __shfl_xor(sq, 8, 64);
+                if (lane == 0) g.data_part[tile - g.data_off / 16] = sq;
+            }
         }
     }
 }
@@ -643,9 +664,15 @@ void hpv_mfma_destroy(HpvMfma* m) {
 
 int hpv_mfma_grad_rows(HpvMfma* m) { return m->bwd_blocks; }
 
-void hpv_mfma_forward(HpvMfma* m, const double* theta, const double* X, double* OUT, int save_act, hipStream_t s) {
+void hpv_mfma_forward(HpvMfma* m, const double* theta, const double* X, double* OUT, int save_act, hipStream_t s,
+                      const MfmaDataTerm* dt) {
     MfmaArgs a = m->base;
     a.theta = theta; a.X = X; a.OUT = OUT; a.save_act = save_act;
+    a.data_off = -1;
+    if (dt && dt->n_data > 0) {
+        a.data_off = dt->data_off; a.ud = dt->ud; a.gbar0 = dt->gbar0; a.data_part = dt->data_part;
+        a.data_scale = dt->scale; a.data_write_gbar = dt->write_gbar;
+    }
     m->fwd(a, m->fwd_blocks, s);
 }
 
