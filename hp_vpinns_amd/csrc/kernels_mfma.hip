@@ -87,6 +87,17 @@ __device__ __forceinline__ void act_saved(double a, double a1s, double& a1, doub
     }
 }
 
+// Lane (q, pt) holds 4 partial sums p[a] (a = 0..3), partial over its own 5 of the 20 contraction indices.
+// Returns sum over the 4 q-lanes of p[a = q]: a two-round reduce-scatter over lanes l^32 and l^16
+// (3 cross-lane moves instead of the 8 of an all-reduce).  Used for output neurons 16..19, which would
+// otherwise occupy a second, 3/4-empty 16-row MFMA tile.
+__device__ __forceinline__ double reduce_scatter_q(const double (&p)[4], int lane) {
+    const bool hi = (lane & 32) != 0, lo = (lane & 16) != 0;
+    const double kA = (hi ? p[2] : p[0]) + __shfl_xor(hi ? p[0] : p[2], 32, 64);
+    const double kB = (hi ? p[3] : p[1]) + __shfl_xor(hi ? p[1] : p[3], 32, 64);
+    return (lo ? kB : kA) + __shfl_xor(lo ? kA : kB, 16, 64);
+}
+
 template <int ACT, int NT1, int NT2>
 struct SlotCount {
     static constexpr int value = 1 + (ACT == HPV_ACT_SIN ? 1 : 0) + NT1 + NT2;
@@ -96,7 +107,7 @@ struct SlotCount {
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int D, int NT1, int NT2, int ACT, int L>
-__global__ void __launch_bounds__(MF_BLOCK, 3) k_fwd_mfma(MfmaArgs g) {
+__global__ void __launch_bounds__(MF_BLOCK, 2) k_fwd_mfma(MfmaArgs g) {
     constexpr int C = 1 + NT1 + NT2;
     constexpr int NS = SlotCount<ACT, NT1, NT2>::value;
     constexpr int SA1 = 1;                                   // slot of A1 (sin only)
@@ -121,12 +132,20 @@ __global__ void __launch_bounds__(MF_BLOCK, 3) k_fwd_mfma(MfmaArgs g) {
     // A-operand fragments W^T[out = 16t+pt][in = 4s+q] and bias fragments of the hidden->hidden layers live in
     // LDS, lane-major (conflict-free ds_read_b64), shared by the block's waves: frees ~60 VGPRs per wave
     extern __shared__ __attribute__((aligned(16))) double fl[];
-    double* WT = fl;                                   // [(L-1)][2][MF_KS][64]
-    double* BH = fl + (L > 1 ? L - 1 : 0) * 2 * MF_KS * 64;   // [(L-1)][MF_KS][64]
-    for (int f = threadIdx.x; f < (L - 1) * 2 * MF_KS * 64; f += MF_BLOCK) {
-        const int ln = f & 63, s_ = (f >> 6) % MF_KS, t_ = (f / (64 * MF_KS)) & 1, i_ = f / (64 * MF_KS * 2) + 1;
-        const int out = 16 * t_ + (ln & 15);
-        WT[f] = (out < MF_H) ? th[g.woff[i_] + (4 * s_ + (ln >> 4)) * MF_H + out] : 0.0;
+    // Output neurons 0..15 go through one 16-row MFMA tile; neurons 16..19 (the would-be second tile, 3/4
+    // padding) are computed on the VALU from WR = W[in = 4s+q][16+a] plus a 3-move reduce-scatter.  fp64 MFMA
+    // and fp64 VALU share one execution resource on gfx950 (measured: no additive throughput), so dropping
+    // the padded tile is a net saving of FP64 issue slots.
+    double* WT = fl;                                   // [(L-1)][MF_KS][64]
+    double* BH = fl + (L > 1 ? L - 1 : 0) * MF_KS * 64;       // [(L-1)][MF_KS][64]
+    double* WR = BH + (L > 1 ? L - 1 : 0) * MF_KS * 64;       // [(L-1)][MF_KS][4 (q)][4 (a)]
+    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += MF_BLOCK) {
+        const int ln = f & 63, s_ = (f >> 6) % MF_KS, i_ = f / (64 * MF_KS) + 1;
+        WT[f] = th[g.woff[i_] + (4 * s_ + (ln >> 4)) * MF_H + (ln & 15)];
+    }
+    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 16; f += MF_BLOCK) {
+        const int a_ = f & 3, q_ = (f >> 2) & 3, s_ = (f >> 4) % MF_KS, i_ = f / (16 * MF_KS) + 1;
+        WR[f] = th[g.woff[i_] + (4 * s_ + q_) * MF_H + 16 + a_];
     }
     for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += MF_BLOCK) {
         const int ln = f & 63, s_ = (f >> 6) % MF_KS, i_ = f / (64 * MF_KS) + 1;
@@ -170,32 +189,41 @@ __global__ void __launch_bounds__(MF_BLOCK, 3) k_fwd_mfma(MfmaArgs g) {
         // ---- hidden -> hidden layers (MFMA) ----
 #pragma unroll
         for (int i = 1; i < L; ++i) {
-            v4d acc[C][2];
+            v4d acc[C];
+            const double* bhl = BH + (i - 1) * MF_KS * 64 + lofs;
 #pragma unroll
-            for (int ch = 0; ch < C; ++ch) {
-                if (ch == 0) {
-                    const double* bhl = BH + (i - 1) * MF_KS * 64 + lofs;
-                    acc[0][0] = v4d{bhl[0], bhl[64], bhl[128], bhl[192]};
-                    acc[0][1] = v4d{bhl[256], 0.0, 0.0, 0.0};
-                } else {
-                    acc[ch][0] = v4d{0.0, 0.0, 0.0, 0.0};
-                    acc[ch][1] = v4d{0.0, 0.0, 0.0, 0.0};
-                }
-            }
+            for (int ch = 0; ch < C; ++ch)
+                acc[ch] = (ch == 0) ? v4d{bhl[0], bhl[64], bhl[128], bhl[192]} : v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < MF_KS; ++s)
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch)
+                    acc[ch] = __builtin_amdgcn_mfma_f64_16x16x4f64(WT[((i - 1) * MF_KS + s) * 64 + lofs], h[ch][s], acc[ch], 0, 0, 0);
+            // neurons 16..19 on the VALU
+            double z16[C];
+            {
+                double wr[MF_KS][4];
+                const double* wrl = WR + (i - 1) * MF_KS * 16 + (lofs >> 4) * 4;
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        acc[ch][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(WT[(((i - 1) * 2 + t) * MF_KS + s) * 64 + lofs], h[ch][s],
-                                                                          acc[ch][t], 0, 0, 0);
+                for (int s = 0; s < MF_KS; ++s)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) wr[s][a] = wrl[s * 16 + a];
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    double pa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) pa[a] = fma(wr[s][a], h[ch][s], pa[a]);
+                    z16[ch] = reduce_scatter_q(pa, lane);
+                }
+                z16[0] += bhl[256];
+            }
             double* svl = sv + (long)i * (NS * MF_KS * 64);
 #pragma unroll
             for (int s = 0; s < MF_KS; ++s) {
-                const int t = s >> 2, r = s & 3;
                 double a, a1, a2;
-                act_fwd<ACT>(acc[0][t][r], a, a1, a2);
+                act_fwd<ACT>(s < 4 ? acc[0][s & 3] : z16[0], a, a1, a2);
                 h[0][s] = a;
                 if (g.save_act) {
                     svl[(0 * MF_KS + s) * 64] = a;
@@ -204,13 +232,13 @@ __global__ void __launch_bounds__(MF_BLOCK, 3) k_fwd_mfma(MfmaArgs g) {
                 double zc[NT1 > 0 ? NT1 : 1];
 #pragma unroll
                 for (int u = 0; u < NT1; ++u) {
-                    zc[u] = acc[1 + u][t][r];
+                    zc[u] = s < 4 ? acc[1 + u][s & 3] : z16[1 + u];
                     if (g.save_act) svl[((SZC + u) * MF_KS + s) * 64] = zc[u];
                     h[1 + u][s] = a1 * zc[u];
                 }
 #pragma unroll
                 for (int b = 0; b < NT2; ++b) {
-                    const double zcc = acc[1 + NT1 + b][t][r];
+                    const double zcc = s < 4 ? acc[1 + NT1 + b][s & 3] : z16[1 + NT1 + b];
                     const double z1 = zc[b < NT1 ? b : 0];
                     if (g.save_act) svl[((SZCC + b) * MF_KS + s) * 64] = zcc;
                     h[1 + NT1 + b][s] = a2 * z1 * z1 + a1 * zcc;
@@ -296,7 +324,8 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
     double* TA = lds + wv * (2 * MF_H * MF_LD);   // per-wave transpose tiles
     double* TB = TA + MF_H * MF_LD;
     const int regA = REGION_A > MF_WAVES * g.P ? REGION_A : MF_WAVES * g.P;
-    double* WN = lds + regA;                      // [(L-1)][2][MF_KS][64]
+    double* WN = lds + regA;                      // [(L-1)][MF_KS][64]  A fragments W[in = pt][out = 4s+q], rows 0..15
+    double* WRB = WN + (L > 1 ? L - 1 : 0) * MF_KS * 64;   // [(L-1)][MF_KS][4 (q)][4 (a)]  W[in = 16+a][out = 4s+q]
 
     // per-lane weight fragments
     double w1[D][MF_KS], wo[MF_KS];
@@ -309,10 +338,13 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
     }
     // A operand of hbar_in^T = W zbar^T : W[in = 16t+pt][out = 4s+q], kept in LDS (not registers) so that
     // two waves per SIMD fit; every wave of the block reads the same lane-major fragments, conflict-free
-    for (int f = threadIdx.x; f < (L - 1) * 2 * MF_KS * 64; f += MF_BLOCK) {
-        const int ln = f & 63, s_ = (f >> 6) % MF_KS, t_ = (f / (64 * MF_KS)) & 1, i_ = f / (64 * MF_KS * 2) + 1;
-        const int in = 16 * t_ + (ln & 15);
-        WN[f] = (in < MF_H) ? th[g.woff[i_] + in * MF_H + 4 * s_ + (ln >> 4)] : 0.0;
+    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += MF_BLOCK) {
+        const int ln = f & 63, s_ = (f >> 6) % MF_KS, i_ = f / (64 * MF_KS) + 1;
+        WN[f] = th[g.woff[i_] + (ln & 15) * MF_H + 4 * s_ + (ln >> 4)];
+    }
+    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 16; f += MF_BLOCK) {
+        const int a_ = f & 3, q_ = (f >> 2) & 3, s_ = (f >> 4) % MF_KS, i_ = f / (16 * MF_KS) + 1;
+        WRB[f] = th[g.woff[i_] + (16 + a_) * MF_H + 4 * s_ + q_];
     }
     __syncthreads();
     double zc1[(NT1 > 0 ? NT1 : 1) * MF_KS];   // z_c of layer 1 = W1[c,:]
@@ -329,6 +361,11 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) dWacc[i][a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+    double accC[LH][4];   // corner dW[16+q][16+a] on the VALU (per-lane partial over the point slot)
+#pragma unroll
+    for (int i = 0; i < LH; ++i)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) accC[i][a] = 0.0;
     double db[L][MF_KS], dW1[D][MF_KS], dWo[MF_KS], dbo = 0.0;
 #pragma unroll
     for (int s = 0; s < MF_KS; ++s) {
@@ -473,21 +510,29 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
                         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                             for (int to = 0; to < 2; ++to)
-                                dWacc[i - 1][ti][to] =
-                                    __builtin_amdgcn_mfma_f64_16x16x4f64(aF[ti][kk], bF[to][kk], dWacc[i - 1][ti][to], 0, 0, 0);
+                                if (!(ti == 1 && to == 1))   // the 4x4 corner tile is 15/16 padding: VALU below
+                                    dWacc[i - 1][ti][to] =
+                                        __builtin_amdgcn_mfma_f64_16x16x4f64(aF[ti][kk], bF[to][kk], dWacc[i - 1][ti][to], 0, 0, 0);
+                    // corner dW[16+q][16+a] += h_in[pt][16+q] * zbar[pt][16+a]: all-gather zbar over the q lanes
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        accC[i - 1][a] = fma(hv[4], __shfl(zbar[ch][4], a * 16 + pt, 64), accC[i - 1][a]);
                 }
                 // hbar_in^T = W zbar^T
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) {
-                    v4d acc[2] = {v4d{0.0, 0.0, 0.0, 0.0}, v4d{0.0, 0.0, 0.0, 0.0}};
+                    v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
+                    double pa[4] = {0.0, 0.0, 0.0, 0.0};
+                    const double* wrl = WRB + (i - 1) * MF_KS * 16 + q * 4;
 #pragma unroll
-                    for (int s = 0; s < MF_KS; ++s)
+                    for (int s = 0; s < MF_KS; ++s) {
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(WN[((i - 1) * MF_KS + s) * 64 + lane], zbar[ch][s], acc, 0, 0, 0);
 #pragma unroll
-                        for (int t = 0; t < 2; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(WN[(((i - 1) * 2 + t) * MF_KS + s) * 64 + lane],
-                                                                          zbar[ch][s], acc[t], 0, 0, 0);
+                        for (int a = 0; a < 4; ++a) pa[a] = fma(wrl[s * 16 + a], zbar[ch][s], pa[a]);   // inputs 16..19: VALU
+                    }
 #pragma unroll
-                    for (int s = 0; s < MF_KS; ++s) hbar[ch][s] = acc[s >> 2][s & 3];
+                    for (int s = 0; s < 4; ++s) hbar[ch][s] = acc[s];
+                    hbar[ch][4] = reduce_scatter_q(pa, lane);
                 }
                 cur = prev;
             }
@@ -517,8 +562,19 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int in = 16 * ti + 4 * r + q, out = 16 * to + pt;
-                    if (in < MF_H && out < MF_H) WP[g.woff[i] + in * MF_H + out] = dWacc[i - 1][ti][to][r];
+                    if (in < MF_H && out < MF_H && !(ti == 1 && to == 1)) WP[g.woff[i] + in * MF_H + out] = dWacc[i - 1][ti][to][r];
                 }
+#pragma unroll
+    for (int i = 1; i < L; ++i)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            double t = accC[i - 1][a];
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 4, 64);
+            t += __shfl_xor(t, 8, 64);
+            if (pt == 0) WP[g.woff[i] + (16 + q) * MF_H + 16 + a] = t;
+        }
     // per-lane partials: reduce over the 16 point lanes of each neuron group
 #pragma unroll
     for (int s = 0; s < MF_KS; ++s) {
@@ -568,11 +624,11 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static size_t fwd_lds_bytes(int L) { return (size_t)(L > 1 ? L - 1 : 0) * 3 * MF_KS * 64 * sizeof(double); }
+static size_t fwd_lds_bytes(int L) { return (size_t)(L > 1 ? L - 1 : 0) * (2 * MF_KS * 64 + MF_KS * 16) * sizeof(double); }
 static size_t bwd_lds_bytes(int P, int L) {
     size_t regA = (size_t)MF_WAVES * 2 * MF_H * MF_LD;
     if ((size_t)MF_WAVES * P > regA) regA = (size_t)MF_WAVES * P;
-    return (regA + (size_t)(L > 1 ? L - 1 : 0) * 2 * MF_KS * 64) * sizeof(double);
+    return (regA + (size_t)(L > 1 ? L - 1 : 0) * (MF_KS * 64 + MF_KS * 16)) * sizeof(double);
 }
 
 template <int D, int NT1, int NT2, int ACT, int L>
