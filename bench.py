@@ -120,6 +120,14 @@ def main():
             dist.destroy_process_group()
         return
 
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json,
+    # produced by scripts/gpu_round.sh on this hardware; FETCH_SIZE corrected x2 as the microarch guide says)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            traffic_tab = json.load(f)
+    except Exception:
+        traffic_tab = {}
     N_local = (model.Nelementx * model.Nelementy * 400) // world  # points per rank
     C, G = 3, gemm_flops_per_row(LAYERS)
     flops = {"mlp_fwd": C * G * N_local, "mlp_bwd": 2 * C * G * N_local}
@@ -136,8 +144,12 @@ def main():
         "loss_after": float(loss3[0]),
         "kernel_ms": ktime,
         "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                     "frac": ach / PEAK_FP64_TFLOPS, "traffic": None,
-                     "flops_per_launch": flops[dom], "avg_ms": ktime[dom]},
+                     "frac": ach / PEAK_FP64_TFLOPS,
+                     "traffic": traffic_tab.get(dom) if world == 1 else None,
+                     "flops_per_launch": flops[dom], "avg_ms": ktime[dom],
+                     "note": "algorithmic fp64 flops of the layer products (2*C*G*N, C=3 channels, G=1720/row) / hipEvent "
+                             "kernel time; peak = fp64 datasheet (matrix = vector on MI355X); measured ubench ceilings on "
+                             "this chip: 47 TFLOP/s v_mfma_f64_16x16x4, 62 TFLOP/s v_fma_f64, not additive"},
     }
     if world == 1 and not args.no_residual_roofline:
         # the per-element projection (residual + adjoint) kernel on a batch larger than the 256 MB
@@ -145,7 +157,8 @@ def main():
         ms, by = model.h.bench_projection(args.residual_elems, 5)
         gbs = by / (ms * 1e-3) / 1e9
         out["roofline_residual"] = {"kernel": "project (residual+adjoint)", "bound": "hbm", "achieved": gbs,
-                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                    "traffic": traffic_tab.get("project_scaled"),
                                     "bytes_per_launch": by, "avg_ms": ms, "n_elem": args.residual_elems}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(s, theta, args.cpu_iters)

@@ -19,6 +19,11 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTI
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_proj -o proj -- python $REPO/scripts/proj_bench.py 262144 3 > $OUT/pmc_fetch_proj.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_proj -o proj -- python $REPO/scripts/proj_bench.py 262144 3 > $OUT/pmc_write_proj.log 2>&1
 cd $REPO
-python scripts/summarize_profiles.py $OUT > $OUT/summary.md 2>&1; cat $OUT/summary.md
+python scripts/summarize_profiles.py $OUT > $OUT/summary.md 2>&1
+echo >> $OUT/summary.md; echo "### iterations/sec of the five BASELINE configs (1 GPU)" >> $OUT/summary.md; echo >> $OUT/summary.md
+python scripts/config_bench.py 2>/dev/null | grep "^|" >> $OUT/summary.md
+echo >> $OUT/summary.md; echo "### fp64 ubench ceilings on this box" >> $OUT/summary.md; echo >> $OUT/summary.md
+echo '```' >> $OUT/summary.md; ./scripts/mfma_f64_peak.bin 2>/dev/null | grep -E "waves/SIMD=2 nacc=8|v_fma_f64 waves/SIMD=2" >> $OUT/summary.md; ./scripts/mix_f64.bin 2>/dev/null >> $OUT/summary.md; echo '```' >> $OUT/summary.md
+cat $OUT/summary.md
 # keep only the small summaries (the traces are large)
 find $OUT -name "*kernel_trace.csv" -size +2M -delete

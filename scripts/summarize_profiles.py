@@ -56,3 +56,20 @@ if sq:
     for k, v in sq.items():
         if v.get("SQ_WAVE_CYCLES", 0) > 1e4:
             print(f"| `{k}` | " + " | ".join(f"{v.get(c, 0):.3g}" for c in cols) + " |")
+
+# machine-readable HBM bytes per launch (corrected) for bench.py's roofline.traffic
+import json
+tj = {}
+fe, wr = pmc("pmc_fetch"), pmc("pmc_write")
+for k in set(fe) | set(wr):
+    b = (2 * fe.get(k, {}).get("FETCH_SIZE", 0.0) + wr.get(k, {}).get("WRITE_SIZE", 0.0)) * 1024
+    if "k_bwd_mfma" in k: tj["mlp_bwd"] = b
+    if "k_fwd_mfma" in k: tj["mlp_fwd"] = b
+    if "k_project" in k: tj["project"] = b
+fe, wr = pmc("pmc_fetch_proj"), pmc("pmc_write_proj")
+for k in set(fe) | set(wr):
+    if "k_project" in k:
+        tj["project_scaled"] = (2 * fe.get(k, {}).get("FETCH_SIZE", 0.0) + wr.get(k, {}).get("WRITE_SIZE", 0.0)) * 1024
+if tj:
+    with open(os.path.join(out, "traffic.json"), "w") as f:
+        json.dump(tj, f, indent=1)
