@@ -24,7 +24,8 @@ EXPORTS = [
     "hpv_set_params", "hpv_get_params", "hpv_loss_and_grad", "hpv_step", "hpv_forward_backward",
     "hpv_reduce_buffer", "hpv_apply_adam", "hpv_eval_loss", "hpv_read_loss", "hpv_sync",
     "hpv_predict", "hpv_get_residuals", "hpv_backend_in_use", "hpv_enable_timing",
-    "hpv_kernel_time_ms", "hpv_bench_projection", "hpv_debug_activation",
+    "hpv_kernel_time_ms", "hpv_bench_projection", "hpv_debug_activation", "hpv_get_state", "hpv_set_state",
+    "hpv_assemble_rhs",
 ]
 
 
@@ -90,6 +91,9 @@ def load():
     lib.hpv_kernel_time_ms.argtypes = [h, C.c_int, _dp, C.POINTER(C.c_long)]
     lib.hpv_bench_projection.argtypes = [h, C.c_long, C.c_int, _dp, _dp]
     lib.hpv_debug_activation.argtypes = [h, _dp, C.c_int, _dp, _dp, _dp]
+    lib.hpv_get_state.argtypes = [h, _dp, C.c_size_t]
+    lib.hpv_set_state.argtypes = [h, _dp, C.c_size_t]
+    lib.hpv_assemble_rhs.argtypes = [h, _dp, C.c_size_t, _dp, C.c_size_t]
     _lib = lib
     return lib
 
@@ -251,6 +255,21 @@ class Handle:
         ms, n = C.c_double(), C.c_long()
         self._chk(self.lib.hpv_kernel_time_ms(self._h, int(which), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def get_state(self):
+        out = np.empty(3 * self.num_params() + 2)
+        self._chk(self.lib.hpv_get_state(self._h, _p(out), out.size))
+        return out
+
+    def set_state(self, state):
+        state = _c(state).reshape(-1)
+        self._chk(self.lib.hpv_set_state(self._h, _p(state), state.size))
+
+    def assemble_rhs(self, f_quad, n_out):
+        f_quad = _c(f_quad).reshape(-1)
+        out = np.empty(int(n_out))
+        self._chk(self.lib.hpv_assemble_rhs(self._h, _p(f_quad), f_quad.size, _p(out), out.size))
+        return out
 
     def debug_activation(self, x):
         x = _c(x).reshape(-1)

@@ -76,6 +76,8 @@ struct hpv_ctx {
     HpvMfma* mfma = nullptr;
     HpvMfma* mfma_data = nullptr;
     HpvMfma* mfma_edge = nullptr;
+    HpvMfma* mfma_pred = nullptr;
+    double* d_jac = nullptr;   // |J_e| of the owned elements (RHS assembly, hpv_assemble_rhs)
     // timing
     bool timing = false;
     TimerClass timers[3];
@@ -488,6 +490,8 @@ void hpv_destroy(hpv_handle h) {
     if (h->mfma) hpv_mfma_destroy(h->mfma);
     if (h->mfma_data) hpv_mfma_destroy(h->mfma_data);
     if (h->mfma_edge) hpv_mfma_destroy(h->mfma_edge);
+    if (h->mfma_pred) hpv_mfma_destroy(h->mfma_pred);
+    if (h->d_jac) (void)hipFree(h->d_jac);
     free_batch(h->var); free_batch(h->data); free_batch(h->edge); free_batch(h->pred);
     double* ptrs[] = {h->d_wtx, h->d_wty, h->d_edge_dphi, h->d_coef, h->d_edge_coef, h->d_F, h->d_R, h->d_loss_e,
                       h->d_deps_e, h->d_udata, h->d_data_part, h->d_theta, h->d_m, h->d_v, h->d_state, h->d_RB};
@@ -575,7 +579,7 @@ int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* g
     int rc;
     h->Nq = N;
     const int nterms = h->pd.nterms;
-    std::vector<double> X((size_t)h->dim * N), coef((size_t)nterms * ne), ecoef((size_t)ne), EX((size_t)2 * ne);
+    std::vector<double> X((size_t)h->dim * N), coef((size_t)nterms * ne), ecoef((size_t)ne), EX((size_t)2 * ne), jac((size_t)ne);
     for (long le = 0; le < ne; ++le) {
         const int e = e_begin + (int)le;
         const int ex = e / ney, ey = e % ney;
@@ -590,6 +594,7 @@ int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* g
                 if (h->dim == 2) X[(size_t)N + p] = gy0 + (gy1 - gy0) / 2 * (h->yi[j] + 1);
             }
         const double Jx = (gx1 - gx0) / 2;
+        jac[le] = (h->dim == 1) ? Jx : ((gx1 - gx0) / 2) * ((gy1 - gy0) / 2);   // P1:276 / P2:393
         if (h->cfg.pde == HPV_PDE_POISSON1D) {
             const double J = Jx;                                     // P1:71
             if (h->cfg.var_form == 1) coef[le] = -J;
@@ -608,6 +613,8 @@ int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* g
         }
     }
     if ((rc = dalloc(h, &h->d_coef, coef.size()))) return rc;
+    if ((rc = dalloc(h, &h->d_jac, jac.size()))) return rc;
+    if (ne > 0 && (rc = upload(h, h->d_jac, jac.data(), jac.size()))) return rc;
     if ((rc = dalloc(h, &h->d_R, (size_t)ne * h->ntx * h->nty))) return rc;
     if ((rc = dalloc(h, &h->d_loss_e, (size_t)ne))) return rc;
     if ((rc = dalloc(h, &h->d_deps_e, (size_t)ne))) return rc;
@@ -762,13 +769,76 @@ int hpv_predict(hpv_handle h, const double* X, int n, double* u_out) {
     if (n < 0 || (n > 0 && (!X || !u_out))) return fail(h, -1, "bad predict arguments");
     if (n == 0) return 0;
     int rc;
-    if (h->pred.N != n) { if ((rc = alloc_batch(h, h->pred, h->nd_val, n, false))) return rc; }
+    if (h->pred.N != n) {
+        if ((rc = alloc_batch(h, h->pred, h->nd_val, n, false))) return rc;
+        if (h->mfma_pred) { hpv_mfma_destroy(h->mfma_pred); h->mfma_pred = nullptr; }
+        if (h->cfg.backend != HPV_BACKEND_GENERIC) h->mfma_pred = hpv_mfma_create(h->nd_val, n, nullptr, false);
+    }
     if ((rc = upload_points(h, h->pred, X, n, h->dim))) return rc;
-    launch_mlp_fwd_generic(h->pred.nd, h->d_theta, h->pred.X, nullptr, h->pred.OUT, n, 0, h->stream);
+    if (h->mfma_pred) hpv_mfma_forward(h->mfma_pred, h->d_theta, h->pred.X, h->pred.OUT, 0, h->stream);
+    else launch_mlp_fwd_generic(h->pred.nd, h->d_theta, h->pred.X, nullptr, h->pred.OUT, n, 0, h->stream);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(u_out, h->pred.OUT, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
+}
+
+// [theta | m | v | beta1^t | beta2^t]: everything a bit-exact resume needs.
+int hpv_get_state(hpv_handle h, double* buf, size_t n) {
+    if (!h || !buf) return -1;
+    const size_t P = (size_t)h->Ptot;
+    if (n != 3 * P + 2) return fail(h, -1, "state buffer has %zu entries, expected %zu", n, 3 * P + 2);
+    HIPCHK(h, hipMemcpyAsync(buf, h->d_theta, P * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(buf + P, h->d_m, P * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(buf + 2 * P, h->d_v, P * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(buf + 3 * P, h->d_state, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int hpv_set_state(hpv_handle h, const double* buf, size_t n) {
+    if (!h || !buf) return -1;
+    const size_t P = (size_t)h->Ptot;
+    if (n != 3 * P + 2) return fail(h, -1, "state buffer has %zu entries, expected %zu", n, 3 * P + 2);
+    int rc;
+    if ((rc = upload(h, h->d_theta, buf, P))) return rc;
+    if ((rc = upload(h, h->d_m, buf + P, P))) return rc;
+    if ((rc = upload(h, h->d_v, buf + 2 * P, P))) return rc;
+    std::vector<double> st((size_t)adam_state_doubles(h->P));
+    for (size_t i = 0; i < st.size(); i += 2) { st[i] = buf[3 * P]; st[i + 1] = buf[3 * P + 1]; }
+    if ((rc = upload(h, h->d_state, st.data(), st.size()))) return rc;
+    h->have_params = true;
+    return 0;
+}
+
+// F_ext[e][k][r] = J_e sum_q w_x phi_r w_y phi_k f(x_q)  (P1:289, P2:405-407) for the owned elements, from
+// the values of f at this handle's quadrature points (element-major, q = j*qx+i): the driver-side RHS
+// assembly done by the projection kernel instead of the reference's Python loops.
+int hpv_assemble_rhs(hpv_handle h, const double* f_quad, size_t n, double* F_out, size_t n_out) {
+    if (!h || !f_quad || !F_out) return -1;
+    if (!h->have_quad || !h->have_tables || !h->have_elems) return fail(h, -3, "set quadrature, tables and elements first");
+    const long NQ = (long)h->qx * h->qy, NR = (long)h->ntx * h->nty, ne = h->n_elem;
+    if (n != (size_t)(ne * NQ) || n_out != (size_t)(ne * NR)) return fail(h, -1, "f has %zu / F has %zu entries, expected %ld / %ld", n, n_out, ne * NQ, ne * NR);
+    if (ne == 0) return 0;
+    double *d_f = nullptr, *d_F = nullptr, *d_le = nullptr;
+    int rc = 0;
+    rc |= dalloc(h, &d_f, n); rc |= dalloc(h, &d_F, n_out); rc |= dalloc(h, &d_le, (size_t)ne);
+    if (!rc) rc = upload(h, d_f, f_quad, n);
+    if (!rc) {
+        ProjDesc pd{};
+        pd.nterms = 1; pd.t[0].dx = 0; pd.t[0].dy = 0; pd.t[0].a0[0] = 1.0;
+        pd.qx = h->qx; pd.qy = h->qy; pd.ntx = h->ntx; pd.nty = h->nty; pd.C = 1;
+        if (h->cfg.backend == HPV_BACKEND_GENERIC ||
+            !launch_project_tp(pd, d_f, nullptr, d_F, nullptr, h->d_jac, ne, h->d_wtx, h->d_wty, nullptr, d_le, nullptr, ne * NQ, ne, 0, h->stream))
+            launch_project(pd, d_f, nullptr, d_F, nullptr, h->d_jac, ne, h->d_wtx, h->d_wty, nullptr, d_le, nullptr, ne * NQ, ne, 0,
+                           nullptr, nullptr, nullptr, nullptr, h->stream);
+        hipError_t e = hipMemcpyAsync(F_out, d_F, n_out * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, -2, "hpv_assemble_rhs failed: %s", hipGetErrorString(e));
+    }
+    double* ptrs[] = {d_f, d_F, d_le};
+    for (double* p : ptrs) if (p) (void)hipFree(p);
+    return rc;
 }
 
 int hpv_get_residuals(hpv_handle h, double* R, size_t n) {

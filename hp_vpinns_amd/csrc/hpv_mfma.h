@@ -7,7 +7,7 @@
 struct HpvMfma;
 
 // Returns nullptr (and a reason) when the network shape is not covered by the fast path.
-HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why);
+HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_store = true);
 void hpv_mfma_destroy(HpvMfma* m);
 int hpv_mfma_grad_rows(HpvMfma* m);
 // Boundary/data term evaluated inside the forward kernel for the data tiles of a merged batch.

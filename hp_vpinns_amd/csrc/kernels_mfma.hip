@@ -664,7 +664,7 @@ static bool pick_L(HpvMfma* m, int L) {
     }
 }
 
-HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why) {
+HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_store) {
     auto no = [&](const char* msg) -> HpvMfma* { if (why) *why = msg; return nullptr; };
     const int L = nd.nl - 1;
     if (L < 1 || L > 4) return no("1..4 hidden layers are covered");
@@ -692,9 +692,11 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why) {
         m->ns = 1 + nd.nT1 + nd.nT2;
     }
     if (!ok) { delete m; return no("channel set / activation combination not instantiated"); }
-    size_t bytes = (size_t)m->ntiles * L * m->ns * MF_KS * 64 * sizeof(double);
-    if (hipMalloc((void**)&m->ACTS, bytes) != hipSuccess) { delete m; return no("hipMalloc of the activation store failed"); }
-    (void)hipMemset(m->ACTS, 0, bytes);
+    if (need_store) {   // forward-only users (predict) run with save_act = 0 and need no activation store
+        size_t bytes = (size_t)m->ntiles * L * m->ns * MF_KS * 64 * sizeof(double);
+        if (hipMalloc((void**)&m->ACTS, bytes) != hipSuccess) { delete m; return no("hipMalloc of the activation store failed"); }
+        (void)hipMemset(m->ACTS, 0, bytes);
+    }
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -144,6 +144,22 @@ class _VPINNBase:
     def backend(self):
         return {_lib.BACKEND_GENERIC: "generic", _lib.BACKEND_MFMA: "mfma"}[self.h.backend_in_use()]
 
+    # -- evaluation & persistence around the path -----------------------------
+    def rel_l2_error(self, X, u_exact):
+        """||u_exact - u_NN||_2 / ||u_exact||_2 on the given points: the L2-error half of the metric."""
+        u_exact = np.asarray(u_exact, dtype=np.float64).reshape(-1, 1)
+        return float(np.linalg.norm(u_exact - self._predict(X), 2) / np.linalg.norm(u_exact, 2))
+
+    def save_checkpoint(self, path):
+        """Parameters + Adam moments + beta powers (.npz); the reference never saves weights."""
+        np.savez(path, state=self.h.get_state(), layers=np.asarray(self.layers), cls=type(self).__name__)
+
+    def load_checkpoint(self, path):
+        d = np.load(path, allow_pickle=False)
+        if list(d["layers"]) != list(self.layers) or str(d["cls"]) != type(self).__name__:
+            raise ValueError("checkpoint was written by a different model")
+        self.h.set_state(d["state"])
+
     def _predict(self, X):
         X = np.asarray(X, dtype=np.float64)
         return self.h.predict(X)[:, None]

@@ -110,6 +110,16 @@ int hpv_sync(hpv_handle h);
 /* u at arbitrary points: VPINN.predict (P1:197-199, P2:255-257).  X is [n][dim] row-major. */
 int hpv_predict(hpv_handle h, const double* X, int n, double* u_out);
 
+/* Checkpoint / resume (the reference never saves weights): the packed state
+ * [theta | Adam m | Adam v | beta1^t | beta2^t], 3*num_params+2 doubles; a resumed run continues bit-exactly. */
+int hpv_get_state(hpv_handle h, double* buf, size_t n);
+int hpv_set_state(hpv_handle h, const double* buf, size_t n);
+
+/* Driver-side RHS assembly on the device: F_ext[e][k][r] = J_e sum_q w phi_r phi_k f(x_q)
+ * (P1:277-291, P2:386-411) for the owned elements from f at the handle's quadrature points
+ * (element-major, q = j*qx+i, n = n_owned*qx*qy); F_out is [n_owned][nty][ntx]. */
+int hpv_assemble_rhs(hpv_handle h, const double* f_quad, size_t n, double* F_out, size_t n_out);
+
 /* Introspection for tests / benchmarks. */
 int hpv_get_residuals(hpv_handle h, double* R, size_t n);   /* R of the owned elements [ne][nty][ntx] */
 int hpv_backend_in_use(hpv_handle h);                       /* HPV_BACKEND_GENERIC or HPV_BACKEND_MFMA */

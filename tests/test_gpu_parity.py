@@ -261,3 +261,43 @@ def test_drivers_end_to_end_training_reduces_the_loss():
     assert r2["u_pred"].shape == (40401, 1)
     r3 = advdiff.run(Opt_Niter=201, Net_layer=[2, 20, 20, 20, 1], verbose=False)
     assert len(r3["total_record"]) == 21 and r3["epsilon"] < 1.0       # moves towards 0.1/pi from 1.0
+
+
+def test_device_rhs_assembly_matches_reference_fixtures():
+    """Row N1: F_ext_total assembled by the projection kernel == the reference's own F_ext_total."""
+    from hp_vpinns_amd.drivers import poisson1d, poisson2d
+    from hp_vpinns_amd.rhs import assemble_F_ext_1d, assemble_F_ext_2d
+    g = gold("poisson2d_cfg4")
+    F = assemble_F_ext_2d(poisson2d.f_ext, g["grid_x"], g["grid_y"], 10, 10, 20)
+    assert F.shape == g["F_ext_total"].shape and rel(F, g["F_ext_total"]) < 1e-13
+    g = gold("poisson2d_small")
+    F = assemble_F_ext_2d(poisson2d.f_ext, g["grid_x"], g["grid_y"], 4, 3, 6)      # generic-kernel shape
+    assert rel(F, g["F_ext_total"]) < 1e-13
+    g = gold("poisson1d_cfg2")
+    F = assemble_F_ext_1d(poisson1d.f_ext, g["grid"], 60, 80)
+    assert F.shape == g["F_ext_total"].shape and rel(F, g["F_ext_total"]) < 1e-12
+    s = poisson2d.setup(N_el_x=8, N_el_y=8, with_test_grid=False, assemble="device")
+    assert rel(s["F_ext_total"], gold("poisson2d_cfg3")["F_ext_total"]) < 1e-13
+
+
+def test_checkpoint_resume_is_bit_exact_and_l2_error(tmp_path):
+    """Row N4: save after 7 iterations, restore into a fresh model, continue: identical to 15 straight."""
+    from hp_vpinns_amd.vpinn import VPINN2D
+    g = gold("poisson2d_small")
+    a = p2_args(g, layers=[2, 20, 20, 20, 1])
+    th = theta0(a[13], 33)
+    m1 = VPINN2D(*a, init_params=th)
+    m1._step(15, False)
+    m2 = VPINN2D(*a, init_params=th)
+    m2._step(7, False)
+    ck = str(tmp_path / "ck.npz")
+    m2.save_checkpoint(ck)
+    m3 = VPINN2D(*a, init_params=np.zeros_like(th))
+    m3.load_checkpoint(ck)
+    m3._step(8, False)
+    assert np.array_equal(m3.h.get_state(), m1.h.get_state())
+    X = np.random.default_rng(1).uniform(-1, 1, (4000, 2))          # predict through the MFMA path
+    u = m1.predict(X)
+    o = __import__("oracle.vpinn_oracle", fromlist=["x"]).OracleVPINN2D(*a, init_params=m1.get_params())
+    assert rel(u, o.predict(X)) < 1e-12
+    assert abs(m1.rel_l2_error(X, u + 1e-3 * np.abs(u)) - 1e-3) < 1e-6
