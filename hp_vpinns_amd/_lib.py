@@ -16,6 +16,7 @@ HPV_MAX_LAYERS = 16
 PDE_POISSON1D, PDE_POISSON2D, PDE_ADVDIFF = 0, 1, 2
 ACT_TANH, ACT_SIN = 0, 1
 BACKEND_AUTO, BACKEND_GENERIC, BACKEND_MFMA = 0, 1, 2
+SCHEME_VPINN, SCHEME_PINN = 0, 1
 
 # every symbol include/hpvpinn.h declares (tests check the .so exports all of them)
 EXPORTS = [
@@ -25,7 +26,7 @@ EXPORTS = [
     "hpv_reduce_buffer", "hpv_apply_adam", "hpv_eval_loss", "hpv_read_loss", "hpv_sync",
     "hpv_predict", "hpv_get_residuals", "hpv_backend_in_use", "hpv_enable_timing",
     "hpv_kernel_time_ms", "hpv_bench_projection", "hpv_debug_activation", "hpv_get_state", "hpv_set_state",
-    "hpv_assemble_rhs",
+    "hpv_assemble_rhs", "hpv_set_collocation",
 ]
 
 
@@ -35,7 +36,7 @@ class HpvConfig(C.Structure):
         ("layers", C.c_int * HPV_MAX_LAYERS),
         ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
         ("lossb_weight", C.c_double), ("V", C.c_double),
-        ("device", C.c_int), ("backend", C.c_int),
+        ("device", C.c_int), ("backend", C.c_int), ("scheme", C.c_int),
     ]
 
 
@@ -72,6 +73,7 @@ def load():
     lib.hpv_set_elements.argtypes = [h, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int]
     lib.hpv_set_rhs.argtypes = [h, _dp, C.c_size_t]
     lib.hpv_set_data.argtypes = [h, _dp, _dp, C.c_int]
+    lib.hpv_set_collocation.argtypes = [h, _dp, _dp, C.c_int]
     lib.hpv_num_params.argtypes = [h]
     lib.hpv_num_params.restype = C.c_size_t
     lib.hpv_set_params.argtypes = [h, _dp, C.c_size_t]
@@ -110,7 +112,7 @@ class Handle:
     """Thin RAII wrapper over an `hpv_handle`; every method maps 1:1 onto a C entry point."""
 
     def __init__(self, pde, var_form, act, layers, lr=1e-3, lossb_weight=1.0, V=1.0, device=0,
-                 backend=BACKEND_AUTO, beta1=0.9, beta2=0.999, eps=1e-8):
+                 backend=BACKEND_AUTO, beta1=0.9, beta2=0.999, eps=1e-8, scheme=SCHEME_VPINN):
         self.lib = load()
         cfg = HpvConfig()
         cfg.pde, cfg.var_form, cfg.act = int(pde), int(var_form), int(act)
@@ -122,7 +124,7 @@ class Handle:
             cfg.layers[i] = v
         cfg.lr, cfg.beta1, cfg.beta2, cfg.eps = lr, beta1, beta2, eps
         cfg.lossb_weight, cfg.V = float(lossb_weight), float(V)
-        cfg.device, cfg.backend = int(device), int(backend)
+        cfg.device, cfg.backend, cfg.scheme = int(device), int(backend), int(scheme)
         self._h = C.c_void_p()
         rc = self.lib.hpv_create(C.byref(self._h), C.byref(cfg))
         if rc != 0:
@@ -178,6 +180,10 @@ class Handle:
     def set_rhs(self, F):
         F = _c(F)
         self._chk(self.lib.hpv_set_rhs(self._h, _p(F), 0 if F is None else F.size))
+
+    def set_collocation(self, X, f):
+        X, f = _c(X), _c(f).reshape(-1)
+        self._chk(self.lib.hpv_set_collocation(self._h, _p(X), _p(f), X.shape[0]))
 
     def set_data(self, X, u):
         X, u = _c(X), _c(u)

@@ -77,6 +77,12 @@ struct hpv_ctx {
     HpvMfma* mfma_data = nullptr;
     HpvMfma* mfma_edge = nullptr;
     HpvMfma* mfma_pred = nullptr;
+    // strong-form PINN branch (scheme == PINNs): collocation batch with the 5 Laplacian channels
+    NetDesc nd_pinn{};
+    Batch colloc;
+    HpvMfma* mfma_colloc = nullptr;
+    double *d_fcol = nullptr, *d_col_part = nullptr;
+    int n_col = 0;
     double* d_jac = nullptr;   // |J_e| of the owned elements (RHS assembly, hpv_assemble_rhs)
     // timing
     bool timing = false;
@@ -295,9 +301,12 @@ AdamArgs adam_args(hpv_ctx* h) {
     return AdamArgs{h->d_theta, h->d_m, h->d_v, h->d_state, h->cfg.lr, h->cfg.beta1, h->cfg.beta2, h->cfg.eps};
 }
 
+int enqueue_pinn_pass(hpv_ctx* h, bool backward, bool fuse_adam);
+
 // One pass over both loss terms.  backward: also the reverse pass and the gradient reduction;
 // fuse_adam: the finalize kernel applies the TF1 Adam update itself (single-GPU training step).
 int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
+    if (h->cfg.scheme == HPV_SCHEME_PINN) return enqueue_pinn_pass(h, backward, fuse_adam);
     int rc = check_ready(h);
     if (rc) return rc;
     const double* eps_ptr = h->has_eps ? h->d_theta + h->P : nullptr;
@@ -363,6 +372,53 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
                     backward && h->pd.edge && h->edge.N > 0 ? h->edge.GPART : nullptr, h->edge.rows, h->d_loss_e, h->n_elem,
                     h->d_deps_e, h->d_data_part, ndp, h->cfg.lossb_weight, h->n_data, h->P, h->has_eps, h->d_RB,
                     backward ? 1 : 0, (backward && fuse_adam) ? &ad : nullptr, h->stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, -2, "kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// scheme == 'PINNs' (P2:128-129): loss = w*lossb + lossp, lossp = mean((u_xx+u_yy-f)^2) at the collocation points
+int enqueue_pinn_pass(hpv_ctx* h, bool backward, bool fuse_adam) {
+    if (!h->have_params) return fail(h, -3, "hpv_set_params has not been called");
+    if (h->n_col <= 0) return fail(h, -3, "hpv_set_collocation has not been called");
+    int rc;
+    if (h->batch_dirty) {   // only the data batch matters here
+        if ((rc = alloc_batch(h, h->data, h->nd_val, h->n_data, true))) return rc;
+        if (h->n_data > 0 && (rc = upload_points(h, h->data, h->Xd_host.data(), h->n_data, h->dim))) return rc;
+        if (h->mfma_data) { hpv_mfma_destroy(h->mfma_data); h->mfma_data = nullptr; }
+        h->merged = false;
+        h->batch_dirty = false;
+    }
+    if (!h->side_active) {
+        if (h->cfg.backend != HPV_BACKEND_GENERIC && !h->mfma_colloc) {
+            std::string why;
+            h->mfma_colloc = hpv_mfma_create(h->colloc.nd, h->colloc.N, &why);
+            if (h->mfma_colloc) {
+                h->backend = HPV_BACKEND_MFMA;
+                if (h->colloc.ACT) { (void)hipFree(h->colloc.ACT); h->colloc.ACT = nullptr; }
+                int rows = hpv_mfma_grad_rows(h->mfma_colloc);
+                if (rows > h->colloc.rows && (rc = dalloc(h, &h->colloc.GPART, (size_t)rows * h->P))) return rc;
+                h->colloc.rows = rows;
+            } else if (h->cfg.backend == HPV_BACKEND_MFMA) return fail(h, -4, "MFMA backend not available: %s", why.c_str());
+        }
+        if ((rc = ensure_small_mfma(h, h->data, &h->mfma_data))) return rc;
+    }
+    run_fwd(h, h->colloc, h->mfma_colloc, backward ? 1 : 0);
+    launch_pinn_residual(h->colloc.OUT, h->d_fcol, h->colloc.GBAR, h->d_col_part, h->colloc.N, h->n_col, backward ? 1 : 0, h->stream);
+    if (backward) run_bwd(h, h->colloc, h->mfma_colloc);
+    int ndp = 0;
+    if (h->n_data > 0) {
+        run_fwd(h, h->data, h->mfma_data, backward ? 1 : 0);
+        ndp = (h->n_data + 255) / 256; if (ndp > 64) ndp = 64;
+        launch_data_loss(h->data.OUT, h->d_udata, backward ? h->data.GBAR : nullptr,
+                         -2.0 * h->cfg.lossb_weight / (double)h->n_data, h->d_data_part, h->n_data, h->stream);
+        if (backward) run_bwd(h, h->data, h->mfma_data);
+    }
+    const AdamArgs ad = adam_args(h);
+    launch_finalize(backward ? h->colloc.GPART : nullptr, h->colloc.rows, backward && h->n_data > 0 ? h->data.GPART : nullptr,
+                    h->data.rows, nullptr, 0, h->d_col_part, pinn_residual_parts(h->n_col), nullptr, h->d_data_part, ndp,
+                    h->cfg.lossb_weight, h->n_data, h->P, 0, h->d_RB, backward ? 1 : 0, (backward && fuse_adam) ? &ad : nullptr,
+                    h->stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, -2, "kernel launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -460,6 +516,10 @@ int hpv_create(hpv_handle* out, const hpv_config* cfg) {
     }
     h->nd_var = make_netdesc(*cfg, nT1, t1, nT2, t2);
     h->nd_val = make_netdesc(*cfg, 0, t1, 0, t2);
+    if (cfg->scheme == HPV_SCHEME_PINN) {
+        if (cfg->pde != HPV_PDE_POISSON2D) { delete h; return fail(nullptr, -1, "scheme PINNs is the Poisson-2D branch (P2:128-129)"); }
+        h->nd_pinn = make_netdesc(*cfg, 2, t1, 2, t2);
+    } else if (cfg->scheme != HPV_SCHEME_VPINN) { delete h; return fail(nullptr, -1, "unknown scheme %d", cfg->scheme); }
     pd.C = h->nd_var.C;
     pd.has_eps = h->has_eps;
     h->P = h->nd_var.P;
@@ -491,6 +551,10 @@ void hpv_destroy(hpv_handle h) {
     if (h->mfma_data) hpv_mfma_destroy(h->mfma_data);
     if (h->mfma_edge) hpv_mfma_destroy(h->mfma_edge);
     if (h->mfma_pred) hpv_mfma_destroy(h->mfma_pred);
+    if (h->mfma_colloc) hpv_mfma_destroy(h->mfma_colloc);
+    free_batch(h->colloc);
+    if (h->d_fcol) (void)hipFree(h->d_fcol);
+    if (h->d_col_part) (void)hipFree(h->d_col_part);
     if (h->d_jac) (void)hipFree(h->d_jac);
     free_batch(h->var); free_batch(h->data); free_batch(h->edge); free_batch(h->pred);
     double* ptrs[] = {h->d_wtx, h->d_wty, h->d_edge_dphi, h->d_coef, h->d_edge_coef, h->d_F, h->d_R, h->d_loss_e,
@@ -672,6 +736,22 @@ int hpv_set_data(hpv_handle h, const double* X, const double* u, int n) {
     return 0;
 }
 
+int hpv_set_collocation(hpv_handle h, const double* X, const double* f, int n) {
+    if (!h) return -1;
+    if (h->cfg.scheme != HPV_SCHEME_PINN) return fail(h, -1, "collocation points belong to scheme PINNs");
+    if (n < 1 || !X || !f) return fail(h, -1, "bad collocation arguments");
+    drop_graph(h);
+    int rc;
+    if (h->mfma_colloc) { hpv_mfma_destroy(h->mfma_colloc); h->mfma_colloc = nullptr; }
+    if ((rc = alloc_batch(h, h->colloc, h->nd_pinn, n, true))) return rc;
+    if ((rc = upload_points(h, h->colloc, X, n, h->dim))) return rc;
+    if ((rc = dalloc(h, &h->d_fcol, (size_t)n))) return rc;
+    if ((rc = upload(h, h->d_fcol, f, (size_t)n))) return rc;
+    if ((rc = dalloc(h, &h->d_col_part, 64))) return rc;
+    h->n_col = n;
+    return 0;
+}
+
 size_t hpv_num_params(hpv_handle h) { return h ? (size_t)h->Ptot : 0; }
 
 int hpv_set_params(hpv_handle h, const double* theta, size_t n) {
@@ -746,7 +826,7 @@ int hpv_loss_and_grad(hpv_handle h, double* loss3, double* grad) {
 int hpv_step(hpv_handle h, int n_iters, double* loss3_after) {
     if (!h) return -1;
     int rc;
-    if (h->use_graph && h->own_stream && !h->timing && n_iters > 0) {
+    if (h->use_graph && h->own_stream && !h->timing && n_iters > 0 && h->cfg.scheme == HPV_SCHEME_VPINN) {
         if ((rc = check_ready(h))) return rc;
         if (!h->g_step && (rc = build_step_graph(h))) return rc;
         for (int it = 0; it < n_iters; ++it) HIPCHK(h, hipGraphLaunch(h->g_step, h->stream));
@@ -852,7 +932,7 @@ int hpv_get_residuals(hpv_handle h, double* R, size_t n) {
 
 int hpv_backend_in_use(hpv_handle h) {
     if (!h) return -1;
-    if (h->have_quad && h->have_tables && h->have_elems && h->batch_dirty) {
+    if (h->cfg.scheme == HPV_SCHEME_VPINN && h->have_quad && h->have_tables && h->have_elems && h->batch_dirty) {
         int rc = assemble_batches(h);   // decides the backend; surfaces "MFMA not available" early
         if (rc) return rc;
     }

@@ -585,3 +585,27 @@ __global__ void k_debug_act(int act, const double* __restrict__ x, int n, double
 void launch_debug_act(int act, const double* x, int n, double* a, double* a1, double* ref, hipStream_t s) {
     hipLaunchKernelGGL(k_debug_act, dim3((n + 255) / 256), dim3(256), 0, s, act, x, n, a, a1, ref);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Strong-form PINN residual of the 2-D Poisson problem (P2:187-194): r = u_xx + u_yy - f at the
+// collocation points; lossp = mean(r^2) (P2:124).  Channels: [u, u_x, u_y, u_xx, u_yy].
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pinn_residual(const double* __restrict__ OUT, const double* __restrict__ f,
+                                                      double* __restrict__ GBAR, double* __restrict__ part, long N,
+                                                      int n, int write_gbar) {
+    __shared__ double red[16];
+    double sq = 0.0;
+    const double sc = 2.0 / (double)n;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        const double r = OUT[3 * N + p] + OUT[4 * N + p] - f[p];
+        sq += r * r;
+        if (write_gbar) { GBAR[3 * N + p] = sc * r; GBAR[4 * N + p] = sc * r; }
+    }
+    sq = block_sum(sq, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = sq / (double)n;
+}
+int pinn_residual_parts(int n) { int b = (n + 255) / 256; return b > 64 ? 64 : (b < 1 ? 1 : b); }
+void launch_pinn_residual(const double* OUT, const double* f, double* GBAR, double* part, long N, int n, int write_gbar,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(k_pinn_residual, dim3(pinn_residual_parts(n)), dim3(256), 0, s, OUT, f, GBAR, part, N, n, write_gbar);
+}

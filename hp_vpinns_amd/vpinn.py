@@ -73,7 +73,8 @@ class _VPINNBase:
     _act = None
     _n_extra = 0
 
-    def _create(self, layers, var_form, LR, lossb_weight, V, init_params, seed, backend, device):
+    def _create(self, layers, var_form, LR, lossb_weight, V, init_params, seed, backend, device,
+                scheme=_lib.SCHEME_VPINN):
         self.layers = [int(v) for v in layers]
         self.rank, self.world, local_rank = dist_info()
         # the collective code path is taken whenever a process group with >1 ranks exists; HPV_FORCE_DIST=1
@@ -85,7 +86,7 @@ class _VPINNBase:
         bk = {"auto": _lib.BACKEND_AUTO, "generic": _lib.BACKEND_GENERIC, "mfma": _lib.BACKEND_MFMA,
               "hip": _lib.BACKEND_AUTO}[backend]
         self.h = _lib.Handle(self._pde, var_form, self._act, self.layers, lr=LR, lossb_weight=lossb_weight,
-                             V=V, device=device, backend=bk)
+                             V=V, device=device, backend=bk, scheme=scheme)
         if init_params is None:
             init_params = xavier_init(self.layers, seed, extra=[1.0] * self._n_extra)
         self._init_params = np.asarray(init_params, dtype=np.float64).reshape(-1).copy()
@@ -234,8 +235,9 @@ class VPINN2D(_VPINNBase):
     def __init__(self, X_u_train, u_train, X_f_train, f_train, X_quad, W_quad, U_exact_total, F_exact_total,
                  gridx, gridy, N_testfcn, X_test, u_test, layers, *, var_form=1, scheme="VPINNs", LR=0.001,
                  lossb_weight=10, init_params=None, seed=1234, backend="auto", device=None, loss_his=None):
-        if scheme != "VPINNs":
-            raise NotImplementedError("scheme='PINNs' (strong-form branch, P2:128-129) is outside the hot path")
+        if scheme not in ("VPINNs", "PINNs"):
+            raise ValueError("scheme is either 'PINNs' or 'VPINNs' (P2:269)")
+        self.scheme = scheme
         self.X_u_train = np.asarray(X_u_train, dtype=np.float64)
         self.utrain = np.asarray(u_train, dtype=np.float64)
         self.xf_train, self.ftrain = X_f_train, f_train
@@ -251,13 +253,20 @@ class VPINN2D(_VPINNBase):
         if self.F_ext_total.shape != (self.Nelementx, self.Nelementy, self.Ntesty, self.Ntestx):
             raise ValueError(f"F_exact_total has shape {self.F_ext_total.shape}, expected "
                              f"{(self.Nelementx, self.Nelementy, self.Ntesty, self.Ntestx)} (P2:414)")
-        self._create(layers, var_form, LR, lossb_weight, 1.0, init_params, seed, backend, device)
-        xi, wx, yi, wy = _tensor_rule(X_quad, W_quad)
-        self.h.set_quadrature(xi, wx, yi, wy)
-        self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntesty, yi))
-        eb, ee = shard_range(self.Nelementx * self.Nelementy, self.rank, self.world)
-        self.h.set_elements(self.gridx, self.gridy, eb, ee)
-        self.h.set_rhs(self.F_ext_total.reshape(-1))
+        self._create(layers, var_form, LR, lossb_weight, 1.0, init_params, seed, backend, device,
+                     scheme=_lib.SCHEME_PINN if scheme == "PINNs" else _lib.SCHEME_VPINN)
+        if scheme == "PINNs":
+            # strong-form branch (P2:128-129): loss = 10 lossb + mean((u_xx+u_yy-f)^2) at X_f_train
+            if self.world > 1:
+                raise NotImplementedError("the PINN branch is single-GPU")
+            self.h.set_collocation(np.asarray(X_f_train, dtype=np.float64), np.asarray(f_train, dtype=np.float64))
+        else:
+            xi, wx, yi, wy = _tensor_rule(X_quad, W_quad)
+            self.h.set_quadrature(xi, wx, yi, wy)
+            self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntesty, yi))
+            eb, ee = shard_range(self.Nelementx * self.Nelementy, self.rank, self.world)
+            self.h.set_elements(self.gridx, self.gridy, eb, ee)
+            self.h.set_rhs(self.F_ext_total.reshape(-1))
         if self.rank == 0:
             self.h.set_data(self.X_u_train, self.utrain.reshape(-1))
         self._finish()

@@ -32,6 +32,7 @@ extern "C" {
 enum { HPV_PDE_POISSON1D = 0, HPV_PDE_POISSON2D = 1, HPV_PDE_ADVDIFF = 2 };
 enum { HPV_ACT_TANH = 0, HPV_ACT_SIN = 1 };
 enum { HPV_BACKEND_AUTO = 0, HPV_BACKEND_GENERIC = 1, HPV_BACKEND_MFMA = 2 };
+enum { HPV_SCHEME_VPINN = 0, HPV_SCHEME_PINN = 1 };
 
 typedef struct hpv_ctx* hpv_handle;
 
@@ -46,6 +47,7 @@ typedef struct hpv_config {
     double V;                     /* advection speed, P3:43                                           */
     int device;                   /* HIP device ordinal                                               */
     int backend;                  /* HPV_BACKEND_*                                                    */
+    int scheme;                   /* HPV_SCHEME_VPINN (default) or HPV_SCHEME_PINN (P2:126-129)       */
 } hpv_config;
 
 /* Construction = the graph-build part of VPINN.__init__ (P1:31-107, P2:28-136, P3:60-197). */
@@ -82,6 +84,10 @@ int hpv_set_rhs(hpv_handle h, const double* F, size_t n);
 /* Boundary / data points of lossb (P1:98, P2:122, P3:184): X is [n][dim] row-major, u is [n].
  * The term is weighted by cfg.lossb_weight.  n = 0 disables it (ranks other than 0). */
 int hpv_set_data(hpv_handle h, const double* X, const double* u, int n);
+
+/* Collocation points of the strong-form PINN branch (`scheme == 'PINNs'`, P2:124-129,
+ * 187-194): lossp = mean((u_xx + u_yy - f)^2) over X_f [n][2] replaces the variational term.  Poisson-2D only. */
+int hpv_set_collocation(hpv_handle h, const double* X, const double* f, int n);
 
 size_t hpv_num_params(hpv_handle h);
 int hpv_set_params(hpv_handle h, const double* theta, size_t n); /* also resets Adam state (P1:107) */

@@ -301,3 +301,18 @@ def test_checkpoint_resume_is_bit_exact_and_l2_error(tmp_path):
     o = __import__("oracle.vpinn_oracle", fromlist=["x"]).OracleVPINN2D(*a, init_params=m1.get_params())
     assert rel(u, o.predict(X)) < 1e-12
     assert abs(m1.rel_l2_error(X, u + 1e-3 * np.abs(u)) - 1e-3) < 1e-6
+
+
+@pytest.mark.parametrize("backend,layers", [("generic", [2, 8, 8, 1]), ("mfma", [2, 20, 20, 20, 1])])
+def test_pinn_strong_form_branch(backend, layers):
+    """Row N3: scheme='PINNs' (P2:128-129): loss = 10 lossb + mean((u_xx+u_yy-f)^2) at the collocation points."""
+    from hp_vpinns_amd.vpinn import VPINN2D
+    from oracle.vpinn_oracle import OracleVPINN2D
+    a = p2_args(gold("poisson2d_default"), layers)
+    th = theta0(a[13], 44)
+    o = OracleVPINN2D(*a, scheme="PINNs", init_params=th)
+    m = VPINN2D(*a, scheme="PINNs", init_params=th, backend=backend)
+    assert m.backend() == backend or backend == "mfma"
+    _check_loss_grad(o, m)
+    _check_traj(o, m, n=8)
+    assert m.backend() == backend
