@@ -13,8 +13,6 @@
 // judged against the HBM roofline on the scaled synthetic batch.
 #include "hpv_internal.h"
 
-#define PJ_BLOCK 256
-#define PJ_WAVES (PJ_BLOCK / 64)
 
 __device__ __forceinline__ double pj_wave_sum(double v) {
 #pragma unroll
@@ -43,8 +41,8 @@ struct ActiveCh {
     int id[HPV_MAXC];           // their channel indices
 };
 
-template <int QX, int QY, int NTX, int NTY, int NA, bool EPS>
-__global__ void __launch_bounds__(PJ_BLOCK) k_project_tp(ProjDesc pd, ActiveCh ac, const double* __restrict__ OUT,
+template <int QX, int QY, int NTX, int NTY, int NA, bool EPS, int PJ_WAVES>
+__global__ void __launch_bounds__(PJ_WAVES * 64) k_project_tp(ProjDesc pd, ActiveCh ac, const double* __restrict__ OUT,
                                                         double* __restrict__ GBAR, double* __restrict__ R,
                                                         const double* __restrict__ F, const double* __restrict__ coef,
                                                         long coef_stride, const double* __restrict__ wtx,
@@ -58,25 +56,43 @@ __global__ void __launch_bounds__(PJ_BLOCK) k_project_tp(ProjDesc pd, ActiveCh a
     constexpr int LDT = QX + 1;
     constexpr int TB_D = EPW * NTY * LDT;
     constexpr int WAVE_DOUBLES = TB_D + 64;
+    constexpr int PJ_BLOCK = PJ_WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // tables in both orientations, so that every contraction walks its table contiguously in the OUTPUT
-    // index (independent accumulators, wide broadcast reads, many LDS reads in flight)
+    // index (independent accumulators, wide broadcast reads, many LDS reads in flight).  The transposed copies
+    // are derived here; ALL global loads of the staging are issued before the first LDS store (one L2 round
+    // trip instead of one per loop iteration -- the staging was most of the kernel's latency at 256 elements).
     double* AXs = sm;                      // [3][NTX][QX]  w_x phi^(d)[r][i]
     double* BYs = AXs + 3 * NTX * QX;      // [3][NTY][QY]  w_y phi^(d)[k][j]
     double* AXT = BYs + 3 * NTY * QY;      // [3][QX][NTX]
     double* BYT = AXT + 3 * NTX * QX;      // [3][QY][NTY]
-    for (int i = threadIdx.x; i < 3 * NTX * QX; i += PJ_BLOCK) {
-        const double v = wtx[i];
-        AXs[i] = v;
-        const int d = i / (NTX * QX), r = (i / QX) % NTX, c = i % QX;
-        AXT[d * (NTX * QX) + c * NTX + r] = v;
-    }
-    for (int i = threadIdx.x; i < 3 * NTY * QY; i += PJ_BLOCK) {
-        const double v = wty[i];
-        BYs[i] = v;
-        const int d = i / (NTY * QY), k = (i / QY) % NTY, c = i % QY;
-        BYT[d * (NTY * QY) + c * NTY + k] = v;
+    {
+        constexpr int NAX = 3 * NTX * QX, NBY = 3 * NTY * QY;
+        constexpr int ITA = (NAX + PJ_BLOCK - 1) / PJ_BLOCK, ITB = (NBY + PJ_BLOCK - 1) / PJ_BLOCK;
+        double va[ITA], vb[ITB];
+#pragma unroll
+        for (int it = 0; it < ITA; ++it) { const int i = it * PJ_BLOCK + threadIdx.x; va[it] = i < NAX ? wtx[i] : 0.0; }
+#pragma unroll
+        for (int it = 0; it < ITB; ++it) { const int i = it * PJ_BLOCK + threadIdx.x; vb[it] = i < NBY ? wty[i] : 0.0; }
+#pragma unroll
+        for (int it = 0; it < ITA; ++it) {
+            const int i = it * PJ_BLOCK + threadIdx.x;
+            if (i < NAX) {
+                AXs[i] = va[it];
+                const int d = i / (NTX * QX), r = (i / QX) % NTX, c = i % QX;
+                AXT[d * (NTX * QX) + c * NTX + r] = va[it];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITB; ++it) {
+            const int i = it * PJ_BLOCK + threadIdx.x;
+            if (i < NBY) {
+                BYs[i] = vb[it];
+                const int d = i / (NTY * QY), k = (i / QY) % NTY, c = i % QY;
+                BYT[d * (NTY * QY) + c * NTY + k] = vb[it];
+            }
+        }
     }
     __syncthreads();
     double* Tb = BYT + 3 * NTY * QY + wv * WAVE_DOUBLES;   // [EPW][NTY][LDT]  transpose tile (T, then V)
@@ -253,19 +269,36 @@ __global__ void __launch_bounds__(PJ_BLOCK) k_project_tp(ProjDesc pd, ActiveCh a
     }
 }
 
+template <int QX, int QY, int NTX, int NTY, int NA, bool EPS, int PJ_WAVES>
+static void launch_tp3(const ProjDesc& pd, const ActiveCh& ac, const double* OUT, double* GBAR, double* R, const double* F,
+                       const double* coef, long coef_stride, const double* wtx, const double* wty, const double* eps_ptr,
+                       double* loss_e, double* deps_e, long N, long n_elem, int do_adjoint, long ngroups, hipStream_t s) {
+    constexpr int LPE = QX > QY ? QX : QY;
+    constexpr int EPW = 64 / LPE;
+    constexpr int WAVE_DOUBLES = EPW * NTY * (QX + 1) + 64;
+    const size_t lds = (size_t)(2 * (3 * NTX * QX + 3 * NTY * QY) + PJ_WAVES * WAVE_DOUBLES) * sizeof(double);
+    long blocks = (ngroups + PJ_WAVES - 1) / PJ_WAVES;
+    if (blocks > 256 * 16) blocks = 256 * 16;   // grid-stride beyond that
+    hipLaunchKernelGGL((k_project_tp<QX, QY, NTX, NTY, NA, EPS, PJ_WAVES>), dim3((unsigned)blocks), dim3(PJ_WAVES * 64), lds, s,
+                       pd, ac, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, N, n_elem, do_adjoint);
+}
+
 template <int QX, int QY, int NTX, int NTY, int NA, bool EPS>
 static bool launch_tp2(const ProjDesc& pd, const ActiveCh& ac, const double* OUT, double* GBAR, double* R, const double* F,
                        const double* coef, long coef_stride, const double* wtx, const double* wty, const double* eps_ptr,
                        double* loss_e, double* deps_e, long N, long n_elem, int do_adjoint, hipStream_t s) {
     constexpr int LPE = QX > QY ? QX : QY;
     constexpr int EPW = 64 / LPE;
-    constexpr int WAVE_DOUBLES = EPW * NTY * (QX + 1) + 64;
-    const size_t lds = (size_t)(2 * (3 * NTX * QX + 3 * NTY * QY) + PJ_WAVES * WAVE_DOUBLES) * sizeof(double);
     const long ngroups = (n_elem + EPW - 1) / EPW;
-    long blocks = (ngroups + PJ_WAVES - 1) / PJ_WAVES;
-    if (blocks > 256 * 16) blocks = 256 * 16;   // grid-stride beyond that
-    hipLaunchKernelGGL((k_project_tp<QX, QY, NTX, NTY, NA, EPS>), dim3((unsigned)blocks), dim3(PJ_BLOCK), lds, s, pd, ac, OUT,
-                       GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, N, n_elem, do_adjoint);
+    // few element groups (config-4 scale): one wavefront per workgroup spreads the groups over as many CUs as
+    // possible (each wave then has a CU's LDS port to itself for its ~800 broadcast table reads); large batches:
+    // four waves per workgroup amortise the table staging
+    if (ngroups <= 1024)
+        launch_tp3<QX, QY, NTX, NTY, NA, EPS, 1>(pd, ac, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, N,
+                                                 n_elem, do_adjoint, ngroups, s);
+    else
+        launch_tp3<QX, QY, NTX, NTY, NA, EPS, 4>(pd, ac, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, N,
+                                                 n_elem, do_adjoint, ngroups, s);
     return true;
 }
 
