@@ -316,3 +316,141 @@ def test_pinn_strong_form_branch(backend, layers):
     _check_loss_grad(o, m)
     _check_traj(o, m, n=8)
     assert m.backend() == backend
+
+
+# ---------------------------------------------------------------------------------------------------
+# Edge cases of the boundary: empty sets, empty shards, non-uniform grids, recording semantics, full size.
+# ---------------------------------------------------------------------------------------------------
+def test_no_boundary_points_and_empty_element_shard():
+    """n_data = 0 -> loss = lossv; a handle that owns NO elements (more ranks than elements) contributes only
+    its data term; the two partial buffers still add up to the full loss / gradient."""
+    from hp_vpinns_amd import _lib
+    from hp_vpinns_amd.testfcn import tables_1d
+    from hp_vpinns_amd.vpinn import VPINN2D, _tensor_rule
+    g = gold("poisson2d_small")
+    a = p2_args(g, layers=[2, 20, 20, 20, 1])
+    th = theta0(a[13], 5)
+    full = VPINN2D(*a, init_params=th)
+    l3, gr = full.loss_and_grad()
+    xi, wx, yi, wy = _tensor_rule(a[4], a[5])
+
+    def handle(eb, ee, with_data):
+        h = _lib.Handle(_lib.PDE_POISSON2D, 1, _lib.ACT_TANH, a[13], lossb_weight=10)
+        h.set_quadrature(xi, wx, yi, wy)
+        h.set_tables(tables_1d(full.Ntestx, xi), tables_1d(full.Ntesty, yi))
+        h.set_elements(a[8], a[9], eb, ee)
+        h.set_rhs(np.asarray(a[7]).reshape(-1))
+        if with_data:
+            h.set_data(a[0], np.asarray(a[1]).reshape(-1))
+        h.set_params(th)
+        return h
+    hv = handle(0, 6, False)                      # all elements, no boundary points
+    l3v, gv = hv.loss_and_grad(True)
+    assert abs(l3v[0] - l3v[2]) == 0 and abs(l3v[2] - l3[2]) < 1e-12 * abs(l3[2]) and l3v[1] == 0
+    hd = handle(3, 3, True)                       # empty shard, boundary points only
+    l3d, gd = hd.loss_and_grad(True)
+    assert l3d[2] == 0 and abs(l3d[0] - (l3[0] - l3[2])) < 1e-12 * abs(l3[0])
+    assert rel(gv + gd, gr) < 1e-12
+    hv.step(3, True)
+    hd.step(3, True)                              # Adam on a data-only handle runs too
+
+
+def test_nonuniform_grid_published_3_element_run():
+    """The reference's published run: grid [-1,-0.1,0.1,1] (P1:270-273), 60 test functions, 80 GLL points."""
+    o, m = _pair_1d("poisson1d_ne3", 1)
+    _check_loss_grad(o, m)
+    _check_traj(o, m, n=5)
+
+
+def test_reference_default_networks():
+    """Reference-default shapes: P1 [1,20,20,20,20,1] sin (P1:236), P2/P3 [2,5,5,5,1] tanh (P2:280, P3:46)."""
+    from hp_vpinns_amd.vpinn import VPINN1D, VPINN2D, VPINNAdvDiff
+    from oracle.vpinn_oracle import OracleVPINN1D, OracleVPINN2D, OracleVPINNAdvDiff
+    a = p1_args(gold("poisson1d_default"))
+    assert a[8] == [1, 20, 20, 20, 20, 1]
+    th = theta0(a[8], 1)
+    _check_loss_grad(OracleVPINN1D(*a, init_params=th), VPINN1D(*a, init_params=th))
+    a = p2_args(gold("poisson2d_default"))
+    assert a[13] == [2, 5, 5, 5, 1]
+    th = theta0(a[13], 2)
+    o, m = OracleVPINN2D(*a, init_params=th), VPINN2D(*a, init_params=th)
+    assert m.backend() == "generic"
+    _check_loss_grad(o, m)
+    _check_traj(o, m, n=5)
+    a = p3_args(gold("advdiff_default"))
+    th = theta0(a[12], 3, extra=[1.0])
+    o, m = OracleVPINNAdvDiff(*a, init_params=th), VPINNAdvDiff(*a, init_params=th)
+    _check_loss_grad(o, m)
+    _check_traj(o, m, n=5)
+
+
+def test_train_recording_semantics_and_early_stop():
+    """P1:201-224: recorded every 10 iterations after the update, early exit below `tresh`; P2:243-244: every
+    iteration; P3:341: the 5-tuple with [it, loss, epsilon, 1] records."""
+    from hp_vpinns_amd.vpinn import VPINN1D, VPINN2D, VPINNAdvDiff
+    from oracle.vpinn_oracle import OracleVPINN1D
+    a = p1_args(gold("poisson1d_small"), layers=[1, 20, 20, 20, 1])
+    th = theta0(a[8], 9)
+    rec = []
+    m = VPINN1D(*a, init_params=th, total_record=rec)
+    m.train(35, 0.0)
+    assert [int(r[0]) for r in rec] == [0, 10, 20, 30]
+    o = OracleVPINN1D(*a, init_params=th)
+    ro = o.train(35, 0.0)
+    assert rel([r[1] for r in rec], [r[1] for r in ro]) < 1e-7
+    m2 = VPINN1D(*a, init_params=th)
+    m2.train(1000, 1e30)                                   # first recorded loss is already below tresh -> stops at it 0
+    assert len(m2.total_record) == 1
+    o1 = OracleVPINN1D(*a, init_params=th)
+    o1.adam_step()
+    assert rel(m2.get_params(), o1.get_params()) < 1e-9   # exactly one update happened before the stop
+    a2 = p2_args(gold("poisson2d_small"), layers=[2, 20, 20, 20, 1])
+    m3 = VPINN2D(*a2, init_params=theta0(a2[13], 9))
+    m3.train(7)
+    assert len(m3.loss_his) == 7
+    a3 = p3_args(gold("advdiff_small"), layers=[2, 20, 20, 20, 1])
+    m4 = VPINNAdvDiff(*a3, init_params=theta0(a3[12], 9, extra=[1.0]))
+    out = m4.train(21, 0.0)
+    assert len(out) == 5 and [int(r[0]) for r in out[1]] == [0, 10, 20] and out[1][0][3] == 1
+
+
+def test_full_size_config4_properties():
+    """BASELINE config 4 at full size (102 400 points): size-independent properties instead of the oracle --
+    (i) two half-domain shards sum to the whole; (ii) loss(theta = 0) = sum_e mean(F_e^2) + w*mean(u_d^2);
+    (iii) the wave-specialised reverse kernel (HPV_BWD=ws) agrees with the default one."""
+    import os
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    s = poisson2d.setup(N_el_x=16, N_el_y=16, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
+    L = [2, 20, 20, 20, 1]
+    th = xavier_init(L, 77)
+    m = poisson2d.build_model(s, L, init_params=th)
+    l3, g = m.loss_and_grad()
+    m0 = poisson2d.build_model(s, L, init_params=np.zeros_like(th))
+    z3 = m0.loss()
+    F = s["F_ext_total"]
+    assert abs(z3[2] - (F ** 2).mean(axis=(2, 3)).sum()) < 1e-10 * z3[2]
+    assert abs(z3[1] - (s["u_train"] ** 2).mean()) < 1e-13
+    os.environ["HPV_BWD"] = "ws"
+    try:
+        mw = poisson2d.build_model(s, L, init_params=th)
+        l3w, gw = mw.loss_and_grad()
+    finally:
+        del os.environ["HPV_BWD"]
+    assert rel(gw, g) < 1e-11 and rel(l3w, l3) < 1e-13
+    from hp_vpinns_amd import _lib
+    from hp_vpinns_amd.testfcn import tables_1d
+    from hp_vpinns_amd.vpinn import _tensor_rule
+    xi, wx, yi, wy = _tensor_rule(s["XY_quad_train"], s["WXY_quad_train"])
+    acc = 0
+    for (b, e, d) in ((0, 128, True), (128, 256, False)):
+        h = _lib.Handle(_lib.PDE_POISSON2D, 1, _lib.ACT_TANH, L, lossb_weight=10)
+        h.set_quadrature(xi, wx, yi, wy)
+        h.set_tables(tables_1d(10, xi), tables_1d(10, yi))
+        h.set_elements(s["grid_x"], s["grid_y"], b, e)
+        h.set_rhs(F.reshape(-1))
+        if d:
+            h.set_data(s["X_u_train"], s["u_train"].reshape(-1))
+        h.set_params(th)
+        acc = acc + h.loss_and_grad(True)[1]
+    assert rel(acc, g) < 1e-11
