@@ -454,3 +454,19 @@ def test_full_size_config4_properties():
         h.set_params(th)
         acc = acc + h.loss_and_grad(True)[1]
     assert rel(acc, g) < 1e-11
+
+
+@pytest.mark.parametrize("vf", [1, 2, 3])
+def test_tall_element_projection_1d(vf):
+    """(80 quad, 60 test) 1-D elements go through the workgroup-per-element projection kernel, incl. the edge
+    term of var_form 3 (P1:89-91)."""
+    o, m = _pair_1d("poisson1d_ne3", vf)
+    _check_loss_grad(o, m)
+    _check_traj(o, m, n=4)
+
+
+@pytest.mark.parametrize("vf", [0, 1])
+def test_tall_element_projection_advdiff_config5(vf):
+    """BASELINE config 5: AdvDiff, 8 elements, 80x80 GLL points and 5x5 test functions per element."""
+    o, m = _pair_adv("advdiff_cfg5", vf)
+    _check_loss_grad(o, m)
