@@ -471,7 +471,8 @@ __device__ __forceinline__ void adam_update(const AdamArgs& ad, int i, double g,
 }
 
 #define FIN_THREADS 1024
-#define FIN_PARTS (FIN_THREADS / 64)
+#define FIN_COLS 16                          // parameters per block (one 128-B row segment per partial row)
+#define FIN_PARTS (FIN_THREADS / FIN_COLS)   // row groups summed in parallel
 __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restrict__ GPART_v, int rows_v,
                                                          const double* __restrict__ GPART_b, int rows_b,
                                                          const double* __restrict__ GPART_e, int rows_e,
@@ -480,25 +481,26 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
                                                          const double* __restrict__ data_part, int n_data_part,
                                                          double lossb_weight, int n_data, int P, int has_eps,
                                                          double* __restrict__ RB, int write_grad, AdamArgs ad) {
-    __shared__ double red[FIN_PARTS * 64];
+    __shared__ double red[FIN_PARTS * FIN_COLS];
     const int Ptot = P + (has_eps ? 1 : 0);
     if (blockIdx.x < gridDim.x - 1) {
-        // 64 parameters per block; 16 row-groups summed in parallel then combined in a fixed order
+        // 16 parameters per block; 64 row-groups summed in parallel (few dependent loads per thread: the kernel is
+        // pure latency), then combined in a fixed order
         if (!write_grad) return;
-        const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
-        const int idx = blockIdx.x * 64 + c;
+        const int c = threadIdx.x & (FIN_COLS - 1), part = threadIdx.x / FIN_COLS;
+        const int idx = blockIdx.x * FIN_COLS + c;
         double acc = 0.0;
         if (idx < P) {
             if (GPART_v) for (int r = part; r < rows_v; r += FIN_PARTS) acc += GPART_v[(long)r * P + idx];
             if (GPART_b) for (int r = part; r < rows_b; r += FIN_PARTS) acc += GPART_b[(long)r * P + idx];
             if (GPART_e) for (int r = part; r < rows_e; r += FIN_PARTS) acc += GPART_e[(long)r * P + idx];
         }
-        red[part * 64 + c] = acc;
+        red[part * FIN_COLS + c] = acc;
         __syncthreads();
         if (part == 0 && idx < P) {
             double t = 0.0;
-#pragma unroll
-            for (int k = 0; k < FIN_PARTS; ++k) t += red[k * 64 + c];
+#pragma unroll 8
+            for (int k = 0; k < FIN_PARTS; ++k) t += red[k * FIN_COLS + c];
             RB[idx] = t;
             if (ad.theta) adam_update(ad, idx, t, ad.state[2 * (blockIdx.x + 1)], ad.state[2 * (blockIdx.x + 1) + 1]);
         }
@@ -540,14 +542,14 @@ void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, i
                      int rows_e, const double* loss_e, long n_elem, const double* deps_e, const double* data_part,
                      int n_data_part, double lossb_weight, int n_data, int P, int has_eps, double* RB, int write_grad,
                      const AdamArgs* fused_adam, hipStream_t s) {
-    int gblocks = (P + 63) / 64;
+    int gblocks = (P + FIN_COLS - 1) / FIN_COLS;
     AdamArgs ad{};
     if (fused_adam && write_grad) ad = *fused_adam;
     hipLaunchKernelGGL(k_finalize, dim3(gblocks + 1), dim3(FIN_THREADS), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e,
                        rows_e, loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB,
                        write_grad, ad);
 }
-int adam_state_doubles(int P) { return 2 * ((P + 63) / 64 + 1); }
+int adam_state_doubles(int P) { return 2 * ((P + FIN_COLS - 1) / FIN_COLS + 1); }
 
 // ------------------------------------------------------------------------------------------------
 // TF1 AdamOptimizer update (tf.train.AdamOptimizer(LR).minimize, P1:103-104):
