@@ -25,6 +25,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define MF_H 20
 #define MF_KS 5        // k-steps of 4 over the 20 inputs
 #define MF_LD 17       // padded leading dimension of the LDS transpose tiles
+#define MF_TR 21       // rows of a transpose tile: 20 neurons + 1 zero row; out-of-range fragment rows are clamped to it
 #define MF_BLOCK 256
 #define MF_WAVES (MF_BLOCK / 64)
 
@@ -326,9 +327,8 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
     const double* __restrict__ th = g.theta;
     // LDS map: [region A: per-wave transpose tiles during the tile loop, per-wave gradient rows in the
     //           epilogue] [region B: A-operand fragments of W for hbar_in^T = W zbar^T, lane-major]
-    constexpr int REGION_A = MF_WAVES * 2 * MF_H * MF_LD;
-    double* TA = lds + wv * (2 * MF_H * MF_LD);   // per-wave transpose tiles
-    double* TB = TA + MF_H * MF_LD;
+    constexpr int REGION_A = MF_WAVES * C * 2 * MF_TR * MF_LD;
+    double* TAB = lds + wv * (C * 2 * MF_TR * MF_LD);   // per-wave transpose tiles, one (h_in, zbar) pair per channel
     const int regA = REGION_A > MF_WAVES * g.P ? REGION_A : MF_WAVES * g.P;
     double* WN = lds + regA;                      // [(L-1)][MF_KS][64]  A fragments W[in = pt][out = 4s+q], rows 0..15
     double* WRB = WN + (L > 1 ? L - 1 : 0) * MF_KS * 64;   // [(L-1)][MF_KS][4 (q)][4 (a)]  W[in = 16+a][out = 4s+q]
@@ -342,6 +342,8 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
         for (int c = 0; c < D; ++c) w1[c][s] = th[g.woff[0] + c * MF_H + j];
         wo[s] = th[g.woff[L] + j];
     }
+    // rows 20..31 of every transpose tile stay zero for the whole kernel (the tile-1 fragments read them)
+    for (int f = lane; f < C * 2 * MF_TR * MF_LD; f += 64) TAB[f] = 0.0;
     // A operand of hbar_in^T = W zbar^T : W[in = 16t+pt][out = 4s+q], kept in LDS (not registers) so that
     // two waves per SIMD fit; every wave of the block reads the same lane-major fragments, conflict-free
     for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += MF_BLOCK) {
@@ -483,29 +485,39 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
                     for (int u = 0; u < NT1; ++u) dW1[u < D ? u : 0][s] += zbar[1 + u][s];
                 }
             } else {
-                // weight gradient: contraction over the 16 points of the tile (and over channels)
+                // weight gradient: contraction over the 16 points of the tile (and over channels).  All channels'
+                // tiles are written first (one wave-level sync), then fragments are read channel by channel, so the
+                // LDS reads of channel ch+1 overlap the MFMAs of channel ch.
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                double h16[C];
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) {
                     double hv[MF_KS];
                     outputs_of(prev, ch, hv);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                    h16[ch] = hv[4];
+                    double* TA = TAB + (2 * ch) * (MF_TR * MF_LD);
+                    double* TB = TA + MF_TR * MF_LD;
 #pragma unroll
                     for (int s = 0; s < MF_KS; ++s) {
                         TA[(4 * s + q) * MF_LD + pt] = hv[s];
                         TB[(4 * s + q) * MF_LD + pt] = zbar[ch][s];
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    const double* TA = TAB + (2 * ch) * (MF_TR * MF_LD);
+                    const double* TB = TA + MF_TR * MF_LD;
                     double aF[2][4], bF[2][4];
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) {
-                            const int row = 16 * t + pt;
-                            const bool ok = row < MF_H;
-                            aF[t][kk] = ok ? TA[row * MF_LD + 4 * kk + q] : 0.0;
-                            bF[t][kk] = ok ? TB[row * MF_LD + 4 * kk + q] : 0.0;
+                            const int row = (t == 0) ? pt : (16 + pt < MF_H ? 16 + pt : MF_H);   // row 20 is all zero
+                            aF[t][kk] = TA[row * MF_LD + 4 * kk + q];
+                            bF[t][kk] = TB[row * MF_LD + 4 * kk + q];
                         }
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
@@ -516,10 +528,10 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
                                 if (!(ti == 1 && to == 1))   // the 4x4 corner tile is 15/16 padding: VALU below
                                     dWacc[i - 1][ti][to] =
                                         __builtin_amdgcn_mfma_f64_16x16x4f64(aF[ti][kk], bF[to][kk], dWacc[i - 1][ti][to], 0, 0, 0);
-                    // corner dW[16+q][16+a] += h_in[pt][16+q] * zbar[pt][16+a]: all-gather zbar over the q lanes
+                    // corner dW[16+q][16+a] += h_in[pt][16+q] * zbar[pt][16+a], zbar read back from its tile
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
-                        accC[i - 1][a] = fma(hv[4], __shfl(zbar[ch][4], a * 16 + pt, 64), accC[i - 1][a]);
+                        accC[i - 1][a] = fma(h16[ch], TB[(16 + a) * MF_LD + pt], accC[i - 1][a]);
                 }
                 // hbar_in^T = W zbar^T
 #pragma unroll
@@ -642,7 +654,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_bwd_ws(MfmaArgs g) {
     constexpr int SZC = 1 + (ACT == HPV_ACT_SIN ? 1 : 0);
     constexpr int SZCC = SZC + NT1;
     constexpr int LH = L > 1 ? L - 1 : 1;
-    constexpr int TILE_D = MF_H * MF_LD;                 // one transposed 20x16 tile (padded)
+    constexpr int TILE_D = MF_TR * MF_LD;                // one transposed 20x16 tile (+12 zero rows, padded)
     constexpr int STAGE_D = C * 2 * TILE_D;              // h_in and zbar tiles of all channels of one layer
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -661,6 +673,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_bwd_ws(MfmaArgs g) {
     double* ST = lds + pair * (2 * STAGE_D);
     double* WN = lds + regA;
     double* WRB = WN + (L > 1 ? L - 1 : 0) * MF_KS * 64;
+    for (int f = threadIdx.x; f < WS_PAIRS * 2 * STAGE_D; f += WS_BLOCK) lds[f] = 0.0;   // zero rows of the tiles
     for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += WS_BLOCK) {
         const int ln = f & 63, s_ = (f >> 6) % MF_KS, i_ = f / (64 * MF_KS) + 1;
         WN[f] = th[g.woff[i_] + (ln & 15) * MF_H + 4 * s_ + (ln >> 4)];
@@ -882,10 +895,9 @@ __global__ void __launch_bounds__(WS_BLOCK) k_bwd_ws(MfmaArgs g) {
                         for (int t = 0; t < 2; ++t)
 #pragma unroll
                             for (int kk = 0; kk < 4; ++kk) {
-                                const int row = 16 * t + pt;
-                                const bool ok = row < MF_H;
-                                aF[t][kk] = ok ? TA[row * MF_LD + 4 * kk + q] : 0.0;
-                                bF[t][kk] = ok ? TB[row * MF_LD + 4 * kk + q] : 0.0;
+                                const int row = (t == 0) ? pt : (16 + pt < MF_H ? 16 + pt : MF_H);   // row 20 is all zero
+                                aF[t][kk] = TA[row * MF_LD + 4 * kk + q];
+                                bF[t][kk] = TB[row * MF_LD + 4 * kk + q];
                             }
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) {
@@ -952,8 +964,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_bwd_ws(MfmaArgs g) {
 // host side
 // ------------------------------------------------------------------------------------------------
 static size_t fwd_lds_bytes(int L) { return (size_t)(L > 1 ? L - 1 : 0) * (2 * MF_KS * 64 + MF_KS * 16) * sizeof(double); }
-static size_t bwd_lds_bytes(int P, int L) {
-    size_t regA = (size_t)MF_WAVES * 2 * MF_H * MF_LD;
+static size_t bwd_lds_bytes(int P, int L, int C) {
+    size_t regA = (size_t)MF_WAVES * C * 2 * MF_TR * MF_LD;
     if ((size_t)MF_WAVES * P > regA) regA = (size_t)MF_WAVES * P;
     return (regA + (size_t)(L > 1 ? L - 1 : 0) * (MF_KS * 64 + MF_KS * 16)) * sizeof(double);
 }
@@ -964,12 +976,12 @@ static void run_fwd(const MfmaArgs& a, int blocks, hipStream_t s) {
 }
 template <int D, int NT1, int NT2, int ACT, int L>
 static void run_bwd(const MfmaArgs& a, int blocks, hipStream_t s) {
-    size_t lds = bwd_lds_bytes(a.P, L);
+    size_t lds = bwd_lds_bytes(a.P, L, 1 + NT1 + NT2);
     hipLaunchKernelGGL((k_bwd_mfma<D, NT1, NT2, ACT, L>), dim3(blocks), dim3(MF_BLOCK), lds, s, a);
 }
 
 static size_t ws_lds_bytes(int P, int C, int L) {
-    size_t regA = (size_t)WS_PAIRS * 2 * C * 2 * MF_H * MF_LD;
+    size_t regA = (size_t)WS_PAIRS * 2 * C * 2 * MF_TR * MF_LD;
     if ((size_t)WS_PAIRS * P > regA) regA = (size_t)WS_PAIRS * P;
     return (regA + (size_t)(L > 1 ? L - 1 : 0) * (MF_KS * 64 + MF_KS * 16)) * sizeof(double);
 }
@@ -990,7 +1002,7 @@ static bool pick(HpvMfma* m) {
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&ow, k_bwd_ws<D, NT1, NT2, ACT, L>, WS_BLOCK, lw) == hipSuccess)
             m->occ_ws = ow;
     }
-    size_t lds = bwd_lds_bytes(m->nd.P, L);
+    size_t lds = bwd_lds_bytes(m->nd.P, L, 1 + NT1 + NT2);
     int of = 1, ob = 1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, k_fwd_mfma<D, NT1, NT2, ACT, L>, MF_BLOCK, fwd_lds_bytes(L));
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_bwd_mfma<D, NT1, NT2, ACT, L>, MF_BLOCK, lds);
