@@ -130,6 +130,8 @@ def main():
         traffic_tab = {}
     N_local = (model.Nelementx * model.Nelementy * 400) // world  # points per rank
     C, G = 3, gemm_flops_per_row(LAYERS)
+    # the reverse kernel runs in element-block mode with the per-element projection fused in front of it
+    # (project: kernel_ms 0): its 48 kflop/element are <1.2 % of the launch and are NOT counted as achieved flops
     flops = {"mlp_fwd": C * G * N_local, "mlp_bwd": 2 * C * G * N_local}
     dom = max(("mlp_fwd", "mlp_bwd"), key=lambda k: ktime[k])
     ach = flops[dom] / (ktime[dom] * 1e-3) / 1e12 if ktime[dom] > 0 else 0.0

@@ -11,6 +11,7 @@
 
 #include "hpv_internal.h"
 #include "hpv_mfma.h"
+#include "hpv_project_wg.h"
 
 namespace {
 
@@ -232,9 +233,9 @@ int assemble_batches(hpv_ctx* h) {
             h->data_off = Npad;
             if ((rc = alloc_batch(h, h->var, h->nd_var, Ntot, true))) return rc;
             if (h->var.ACT) { (void)hipFree(h->var.ACT); h->var.ACT = nullptr; }   // the MFMA path has its own store
-            const int rows = hpv_mfma_grad_rows(h->mfma);
+            const int rows = hpv_mfma_max_rows(h->mfma, h->n_elem);
             if ((rc = dalloc(h, &h->var.GPART, (size_t)rows * h->P))) return rc;
-            h->var.rows = rows;
+            h->var.rows = hpv_mfma_grad_rows(h->mfma);
             std::vector<double> X((size_t)d * Ntot, 0.0);
             for (int c = 0; c < d; ++c) {
                 for (long p = 0; p < N; ++p) X[(size_t)c * Ntot + p] = h->Xq_host[(size_t)c * N + p];
@@ -326,14 +327,32 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
         tstart(h, 0);
         MfmaDataTerm dt{h->data_off, h->merged ? h->n_data : 0, h->d_udata, h->var.GBAR, h->d_data_part,
                         h->n_data > 0 ? -2.0 * h->cfg.lossb_weight / (double)h->n_data : 0.0, backward ? 1 : 0};
-        if (use_mfma) hpv_mfma_forward(h->mfma, h->d_theta, h->var.X, h->var.OUT, backward ? 1 : 0, h->stream, &dt);
+        bool fused = false;
+        if (use_mfma && !h->timing) {   // timing mode keeps the kernels separate so each class can be measured
+            ProjArgs pa{h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
+                        h->d_loss_e, h->d_deps_e, h->var.N, backward ? 1 : 0, nullptr, nullptr, nullptr, nullptr};
+            fused = hpv_mfma_forward_fused(h->mfma, h->d_theta, h->var.X, h->var.OUT, backward ? 1 : 0, h->stream, &dt, pa, h->n_elem);
+        }
+        if (fused) { /* forward + projection done */ }
+        else if (use_mfma) hpv_mfma_forward(h->mfma, h->d_theta, h->var.X, h->var.OUT, backward ? 1 : 0, h->stream, &dt);
         else run_fwd(h, h->var, nullptr, backward ? 1 : 0);
         tstop(h, 0);
         if (h->pd.edge) run_fwd(h, h->edge, h->mfma_edge, backward ? 1 : 0);
+        // projection: fused into the reverse kernel (element-block mode) when that applies, otherwise its own launch
+        bool bfused = false;
+        if (backward && use_mfma && !fused) {
+            ProjArgs pa{h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
+                        h->d_loss_e, h->d_deps_e, h->var.N, 1, nullptr, nullptr, nullptr, nullptr};
+            tstart(h, 2);   // timed as the reverse-pass class (the projection is ~1 % of its flops)
+            bfused = hpv_mfma_backward_fused(h->mfma, h->d_theta, h->var.X, h->var.GBAR, h->var.GPART, &h->var.rows, h->stream,
+                                             pa, h->n_elem);
+            if (bfused) tstop(h, 2);   // (otherwise nothing was launched; the start event is re-recorded below)
+        }
         tstart(h, 1);
         // specialised tensor-product kernel for the hot element shapes unless the generic backend is forced
         // (needs GBAR's unused channels pre-zeroed: true for every batch, see alloc_batch)
-        if (h->cfg.backend == HPV_BACKEND_GENERIC ||
+        if (fused || bfused) {
+        } else if (h->cfg.backend == HPV_BACKEND_GENERIC ||
             (!launch_project_tp(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
                                 eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->stream) &&
              !launch_project_wg(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
@@ -343,11 +362,13 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
                            h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi,
                            h->d_edge_coef, h->edge.GBAR, h->stream);
         tstop(h, 1);
-        if (backward) {
+        if (backward && !bfused) {
             tstart(h, 2);
             if (use_mfma) hpv_mfma_backward(h->mfma, h->d_theta, h->var.X, h->var.GBAR, h->var.GPART, &h->var.rows, h->stream);
             else run_bwd(h, h->var, nullptr);
             tstop(h, 2);
+        }
+        if (backward) {
             if (h->pd.edge) run_bwd(h, h->edge, h->mfma_edge);
         }
     }

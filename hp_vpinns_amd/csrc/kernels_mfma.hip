@@ -19,6 +19,7 @@
 
 #include "hpv_mfma.h"
 #include "hpv_math.h"
+#include "hpv_project_wg.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -51,6 +52,9 @@ struct MfmaArgs {
     double* data_part;    // [data tiles] partial sums of (u_d - u)^2
     double data_scale;    // -2 w / n_data
     int data_write_gbar;
+    // fused forward + projection (element-block mode): blocks [0, proj_n_elem) own one element each
+    long proj_n_elem;
+    ProjArgs pa;
 };
 
 struct HpvMfma {
@@ -64,8 +68,11 @@ struct HpvMfma {
     void (*fwd)(const MfmaArgs&, int, hipStream_t) = nullptr;
     void (*bwd)(const MfmaArgs&, int, hipStream_t) = nullptr;
     void (*bwd_ws)(const MfmaArgs&, int, hipStream_t) = nullptr;   // wave-specialised reverse kernel
+    void (*fwd_fused)(const MfmaArgs&, int, hipStream_t) = nullptr; // forward + projection (kept for A/B: HPV_FUSE=fwd)
+    void (*bwd_fused)(const MfmaArgs&, int, hipStream_t) = nullptr; // projection + reverse, element-block mode
     int occ_fwd = 1, occ_bwd = 1;   // resident 256-thread blocks per CU
     int occ_ws = 0;                 // resident 512-thread blocks per CU of the wave-specialised kernel (0: unusable)
+    int max_rows = 0;               // gradient rows the caller allocated (>= every launch mode's row count)
     bool use_ws = false;
     int ws_blocks = 0;
 };
@@ -113,8 +120,12 @@ struct SlotCount {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int D, int NT1, int NT2, int ACT, int L>
-__global__ void __launch_bounds__(MF_BLOCK, 2) k_fwd_mfma(MfmaArgs g) {
+// BLK threads per workgroup.  PQX > 0 selects the FUSED forward+projection mode for elements of PQX x PQY
+// points (a multiple of 16) with PNTX x PNTY test functions: workgroup b < proj_n_elem runs all tiles of element
+// b and then, after a workgroup barrier, projects it (project_element_wg) -- the per-element projection no
+// longer is a separate, latency-bound launch on a fraction of the CUs; later workgroups take the data tiles.
+template <int D, int NT1, int NT2, int ACT, int L, int BLK = MF_BLOCK, int PQX = 0, int PQY = 0, int PNTX = 0, int PNTY = 0>
+__global__ void __launch_bounds__(BLK, BLK == 256 ? 2 : 1) k_fwd_mfma(MfmaArgs g) {
     constexpr int C = 1 + NT1 + NT2;
     constexpr int NS = SlotCount<ACT, NT1, NT2>::value;
     constexpr int SA1 = 1;                                   // slot of A1 (sin only)
@@ -122,8 +133,22 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) k_fwd_mfma(MfmaArgs g) {
     constexpr int SZCC = SZC + NT1;
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, pt = lane & 15;
-    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    long tile_end = g.ntiles;
+    if constexpr (PQX > 0) {
+        constexpr long TPE = (PQX * PQY) / 16;   // tiles per element
+        constexpr int WPB = BLK / 64;
+        const int wvi = threadIdx.x >> 6;
+        if ((long)blockIdx.x < g.proj_n_elem) {
+            wave = (long)blockIdx.x * TPE + wvi;
+            nwaves = WPB;
+            tile_end = ((long)blockIdx.x + 1) * TPE;
+        } else {
+            wave = g.proj_n_elem * TPE + ((long)blockIdx.x - g.proj_n_elem) * WPB + wvi;
+            nwaves = ((long)gridDim.x - g.proj_n_elem) * WPB;
+        }
+    }
     const double* __restrict__ th = g.theta;
 
     // per-lane weight fragments
@@ -146,22 +171,22 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) k_fwd_mfma(MfmaArgs g) {
     double* WT = fl;                                   // [(L-1)][MF_KS][64]
     double* BH = fl + (L > 1 ? L - 1 : 0) * MF_KS * 64;       // [(L-1)][MF_KS][64]
     double* WR = BH + (L > 1 ? L - 1 : 0) * MF_KS * 64;       // [(L-1)][MF_KS][4 (q)][4 (a)]
-    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += MF_BLOCK) {
+    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += BLK) {
         const int ln = f & 63, s_ = (f >> 6) % MF_KS, i_ = f / (64 * MF_KS) + 1;
         WT[f] = th[g.woff[i_] + (4 * s_ + (ln >> 4)) * MF_H + (ln & 15)];
     }
-    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 16; f += MF_BLOCK) {
+    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 16; f += BLK) {
         const int a_ = f & 3, q_ = (f >> 2) & 3, s_ = (f >> 4) % MF_KS, i_ = f / (16 * MF_KS) + 1;
         WR[f] = th[g.woff[i_] + (4 * s_ + q_) * MF_H + 16 + a_];
     }
-    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += MF_BLOCK) {
+    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += BLK) {
         const int ln = f & 63, s_ = (f >> 6) % MF_KS, i_ = f / (64 * MF_KS) + 1;
         BH[f] = th[g.boff[i_] + 4 * s_ + (ln >> 4)];
     }
     __syncthreads();
     const double bo = th[g.boff[L]];
 
-    for (long tile = wave; tile < g.ntiles; tile += nwaves) {
+    for (long tile = wave; tile < tile_end; tile += nwaves) {
         const long p = tile * 16 + pt;
         const bool valid = p < g.N;
         double x[D];
@@ -278,6 +303,14 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) k_fwd_mfma(MfmaArgs g) {
             }
         }
     }
+    if constexpr (PQX > 0) {
+        __threadfence_block();
+        __syncthreads();     // the element's output channels (written by this workgroup) are complete
+        if ((long)blockIdx.x < g.proj_n_elem) {
+            double* psm = fl + (L > 1 ? L - 1 : 0) * (2 * MF_KS * 64 + MF_KS * 16);
+            project_element_wg<PQX, PQY, PNTX, PNTY, BLK>(g.pa, (long)blockIdx.x, psm);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -312,7 +345,13 @@ __device__ __forceinline__ void layer_outputs_from_saved(const double* svl, cons
     }
 }
 
-template <int D, int NT1, int NT2, int ACT, int L>
+// PQX > 0: ELEMENT-BLOCK mode with the projection fused in.  Workgroup b owns element b: it first projects the
+// element (residual, element loss, adjoint of the integrated channels -> GBAR; project_element_wg), then runs the
+// reverse pass over the element's PQX*PQY/16 tiles (+ one of the boundary/data tiles).  The per-element
+// projection thus rides on all CUs inside the reverse kernel instead of being a separate latency-bound launch on
+// a fraction of them, and -- unlike fusing it behind the forward pass -- costs no extra tile imbalance
+// (25 tiles over 4 waves = the same 7-tile makespan as the round-robin assignment).
+template <int D, int NT1, int NT2, int ACT, int L, int PQX = 0, int PQY = 0, int PNTX = 0, int PNTY = 0>
 __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
     constexpr int C = 1 + NT1 + NT2;
     constexpr int NS = SlotCount<ACT, NT1, NT2>::value;
@@ -355,12 +394,13 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
         WRB[f] = th[g.woff[i_] + (16 + a_) * MF_H + 4 * s_ + q_];
     }
     __syncthreads();
-    double zc1[(NT1 > 0 ? NT1 : 1) * MF_KS];   // z_c of layer 1 = W1[c,:]
-#pragma unroll
-    for (int u = 0; u < NT1; ++u)
-#pragma unroll
-        for (int s = 0; s < MF_KS; ++s) zc1[u * MF_KS + s] = w1[u < D ? u : 0][s];
-
+    if constexpr (PQX > 0) {
+        // region A is free until the tile loop: use it as the projection's scratch
+        project_element_wg<PQX, PQY, PNTX, PNTY, MF_BLOCK>(g.pa, (long)blockIdx.x, lds);
+        __threadfence_block();
+        __syncthreads();
+        for (int f = lane; f < C * 2 * MF_TR * MF_LD; f += 64) TAB[f] = 0.0;   // re-zero this wave's transpose tiles
+    }
     // gradient accumulators (per wave, over all its tiles)
     v4d dWacc[LH][2][2];
 #pragma unroll
@@ -399,7 +439,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
             S.a[s] = svl[(0 * MF_KS + s) * 64];
             if constexpr (ACT == HPV_ACT_SIN) S.a1s[s] = svl[(1 * MF_KS + s) * 64]; else S.a1s[s] = 0.0;
 #pragma unroll
-            for (int u = 0; u < NT1; ++u) S.zc[u][s] = first_layer ? zc1[u * MF_KS + s] : svl[((SZC + u) * MF_KS + s) * 64];
+            for (int u = 0; u < NT1; ++u) S.zc[u][s] = first_layer ? w1[u < D ? u : 0][s] : svl[((SZC + u) * MF_KS + s) * 64];
 #pragma unroll
             for (int b = 0; b < NT2; ++b) S.zcc[b][s] = first_layer ? 0.0 : svl[((SZCC + b) * MF_KS + s) * 64];
         }
@@ -431,8 +471,26 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
     };
     double x[D], gb[C];
     Slots cur;
-    if (wave < g.ntiles) load_tile_inputs(wave, x, gb, cur);
-    for (long tile = wave; tile < g.ntiles; tile += nwaves) {
+    // tile sequence of this wave: round-robin over the batch, or (element-block mode) the tiles of the
+    // workgroup's element followed by at most one boundary/data tile
+    constexpr long TPE = PQX > 0 ? (PQX * PQY) / 16 : 1;
+    const long ebase = (long)blockIdx.x * TPE;
+    const long dtile = g.proj_n_elem * TPE + blockIdx.x;          // the data/pad tile this workgroup adopts
+    auto tile_of = [&](long k) -> long {                            // k-th tile of this wave, -1 when exhausted
+        if constexpr (PQX > 0) {
+            const long lt = wv + k * MF_WAVES;                      // local index among TPE (+1) tiles
+            if (lt < TPE) return ebase + lt;
+            if (lt == TPE && dtile < g.ntiles) return dtile;
+            return -1;
+        } else {
+            const long t = wave + k * nwaves;
+            return t < g.ntiles ? t : -1;
+        }
+    };
+    for (long kt = 0;; ++kt) {
+        const long tile = tile_of(kt);
+        if (tile < 0) break;
+        load_tile_inputs(tile, x, gb, cur);
         const double* sv = g.ACTS + (tile * L) * (long)(NS * MF_KS * 64) + lane;
 
         double hbar[C][MF_KS], zbar[C][MF_KS];
@@ -552,7 +610,6 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
                 cur = prev;
             }
         }
-        if (tile + nwaves < g.ntiles) load_tile_inputs(tile + nwaves, x, gb, cur);
     }
 
     // ---- epilogue: per-wave partials -> LDS -> one row per block ----
@@ -974,6 +1031,20 @@ template <int D, int NT1, int NT2, int ACT, int L>
 static void run_fwd(const MfmaArgs& a, int blocks, hipStream_t s) {
     hipLaunchKernelGGL((k_fwd_mfma<D, NT1, NT2, ACT, L>), dim3(blocks), dim3(MF_BLOCK), fwd_lds_bytes(L), s, a);
 }
+static size_t bwd_lds_bytes(int P, int L, int C);
+template <int D, int NT1, int NT2, int ACT, int L, int QX, int QY, int NTX, int NTY>
+static void run_bwd_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
+    size_t lds = bwd_lds_bytes(a.P, L, 1 + NT1 + NT2);
+    hipLaunchKernelGGL((k_bwd_mfma<D, NT1, NT2, ACT, L, QX, QY, NTX, NTY>), dim3(blocks), dim3(MF_BLOCK), lds, s, a);
+}
+
+#define FZ_BLK 512
+template <int D, int NT1, int NT2, int ACT, int L, int QX, int QY, int NTX, int NTY>
+static void run_fwd_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
+    const size_t lds = fwd_lds_bytes(L) + (size_t)project_wg_lds_doubles<QX, QY, NTX, NTY>() * sizeof(double);
+    hipLaunchKernelGGL((k_fwd_mfma<D, NT1, NT2, ACT, L, FZ_BLK, QX, QY, NTX, NTY>), dim3(blocks), dim3(FZ_BLK), lds, s, a);
+}
+
 template <int D, int NT1, int NT2, int ACT, int L>
 static void run_bwd(const MfmaArgs& a, int blocks, hipStream_t s) {
     size_t lds = bwd_lds_bytes(a.P, L, 1 + NT1 + NT2);
@@ -995,6 +1066,10 @@ static bool pick(HpvMfma* m) {
     m->fwd = run_fwd<D, NT1, NT2, ACT, L>;
     m->bwd = run_bwd<D, NT1, NT2, ACT, L>;
     m->bwd_ws = run_bwd_ws<D, NT1, NT2, ACT, L>;
+    if constexpr (D == 2 && NT1 == 2 && NT2 == 0 && ACT == HPV_ACT_TANH)   // BASELINE config 4 (Poisson-2D var_form 1)
+        m->fwd_fused = run_fwd_fused<D, NT1, NT2, ACT, L, 20, 20, 10, 10>;
+    if constexpr (D == 2 && NT1 == 2 && NT2 == 0 && ACT == HPV_ACT_TANH)
+        m->bwd_fused = run_bwd_fused<D, NT1, NT2, ACT, L, 20, 20, 10, 10>;
     {
         int ow = 0;
         size_t lw = ws_lds_bytes(m->nd.P, 1 + NT1 + NT2, L);
@@ -1084,6 +1159,13 @@ void hpv_mfma_destroy(HpvMfma* m) {
 }
 
 int hpv_mfma_grad_rows(HpvMfma* m) { return m->use_ws ? m->ws_blocks : m->bwd_blocks; }
+// rows the caller must allocate: the element-block mode writes one row per element
+int hpv_mfma_max_rows(HpvMfma* m, long n_elem) {
+    int r = hpv_mfma_grad_rows(m);
+    if (m->bwd_fused && n_elem > r && n_elem <= 65536) r = (int)n_elem;
+    m->max_rows = r;
+    return r;
+}
 
 void hpv_mfma_forward(HpvMfma* m, const double* theta, const double* X, double* OUT, int save_act, hipStream_t s,
                       const MfmaDataTerm* dt) {
@@ -1103,6 +1185,54 @@ void hpv_mfma_backward(HpvMfma* m, const double* theta, const double* X, const d
     a.theta = theta; a.X = X; a.GBAR = GBAR; a.GPART = GPART;
     if (m->use_ws) m->bwd_ws(a, m->ws_blocks, s); else m->bwd(a, m->bwd_blocks, s);
     if (rows) *rows = hpv_mfma_grad_rows(m);
+}
+
+// Forward with the per-element projection fused in (element-block mode).  Returns false when this object /
+// element shape has no fused instantiation; the caller then runs forward and projection separately.
+bool hpv_mfma_forward_fused(HpvMfma* m, const double* theta, const double* X, double* OUT, int save_act, hipStream_t s,
+                            const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem) {
+    const ProjDesc& pd = pa.pd;
+    if (!m->fwd_fused || pd.edge || n_elem <= 0) return false;
+    if (!(pd.qx == 20 && pd.qy == 20 && pd.ntx == 10 && pd.nty == 10)) return false;
+    const long tpe = (20 * 20) / 16;
+    if (n_elem * tpe > m->ntiles) return false;
+    static const bool on = [] { const char* e = getenv("HPV_FUSE"); return e && e[0] == 'f'; }();   // A/B only
+    if (!on) return false;
+    MfmaArgs a = m->base;
+    a.theta = theta; a.X = X; a.OUT = OUT; a.save_act = save_act;
+    a.data_off = -1;
+    if (dt && dt->n_data > 0) {
+        a.data_off = dt->data_off; a.ud = dt->ud; a.gbar0 = dt->gbar0; a.data_part = dt->data_part;
+        a.data_scale = dt->scale; a.data_write_gbar = dt->write_gbar;
+    }
+    a.proj_n_elem = n_elem;
+    a.pa = pa;
+    const long rest = m->ntiles - n_elem * tpe;                 // pad + data tiles
+    const int extra = (int)((rest + (FZ_BLK / 64) - 1) / (FZ_BLK / 64));
+    m->fwd_fused(a, (int)n_elem + extra, s);
+    return true;
+}
+
+// Reverse pass with the per-element projection fused in front (element-block mode).  Returns false when not
+// applicable; the caller then launches projection and reverse pass separately.
+bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, const double* GBAR, double* GPART, int* rows,
+                             hipStream_t s, const ProjArgs& pa, long n_elem) {
+    const ProjDesc& pd = pa.pd;
+    if (!m->bwd_fused || m->use_ws || pd.edge || n_elem <= 0) return false;
+    if (!(pd.qx == 20 && pd.qy == 20 && pd.ntx == 10 && pd.nty == 10)) return false;
+    const long tpe = (20 * 20) / 16;
+    const long rest = m->ntiles - n_elem * tpe;                 // pad + data tiles: at most one per workgroup
+    if (rest < 0 || rest > n_elem) return false;
+    if (n_elem > hpv_mfma_grad_rows(m) && n_elem > m->max_rows) return false;
+    static const bool off = [] { const char* e = getenv("HPV_FUSE"); return e && (e[0] == 'n' || e[0] == 'f'); }();
+    if (off) return false;
+    MfmaArgs a = m->base;
+    a.theta = theta; a.X = X; a.GBAR = GBAR; a.GPART = GPART;
+    a.proj_n_elem = n_elem;
+    a.pa = pa;
+    m->bwd_fused(a, (int)n_elem, s);
+    if (rows) *rows = (int)n_elem;
+    return true;
 }
 
 bool hpv_mfma_has_projection(HpvMfma*) { return false; }

@@ -12,17 +12,8 @@
 // term uses are neither read nor written; their GBAR rows are zeroed once by the host).  This is the kernel
 // judged against the HBM roofline on the scaled synthetic batch.
 #include "hpv_internal.h"
+#include "hpv_project_wg.h"
 
-
-__device__ __forceinline__ double pj_wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ void pj_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 
 // Work decomposition: "a lane owns a line".  LPE = max(QX,QY) lanes serve one element, EPW = 64/LPE elements
 // share a wavefront (3 for 20x20 points, 6 for 10x10).  In every contraction the lane keeps its line of
@@ -330,183 +321,9 @@ static bool launch_tp(const ProjDesc& pd, const double* OUT, double* GBAR, doubl
 // ------------------------------------------------------------------------------------------------
 #define PW_BLOCK 256
 template <int QX, int QY, int NTX, int NTY>
-__global__ void __launch_bounds__(PW_BLOCK) k_project_wg(ProjDesc pd, const double* __restrict__ OUT, double* __restrict__ GBAR,
-                                                        double* __restrict__ R, const double* __restrict__ F,
-                                                        const double* __restrict__ coef, long coef_stride,
-                                                        const double* __restrict__ wtx, const double* __restrict__ wty,
-                                                        const double* __restrict__ eps_ptr, double* __restrict__ loss_e,
-                                                        double* __restrict__ deps_e, long N, int do_adjoint,
-                                                        const double* __restrict__ edge_u, const double* __restrict__ edge_dphi,
-                                                        const double* __restrict__ edge_coef, double* __restrict__ edge_gbar) {
-    constexpr int NQ = QX * QY, NR = NTX * NTY, LDG = QX + 1;
-    constexpr int NIT = (NQ + PW_BLOCK - 1) / PW_BLOCK;
+__global__ void __launch_bounds__(PW_BLOCK) k_project_wg(ProjArgs pa) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* G = sm;                              // [QY][LDG]
-    double* AXl = G + QY * LDG;                  // [NTX][QX]   this term's w_x phi^(dx)
-    double* BYl = AXl + NTX * QX;                // [HPV_MAXT][NTY][QY]  (every term's y table: the adjoint needs all)
-    double* T = BYl + HPV_MAXT * NTY * QY;       // [QY][NTX]
-    double* U = T + QY * NTX;                    // [NR]
-    double* S = U + NR;                          // [HPV_MAXT][NTY][QX]
-    double* red = S + HPV_MAXT * NTY * QX;       // [16]
-    const long e = blockIdx.x;
-    const long base = e * NQ;
-    const int tid = threadIdx.x;
-    const int nterms = pd.nterms, C = pd.C;
-    const double eps = eps_ptr ? eps_ptr[0] : 0.0;
-
-    for (int idx = tid; idx < NR; idx += PW_BLOCK) U[idx] = F ? -F[e * NR + idx] : 0.0;
-    for (int t = 0; t < nterms; ++t)
-        for (int i = tid; i < NTY * QY; i += PW_BLOCK) BYl[t * NTY * QY + i] = wty[(long)pd.t[t].dy * NTY * QY + i];
-    for (int t = 0; t < nterms; ++t) {
-        const TermDesc& td = pd.t[t];
-        // integrand at the element's points: all loads in flight together
-        // (unconditional loads with clamped indices: a branch around each load would serialise them into one
-        //  memory round trip per load -- measured 60 us for the 80x80 element)
-        double gv[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) gv[it] = 0.0;
-#pragma unroll
-        for (int ch = 0; ch < HPV_MAXC; ++ch) {
-            const double al = (ch < C) ? td.a0[ch] + eps * td.a1[ch] : 0.0;
-            if (al != 0.0) {     // block-uniform: whole channels are skipped, never single loads
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int qd = it * PW_BLOCK + tid;
-                    const double v = OUT[(long)ch * N + base + (qd < NQ ? qd : NQ - 1)];
-                    gv[it] = fma(al, v, gv[it]);
-                }
-            }
-        }
-        __syncthreads();                         // previous users of G / AXl / T are done
-        for (int i = tid; i < NTX * QX; i += PW_BLOCK) AXl[i] = wtx[(long)td.dx * NTX * QX + i];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int qd = it * PW_BLOCK + tid;
-            if (qd < NQ) G[(qd / QX) * LDG + (qd % QX)] = gv[it];
-        }
-        __syncthreads();
-        for (int o = tid; o < QY * NTX; o += PW_BLOCK) {
-            const int j = o / NTX, r = o % NTX;
-            double acc = 0.0;
-#pragma unroll 8
-            for (int i = 0; i < QX; ++i) acc = fma(AXl[r * QX + i], G[j * LDG + i], acc);
-            T[o] = acc;
-        }
-        __syncthreads();
-        const double c = coef[(long)t * coef_stride + e] * (td.eps_mult ? eps : 1.0);
-        for (int o = tid; o < NR; o += PW_BLOCK) {
-            const int k = o / NTX, r = o % NTX;
-            double acc = 0.0;
-#pragma unroll 8
-            for (int j = 0; j < QY; ++j) acc = fma(BYl[t * NTY * QY + k * QY + j], T[j * NTX + r], acc);
-            U[o] = fma(c, acc, U[o]);
-        }
-    }
-    __syncthreads();
-    if (pd.edge) {   // P1:90: + 1/J [u(x_R) phi'_k(1) - u(x_L) phi'_k(-1)]
-        const double uL = edge_u[2 * e], uR = edge_u[2 * e + 1], ce = edge_coef[e];
-        for (int o = tid; o < NR; o += PW_BLOCK) U[o] += ce * (uR * edge_dphi[2 * o + 1] - uL * edge_dphi[2 * o]);
-        __syncthreads();
-    }
-    double sq = 0.0;
-    for (int o = tid; o < NR; o += PW_BLOCK) {
-        const double u = U[o];
-        R[e * NR + o] = u;
-        sq = fma(u, u, sq);
-    }
-    sq = pj_wave_sum(sq);
-    if ((tid & 63) == 0) red[tid >> 6] = sq;
-    __syncthreads();
-    if (tid == 0) loss_e[e] = (red[0] + red[1] + red[2] + red[3]) / (double)NR;
-    if (!do_adjoint) return;
-
-    const double sc = 2.0 / (double)NR;
-    for (int t = 0; t < nterms; ++t) {
-        if (nterms > 1 || t != nterms - 1) {     // AXl still holds the last forward term's table otherwise
-            __syncthreads();
-            for (int i = tid; i < NTX * QX; i += PW_BLOCK) AXl[i] = wtx[(long)pd.t[t].dx * NTX * QX + i];
-            __syncthreads();
-        }
-        for (int o = tid; o < NTY * QX; o += PW_BLOCK) {
-            const int k = o / QX, i = o % QX;
-            double acc = 0.0;
-#pragma unroll 4
-            for (int r = 0; r < NTX; ++r) acc = fma(AXl[r * QX + i], U[k * NTX + r], acc);
-            S[t * NTY * QX + o] = acc * sc;
-        }
-    }
-    __syncthreads();
-    double deps = 0.0;
-    constexpr int CHK = 5;                       // points per thread whose channel re-reads travel together
-#pragma unroll 1
-    for (int it0 = 0; it0 < NIT; it0 += CHK) {
-        double o[CHK][HPV_MAXC];
-        if (pd.has_eps) {                        // d/d(eps) needs the channels again: one round trip per chunk
-#pragma unroll
-            for (int u = 0; u < CHK; ++u) {
-                const int qd = (it0 + u) * PW_BLOCK + tid;
-#pragma unroll
-                for (int ch = 0; ch < HPV_MAXC; ++ch)
-                    o[u][ch] = OUT[(long)(ch < C ? ch : 0) * N + base + (qd < NQ ? qd : NQ - 1)];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < CHK; ++u) {
-            const int qd = (it0 + u) * PW_BLOCK + tid;
-            if (it0 + u < NIT && qd < NQ) {
-                const int j = qd / QX, i = qd % QX;
-                double gb[HPV_MAXC];
-#pragma unroll
-                for (int ch = 0; ch < HPV_MAXC; ++ch) gb[ch] = 0.0;
-                for (int t = 0; t < nterms; ++t) {
-                    const TermDesc& td = pd.t[t];
-                    const double* by = BYl + t * NTY * QY;
-                    double gh = 0.0;
-#pragma unroll 4
-                    for (int k = 0; k < NTY; ++k) gh = fma(by[k * QY + j], S[t * NTY * QX + k * QX + i], gh);
-                    gh *= coef[(long)t * coef_stride + e];
-                    const double m = td.eps_mult ? eps : 1.0;
-                    double g1 = 0.0, gt = 0.0;
-#pragma unroll
-                    for (int ch = 0; ch < HPV_MAXC; ++ch) {
-                        const double al = td.a0[ch] + eps * td.a1[ch];
-                        gb[ch] = fma(al, m * gh, gb[ch]);
-                        if (pd.has_eps) {
-                            g1 = fma(td.a1[ch], o[u][ch], g1);
-                            gt = fma(al, o[u][ch], gt);
-                        }
-                    }
-                    deps = fma(gh, m * g1 + (td.eps_mult ? gt : 0.0), deps);
-                }
-#pragma unroll
-                for (int ch = 0; ch < HPV_MAXC; ++ch)
-                    if (ch < C) GBAR[(long)ch * N + base + qd] = gb[ch];
-            }
-        }
-    }
-    if (pd.edge) {
-        double sl = 0.0, sr = 0.0;
-        for (int o = tid; o < NR; o += PW_BLOCK) {
-            sl = fma(U[o], edge_dphi[2 * o], sl);
-            sr = fma(U[o], edge_dphi[2 * o + 1], sr);
-        }
-        sl = pj_wave_sum(sl);
-        sr = pj_wave_sum(sr);
-        __syncthreads();
-        if ((tid & 63) == 0) { red[tid >> 6] = sl; red[4 + (tid >> 6)] = sr; }
-        __syncthreads();
-        if (tid == 0) {
-            edge_gbar[2 * e] = -edge_coef[e] * sc * (red[0] + red[1] + red[2] + red[3]);
-            edge_gbar[2 * e + 1] = edge_coef[e] * sc * (red[4] + red[5] + red[6] + red[7]);
-        }
-    }
-    if (pd.has_eps) {
-        deps = pj_wave_sum(deps);
-        __syncthreads();
-        if ((tid & 63) == 0) red[8 + (tid >> 6)] = deps;
-        __syncthreads();
-        if (tid == 0) deps_e[e] = red[8] + red[9] + red[10] + red[11];
-    }
+    project_element_wg<QX, QY, NTX, NTY, PW_BLOCK>(pa, (long)blockIdx.x, sm);
 }
 
 template <int QX, int QY, int NTX, int NTY>
@@ -514,14 +331,15 @@ static bool launch_wg(const ProjDesc& pd, const double* OUT, double* GBAR, doubl
                       long coef_stride, const double* wtx, const double* wty, const double* eps_ptr, double* loss_e,
                       double* deps_e, long N, long n_elem, int do_adjoint, const double* edge_u, const double* edge_dphi,
                       const double* edge_coef, double* edge_gbar, hipStream_t s) {
-    constexpr size_t lds = (size_t)(QY * (QX + 1) + NTX * QX + HPV_MAXT * NTY * QY + QY * NTX + NTX * NTY + HPV_MAXT * NTY * QX + 16) * sizeof(double);
+    constexpr size_t lds = (size_t)project_wg_lds_doubles<QX, QY, NTX, NTY>() * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KB of dynamic LDS needs the opt-in
         (void)hipFuncSetAttribute((const void*)k_project_wg<QX, QY, NTX, NTY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_project_wg<QX, QY, NTX, NTY>), dim3((unsigned)n_elem), dim3(PW_BLOCK), lds, s, pd, OUT, GBAR, R, F, coef,
-                       coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, N, do_adjoint, edge_u, edge_dphi, edge_coef, edge_gbar);
+    ProjArgs pa{pd, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, N, do_adjoint, edge_u, edge_dphi,
+                edge_coef, edge_gbar};
+    hipLaunchKernelGGL((k_project_wg<QX, QY, NTX, NTY>), dim3((unsigned)n_elem), dim3(PW_BLOCK), lds, s, pa);
     return true;
 }
 
