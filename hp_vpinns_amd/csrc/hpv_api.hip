@@ -348,7 +348,7 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
                                              pa, h->n_elem);
             if (bfused) tstop(h, 2);   // (otherwise nothing was launched; the start event is re-recorded below)
         }
-        tstart(h, 1);
+        if (!(fused || bfused)) tstart(h, 1);
         // specialised tensor-product kernel for the hot element shapes unless the generic backend is forced
         // (needs GBAR's unused channels pre-zeroed: true for every batch, see alloc_batch)
         if (fused || bfused) {
@@ -361,7 +361,7 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
             launch_project(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
                            h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi,
                            h->d_edge_coef, h->edge.GBAR, h->stream);
-        tstop(h, 1);
+        if (!(fused || bfused)) tstop(h, 1);
         if (backward && !bfused) {
             tstart(h, 2);
             if (use_mfma) hpv_mfma_backward(h->mfma, h->d_theta, h->var.X, h->var.GBAR, h->var.GPART, &h->var.rows, h->stream);
