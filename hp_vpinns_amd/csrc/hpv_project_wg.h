@@ -37,7 +37,7 @@ struct ProjArgs {
 
 template <int QX, int QY, int NTX, int NTY>
 constexpr int project_wg_lds_doubles() {
-    return QY * (QX + 1) + NTX * QX + HPV_MAXT * NTY * QY + QY * NTX + NTX * NTY + HPV_MAXT * NTY * QX + 32;
+    return QY * (QX + 1) + HPV_MAXT * NTX * QX + HPV_MAXT * NTY * QY + QY * NTX + NTX * NTY + HPV_MAXT * NTY * QX + 32;
 }
 
 // Projection (+ adjoint) of ONE element by a whole workgroup of PW_BLOCK threads; `sm` = its LDS scratch of
@@ -67,8 +67,8 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
     constexpr int NQ = QX * QY, NR = NTX * NTY, LDG = QX + 1;
     constexpr int NIT = (NQ + PW_BLOCK - 1) / PW_BLOCK;
     double* G = sm;                              // [QY][LDG]
-    double* AXl = G + QY * LDG;                  // [NTX][QX]   this term's w_x phi^(dx)
-    double* BYl = AXl + NTX * QX;                // [HPV_MAXT][NTY][QY]  (every term's y table: the adjoint needs all)
+    double* AXl = G + QY * LDG;                  // [HPV_MAXT][NTX][QX]  every term's w_x phi^(dx)
+    double* BYl = AXl + HPV_MAXT * NTX * QX;     // [HPV_MAXT][NTY][QY]  every term's w_y phi^(dy)
     double* T = BYl + HPV_MAXT * NTY * QY;       // [QY][NTX]
     double* U = T + QY * NTX;                    // [NR]
     double* S = U + NR;                          // [HPV_MAXT][NTY][QX]
@@ -78,42 +78,81 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
     const int nterms = pd.nterms, C = pd.C;
     const double eps = eps_ptr ? eps_ptr[0] : 0.0;
 
-    for (int idx = tid; idx < NR; idx += PW_BLOCK) U[idx] = F ? -F[e * NR + idx] : 0.0;
-    for (int t = 0; t < nterms; ++t)
-        for (int i = tid; i < NTY * QY; i += PW_BLOCK) BYl[t * NTY * QY + i] = wty[(long)pd.t[t].dy * NTY * QY + i];
-    for (int t = 0; t < nterms; ++t) {
-        const TermDesc& td = pd.t[t];
-        // integrand at the element's points: all loads in flight together
-        // (unconditional loads with clamped indices: a branch around each load would serialise them into one
-        //  memory round trip per load -- measured 60 us for the 80x80 element)
-        double gv[NIT];
+    // ---- every global read of the forward half is issued up front (ONE memory round trip): the right-hand
+    //      side, both tables of every term, and every term's integrand at this thread's points ----
+    constexpr int ITX = (NTX * QX + PW_BLOCK - 1) / PW_BLOCK, ITY = (NTY * QY + PW_BLOCK - 1) / PW_BLOCK;
+    constexpr int ITR = (NR + PW_BLOCK - 1) / PW_BLOCK;
+    double gv[HPV_MAXT][NIT], tax[HPV_MAXT][ITX], tby[HPV_MAXT][ITY], fr[ITR];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) gv[it] = 0.0;
+    for (int it = 0; it < ITR; ++it) {
+        const int idx = it * PW_BLOCK + tid;
+        fr[it] = (F && idx < NR) ? -F[e * NR + idx] : 0.0;
+    }
 #pragma unroll
-        for (int ch = 0; ch < HPV_MAXC; ++ch) {
-            const double al = (ch < C) ? td.a0[ch] + eps * td.a1[ch] : 0.0;
-            if (al != 0.0) {     // block-uniform: whole channels are skipped, never single loads
+    for (int t = 0; t < HPV_MAXT; ++t) {
+        const int dx = t < nterms ? pd.t[t].dx : 0, dy = t < nterms ? pd.t[t].dy : 0;
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int qd = it * PW_BLOCK + tid;
-                    const double v = OUT[(long)ch * N + base + (qd < NQ ? qd : NQ - 1)];
-                    gv[it] = fma(al, v, gv[it]);
+        for (int it = 0; it < ITX; ++it) {
+            const int i = it * PW_BLOCK + tid;
+            tax[t][it] = wtx[(long)dx * NTX * QX + (i < NTX * QX ? i : 0)];
+        }
+#pragma unroll
+        for (int it = 0; it < ITY; ++it) {
+            const int i = it * PW_BLOCK + tid;
+            tby[t][it] = wty[(long)dy * NTY * QY + (i < NTY * QY ? i : 0)];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) gv[t][it] = 0.0;
+        if (t < nterms) {
+#pragma unroll
+            for (int ch = 0; ch < HPV_MAXC; ++ch) {
+                const double al = (ch < C) ? pd.t[t].a0[ch] + eps * pd.t[t].a1[ch] : 0.0;
+                if (al != 0.0) {     // block-uniform: whole channels are skipped, never single loads (a branch per load
+                                     // would serialise them: measured 60 us for the 80x80 element)
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int qd = it * PW_BLOCK + tid;
+                        const double v = OUT[(long)ch * N + base + (qd < NQ ? qd : NQ - 1)];
+                        gv[t][it] = fma(al, v, gv[t][it]);
+                    }
                 }
             }
         }
-        __syncthreads();                         // previous users of G / AXl / T are done
-        for (int i = tid; i < NTX * QX; i += PW_BLOCK) AXl[i] = wtx[(long)td.dx * NTX * QX + i];
+    }
+#pragma unroll
+    for (int it = 0; it < ITR; ++it) {
+        const int idx = it * PW_BLOCK + tid;
+        if (idx < NR) U[idx] = fr[it];
+    }
+#pragma unroll
+    for (int t = 0; t < HPV_MAXT; ++t) {
+#pragma unroll
+        for (int it = 0; it < ITX; ++it) {
+            const int i = it * PW_BLOCK + tid;
+            if (i < NTX * QX) AXl[t * NTX * QX + i] = tax[t][it];
+        }
+#pragma unroll
+        for (int it = 0; it < ITY; ++it) {
+            const int i = it * PW_BLOCK + tid;
+            if (i < NTY * QY) BYl[t * NTY * QY + i] = tby[t][it];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < HPV_MAXT; ++t) {
+        if (t >= nterms) break;
+        const TermDesc& td = pd.t[t];
+        __syncthreads();                         // tables staged / previous users of G and T are done
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int qd = it * PW_BLOCK + tid;
-            if (qd < NQ) G[(qd / QX) * LDG + (qd % QX)] = gv[it];
+            if (qd < NQ) G[(qd / QX) * LDG + (qd % QX)] = gv[t][it];
         }
         __syncthreads();
         for (int o = tid; o < QY * NTX; o += PW_BLOCK) {
             const int j = o / NTX, r = o % NTX;
             double acc = 0.0;
 #pragma unroll 8
-            for (int i = 0; i < QX; ++i) acc = fma(AXl[r * QX + i], G[j * LDG + i], acc);
+            for (int i = 0; i < QX; ++i) acc = fma(AXl[t * NTX * QX + r * QX + i], G[j * LDG + i], acc);
             T[o] = acc;
         }
         __syncthreads();
@@ -146,16 +185,11 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
 
     const double sc = 2.0 / (double)NR;
     for (int t = 0; t < nterms; ++t) {
-        if (nterms > 1 || t != nterms - 1) {     // AXl still holds the last forward term's table otherwise
-            __syncthreads();
-            for (int i = tid; i < NTX * QX; i += PW_BLOCK) AXl[i] = wtx[(long)pd.t[t].dx * NTX * QX + i];
-            __syncthreads();
-        }
         for (int o = tid; o < NTY * QX; o += PW_BLOCK) {
             const int k = o / QX, i = o % QX;
             double acc = 0.0;
 #pragma unroll 4
-            for (int r = 0; r < NTX; ++r) acc = fma(AXl[r * QX + i], U[k * NTX + r], acc);
+            for (int r = 0; r < NTX; ++r) acc = fma(AXl[t * NTX * QX + r * QX + i], U[k * NTX + r], acc);
             S[t * NTY * QX + o] = acc * sc;
         }
     }
