@@ -34,8 +34,8 @@ def gemm_flops_per_row(layers):
     return 2 * sum(layers[l] * layers[l + 1] for l in range(len(layers) - 1))
 
 
-def cpu_baseline(setup, theta, iters):
-    """The oracle (reference-structured torch-fp64 restatement) timed on this host's cores."""
+def cpu_baseline(setup, theta, iters, vectorized=False):
+    """The oracle (reference-structured torch-fp64 restatement, or its vectorised variant) timed on this host."""
     import torch
     # tiny-op graphs get slower with many threads (128 threads: 26 s/iter vs 4 s/iter at 8 on the
     # same box class), so the baseline is pinned to 8 threads -- stated in "cores"
@@ -45,15 +45,19 @@ def cpu_baseline(setup, theta, iters):
     o = OracleVPINN2D(s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"],
                       s["WXY_quad_train"], None, s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"],
                       s["X_u_train"], s["u_train"], LAYERS, init_params=theta)
+    o.vectorized = vectorized
     o.adam_step()  # warm-up (allocations, thread pool)
     t0 = time.time()
     for _ in range(iters):
         o.adam_step()
     dt = time.time() - t0
+    how = ("vectorised oracle (all elements batched, projection as one einsum; the strong CPU baseline B of BASELINE.md)"
+           if vectorized else
+           "reference-structured oracle (per-element Python loop, one reduction per test-function pair, autograd double "
+           "backward; baseline A of BASELINE.md)")
     return {"value": iters / dt, "unit": "it/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "%d full iterations of the same config-4 workload, reference-structured oracle "
-                      "(per-element Python loop, one reduction per test-function pair, autograd double backward), "
-                      "host has %d logical cpus" % (iters, os.cpu_count())}
+            "sample": "%d full iterations of the same config-4 workload, %s, host has %d logical cpus"
+                      % (iters, how, os.cpu_count())}
 
 
 def main():
@@ -168,6 +172,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(s, theta, args.cpu_iters)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        out["cpu_baseline_vectorized"] = cpu_baseline(s, theta, 10, vectorized=True)
+        out["speedup_vs_cpu_baseline_vectorized"] = out["value"] / out["cpu_baseline_vectorized"]["value"]
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

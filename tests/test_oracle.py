@@ -103,3 +103,15 @@ def test_advdiff_epsilon_moves_and_5tuple():
     out = o.train(12, 0.0)
     assert len(out) == 5 and len(out[1]) == 2
     assert float(o.get_params()[-1]) != 1.0
+
+
+def test_vectorized_oracle_equals_structured():
+    """The batched/einsum variant timed as CPU baseline B computes the same loss and gradient."""
+    a = p2_args(gold("poisson2d_small"))
+    th = theta0(a[13], 17)
+    o1 = O.OracleVPINN2D(*a, init_params=th)
+    o2 = O.OracleVPINN2D(*a, init_params=th)
+    o2.vectorized = True
+    (l1, g1), (l2, g2) = o1.loss_and_grad(), o2.loss_and_grad()
+    assert np.abs(np.array(l1) - np.array(l2)).max() < 1e-12 * abs(l1[0])
+    assert np.abs(g1 - g2).max() < 1e-11 * np.abs(g1).max()
