@@ -94,6 +94,7 @@ struct hpv_ctx {
     bool side_active = false;            // true only while capturing
     bool use_graph = true;
     hipGraphExec_t g_step = nullptr;
+    hipGraphExec_t g_stepK = nullptr;    // HPV_GRAPH_ITERS iterations per replay (fewer inter-graph gaps)
 };
 
 namespace {
@@ -448,12 +449,14 @@ int enqueue_pinn_pass(hpv_ctx* h, bool backward, bool fuse_adam) {
     return 0;
 }
 
+#define HPV_GRAPH_ITERS 8
 void drop_graph(hpv_ctx* h) {
     if (h->g_step) { (void)hipGraphExecDestroy(h->g_step); h->g_step = nullptr; }
+    if (h->g_stepK) { (void)hipGraphExecDestroy(h->g_stepK); h->g_stepK = nullptr; }
 }
 
-// Capture one whole training iteration (incl. the Adam update) into an executable graph.
-int build_step_graph(hpv_ctx* h) {
+// Capture `iters` whole training iterations (incl. the Adam updates) into an executable graph.
+int build_step_graph(hpv_ctx* h, int iters, hipGraphExec_t* out) {
     int rc;
     // one direct pass first: lazily created objects (small-batch MFMA stores) must exist before capture
     if ((rc = ensure_small_mfma(h, h->data, &h->mfma_data))) return rc;
@@ -462,14 +465,14 @@ int build_step_graph(hpv_ctx* h) {
     hipGraph_t graph = nullptr;
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     h->side_active = true;
-    rc = enqueue_pass(h, true, true);   // forward .. finalize with the Adam update fused in
+    for (int k = 0; k < iters && !rc; ++k) rc = enqueue_pass(h, true, true);   // forward .. finalize (+ fused Adam)
     h->side_active = false;
     hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) return fail(h, -2, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-    e = hipGraphInstantiate(&h->g_step, graph, nullptr, nullptr, 0);
+    e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) { h->g_step = nullptr; return fail(h, -2, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { *out = nullptr; return fail(h, -2, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
     return 0;
 }
 
@@ -852,8 +855,13 @@ int hpv_step(hpv_handle h, int n_iters, double* loss3_after) {
     int rc;
     if (h->use_graph && h->own_stream && !h->timing && n_iters > 0 && h->cfg.scheme == HPV_SCHEME_VPINN) {
         if ((rc = check_ready(h))) return rc;
-        if (!h->g_step && (rc = build_step_graph(h))) return rc;
-        for (int it = 0; it < n_iters; ++it) HIPCHK(h, hipGraphLaunch(h->g_step, h->stream));
+        if (!h->g_step && (rc = build_step_graph(h, 1, &h->g_step))) return rc;
+        int it = 0;
+        if (n_iters >= 2 * HPV_GRAPH_ITERS) {
+            if (!h->g_stepK && (rc = build_step_graph(h, HPV_GRAPH_ITERS, &h->g_stepK))) return rc;
+            for (; it + HPV_GRAPH_ITERS <= n_iters; it += HPV_GRAPH_ITERS) HIPCHK(h, hipGraphLaunch(h->g_stepK, h->stream));
+        }
+        for (; it < n_iters; ++it) HIPCHK(h, hipGraphLaunch(h->g_step, h->stream));
     } else {
         for (int it = 0; it < n_iters; ++it)
             if ((rc = enqueue_pass(h, true, true))) return rc;
