@@ -93,6 +93,8 @@ class _VPINNBase:
         if self._init_params.size != n_params(self.layers, self._n_extra):
             raise ValueError("init_params has the wrong length")
         self._reducer = None
+        self._dist_warm = False
+        self._dist_graphs = {}
         if self._dist:
             import torch
             torch.cuda.set_device(device)
@@ -110,15 +112,61 @@ class _VPINNBase:
         """n Adam iterations; returns loss3 evaluated after the last update if read_loss."""
         if not self._dist:
             return self.h.step(n, read_loss)
-        for _ in range(n):
-            self.h.forward_backward()
-            self._reducer.allreduce()
-            self.h.apply_adam()
+        left = n
+        if n >= 4 and os.environ.get("HPV_DIST_GRAPH", "1") != "0":
+            if not self._dist_warm:      # communicator set-up and lazily created device objects must precede a capture
+                self._dist_iter()
+                self._dist_warm = True
+                left -= 1
+            k = left if left <= 16 else self._DIST_GRAPH_ITERS
+            g = self._dist_graph(k) if k >= 2 else None
+            if g is not None:
+                for _ in range(left // k):
+                    g.replay()
+                left %= k
+        for _ in range(left):
+            self._dist_iter()
         if not read_loss:
             return None
         self.h.eval_loss()
         self._reducer.allreduce()
         return self.h.read_loss()
+
+    _DIST_GRAPH_ITERS = 8
+
+    def _dist_iter(self):
+        """One multi-GPU iteration: partial sums of this shard -> one all-reduce of the packed buffer -> Adam."""
+        self.h.forward_backward()
+        self._reducer.allreduce()
+        self.h.apply_adam()
+
+    def _dist_graph(self, k):
+        """`k` multi-GPU iterations -- kernels AND the RCCL all-reduce -- captured once into a hipGraph
+        (through torch's capture so that ProcessGroupNCCL records the collective on the capture stream):
+        the host then issues one graph launch per k iterations instead of 3k enqueues.  Any failure to
+        capture falls back to the eager loop for the rest of the run."""
+        if k in self._dist_graphs:
+            return self._dist_graphs[k]
+        import torch
+        g = None
+        main = torch.cuda.current_stream()
+        try:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.h.set_stream(torch.cuda.current_stream().cuda_stream)
+                for _ in range(k):
+                    self._dist_iter()
+        except Exception as e:  # noqa: BLE001 -- eager loop is always available
+            import warnings
+            warnings.warn(f"hp_vpinns_amd: multi-GPU graph capture unavailable ({e}); running the eager loop")
+            g = None
+            for kk in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16):
+                self._dist_graphs[kk] = None
+        finally:
+            self.h.set_stream(main.cuda_stream)
+        self._dist_graphs[k] = g
+        return g
 
     def loss_and_grad(self):
         """({loss, lossb, lossv}, d loss / d theta) at the current parameters (global over ranks)."""

@@ -242,6 +242,19 @@ def test_reduce_buffer_is_a_zero_copy_torch_view():
             assert m2._dist and m2._reducer.active
             _check_loss_grad(o2, m2)
             _check_traj(o2, m2, n=6)
+            # 27 iterations in one call: 1 eager + 3 replays of the captured 8-iteration graph
+            # (kernels + all-reduce + Adam inside one hipGraph) + 2 eager
+            for _ in range(27):
+                o2.adam_step()
+            l3 = m2._step(27, True)
+            assert m2._dist_graphs.get(8) is not None, "multi-GPU iteration graph was not captured"
+            assert abs(l3[0] - float(o2.loss_parts()[0])) < TRAJ_TOL * abs(l3[0])
+            assert rel(m2.get_params(), o2.get_params()) < TRAJ_TOL
+            l3b = m2._step(11, True)             # a second size: 11-iteration graph
+            for _ in range(11):
+                o2.adam_step()
+            assert m2._dist_graphs.get(11) is not None
+            assert abs(l3b[0] - float(o2.loss_parts()[0])) < TRAJ_TOL * abs(l3b[0])
         finally:
             del os.environ["HPV_FORCE_DIST"]
     finally:
