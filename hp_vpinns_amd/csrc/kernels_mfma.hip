@@ -124,7 +124,11 @@ struct SlotCount {
 // points (a multiple of 16) with PNTX x PNTY test functions: workgroup b < proj_n_elem runs all tiles of element
 // b and then, after a workgroup barrier, projects it (project_element_wg) -- the per-element projection no
 // longer is a separate, latency-bound launch on a fraction of the CUs; later workgroups take the data tiles.
-template <int D, int NT1, int NT2, int ACT, int L, int BLK = MF_BLOCK, int PQX = 0, int PQY = 0, int PNTX = 0, int PNTY = 0>
+// SAVE: the activation store for the reverse pass is a compile-time choice -- a run-time flag put a scalar branch
+// around every store, which cut each layer's activation math into one basic block per value (no interleaving of
+// the five independent tanh chains of a lane).
+template <int D, int NT1, int NT2, int ACT, int L, int BLK = MF_BLOCK, int PQX = 0, int PQY = 0, int PNTX = 0, int PNTY = 0,
+          bool SAVE = true>
 __global__ void __launch_bounds__(BLK, BLK == 256 ? 2 : 1) k_fwd_mfma(MfmaArgs g) {
     constexpr int C = 1 + NT1 + NT2;
     constexpr int NS = SlotCount<ACT, NT1, NT2>::value;
@@ -206,7 +210,7 @@ __global__ void __launch_bounds__(BLK, BLK == 256 ? 2 : 1) k_fwd_mfma(MfmaArgs g
             double a, a1, a2;
             act_fwd<ACT>(z, a, a1, a2);
             h[0][s] = a;
-            if (g.save_act) {
+            if constexpr (SAVE) {
                 sv[(0 * MF_KS + s) * 64] = a;
                 if constexpr (ACT == HPV_ACT_SIN) sv[(SA1 * MF_KS + s) * 64] = a1;
             }
@@ -257,7 +261,7 @@ __global__ void __launch_bounds__(BLK, BLK == 256 ? 2 : 1) k_fwd_mfma(MfmaArgs g
                 double a, a1, a2;
                 act_fwd<ACT>(s < 4 ? acc[0][s & 3] : z16[0], a, a1, a2);
                 h[0][s] = a;
-                if (g.save_act) {
+                if constexpr (SAVE) {
                     svl[(0 * MF_KS + s) * 64] = a;
                     if constexpr (ACT == HPV_ACT_SIN) svl[(SA1 * MF_KS + s) * 64] = a1;
                 }
@@ -265,14 +269,14 @@ __global__ void __launch_bounds__(BLK, BLK == 256 ? 2 : 1) k_fwd_mfma(MfmaArgs g
 #pragma unroll
                 for (int u = 0; u < NT1; ++u) {
                     zc[u] = s < 4 ? acc[1 + u][s & 3] : z16[1 + u];
-                    if (g.save_act) svl[((SZC + u) * MF_KS + s) * 64] = zc[u];
+                    if constexpr (SAVE) svl[((SZC + u) * MF_KS + s) * 64] = zc[u];
                     h[1 + u][s] = a1 * zc[u];
                 }
 #pragma unroll
                 for (int b = 0; b < NT2; ++b) {
                     const double zcc = s < 4 ? acc[1 + NT1 + b][s & 3] : z16[1 + NT1 + b];
                     const double z1 = zc[b < NT1 ? b : 0];
-                    if (g.save_act) svl[((SZCC + b) * MF_KS + s) * 64] = zcc;
+                    if constexpr (SAVE) svl[((SZCC + b) * MF_KS + s) * 64] = zcc;
                     h[1 + NT1 + b][s] = a2 * z1 * z1 + a1 * zcc;
                 }
             }
@@ -1029,7 +1033,11 @@ static size_t bwd_lds_bytes(int P, int L, int C) {
 
 template <int D, int NT1, int NT2, int ACT, int L>
 static void run_fwd(const MfmaArgs& a, int blocks, hipStream_t s) {
-    hipLaunchKernelGGL((k_fwd_mfma<D, NT1, NT2, ACT, L>), dim3(blocks), dim3(MF_BLOCK), fwd_lds_bytes(L), s, a);
+    if (a.save_act)
+        hipLaunchKernelGGL((k_fwd_mfma<D, NT1, NT2, ACT, L>), dim3(blocks), dim3(MF_BLOCK), fwd_lds_bytes(L), s, a);
+    else
+        hipLaunchKernelGGL((k_fwd_mfma<D, NT1, NT2, ACT, L, MF_BLOCK, 0, 0, 0, 0, false>), dim3(blocks), dim3(MF_BLOCK),
+                           fwd_lds_bytes(L), s, a);
 }
 static size_t bwd_lds_bytes(int P, int L, int C);
 template <int D, int NT1, int NT2, int ACT, int L, int QX, int QY, int NTX, int NTY>
@@ -1192,7 +1200,7 @@ void hpv_mfma_backward(HpvMfma* m, const double* theta, const double* X, const d
 bool hpv_mfma_forward_fused(HpvMfma* m, const double* theta, const double* X, double* OUT, int save_act, hipStream_t s,
                             const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem) {
     const ProjDesc& pd = pa.pd;
-    if (!m->fwd_fused || pd.edge || n_elem <= 0) return false;
+    if (!m->fwd_fused || pd.edge || n_elem <= 0 || !save_act) return false;   // (the fused instantiation always stores)
     if (!(pd.qx == 20 && pd.qy == 20 && pd.ntx == 10 && pd.nty == 10)) return false;
     const long tpe = (20 * 20) / 16;
     if (n_elem * tpe > m->ntiles) return false;

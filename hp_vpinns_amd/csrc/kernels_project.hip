@@ -32,8 +32,14 @@ struct ActiveCh {
     int id[HPV_MAXC];           // their channel indices
 };
 
-template <int QX, int QY, int NTX, int NTY, int NA, bool EPS, int PJ_WAVES>
-__global__ void __launch_bounds__(PJ_WAVES * 64) k_project_tp(ProjDesc pd, ActiveCh ac, const double* __restrict__ OUT,
+// OH ("one-hot"): term t integrates exactly the active channel t and nothing else (Poisson-2D var_form 1: u_x, u_y).
+// The integrand column then IS the prefetched channel column (alpha folds into the term coefficient) and the
+// adjoint column of term t is stored straight to channel t -- no gcol / gacc copies.  With 8 waves per workgroup the
+// channel column of a term is loaded when the term starts (124 VGPRs, 4 waves per SIMD, 2 x 63.6 KB LDS per CU):
+// measured 3.6 TB/s against 3.15 TB/s for the 202-VGPR / 2-waves-per-SIMD general variant on the 2^18-element batch
+// (5 waves per SIMD spills: 2.5 TB/s).
+template <int QX, int QY, int NTX, int NTY, int NA, bool EPS, int PJ_WAVES, bool OH = false>
+__global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : 1) k_project_tp(ProjDesc pd, ActiveCh ac, const double* __restrict__ OUT,
                                                         double* __restrict__ GBAR, double* __restrict__ R,
                                                         const double* __restrict__ F, const double* __restrict__ coef,
                                                         long coef_stride, const double* __restrict__ wtx,
@@ -107,30 +113,47 @@ __global__ void __launch_bounds__(PJ_WAVES * 64) k_project_tp(ProjDesc pd, Activ
         double u[NTX];
 #pragma unroll
         for (int r = 0; r < NTX; ++r) u[r] = (row && F) ? -F[e * NR + li * NTX + r] : 0.0;
+        constexpr bool LATE = OH && PJ_WAVES == 8;   // 4 waves/SIMD (124 VGPRs): the other waves hide the per-term round trip
         double o[NA][QY];
+        if constexpr (!LATE) {
 #pragma unroll
-        for (int a = 0; a < NA; ++a)
+            for (int a = 0; a < NA; ++a)
 #pragma unroll
-            for (int j = 0; j < QY; ++j) o[a][j] = col ? Oe[(long)ac.id[a] * N + j * QX] : 0.0;
-        double gacc[NA][QY];
+                for (int j = 0; j < QY; ++j) o[a][j] = col ? Oe[(long)ac.id[a] * N + j * QX] : 0.0;
+        }
+        double gacc[OH ? 1 : NA][OH ? 1 : QY];
+        if constexpr (!OH) {
 #pragma unroll
-        for (int a = 0; a < NA; ++a)
+            for (int a = 0; a < NA; ++a)
 #pragma unroll
-            for (int j = 0; j < QY; ++j) gacc[a][j] = 0.0;
+                for (int j = 0; j < QY; ++j) gacc[a][j] = 0.0;
+        }
 
 #pragma unroll
-        for (int t = 0; t < HPV_MAXT; ++t) {
-            if (t >= nterms) break;
+        for (int t = 0; t < (OH ? NA : HPV_MAXT); ++t) {
+            if (!OH && t >= nterms) break;
             const TermDesc& td = pd.t[t];
             // (a) integrand column of this term from the prefetched channels
             double gcol[QY];
+            double alpha_t = 1.0;
+            if constexpr (OH) {
+                alpha_t = td.a0[ac.id[t]] + eps * td.a1[ac.id[t]];
+                if constexpr (LATE) {
 #pragma unroll
-            for (int j = 0; j < QY; ++j) gcol[j] = 0.0;
+                    for (int j = 0; j < QY; ++j) gcol[j] = col ? Oe[(long)ac.id[t] * N + j * QX] : 0.0;
+                } else {
 #pragma unroll
-            for (int a = 0; a < NA; ++a) {
-                const double al = td.a0[ac.id[a]] + eps * td.a1[ac.id[a]];
+                    for (int j = 0; j < QY; ++j) gcol[j] = o[t][j];
+                }
+            } else {
 #pragma unroll
-                for (int j = 0; j < QY; ++j) gcol[j] = fma(al, o[a][j], gcol[j]);
+                for (int j = 0; j < QY; ++j) gcol[j] = 0.0;
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    const double al = td.a0[ac.id[a]] + eps * td.a1[ac.id[a]];
+#pragma unroll
+                    for (int j = 0; j < QY; ++j) gcol[j] = fma(al, o[a][j], gcol[j]);
+                }
             }
             pj_wave_sync();   // previous readers of Tb are done
             // (b) y-contraction, lane = column i
@@ -150,7 +173,7 @@ __global__ void __launch_bounds__(PJ_WAVES * 64) k_project_tp(ProjDesc pd, Activ
             // (c) x-contraction, lane = residual row k
             if (row) {
                 const double* axt = AXT + td.dx * (NTX * QX);
-                const double c = coef[(long)t * coef_stride + e] * (td.eps_mult ? eps : 1.0);
+                const double c = coef[(long)t * coef_stride + e] * (td.eps_mult ? eps : 1.0) * alpha_t;
                 double trow[QX], acc[NTX];
 #pragma unroll
                 for (int i = 0; i < QX; ++i) trow[i] = Tb[slot * (NTY * LDT) + li * LDT + i];
@@ -186,8 +209,8 @@ __global__ void __launch_bounds__(PJ_WAVES * 64) k_project_tp(ProjDesc pd, Activ
 
         double deps = 0.0;
 #pragma unroll
-        for (int t = 0; t < HPV_MAXT; ++t) {
-            if (t >= nterms) break;
+        for (int t = 0; t < (OH ? NA : HPV_MAXT); ++t) {
+            if (!OH && t >= nterms) break;
             const TermDesc& td = pd.t[t];
             pj_wave_sync();
             // (d) V[k][i] = sum_r AX[r][i] Rs[k][r], lane = row k
@@ -218,11 +241,18 @@ __global__ void __launch_bounds__(PJ_WAVES * 64) k_project_tp(ProjDesc pd, Activ
                 for (int k = 0; k < NTY; ++k)
 #pragma unroll
                     for (int j = 0; j < QY; ++j) gh[j] = fma(by[k * QY + j], vcol[k], gh[j]);
+                if constexpr (OH) {   // term t <-> channel t: its adjoint column goes out directly, coalesced
+                    const double al = (td.a0[ac.id[t]] + eps * td.a1[ac.id[t]]) * (m * c);
+                    double* __restrict__ Ge = GBAR + e * NQ + li + (long)ac.id[t] * N;
 #pragma unroll
-                for (int a = 0; a < NA; ++a) {
-                    const double al = (td.a0[ac.id[a]] + eps * td.a1[ac.id[a]]) * (m * c);
+                    for (int j = 0; j < QY; ++j) Ge[j * QX] = al * gh[j];
+                } else {
 #pragma unroll
-                    for (int j = 0; j < QY; ++j) gacc[a][j] = fma(al, gh[j], gacc[a][j]);
+                    for (int a = 0; a < NA; ++a) {
+                        const double al = (td.a0[ac.id[a]] + eps * td.a1[ac.id[a]]) * (m * c);
+#pragma unroll
+                        for (int j = 0; j < QY; ++j) gacc[a][j] = fma(al, gh[j], gacc[a][j]);
+                    }
                 }
                 if constexpr (EPS) {   // d loss / d epsilon (P3:63): through alpha(eps) and eps-multiplied terms
 #pragma unroll
@@ -239,7 +269,7 @@ __global__ void __launch_bounds__(PJ_WAVES * 64) k_project_tp(ProjDesc pd, Activ
             }
         }
         // (f) adjoint of the integrated channels, coalesced (channels no term uses are never touched)
-        if (col) {
+        if (!OH && col) {
             double* __restrict__ Ge = GBAR + e * NQ + li;
 #pragma unroll
             for (int a = 0; a < NA; ++a)
@@ -260,7 +290,7 @@ __global__ void __launch_bounds__(PJ_WAVES * 64) k_project_tp(ProjDesc pd, Activ
     }
 }
 
-template <int QX, int QY, int NTX, int NTY, int NA, bool EPS, int PJ_WAVES>
+template <int QX, int QY, int NTX, int NTY, int NA, bool EPS, int PJ_WAVES, bool OH = false>
 static void launch_tp3(const ProjDesc& pd, const ActiveCh& ac, const double* OUT, double* GBAR, double* R, const double* F,
                        const double* coef, long coef_stride, const double* wtx, const double* wty, const double* eps_ptr,
                        double* loss_e, double* deps_e, long N, long n_elem, int do_adjoint, long ngroups, hipStream_t s) {
@@ -270,7 +300,15 @@ static void launch_tp3(const ProjDesc& pd, const ActiveCh& ac, const double* OUT
     const size_t lds = (size_t)(2 * (3 * NTX * QX + 3 * NTY * QY) + PJ_WAVES * WAVE_DOUBLES) * sizeof(double);
     long blocks = (ngroups + PJ_WAVES - 1) / PJ_WAVES;
     if (blocks > 256 * 16) blocks = 256 * 16;   // grid-stride beyond that
-    hipLaunchKernelGGL((k_project_tp<QX, QY, NTX, NTY, NA, EPS, PJ_WAVES>), dim3((unsigned)blocks), dim3(PJ_WAVES * 64), lds, s,
+    if (lds > 65536) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)k_project_tp<QX, QY, NTX, NTY, NA, EPS, PJ_WAVES, OH>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL((k_project_tp<QX, QY, NTX, NTY, NA, EPS, PJ_WAVES, OH>), dim3((unsigned)blocks), dim3(PJ_WAVES * 64), lds, s,
                        pd, ac, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, N, n_elem, do_adjoint);
 }
 
@@ -284,12 +322,22 @@ static bool launch_tp2(const ProjDesc& pd, const ActiveCh& ac, const double* OUT
     // few element groups (config-4 scale): one wavefront per workgroup spreads the groups over as many CUs as
     // possible (each wave then has a CU's LDS port to itself for its ~800 broadcast table reads); large batches:
     // four waves per workgroup amortise the table staging
-    if (ngroups <= 1024)
-        launch_tp3<QX, QY, NTX, NTY, NA, EPS, 1>(pd, ac, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, N,
-                                                 n_elem, do_adjoint, ngroups, s);
-    else
-        launch_tp3<QX, QY, NTX, NTY, NA, EPS, 4>(pd, ac, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, N,
-                                                 n_elem, do_adjoint, ngroups, s);
+    // one-hot term/channel structure (see k_project_tp): term t integrates active channel t only
+    bool onehot = !EPS && pd.nterms == NA && NA >= 2;
+    for (int t = 0; t < pd.nterms && onehot; ++t)
+        for (int a = 0; a < NA; ++a)
+            if (a != t && (pd.t[t].a0[ac.id[a]] != 0.0 || pd.t[t].a1[ac.id[a]] != 0.0)) onehot = false;
+#define HPV_GO(W_, OH_)                                                                                                  \
+    launch_tp3<QX, QY, NTX, NTY, NA, EPS, W_, OH_>(pd, ac, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, \
+                                                   N, n_elem, do_adjoint, ngroups, s)
+    if constexpr (!EPS && NA >= 2) {
+        if (onehot) {
+            if (ngroups <= 1024) HPV_GO(1, true); else HPV_GO(8, true);
+            return true;
+        }
+    }
+    if (ngroups <= 1024) HPV_GO(1, false); else HPV_GO(4, false);
+#undef HPV_GO
     return true;
 }
 
