@@ -190,12 +190,27 @@ __global__ void __launch_bounds__(BLK, BLK == 256 ? 2 : 1) k_fwd_mfma(MfmaArgs g
     __syncthreads();
     const double bo = th[g.boff[L]];
 
+    // the coordinates of the NEXT tile are fetched while this one computes (2 doubles per lane): otherwise every
+    // tile starts with a full HBM round trip in front of a ~10 us dependent chain
+    double xn[D];
+    {
+        long p0 = wave * 16 + pt;
+        p0 = p0 < g.N ? p0 : g.N - 1;
+#pragma unroll
+        for (int c = 0; c < D; ++c) xn[c] = g.X[(long)c * g.N + p0];
+    }
     for (long tile = wave; tile < tile_end; tile += nwaves) {
         const long p = tile * 16 + pt;
         const bool valid = p < g.N;
         double x[D];
 #pragma unroll
-        for (int c = 0; c < D; ++c) x[c] = valid ? g.X[(long)c * g.N + p] : 0.0;
+        for (int c = 0; c < D; ++c) x[c] = valid ? xn[c] : 0.0;
+        {
+            long pn = (tile + nwaves) * 16 + pt;
+            pn = pn < g.N ? pn : g.N - 1;
+#pragma unroll
+            for (int c = 0; c < D; ++c) xn[c] = g.X[(long)c * g.N + pn];
+        }
         double h[C][MF_KS];
         double* sv = g.ACTS + (tile * L) * (long)(NS * MF_KS * 64) + lane;
         int lofs = lane;                       // opaque per iteration: keeps the LDS fragment reads inside the
@@ -406,13 +421,12 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
         for (int f = lane; f < C * 2 * MF_TR * MF_LD; f += 64) TAB[f] = 0.0;   // re-zero this wave's transpose tiles
     }
     // gradient accumulators (per wave, over all its tiles)
-    v4d dWacc[LH][2][2];
+    // dW of a hidden->hidden layer = one 16x16 MFMA tile (in, out < 16) + two 4x16 strips on v_mfma_f64_4x4x4_4b
+    // (4 blocks of 4x4x4, no padding: a 16x16x4 tile there would be 3/4 zeros) + the 4x4 corner on the VALU
+    v4d dWacc[LH];
+    double dS10[LH], dS01[LH];   // lane (q,pt): dW[in = 16+q][out = pt]  and  dW[in = pt][out = 16+q]
 #pragma unroll
-    for (int i = 0; i < LH; ++i)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) dWacc[i][a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < LH; ++i) { dWacc[i] = v4d{0.0, 0.0, 0.0, 0.0}; dS10[i] = 0.0; dS01[i] = 0.0; }
     double accC[LH][4];   // corner dW[16+q][16+a] on the VALU (per-lane partial over the point slot)
 #pragma unroll
     for (int i = 0; i < LH; ++i)
@@ -463,7 +477,8 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
         }
     };
 
-    // (requesting the next tile's inputs one tile ahead was measured: no gain, more registers)
+    // (requesting the next tile's inputs ahead -- at the loop top, or late, during the first layer -- was measured twice:
+    //  no gain, 100 more registers)
     auto load_tile_inputs = [&](long tile, double (&x)[D], double (&gb)[C], Slots& S) {
         const long p = tile * 16 + pt;
         const bool valid = p < g.N;
@@ -572,24 +587,24 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
                 for (int ch = 0; ch < C; ++ch) {
                     const double* TA = TAB + (2 * ch) * (MF_TR * MF_LD);
                     const double* TB = TA + MF_TR * MF_LD;
-                    double aF[2][4], bF[2][4];
+                    // operand fragments, k-step kk = points 4kk..4kk+3 (k index = q):
+                    //   aF/bF: rows in/out = pt of the transposed tiles (16x16 tile; B operands of the strips)
+                    //   aS/bS: rows 16 + (lane & 3) (A operands of the 4x4x4 strips, same for all four blocks)
+                    double aF[4], bF[4], aS[4], bS[4];
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
+                    for (int kk = 0; kk < 4; ++kk) {
+                        aF[kk] = TA[pt * MF_LD + 4 * kk + q];
+                        bF[kk] = TB[pt * MF_LD + 4 * kk + q];
+                        aS[kk] = TA[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                        bS[kk] = TB[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                    }
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            const int row = (t == 0) ? pt : (16 + pt < MF_H ? 16 + pt : MF_H);   // row 20 is all zero
-                            aF[t][kk] = TA[row * MF_LD + 4 * kk + q];
-                            bF[t][kk] = TB[row * MF_LD + 4 * kk + q];
-                        }
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                            for (int to = 0; to < 2; ++to)
-                                if (!(ti == 1 && to == 1))   // the 4x4 corner tile is 15/16 padding: VALU below
-                                    dWacc[i - 1][ti][to] =
-                                        __builtin_amdgcn_mfma_f64_16x16x4f64(aF[ti][kk], bF[to][kk], dWacc[i - 1][ti][to], 0, 0, 0);
+                    for (int kk = 0; kk < 4; ++kk) {
+                        dWacc[i - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[kk], bF[kk], dWacc[i - 1], 0, 0, 0);
+                        // D_b[i'][j] = sum_k A[i'][k] B_b[k][j]; D lane l <-> (i' = l>>4, 4b+j = l&15)
+                        dS10[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(aS[kk], bF[kk], dS10[i - 1], 0, 0, 0);   // h[.,16+i'] x zbar[.,out]
+                        dS01[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(bS[kk], aF[kk], dS01[i - 1], 0, 0, 0);   // zbar[.,16+i'] x h[.,in]
+                    }
                     // corner dW[16+q][16+a] += h_in[pt][16+q] * zbar[pt][16+a], zbar read back from its tile
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
@@ -622,18 +637,14 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
     for (int idx = lane; idx < g.P; idx += 64) WP[idx] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // hidden->hidden weight gradients: complete sums over this wave's points, D layout (row = in, col = out)
+    // hidden->hidden weight gradients: complete sums over this wave's points, D layouts (see the accumulators)
 #pragma unroll
-    for (int i = 1; i < L; ++i)
+    for (int i = 1; i < L; ++i) {
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int to = 0; to < 2; ++to)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int in = 16 * ti + 4 * r + q, out = 16 * to + pt;
-                    if (in < MF_H && out < MF_H && !(ti == 1 && to == 1)) WP[g.woff[i] + in * MF_H + out] = dWacc[i - 1][ti][to][r];
-                }
+        for (int r = 0; r < 4; ++r) WP[g.woff[i] + (4 * r + q) * MF_H + pt] = dWacc[i - 1][r];
+        WP[g.woff[i] + (16 + q) * MF_H + pt] = dS10[i - 1];
+        WP[g.woff[i] + pt * MF_H + 16 + q] = dS01[i - 1];
+    }
 #pragma unroll
     for (int i = 1; i < L; ++i)
 #pragma unroll
