@@ -250,25 +250,23 @@ __global__ void __launch_bounds__(BLK, BLK == 256 ? 2 : 1) k_fwd_mfma(MfmaArgs g
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch)
                     acc[ch] = __builtin_amdgcn_mfma_f64_16x16x4f64(WT[((i - 1) * MF_KS + s) * 64 + lofs], h[ch][s], acc[ch], 0, 0, 0);
-            // neurons 16..19 on the VALU
+            // neurons 16..19: Z^T[16+i'][pt] = sum_in W[in][16+i'] h[in][pt] on v_mfma_f64_4x4x4_4b (four 4x4x4 blocks = the
+            // four groups of 4 points; no padding).  A[i'][k] = W[4s+k][16+i'] (lane: k = q, i' = lane&3, same for every
+            // block), B_b[k][j] = h[4s+k][pt = 4b+j] = this lane's own h[ch][s]; D lane (q,pt) = neuron 16+q at point pt,
+            // i.e. exactly the lane's fifth value.
             double z16[C];
             {
-                double wr[MF_KS][4];
-                const double* wrl = WR + (i - 1) * MF_KS * 16 + (lofs >> 4) * 4;
+                const double* wrl = WR + (i - 1) * MF_KS * 16 + (lofs >> 4) * 4 + (lofs & 3);
+                double wr[MF_KS];
 #pragma unroll
-                for (int s = 0; s < MF_KS; ++s)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) wr[s][a] = wrl[s * 16 + a];
+                for (int s = 0; s < MF_KS; ++s) wr[s] = wrl[s * 16];
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) {
-                    double pa[4] = {0.0, 0.0, 0.0, 0.0};
+                    double zz = (ch == 0) ? bhl[256] : 0.0;
 #pragma unroll
-                    for (int s = 0; s < MF_KS; ++s)
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) pa[a] = fma(wr[s][a], h[ch][s], pa[a]);
-                    z16[ch] = reduce_scatter_q(pa, lane);
+                    for (int s = 0; s < MF_KS; ++s) zz = __builtin_amdgcn_mfma_f64_4x4x4f64(wr[s], h[ch][s], zz, 0, 0, 0);
+                    z16[ch] = zz;
                 }
-                z16[0] += bhl[256];
             }
             double* svl = sv + (long)i * (NS * MF_KS * 64);
 #pragma unroll
@@ -427,11 +425,11 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
     double dS10[LH], dS01[LH];   // lane (q,pt): dW[in = 16+q][out = pt]  and  dW[in = pt][out = 16+q]
 #pragma unroll
     for (int i = 0; i < LH; ++i) { dWacc[i] = v4d{0.0, 0.0, 0.0, 0.0}; dS10[i] = 0.0; dS01[i] = 0.0; }
-    double accC[LH][4];   // corner dW[16+q][16+a] on the VALU (per-lane partial over the point slot)
+    // corner dW[16+i'][16+j]: one 4x4x4_4b MFMA per channel whose four blocks are the four groups of 4 points; lane
+    // (q, 4b+j) holds the partial sum of block b for (in = 16+q, out = 16+j), the blocks are summed in the epilogue
+    double accC[LH];
 #pragma unroll
-    for (int i = 0; i < LH; ++i)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) accC[i][a] = 0.0;
+    for (int i = 0; i < LH; ++i) accC[i] = 0.0;
     double db[L][MF_KS], dW1[D][MF_KS], dWo[MF_KS], dbo = 0.0;
 #pragma unroll
     for (int s = 0; s < MF_KS; ++s) {
@@ -567,12 +565,10 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
                 // LDS reads of channel ch+1 overlap the MFMAs of channel ch.
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                double h16[C];
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) {
                     double hv[MF_KS];
                     outputs_of(prev, ch, hv);
-                    h16[ch] = hv[4];
                     double* TA = TAB + (2 * ch) * (MF_TR * MF_LD);
                     double* TB = TA + MF_TR * MF_LD;
 #pragma unroll
@@ -605,26 +601,24 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
                         dS10[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(aS[kk], bF[kk], dS10[i - 1], 0, 0, 0);   // h[.,16+i'] x zbar[.,out]
                         dS01[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(bS[kk], aF[kk], dS01[i - 1], 0, 0, 0);   // zbar[.,16+i'] x h[.,in]
                     }
-                    // corner dW[16+q][16+a] += h_in[pt][16+q] * zbar[pt][16+a], zbar read back from its tile
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-                        accC[i - 1][a] = fma(h16[ch], TB[(16 + a) * MF_LD + pt], accC[i - 1][a]);
+                    // corner: A_b[i'][k] = h[pt = 4b+k][16+i'], B_b[k][j] = zbar[pt = 4b+k][16+j]  (k = q, b = (lane&15)>>2)
+                    accC[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(TA[(16 + (lane & 3)) * MF_LD + (pt & 12) + q],
+                                                                   TB[(16 + (lane & 3)) * MF_LD + (pt & 12) + q], accC[i - 1], 0, 0, 0);
                 }
                 // hbar_in^T = W zbar^T
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) {
                     v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
-                    double pa[4] = {0.0, 0.0, 0.0, 0.0};
-                    const double* wrl = WRB + (i - 1) * MF_KS * 16 + q * 4;
+                    double h4 = 0.0;   // inputs 16..19 on the 4x4x4 MFMA: A[i'][k] = W[16+i'][4s+k], B = this lane's zbar, D lane = (16+q, pt)
+                    const double* wrl = WRB + (i - 1) * MF_KS * 16 + q * 4 + (lane & 3);
 #pragma unroll
                     for (int s = 0; s < MF_KS; ++s) {
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(WN[((i - 1) * MF_KS + s) * 64 + lane], zbar[ch][s], acc, 0, 0, 0);
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) pa[a] = fma(wrl[s * 16 + a], zbar[ch][s], pa[a]);   // inputs 16..19: VALU
+                        h4 = __builtin_amdgcn_mfma_f64_4x4x4f64(wrl[s * 16], zbar[ch][s], h4, 0, 0, 0);
                     }
 #pragma unroll
                     for (int s = 0; s < 4; ++s) hbar[ch][s] = acc[s];
-                    hbar[ch][4] = reduce_scatter_q(pa, lane);
+                    hbar[ch][4] = h4;
                 }
                 cur = prev;
             }
@@ -646,16 +640,12 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
         WP[g.woff[i] + pt * MF_H + 16 + q] = dS01[i - 1];
     }
 #pragma unroll
-    for (int i = 1; i < L; ++i)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            double t = accC[i - 1][a];
-            t += __shfl_xor(t, 1, 64);
-            t += __shfl_xor(t, 2, 64);
-            t += __shfl_xor(t, 4, 64);
-            t += __shfl_xor(t, 8, 64);
-            if (pt == 0) WP[g.woff[i] + (16 + q) * MF_H + 16 + a] = t;
-        }
+    for (int i = 1; i < L; ++i) {
+        double t = accC[i - 1];
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        if (pt < 4) WP[g.woff[i] + (16 + q) * MF_H + 16 + pt] = t;
+    }
     // per-lane partials: reduce over the 16 point lanes of each neuron group
 #pragma unroll
     for (int s = 0; s < MF_KS; ++s) {
