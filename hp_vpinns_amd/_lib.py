@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhpvpinn.so")
+LIB_PATH = os.environ.get("HPV_LIBRARY") or os.path.join(_HERE, "libhpvpinn.so")   # (override: another build of the same library)
 
 HPV_MAX_LAYERS = 16
 PDE_POISSON1D, PDE_POISSON2D, PDE_ADVDIFF = 0, 1, 2

@@ -26,8 +26,12 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define MF_H 20
 #define MF_KS 5        // k-steps of 4 over the 20 inputs
 #define MF_LD 17       // padded leading dimension of the LDS transpose tiles
+#define MF_TRB 20      // rows of a transpose tile of k_bwd_mfma (20 neurons; every fragment row is in range)
 #define MF_TR 21       // rows of a transpose tile: 20 neurons + 1 zero row; out-of-range fragment rows are clamped to it
 #define MF_BLOCK 256
+#ifndef HPV_BWD_MINW
+#define HPV_BWD_MINW 1
+#endif
 #define MF_WAVES (MF_BLOCK / 64)
 
 struct MfmaArgs {
@@ -368,8 +372,11 @@ __device__ __forceinline__ void layer_outputs_from_saved(const double* svl, cons
 // projection thus rides on all CUs inside the reverse kernel instead of being a separate latency-bound launch on
 // a fraction of them, and -- unlike fusing it behind the forward pass -- costs no extra tile imbalance
 // (25 tiles over 4 waves = the same 7-tile makespan as the round-robin assignment).
-template <int D, int NT1, int NT2, int ACT, int L, int PQX = 0, int PQY = 0, int PNTX = 0, int PNTY = 0>
-__global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
+// WAVES = wavefronts per workgroup: 4 (one per SIMD), or 8 in element-block mode -- two waves per SIMD (<= 256 registers
+// each) that cover each other's LDS-transpose / MFMA-result latencies, with the same 7-tile makespan per SIMD (25 tiles
+// over 8 waves = 4,3,3,3 | 3,3,3,3) and the element's projection spread over twice the threads.
+template <int D, int NT1, int NT2, int ACT, int L, int PQX = 0, int PQY = 0, int PNTX = 0, int PNTY = 0, int WAVES = MF_WAVES>
+__global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : HPV_BWD_MINW) k_bwd_mfma(MfmaArgs g) {
     constexpr int C = 1 + NT1 + NT2;
     constexpr int NS = SlotCount<ACT, NT1, NT2>::value;
     constexpr int SZC = 1 + (ACT == HPV_ACT_SIN ? 1 : 0);
@@ -383,40 +390,36 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
     const double* __restrict__ th = g.theta;
     // LDS map: [region A: per-wave transpose tiles during the tile loop, per-wave gradient rows in the
     //           epilogue] [region B: A-operand fragments of W for hbar_in^T = W zbar^T, lane-major]
-    constexpr int REGION_A = MF_WAVES * C * 2 * MF_TR * MF_LD;
-    double* TAB = lds + wv * (C * 2 * MF_TR * MF_LD);   // per-wave transpose tiles, one (h_in, zbar) pair per channel
-    const int regA = REGION_A > MF_WAVES * g.P ? REGION_A : MF_WAVES * g.P;
+    constexpr int REGION_A = WAVES * C * 2 * MF_TRB * MF_LD;
+    double* TAB = lds + wv * (C * 2 * MF_TRB * MF_LD);   // per-wave transpose tiles, one (h_in, zbar) pair per channel
+    const int regA = REGION_A > WAVES * g.P ? REGION_A : WAVES * g.P;
     double* WN = lds + regA;                      // [(L-1)][MF_KS][64]  A fragments W[in = pt][out = 4s+q], rows 0..15
     double* WRB = WN + (L > 1 ? L - 1 : 0) * MF_KS * 64;   // [(L-1)][MF_KS][4 (q)][4 (a)]  W[in = 16+a][out = 4s+q]
 
     // per-lane weight fragments
-    double w1[D][MF_KS], wo[MF_KS];
-#pragma unroll
-    for (int s = 0; s < MF_KS; ++s) {
-        const int j = 4 * s + q;
-#pragma unroll
-        for (int c = 0; c < D; ++c) w1[c][s] = th[g.woff[0] + c * MF_H + j];
-        wo[s] = th[g.woff[L] + j];
+    // first-layer and head weights of this lane's neurons: lane-major in LDS, re-read per tile (not 30 resident VGPRs)
+    double* W1O = WRB + (L > 1 ? L - 1 : 0) * MF_KS * 16;    // [(D+1)][MF_KS][64]
+    for (int f = threadIdx.x; f < (D + 1) * MF_KS * 64; f += (WAVES * 64)) {
+        const int ln = f & 63, s_ = (f >> 6) % MF_KS, c_ = f / (64 * MF_KS);
+        const int j = 4 * s_ + (ln >> 4);
+        W1O[f] = c_ < D ? th[g.woff[0] + c_ * MF_H + j] : th[g.woff[L] + j];
     }
-    // rows 20..31 of every transpose tile stay zero for the whole kernel (the tile-1 fragments read them)
-    for (int f = lane; f < C * 2 * MF_TR * MF_LD; f += 64) TAB[f] = 0.0;
     // A operand of hbar_in^T = W zbar^T : W[in = 16t+pt][out = 4s+q], kept in LDS (not registers) so that
     // two waves per SIMD fit; every wave of the block reads the same lane-major fragments, conflict-free
-    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += MF_BLOCK) {
+    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += (WAVES * 64)) {
         const int ln = f & 63, s_ = (f >> 6) % MF_KS, i_ = f / (64 * MF_KS) + 1;
         WN[f] = th[g.woff[i_] + (ln & 15) * MF_H + 4 * s_ + (ln >> 4)];
     }
-    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 16; f += MF_BLOCK) {
+    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 16; f += (WAVES * 64)) {
         const int a_ = f & 3, q_ = (f >> 2) & 3, s_ = (f >> 4) % MF_KS, i_ = f / (16 * MF_KS) + 1;
         WRB[f] = th[g.woff[i_] + (16 + a_) * MF_H + 4 * s_ + q_];
     }
     __syncthreads();
     if constexpr (PQX > 0) {
         // region A is free until the tile loop: use it as the projection's scratch
-        project_element_wg<PQX, PQY, PNTX, PNTY, MF_BLOCK>(g.pa, (long)blockIdx.x, lds);
+        project_element_wg<PQX, PQY, PNTX, PNTY, (WAVES * 64)>(g.pa, (long)blockIdx.x, lds);
         __threadfence_block();
         __syncthreads();
-        for (int f = lane; f < C * 2 * MF_TR * MF_LD; f += 64) TAB[f] = 0.0;   // re-zero this wave's transpose tiles
     }
     // gradient accumulators (per wave, over all its tiles)
     // dW of a hidden->hidden layer = one 16x16 MFMA tile (in, out < 16) + two 4x16 strips on v_mfma_f64_4x4x4_4b
@@ -449,13 +452,14 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
         double zc[NT1 > 0 ? NT1 : 1][MF_KS];
         double zcc[NT2 > 0 ? NT2 : 1][MF_KS];
     };
+    int lofs = lane;
     auto load_slots = [&](const double* svl, bool first_layer, Slots& S) {
 #pragma unroll
         for (int s = 0; s < MF_KS; ++s) {
             S.a[s] = svl[(0 * MF_KS + s) * 64];
             if constexpr (ACT == HPV_ACT_SIN) S.a1s[s] = svl[(1 * MF_KS + s) * 64]; else S.a1s[s] = 0.0;
 #pragma unroll
-            for (int u = 0; u < NT1; ++u) S.zc[u][s] = first_layer ? w1[u < D ? u : 0][s] : svl[((SZC + u) * MF_KS + s) * 64];
+            for (int u = 0; u < NT1; ++u) S.zc[u][s] = first_layer ? W1O[((u < D ? u : 0) * MF_KS + s) * 64 + lofs] : svl[((SZC + u) * MF_KS + s) * 64];
 #pragma unroll
             for (int b = 0; b < NT2; ++b) S.zcc[b][s] = first_layer ? 0.0 : svl[((SZCC + b) * MF_KS + s) * 64];
         }
@@ -495,7 +499,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
     const long dtile = g.proj_n_elem * TPE + blockIdx.x;          // the data/pad tile this workgroup adopts
     auto tile_of = [&](long k) -> long {                            // k-th tile of this wave, -1 when exhausted
         if constexpr (PQX > 0) {
-            const long lt = wv + k * MF_WAVES;                      // local index among TPE (+1) tiles
+            const long lt = wv + k * WAVES;                      // local index among TPE (+1) tiles
             if (lt < TPE) return ebase + lt;
             if (lt == TPE && dtile < g.ntiles) return dtile;
             return -1;
@@ -507,6 +511,8 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
     for (long kt = 0;; ++kt) {
         const long tile = tile_of(kt);
         if (tile < 0) break;
+        lofs = lane;
+        asm volatile("" : "+v"(lofs));   // opaque per tile: the LDS weight reads stay inside the loop
         load_tile_inputs(tile, x, gb, cur);
         const double* sv = g.ACTS + (tile * L) * (long)(NS * MF_KS * 64) + lane;
 
@@ -519,7 +525,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
 #pragma unroll
             for (int s = 0; s < MF_KS; ++s) {
                 dWo[s] = fma(hv[s], gb[ch], dWo[s]);
-                hbar[ch][s] = gb[ch] * wo[s];
+                hbar[ch][s] = gb[ch] * W1O[(D * MF_KS + s) * 64 + lofs];
             }
         }
         if (q == 0) dbo += gb[0];
@@ -569,8 +575,8 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
                 for (int ch = 0; ch < C; ++ch) {
                     double hv[MF_KS];
                     outputs_of(prev, ch, hv);
-                    double* TA = TAB + (2 * ch) * (MF_TR * MF_LD);
-                    double* TB = TA + MF_TR * MF_LD;
+                    double* TA = TAB + (2 * ch) * (MF_TRB * MF_LD);
+                    double* TB = TA + MF_TRB * MF_LD;
 #pragma unroll
                     for (int s = 0; s < MF_KS; ++s) {
                         TA[(4 * s + q) * MF_LD + pt] = hv[s];
@@ -581,8 +587,8 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) {
-                    const double* TA = TAB + (2 * ch) * (MF_TR * MF_LD);
-                    const double* TB = TA + MF_TR * MF_LD;
+                    const double* TA = TAB + (2 * ch) * (MF_TRB * MF_LD);
+                    const double* TB = TA + MF_TRB * MF_LD;
                     // operand fragments, k-step kk = points 4kk..4kk+3 (k index = q):
                     //   aF/bF: rows in/out = pt of the transposed tiles (16x16 tile; B operands of the strips)
                     //   aS/bS: rows 16 + (lane & 3) (A operands of the 4x4x4 strips, same for all four blocks)
@@ -687,7 +693,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_bwd_mfma(MfmaArgs g) {
     for (int idx = threadIdx.x; idx < g.P; idx += blockDim.x) {
         double acc = 0.0;
 #pragma unroll
-        for (int w = 0; w < MF_WAVES; ++w) acc += W0[(long)w * g.P + idx];
+        for (int w = 0; w < WAVES; ++w) acc += W0[(long)w * g.P + idx];
         row[idx] = acc;
     }
 }
@@ -1026,10 +1032,10 @@ __global__ void __launch_bounds__(WS_BLOCK) k_bwd_ws(MfmaArgs g) {
 // host side
 // ------------------------------------------------------------------------------------------------
 static size_t fwd_lds_bytes(int L) { return (size_t)(L > 1 ? L - 1 : 0) * (2 * MF_KS * 64 + MF_KS * 16) * sizeof(double); }
-static size_t bwd_lds_bytes(int P, int L, int C) {
-    size_t regA = (size_t)MF_WAVES * C * 2 * MF_TR * MF_LD;
-    if ((size_t)MF_WAVES * P > regA) regA = (size_t)MF_WAVES * P;
-    return (regA + (size_t)(L > 1 ? L - 1 : 0) * (MF_KS * 64 + MF_KS * 16)) * sizeof(double);
+static size_t bwd_lds_bytes(int P, int L, int C, int waves = MF_WAVES) {
+    size_t regA = (size_t)waves * C * 2 * MF_TRB * MF_LD;
+    if ((size_t)waves * P > regA) regA = (size_t)waves * P;
+    return (regA + (size_t)(L > 1 ? L - 1 : 0) * (MF_KS * 64 + MF_KS * 16) + 3 * MF_KS * 64) * sizeof(double);
 }
 
 template <int D, int NT1, int NT2, int ACT, int L>
@@ -1040,11 +1046,18 @@ static void run_fwd(const MfmaArgs& a, int blocks, hipStream_t s) {
         hipLaunchKernelGGL((k_fwd_mfma<D, NT1, NT2, ACT, L, MF_BLOCK, 0, 0, 0, 0, false>), dim3(blocks), dim3(MF_BLOCK),
                            fwd_lds_bytes(L), s, a);
 }
-static size_t bwd_lds_bytes(int P, int L, int C);
+static size_t bwd_lds_bytes(int P, int L, int C, int waves);
 template <int D, int NT1, int NT2, int ACT, int L, int QX, int QY, int NTX, int NTY>
 static void run_bwd_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
-    size_t lds = bwd_lds_bytes(a.P, L, 1 + NT1 + NT2);
-    hipLaunchKernelGGL((k_bwd_mfma<D, NT1, NT2, ACT, L, QX, QY, NTX, NTY>), dim3(blocks), dim3(MF_BLOCK), lds, s, a);
+    constexpr int FW = L <= 3 ? 8 : 4;   // wavefronts per element block (a 4-hidden-layer net needs > 256 registers per wave)
+    size_t lds = bwd_lds_bytes(a.P, L, 1 + NT1 + NT2, FW);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_bwd_mfma<D, NT1, NT2, ACT, L, QX, QY, NTX, NTY, FW>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_bwd_mfma<D, NT1, NT2, ACT, L, QX, QY, NTX, NTY, FW>), dim3(blocks), dim3(FW * 64), lds, s, a);
 }
 
 #define FZ_BLK 512
