@@ -29,9 +29,6 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define MF_TRB 20      // rows of a transpose tile of k_bwd_mfma (20 neurons; every fragment row is in range)
 #define MF_TR 21       // rows of a transpose tile: 20 neurons + 1 zero row; out-of-range fragment rows are clamped to it
 #define MF_BLOCK 256
-#ifndef HPV_BWD_MINW
-#define HPV_BWD_MINW 1
-#endif
 #define MF_WAVES (MF_BLOCK / 64)
 
 struct MfmaArgs {
@@ -373,10 +370,11 @@ __device__ __forceinline__ void layer_outputs_from_saved(const double* svl, cons
 // a fraction of them, and -- unlike fusing it behind the forward pass -- costs no extra tile imbalance
 // (25 tiles over 4 waves = the same 7-tile makespan as the round-robin assignment).
 // WAVES = wavefronts per workgroup: 4 (one per SIMD), or 8 in element-block mode -- two waves per SIMD (<= 256 registers
-// each) that cover each other's LDS-transpose / MFMA-result latencies, with the same 7-tile makespan per SIMD (25 tiles
+// each; also chosen for 4-wave blocks whenever channels x layers <= 10, where that costs no spills) that cover each
+// other's LDS-transpose / MFMA-result latencies, with the same 7-tile makespan per SIMD (25 tiles
 // over 8 waves = 4,3,3,3 | 3,3,3,3) and the element's projection spread over twice the threads.
 template <int D, int NT1, int NT2, int ACT, int L, int PQX = 0, int PQY = 0, int PNTX = 0, int PNTY = 0, int WAVES = MF_WAVES>
-__global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : HPV_BWD_MINW) k_bwd_mfma(MfmaArgs g) {
+__global__ void __launch_bounds__(WAVES * 64, (WAVES == 8 || (1 + NT1 + NT2) * L <= 10) ? 2 : 1) k_bwd_mfma(MfmaArgs g) {
     constexpr int C = 1 + NT1 + NT2;
     constexpr int NS = SlotCount<ACT, NT1, NT2>::value;
     constexpr int SZC = 1 + (ACT == HPV_ACT_SIN ? 1 : 0);
