@@ -1,18 +1,24 @@
 // MFMA fast path: Taylor-mode MLP forward / reverse for 20-wide hidden layers on gfx950 using
-// v_mfma_f64_16x16x4_f64.
+// v_mfma_f64_16x16x4_f64 and v_mfma_f64_4x4x4_4b_f64.
 //
 // Formulation (everything "transposed" so layer outputs feed the next MFMA straight from registers):
 //   one wavefront owns a tile of 16 quadrature points.  For a hidden->hidden layer
-//       Z^T[out][pt] = W^T[out][in] * H^T[in][pt]          (M = out (20 -> 2 tiles of 16), K = in = 20 = 5 k-steps, N = 16 points)
-//   A operand (lane l: A[m = l&15][k = l>>4])  = W^T  -> per-lane constants held in registers,
-//   B operand (lane l: B[k = l>>4][n = l&15])  = H^T  -> lane holds neuron 4s+(l>>4), point l&15 for k-step s,
-//   D         (lane l, reg r: row (l>>4)+4r, col l&15) -> neuron 16t+4r+(l>>4), point l&15.
-//   D register (t,r) is exactly the B operand of k-step s = 4t+r of the next layer: no LDS, no shuffles.
+//       Z^T[out][pt] = W^T[out][in] * H^T[in][pt]          (M = out = 20 = 16 + 4, K = in = 20 = 5 k-steps, N = 16 points)
+//   16x16x4:  A (lane l: A[m = l&15][k = l>>4]) = W^T fragments (LDS, lane-major),
+//             B (lane l: B[k = l>>4][n = l&15]) = H^T -> lane holds neuron 4s+(l>>4), point l&15 for k-step s,
+//             D (lane l, reg r: row (l>>4)+4r, col l&15) -> neuron 4r+(l>>4), point l&15:
+//             D register r is exactly the B operand of k-step r of the next layer: no LDS, no shuffles.
+//   4x4x4_4b (four independent 4x4x4 blocks b = (l&15)>>2; A_b[i = l&3][k = l>>4], B_b[k = l>>4][j = l&3],
+//             D_b[i = l>>4][j = l&3]; layout probed on the device, scripts/mfma_4x4_probe.hip): the remaining output
+//             neurons 16..19 with the four blocks = the four groups of 4 points; B is the SAME register as for the
+//             16x16x4 tile and D lands on the lane's fifth value (neuron 16+(l>>4), point l&15) -- a second 16-row
+//             tile would be 3/4 padding, and fp64 MFMA / VALU share one datapath on this chip, so padding is pure loss.
 //   Each lane therefore carries 5 useful values per channel per layer (neurons 4s+q, s=0..4, q = l>>4)
 //   for point pt = l&15, and all activation math runs on full 64-lane VALU instructions.
 //   The reverse pass uses the same chaining for hbar_in^T = W * zbar^T; only the weight gradient
 //   dW[in][out] = sum_pt h_in[pt][in] zbar[pt][out] contracts over points, which needs the operands in the
-//   other orientation -> one small per-wave LDS transpose per channel and layer (cheap next to 64-cycle MFMAs).
+//   other orientation -> one per-wave LDS transpose per channel and layer; dW = one 16x16 tile (16x16x4) + the
+//   4x16 and 16x4 strips and the 4x4 corner on 4x4x4_4b.
 //
 // First layer (d -> 20) and linear head (20 -> 1) are VALU work (K = 1..2 and M = 1 are no MFMA shapes).
 #include <cstdlib>
@@ -27,7 +33,6 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define MF_KS 5        // k-steps of 4 over the 20 inputs
 #define MF_LD 17       // padded leading dimension of the LDS transpose tiles
 #define MF_TRB 20      // rows of a transpose tile of k_bwd_mfma (20 neurons; every fragment row is in range)
-#define MF_TR 21       // rows of a transpose tile: 20 neurons + 1 zero row; out-of-range fragment rows are clamped to it
 #define MF_BLOCK 256
 #define MF_WAVES (MF_BLOCK / 64)
 
@@ -68,14 +73,11 @@ struct HpvMfma {
     MfmaArgs base;
     void (*fwd)(const MfmaArgs&, int, hipStream_t) = nullptr;
     void (*bwd)(const MfmaArgs&, int, hipStream_t) = nullptr;
-    void (*bwd_ws)(const MfmaArgs&, int, hipStream_t) = nullptr;   // wave-specialised reverse kernel
     void (*fwd_fused)(const MfmaArgs&, int, hipStream_t) = nullptr; // forward + projection (kept for A/B: HPV_FUSE=fwd)
     void (*bwd_fused)(const MfmaArgs&, int, hipStream_t) = nullptr; // projection + reverse, element-block mode
     int occ_fwd = 1, occ_bwd = 1;   // resident 256-thread blocks per CU
-    int occ_ws = 0;                 // resident 512-thread blocks per CU of the wave-specialised kernel (0: unusable)
     int max_rows = 0;               // gradient rows the caller allocated (>= every launch mode's row count)
-    bool use_ws = false;
-    int ws_blocks = 0;
+    bool fuse_bwd = true, fuse_fwd = false;   // HPV_FUSE=n / f at creation (A/B switches; default: projection fused into the reverse kernel)
 };
 
 template <int ACT>
@@ -100,17 +102,6 @@ __device__ __forceinline__ void act_saved(double a, double a1s, double& a1, doub
         a2 = -a;
         a3 = -a1s;
     }
-}
-
-// Lane (q, pt) holds 4 partial sums p[a] (a = 0..3), partial over its own 5 of the 20 contraction indices.
-// Returns sum over the 4 q-lanes of p[a = q]: a two-round reduce-scatter over lanes l^32 and l^16
-// (3 cross-lane moves instead of the 8 of an all-reduce).  Used for output neurons 16..19, which would
-// otherwise occupy a second, 3/4-empty 16-row MFMA tile.
-__device__ __forceinline__ double reduce_scatter_q(const double (&p)[4], int lane) {
-    const bool hi = (lane & 32) != 0, lo = (lane & 16) != 0;
-    const double kA = (hi ? p[2] : p[0]) + __shfl_xor(hi ? p[0] : p[2], 32, 64);
-    const double kB = (hi ? p[3] : p[1]) + __shfl_xor(hi ? p[1] : p[3], 32, 64);
-    return (lo ? kB : kA) + __shfl_xor(lo ? kA : kB, 16, 64);
 }
 
 template <int ACT, int NT1, int NT2>
@@ -697,336 +688,6 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES == 8 || (1 + NT1 + NT2) * L
 }
 
 // ------------------------------------------------------------------------------------------------
-// reverse, wave-specialised: the single-role kernel above needs ~500 registers per wave (dW accumulators
-// of every layer + bias/first-layer/head partials + double-buffered slots + the chain state), i.e. one wave
-// per SIMD, and its MFMA, VALU, LDS and wait phases serialise inside that wave.  Here a workgroup is four
-// PAIRS of wavefronts working on the same tile:
-//   role A ("chain")   : slots -> activation-backward -> zbar, hbar_in^T = W zbar^T (MFMA rows 0..15 + VALU
-//                         rows 16..19), first-layer / head / first-bias partials; it publishes, per hidden->hidden
-//                         layer, the transposed tiles of h_in and zbar of all channels in LDS;
-//   role B ("gradient"): reads the operand fragments of dW = sum_pt h_in^T zbar from those tiles, issues the
-//                         dW MFMAs (+ 4x4 corner and bias gradients on the VALU) and owns the dW accumulators.
-// Each role fits in <= 256 registers, so an A and a B wave share every SIMD and overlap each other's
-// MFMA / VALU / LDS / memory phases.  Hand-off = one workgroup barrier per layer with double-buffered tiles
-// (fill(k) | barrier_k | consume(k) overlaps fill(k+1); buffer k%2 is refilled only after barrier_{k+1}).
-// ------------------------------------------------------------------------------------------------
-#define WS_PAIRS 4
-#define WS_BLOCK (2 * WS_PAIRS * 64)
-
-template <int D, int NT1, int NT2, int ACT, int L>
-__global__ void __launch_bounds__(WS_BLOCK) k_bwd_ws(MfmaArgs g) {
-    constexpr int C = 1 + NT1 + NT2;
-    constexpr int NS = SlotCount<ACT, NT1, NT2>::value;
-    constexpr int SZC = 1 + (ACT == HPV_ACT_SIN ? 1 : 0);
-    constexpr int SZCC = SZC + NT1;
-    constexpr int LH = L > 1 ? L - 1 : 1;
-    constexpr int TILE_D = MF_TR * MF_LD;                // one transposed 20x16 tile (+12 zero rows, padded)
-    constexpr int STAGE_D = C * 2 * TILE_D;              // h_in and zbar tiles of all channels of one layer
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const bool roleA = wv < WS_PAIRS;
-    const int pair = roleA ? wv : wv - WS_PAIRS;
-    const int q = lane >> 4, pt = lane & 15;
-    const long pair_global = (long)blockIdx.x * WS_PAIRS + pair;
-    const long npairs = (long)gridDim.x * WS_PAIRS;
-    // every wave of the block executes the same number of iterations (barrier counts must match)
-    const long first = (long)blockIdx.x * WS_PAIRS;
-    const long niter = first < g.ntiles ? (g.ntiles - first + npairs - 1) / npairs : 0;
-    const double* __restrict__ th = g.theta;
-    // LDS map: [stage buffers: WS_PAIRS x 2 x STAGE_D | gradient rows in the epilogue] [WN fragments] [WRB]
-    const int stage_region = WS_PAIRS * 2 * STAGE_D;
-    const int regA = stage_region > WS_PAIRS * g.P ? stage_region : WS_PAIRS * g.P;
-    double* ST = lds + pair * (2 * STAGE_D);
-    double* WN = lds + regA;
-    double* WRB = WN + (L > 1 ? L - 1 : 0) * MF_KS * 64;
-    for (int f = threadIdx.x; f < WS_PAIRS * 2 * STAGE_D; f += WS_BLOCK) lds[f] = 0.0;   // zero rows of the tiles
-    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += WS_BLOCK) {
-        const int ln = f & 63, s_ = (f >> 6) % MF_KS, i_ = f / (64 * MF_KS) + 1;
-        WN[f] = th[g.woff[i_] + (ln & 15) * MF_H + 4 * s_ + (ln >> 4)];
-    }
-    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 16; f += WS_BLOCK) {
-        const int a_ = f & 3, q_ = (f >> 2) & 3, s_ = (f >> 4) % MF_KS, i_ = f / (16 * MF_KS) + 1;
-        WRB[f] = th[g.woff[i_] + (16 + a_) * MF_H + 4 * s_ + q_];
-    }
-    __syncthreads();
-
-    if (roleA) {
-        // ---------------------------------- role A: the adjoint chain ----------------------------------
-        double w1[D][MF_KS], wo[MF_KS];
-#pragma unroll
-        for (int s = 0; s < MF_KS; ++s) {
-            const int j = 4 * s + q;
-#pragma unroll
-            for (int c = 0; c < D; ++c) w1[c][s] = th[g.woff[0] + c * MF_H + j];
-            wo[s] = th[g.woff[L] + j];
-        }
-        double db0[MF_KS], dW1[D][MF_KS], dWo[MF_KS], dbo = 0.0;
-#pragma unroll
-        for (int s = 0; s < MF_KS; ++s) {
-            dWo[s] = 0.0; db0[s] = 0.0;
-#pragma unroll
-            for (int c = 0; c < D; ++c) dW1[c][s] = 0.0;
-        }
-        struct Slots {
-            double a[MF_KS], a1s[MF_KS];
-            double zc[NT1 > 0 ? NT1 : 1][MF_KS];
-            double zcc[NT2 > 0 ? NT2 : 1][MF_KS];
-        };
-        auto load_slots = [&](const double* svl, bool first_layer, Slots& S) {
-#pragma unroll
-            for (int s = 0; s < MF_KS; ++s) {
-                S.a[s] = svl[(0 * MF_KS + s) * 64];
-                if constexpr (ACT == HPV_ACT_SIN) S.a1s[s] = svl[(1 * MF_KS + s) * 64]; else S.a1s[s] = 0.0;
-#pragma unroll
-                for (int u = 0; u < NT1; ++u) S.zc[u][s] = first_layer ? w1[u < D ? u : 0][s] : svl[((SZC + u) * MF_KS + s) * 64];
-#pragma unroll
-                for (int b = 0; b < NT2; ++b) S.zcc[b][s] = first_layer ? 0.0 : svl[((SZCC + b) * MF_KS + s) * 64];
-            }
-        };
-        auto outputs_of = [&](const Slots& S, int ch, double (&hv)[MF_KS]) {
-#pragma unroll
-            for (int s = 0; s < MF_KS; ++s) {
-                double a1, a2, a3;
-                act_saved<ACT>(S.a[s], S.a1s[s], a1, a2, a3);
-                if (ch == 0) hv[s] = S.a[s];
-                else if (ch <= NT1) hv[s] = a1 * S.zc[(ch - 1) < NT1 ? (ch - 1) : 0][s];
-                else {
-                    const int b = ch - 1 - NT1;
-                    const double z1 = S.zc[b < NT1 ? b : 0][s];
-                    hv[s] = a2 * z1 * z1 + a1 * S.zcc[b < NT2 ? b : 0][s];
-                }
-            }
-        };
-        for (long n = 0; n < niter; ++n) {
-            const long tile = pair_global + n * npairs;
-            const bool tv = tile < g.ntiles;            // wave-uniform
-            const long tl = tv ? tile : 0;
-            const long p = tl * 16 + pt;
-            const bool valid = tv && p < g.N;
-            double x[D], gb[C];
-#pragma unroll
-            for (int c = 0; c < D; ++c) x[c] = valid ? g.X[(long)c * g.N + p] : 0.0;
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) gb[ch] = valid ? g.GBAR[(long)ch * g.N + p] : 0.0;
-            const double* sv = g.ACTS + (tl * L) * (long)(NS * MF_KS * 64) + lane;
-            Slots cur;
-            load_slots(sv + (long)(L - 1) * (NS * MF_KS * 64), L == 1, cur);
-            double hbar[C][MF_KS], zbar[C][MF_KS];
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) {
-                double hv[MF_KS];
-                outputs_of(cur, ch, hv);
-#pragma unroll
-                for (int s = 0; s < MF_KS; ++s) {
-                    dWo[s] = fma(hv[s], gb[ch], dWo[s]);
-                    hbar[ch][s] = gb[ch] * wo[s];
-                }
-            }
-            if (q == 0) dbo += gb[0];
-#pragma unroll
-            for (int i = L - 1; i >= 0; --i) {
-                Slots prev;
-                if (i > 0) load_slots(sv + (long)(i - 1) * (NS * MF_KS * 64), i == 1, prev);
-#pragma unroll
-                for (int s = 0; s < MF_KS; ++s) {
-                    double a1, a2, a3;
-                    act_saved<ACT>(cur.a[s], cur.a1s[s], a1, a2, a3);
-                    double zb = hbar[0][s] * a1;
-#pragma unroll
-                    for (int u = 0; u < NT1; ++u) {
-                        zbar[1 + u][s] = hbar[1 + u][s] * a1;
-                        zb += hbar[1 + u][s] * a2 * cur.zc[u][s];
-                    }
-#pragma unroll
-                    for (int b = 0; b < NT2; ++b) {
-                        const int u = b < NT1 ? b : 0;
-                        const double hb = hbar[1 + NT1 + b][s];
-                        zbar[1 + NT1 + b][s] = hb * a1;
-                        zbar[1 + u][s] += 2.0 * hb * a2 * cur.zc[u][s];
-                        zb += hb * (a3 * cur.zc[u][s] * cur.zc[u][s] + a2 * cur.zcc[b][s]);
-                    }
-                    zbar[0][s] = zb;
-                }
-                if (i == 0) {
-#pragma unroll
-                    for (int s = 0; s < MF_KS; ++s) {
-                        db0[s] += zbar[0][s];
-#pragma unroll
-                        for (int c = 0; c < D; ++c) dW1[c][s] += x[c] * zbar[0][s];
-#pragma unroll
-                        for (int u = 0; u < NT1; ++u) dW1[u < D ? u : 0][s] += zbar[1 + u][s];
-                    }
-                } else {
-                    // publish the transposed tiles of this layer (stage k) for the partner wave
-                    const long k = n * (L - 1) + (L - 1 - i);
-                    double* SB = ST + (k & 1) * STAGE_D;
-                    if (tv) {
-#pragma unroll
-                        for (int ch = 0; ch < C; ++ch) {
-                            double hv[MF_KS];
-                            outputs_of(prev, ch, hv);
-#pragma unroll
-                            for (int s = 0; s < MF_KS; ++s) {
-                                SB[(2 * ch) * TILE_D + (4 * s + q) * MF_LD + pt] = hv[s];
-                                SB[(2 * ch + 1) * TILE_D + (4 * s + q) * MF_LD + pt] = zbar[ch][s];
-                            }
-                        }
-                    }
-                    __syncthreads();   // barrier_k
-                    // hbar_in^T = W zbar^T (overlaps the partner's dW MFMAs of this layer)
-#pragma unroll
-                    for (int ch = 0; ch < C; ++ch) {
-                        v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
-                        double pa[4] = {0.0, 0.0, 0.0, 0.0};
-                        const double* wrl = WRB + (i - 1) * MF_KS * 16 + q * 4;
-#pragma unroll
-                        for (int s = 0; s < MF_KS; ++s) {
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(WN[((i - 1) * MF_KS + s) * 64 + lane], zbar[ch][s], acc, 0, 0, 0);
-#pragma unroll
-                            for (int a = 0; a < 4; ++a) pa[a] = fma(wrl[s * 16 + a], zbar[ch][s], pa[a]);
-                        }
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) hbar[ch][s] = acc[s];
-                        hbar[ch][4] = reduce_scatter_q(pa, lane);
-                    }
-                    cur = prev;
-                }
-            }
-        }
-        // ---- epilogue (role A) ----
-        __syncthreads();                       // all stage buffers are dead: region A becomes the gradient rows
-        double* WP = lds + (long)pair * g.P;
-        for (int idx = lane; idx < g.P; idx += 64) WP[idx] = 0.0;
-        __syncthreads();                       // rows zeroed before either role fills its part
-#pragma unroll
-        for (int s = 0; s < MF_KS; ++s) {
-            const int j = 4 * s + q;
-            double v[D + 2];
-            v[0] = db0[s];
-#pragma unroll
-            for (int c = 0; c < D; ++c) v[1 + c] = dW1[c][s];
-            v[D + 1] = dWo[s];
-#pragma unroll
-            for (int kx = 0; kx < D + 2; ++kx) {
-                double t = v[kx];
-                t += __shfl_xor(t, 1, 64);
-                t += __shfl_xor(t, 2, 64);
-                t += __shfl_xor(t, 4, 64);
-                t += __shfl_xor(t, 8, 64);
-                v[kx] = t;
-            }
-            if (pt == 0) {
-                WP[g.boff[0] + j] = v[0];
-#pragma unroll
-                for (int c = 0; c < D; ++c) WP[g.woff[0] + c * MF_H + j] = v[1 + c];
-                WP[g.woff[L] + j] = v[D + 1];
-            }
-        }
-        {
-            double t = dbo;
-            t += __shfl_xor(t, 1, 64);
-            t += __shfl_xor(t, 2, 64);
-            t += __shfl_xor(t, 4, 64);
-            t += __shfl_xor(t, 8, 64);
-            if (lane == 0) WP[g.boff[L]] = t;
-        }
-    } else {
-        // ---------------------------------- role B: weight gradients ----------------------------------
-        v4d dWacc[LH][3];   // tiles (0,0), (0,1), (1,0); the (1,1) corner is VALU work
-        double accC[LH][4], dbh[LH][MF_KS];
-#pragma unroll
-        for (int i = 0; i < LH; ++i) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) dWacc[i][a] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int a = 0; a < 4; ++a) accC[i][a] = 0.0;
-#pragma unroll
-            for (int s = 0; s < MF_KS; ++s) dbh[i][s] = 0.0;
-        }
-        for (long n = 0; n < niter; ++n) {
-            const long tile = pair_global + n * npairs;
-            const bool tv = tile < g.ntiles;
-#pragma unroll
-            for (int i = L - 1; i >= 1; --i) {
-                const long k = n * (L - 1) + (L - 1 - i);
-                const double* SB = ST + (k & 1) * STAGE_D;
-                __syncthreads();   // barrier_k: the chain wave has published stage k
-                if (tv) {
-#pragma unroll
-                    for (int ch = 0; ch < C; ++ch) {
-                        const double* TA = SB + (2 * ch) * TILE_D;
-                        const double* TB = TA + TILE_D;
-                        double aF[2][4], bF[2][4];
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int kk = 0; kk < 4; ++kk) {
-                                const int row = (t == 0) ? pt : (16 + pt < MF_H ? 16 + pt : MF_H);   // row 20 is all zero
-                                aF[t][kk] = TA[row * MF_LD + 4 * kk + q];
-                                bF[t][kk] = TB[row * MF_LD + 4 * kk + q];
-                            }
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            dWacc[i - 1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[0][kk], bF[0][kk], dWacc[i - 1][0], 0, 0, 0);
-                            dWacc[i - 1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[0][kk], bF[1][kk], dWacc[i - 1][1], 0, 0, 0);
-                            dWacc[i - 1][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[1][kk], bF[0][kk], dWacc[i - 1][2], 0, 0, 0);
-                        }
-                        // 4x4 corner dW[16+q][16+a] and (value channel) the bias gradient, straight from the tiles
-                        const double h16 = TA[(16 + q) * MF_LD + pt];
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) accC[i - 1][a] = fma(h16, TB[(16 + a) * MF_LD + pt], accC[i - 1][a]);
-                        if (ch == 0) {
-#pragma unroll
-                            for (int s = 0; s < MF_KS; ++s) dbh[i - 1][s] += TB[(4 * s + q) * MF_LD + pt];
-                        }
-                    }
-                }
-            }
-        }
-        // ---- epilogue (role B) ----
-        __syncthreads();
-        double* WP = lds + (long)pair * g.P;
-        __syncthreads();                       // partner has zeroed the row
-#pragma unroll
-        for (int i = 1; i < L; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int in0 = 4 * r + q, out0 = pt;                 // tile (0,0)
-                WP[g.woff[i] + in0 * MF_H + out0] = dWacc[i - 1][0][r];
-                if (16 + pt < MF_H) WP[g.woff[i] + in0 * MF_H + 16 + pt] = dWacc[i - 1][1][r];      // tile (0,1)
-                if (16 + in0 < MF_H) WP[g.woff[i] + (16 + in0) * MF_H + out0] = dWacc[i - 1][2][r]; // tile (1,0)
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                double t = accC[i - 1][a];
-                t += __shfl_xor(t, 1, 64);
-                t += __shfl_xor(t, 2, 64);
-                t += __shfl_xor(t, 4, 64);
-                t += __shfl_xor(t, 8, 64);
-                if (pt == 0) WP[g.woff[i] + (16 + q) * MF_H + 16 + a] = t;
-            }
-#pragma unroll
-            for (int s = 0; s < MF_KS; ++s) {
-                double t = dbh[i - 1][s];
-                t += __shfl_xor(t, 1, 64);
-                t += __shfl_xor(t, 2, 64);
-                t += __shfl_xor(t, 4, 64);
-                t += __shfl_xor(t, 8, 64);
-                if (pt == 0) WP[g.boff[i] + 4 * s + q] = t;
-            }
-        }
-    }
-    __syncthreads();
-    double* row = g.GPART + (long)blockIdx.x * g.P;
-    for (int idx = threadIdx.x; idx < g.P; idx += blockDim.x) {
-        double acc = 0.0;
-#pragma unroll
-        for (int w = 0; w < WS_PAIRS; ++w) acc += lds[(long)w * g.P + idx];
-        row[idx] = acc;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static size_t fwd_lds_bytes(int L) { return (size_t)(L > 1 ? L - 1 : 0) * (2 * MF_KS * 64 + MF_KS * 16) * sizeof(double); }
@@ -1071,32 +732,14 @@ static void run_bwd(const MfmaArgs& a, int blocks, hipStream_t s) {
     hipLaunchKernelGGL((k_bwd_mfma<D, NT1, NT2, ACT, L>), dim3(blocks), dim3(MF_BLOCK), lds, s, a);
 }
 
-static size_t ws_lds_bytes(int P, int C, int L) {
-    size_t regA = (size_t)WS_PAIRS * 2 * C * 2 * MF_TR * MF_LD;
-    if ((size_t)WS_PAIRS * P > regA) regA = (size_t)WS_PAIRS * P;
-    return (regA + (size_t)(L > 1 ? L - 1 : 0) * (MF_KS * 64 + MF_KS * 16)) * sizeof(double);
-}
-template <int D, int NT1, int NT2, int ACT, int L>
-static void run_bwd_ws(const MfmaArgs& a, int blocks, hipStream_t s) {
-    hipLaunchKernelGGL((k_bwd_ws<D, NT1, NT2, ACT, L>), dim3(blocks), dim3(WS_BLOCK), ws_lds_bytes(a.P, 1 + NT1 + NT2, L), s, a);
-}
-
 template <int D, int NT1, int NT2, int ACT, int L>
 static bool pick(HpvMfma* m) {
     m->fwd = run_fwd<D, NT1, NT2, ACT, L>;
     m->bwd = run_bwd<D, NT1, NT2, ACT, L>;
-    m->bwd_ws = run_bwd_ws<D, NT1, NT2, ACT, L>;
     if constexpr (D == 2 && NT1 == 2 && NT2 == 0 && ACT == HPV_ACT_TANH)   // BASELINE config 4 (Poisson-2D var_form 1)
         m->fwd_fused = run_fwd_fused<D, NT1, NT2, ACT, L, 20, 20, 10, 10>;
     if constexpr (D == 2 && NT1 == 2 && NT2 == 0 && ACT == HPV_ACT_TANH)
         m->bwd_fused = run_bwd_fused<D, NT1, NT2, ACT, L, 20, 20, 10, 10>;
-    {
-        int ow = 0;
-        size_t lw = ws_lds_bytes(m->nd.P, 1 + NT1 + NT2, L);
-        if (lw <= 160 * 1024 &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&ow, k_bwd_ws<D, NT1, NT2, ACT, L>, WS_BLOCK, lw) == hipSuccess)
-            m->occ_ws = ow;
-    }
     size_t lds = bwd_lds_bytes(m->nd.P, L, 1 + NT1 + NT2);
     int of = 1, ob = 1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, k_fwd_mfma<D, NT1, NT2, ACT, L>, MF_BLOCK, fwd_lds_bytes(L));
@@ -1158,11 +801,10 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
     // over its tiles), so weight fragments are loaded and gradient rows written once per resident wave
     m->fwd_blocks = (int)std::min<long>(want, (long)cus * std::max(1, m->occ_fwd));
     m->bwd_blocks = (int)std::min<long>(want, (long)cus * std::max(1, m->occ_bwd));
-    {   // the wave-specialised kernel needs a hidden->hidden layer and pays off once every CU has work
-        const char* e = getenv("HPV_BWD");
-        const bool force_ws = e && e[0] == 'w', force_classic = e && e[0] == 'c';
-        m->ws_blocks = (int)std::min<long>(want, (long)cus * std::max(1, m->occ_ws));
-        m->use_ws = m->occ_ws > 0 && L > 1 && !force_classic && force_ws;   // opt-in: measured 65 vs 58 us at config 4 (block-wide barriers + shared fp64 pipe)
+    {
+        const char* e = getenv("HPV_FUSE");
+        m->fuse_bwd = !(e && (e[0] == 'n' || e[0] == 'f'));
+        m->fuse_fwd = e && e[0] == 'f';
     }
     MfmaArgs& a = m->base;
     a = MfmaArgs{};
@@ -1178,7 +820,7 @@ void hpv_mfma_destroy(HpvMfma* m) {
     delete m;
 }
 
-int hpv_mfma_grad_rows(HpvMfma* m) { return m->use_ws ? m->ws_blocks : m->bwd_blocks; }
+int hpv_mfma_grad_rows(HpvMfma* m) { return m->bwd_blocks; }
 // rows the caller must allocate: the element-block mode writes one row per element
 int hpv_mfma_max_rows(HpvMfma* m, long n_elem) {
     int r = hpv_mfma_grad_rows(m);
@@ -1203,7 +845,7 @@ void hpv_mfma_backward(HpvMfma* m, const double* theta, const double* X, const d
                        hipStream_t s) {
     MfmaArgs a = m->base;
     a.theta = theta; a.X = X; a.GBAR = GBAR; a.GPART = GPART;
-    if (m->use_ws) m->bwd_ws(a, m->ws_blocks, s); else m->bwd(a, m->bwd_blocks, s);
+    m->bwd(a, m->bwd_blocks, s);
     if (rows) *rows = hpv_mfma_grad_rows(m);
 }
 
@@ -1216,8 +858,7 @@ bool hpv_mfma_forward_fused(HpvMfma* m, const double* theta, const double* X, do
     if (!(pd.qx == 20 && pd.qy == 20 && pd.ntx == 10 && pd.nty == 10)) return false;
     const long tpe = (20 * 20) / 16;
     if (n_elem * tpe > m->ntiles) return false;
-    static const bool on = [] { const char* e = getenv("HPV_FUSE"); return e && e[0] == 'f'; }();   // A/B only
-    if (!on) return false;
+    if (!m->fuse_fwd) return false;   // A/B only
     MfmaArgs a = m->base;
     a.theta = theta; a.X = X; a.OUT = OUT; a.save_act = save_act;
     a.data_off = -1;
@@ -1238,14 +879,12 @@ bool hpv_mfma_forward_fused(HpvMfma* m, const double* theta, const double* X, do
 bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, const double* GBAR, double* GPART, int* rows,
                              hipStream_t s, const ProjArgs& pa, long n_elem) {
     const ProjDesc& pd = pa.pd;
-    if (!m->bwd_fused || m->use_ws || pd.edge || n_elem <= 0) return false;
+    if (!m->bwd_fused || !m->fuse_bwd || pd.edge || n_elem <= 0) return false;
     if (!(pd.qx == 20 && pd.qy == 20 && pd.ntx == 10 && pd.nty == 10)) return false;
     const long tpe = (20 * 20) / 16;
     const long rest = m->ntiles - n_elem * tpe;                 // pad + data tiles: at most one per workgroup
     if (rest < 0 || rest > n_elem) return false;
     if (n_elem > hpv_mfma_grad_rows(m) && n_elem > m->max_rows) return false;
-    static const bool off = [] { const char* e = getenv("HPV_FUSE"); return e && (e[0] == 'n' || e[0] == 'f'); }();
-    if (off) return false;
     MfmaArgs a = m->base;
     a.theta = theta; a.X = X; a.GBAR = GBAR; a.GPART = GPART;
     a.proj_n_elem = n_elem;

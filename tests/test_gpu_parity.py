@@ -430,7 +430,7 @@ def test_train_recording_semantics_and_early_stop():
 def test_full_size_config4_properties():
     """BASELINE config 4 at full size (102 400 points): size-independent properties instead of the oracle --
     (i) two half-domain shards sum to the whole; (ii) loss(theta = 0) = sum_e mean(F_e^2) + w*mean(u_d^2);
-    (iii) the wave-specialised reverse kernel (HPV_BWD=ws) agrees with the default one."""
+    (iii) the separate projection + reverse launches (HPV_FUSE=n) agree with the default fused reverse kernel."""
     import os
     from hp_vpinns_amd.drivers import poisson2d
     from hp_vpinns_amd.init import xavier_init
@@ -444,12 +444,12 @@ def test_full_size_config4_properties():
     F = s["F_ext_total"]
     assert abs(z3[2] - (F ** 2).mean(axis=(2, 3)).sum()) < 1e-10 * z3[2]
     assert abs(z3[1] - (s["u_train"] ** 2).mean()) < 1e-13
-    os.environ["HPV_BWD"] = "ws"
+    os.environ["HPV_FUSE"] = "n"
     try:
         mw = poisson2d.build_model(s, L, init_params=th)
         l3w, gw = mw.loss_and_grad()
     finally:
-        del os.environ["HPV_BWD"]
+        del os.environ["HPV_FUSE"]
     assert rel(gw, g) < 1e-11 and rel(l3w, l3) < 1e-13
     from hp_vpinns_amd import _lib
     from hp_vpinns_amd.testfcn import tables_1d
