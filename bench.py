@@ -163,7 +163,7 @@ def main():
     if world == 1 and not args.no_residual_roofline:
         # the per-element projection (residual + adjoint) kernel on a batch larger than the 256 MB
         # Infinity Cache: 2^18 elements of the config-4 element shape, random channels
-        ms, by = model.h.bench_projection(args.residual_elems, 5)
+        ms, by = model.h.bench_projection(args.residual_elems, 10)
         gbs = by / (ms * 1e-3) / 1e9
         out["roofline_residual"] = {"kernel": "project (residual+adjoint)", "bound": "hbm", "achieved": gbs,
                                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
