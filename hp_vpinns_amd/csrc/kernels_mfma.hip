@@ -60,6 +60,7 @@ struct MfmaArgs {
     int data_write_gbar;
     // fused forward + projection (element-block mode): blocks [0, proj_n_elem) own one element each
     long proj_n_elem;
+    int proj_split;       // workgroups per element in the reverse kernel's element-block mode (1, 2, 4 or 8)
     ProjArgs pa;
 };
 
@@ -76,6 +77,7 @@ struct HpvMfma {
     void (*fwd_fused)(const MfmaArgs&, int, hipStream_t) = nullptr; // forward + projection (kept for A/B: HPV_FUSE=fwd)
     void (*bwd_fused)(const MfmaArgs&, int, hipStream_t) = nullptr; // projection + reverse, element-block mode
     int occ_fwd = 1, occ_bwd = 1;   // resident 256-thread blocks per CU
+    int n_cus = 256;                // compute units of the device
     int max_rows = 0;               // gradient rows the caller allocated (>= every launch mode's row count)
     bool fuse_bwd = true, fuse_fwd = false;   // HPV_FUSE=n / f at creation (A/B switches; default: projection fused into the reverse kernel)
 };
@@ -406,7 +408,8 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES == 8 || (1 + NT1 + NT2) * L
     __syncthreads();
     if constexpr (PQX > 0) {
         // region A is free until the tile loop: use it as the projection's scratch
-        project_element_wg<PQX, PQY, PNTX, PNTY, (WAVES * 64)>(g.pa, (long)blockIdx.x, lds);
+        // (with proj_split > 1 the workgroups sharing an element all project it: identical values, benign duplicate stores)
+        project_element_wg<PQX, PQY, PNTX, PNTY, (WAVES * 64)>(g.pa, (long)blockIdx.x / g.proj_split, lds);
         __threadfence_block();
         __syncthreads();
     }
@@ -484,13 +487,17 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES == 8 || (1 + NT1 + NT2) * L
     // tile sequence of this wave: round-robin over the batch, or (element-block mode) the tiles of the
     // workgroup's element followed by at most one boundary/data tile
     constexpr long TPE = PQX > 0 ? (PQX * PQY) / 16 : 1;
-    const long ebase = (long)blockIdx.x * TPE;
+    // element-block mode: workgroup b owns part (b % split) of element b / split -- small shards (multi-GPU) spread
+    // an element over up to 8 workgroups so that all CUs work, each projecting the element for itself
+    const int split = PQX > 0 ? g.proj_split : 1, part = PQX > 0 ? (int)(blockIdx.x % split) : 0;
+    const long tl0 = (part * TPE) / split, n_own = ((part + 1) * TPE) / split - tl0;
+    const long ebase = ((long)blockIdx.x / split) * TPE + tl0;
     const long dtile = g.proj_n_elem * TPE + blockIdx.x;          // the data/pad tile this workgroup adopts
     auto tile_of = [&](long k) -> long {                            // k-th tile of this wave, -1 when exhausted
         if constexpr (PQX > 0) {
             const long lt = wv + k * WAVES;                      // local index among TPE (+1) tiles
-            if (lt < TPE) return ebase + lt;
-            if (lt == TPE && dtile < g.ntiles) return dtile;
+            if (lt < n_own) return ebase + lt;
+            if (lt == n_own && dtile < g.ntiles) return dtile;
             return -1;
         } else {
             const long t = wave + k * nwaves;
@@ -795,6 +802,7 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    m->n_cus = cus;
     const long tiles_per_block = MF_WAVES;
     long want = (m->ntiles + tiles_per_block - 1) / tiles_per_block;
     // persistent-style grids: exactly the number of blocks that are resident at once (the wave loops
@@ -821,10 +829,18 @@ void hpv_mfma_destroy(HpvMfma* m) {
 }
 
 int hpv_mfma_grad_rows(HpvMfma* m) { return m->bwd_blocks; }
-// rows the caller must allocate: the element-block mode writes one row per element
+// Workgroups per element of the fused reverse kernel: one when the shard has an element for every CU, more for the
+// small shards of a multi-GPU run (each workgroup walks 1/split of the element's 25 tiles).
+static int fused_split(HpvMfma* m, long n_elem) {
+    int split = 1;
+    while (split < 8 && n_elem * split * 2 <= m->n_cus) split *= 2;
+    return split;
+}
+// rows the caller must allocate: the element-block mode writes one row per workgroup
 int hpv_mfma_max_rows(HpvMfma* m, long n_elem) {
     int r = hpv_mfma_grad_rows(m);
-    if (m->bwd_fused && n_elem > r && n_elem <= 65536) r = (int)n_elem;
+    const long fused_rows = n_elem * fused_split(m, n_elem);
+    if (m->bwd_fused && fused_rows > r && fused_rows <= 65536) r = (int)fused_rows;
     m->max_rows = r;
     return r;
 }
@@ -883,14 +899,17 @@ bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, c
     if (!(pd.qx == 20 && pd.qy == 20 && pd.ntx == 10 && pd.nty == 10)) return false;
     const long tpe = (20 * 20) / 16;
     const long rest = m->ntiles - n_elem * tpe;                 // pad + data tiles: at most one per workgroup
-    if (rest < 0 || rest > n_elem) return false;
-    if (n_elem > hpv_mfma_grad_rows(m) && n_elem > m->max_rows) return false;
+    const int split = fused_split(m, n_elem);
+    const long blocks = n_elem * split;
+    if (rest < 0 || rest > blocks) return false;
+    if (blocks > hpv_mfma_grad_rows(m) && blocks > m->max_rows) return false;
     MfmaArgs a = m->base;
     a.theta = theta; a.X = X; a.GBAR = GBAR; a.GPART = GPART;
     a.proj_n_elem = n_elem;
+    a.proj_split = split;
     a.pa = pa;
-    m->bwd_fused(a, (int)n_elem, s);
-    if (rows) *rows = (int)n_elem;
+    m->bwd_fused(a, (int)blocks, s);
+    if (rows) *rows = (int)blocks;
     return true;
 }
 

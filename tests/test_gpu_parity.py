@@ -485,28 +485,36 @@ def test_tall_element_projection_advdiff_config5(vf):
     _check_loss_grad(o, m)
 
 
-def test_fused_forward_projection_config4_element_shape():
-    """20x20-point / 10x10-test elements (BASELINE config 4 shape, here 2x3 elements): the forward kernel runs in
-    element-block mode with the projection fused in; parity against the oracle and against the unfused path."""
+@pytest.mark.parametrize("nex,ney", [(2, 3), (8, 8), (8, 16)])
+def test_fused_projection_reverse_config4_element_shape(nex, ney):
+    """20x20-point / 10x10-test elements (BASELINE config 4 shape): the reverse kernel runs in element-block mode with
+    the projection fused in, and small shards (what one GPU of an 8-GPU run owns) spread an element over 8 / 4 / 2
+    workgroups that each project it; parity against the oracle (smallest case) and against the unfused launches."""
     import os
     from hp_vpinns_amd.drivers import poisson2d
     from hp_vpinns_amd.init import xavier_init
     from oracle.vpinn_oracle import OracleVPINN2D
-    s = poisson2d.setup(N_el_x=2, N_el_y=3, N_test_x=10, N_test_y=10, N_quad=20, N_bound=13, with_test_grid=False)
+    s = poisson2d.setup(N_el_x=nex, N_el_y=ney, N_test_x=10, N_test_y=10, N_quad=20, N_bound=13, with_test_grid=False)
     L = [2, 20, 20, 20, 1]
     th = xavier_init(L, 5)
-    o = OracleVPINN2D(s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"], s["WXY_quad_train"],
-                      None, s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"], None, None, L, init_params=th)
     m = poisson2d.build_model(s, L, init_params=th)
     assert m.backend() == "mfma"
-    _check_loss_grad(o, m)
-    r_f = m.h.residuals(6 * 100)
-    _check_traj(o, m, n=6)
-    os.environ["HPV_NO_FUSE"] = "1"   # note: read once per process; the comparison below therefore uses timing mode
-    m2 = poisson2d.build_model(s, L, init_params=th)
-    m2.h.enable_timing(True)          # timing mode never fuses
-    l3, g = m2.loss_and_grad()
-    r_u = m2.h.residuals(6 * 100)
-    m3 = poisson2d.build_model(s, L, init_params=th)
-    l3f, gf = m3.loss_and_grad()
+    if nex * ney <= 6:
+        o = OracleVPINN2D(s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"], s["WXY_quad_train"],
+                          None, s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"], None, None, L, init_params=th)
+        _check_loss_grad(o, m)
+        _check_traj(o, m, n=6)
+        m = poisson2d.build_model(s, L, init_params=th)
+    l3f, gf = m.loss_and_grad()
+    r_f = m.h.residuals(nex * ney * 100)
+    os.environ["HPV_FUSE"] = "n"      # separate projection and reverse launches (read when the handle is built)
+    try:
+        m2 = poisson2d.build_model(s, L, init_params=th)
+        l3, g = m2.loss_and_grad()
+        r_u = m2.h.residuals(nex * ney * 100)
+    finally:
+        del os.environ["HPV_FUSE"]
     assert rel(gf, g) < 1e-12 and rel(l3f, l3) < 1e-13 and rel(r_f, r_u) < 1e-12
+    for _ in range(2):                # duplicate projections by the workgroups of an element: results must be reproducible
+        l3b, gb = m.loss_and_grad()
+        assert np.array_equal(gb, gf) and np.array_equal(l3b, l3f)
