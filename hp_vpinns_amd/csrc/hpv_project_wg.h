@@ -35,9 +35,17 @@ struct ProjArgs {
     double* edge_gbar;
 };
 
+// lanes per output of a contraction of length K with n_out outputs on `block` threads: the largest power of two
+// (<= 64, <= K) that still gives every output its own lane group in one pass
+constexpr int pj_splitk(int n_out, int K, int block) {
+    int s = 1;
+    while (2 * s <= 64 && 2 * s <= K && n_out * 2 * s <= block) s *= 2;
+    return s >= 4 ? s : 1;   // a 2-way split measured slower than none (80x80 element: 30.5 vs 28.0 us)
+}
+
 template <int QX, int QY, int NTX, int NTY>
 constexpr int project_wg_lds_doubles() {
-    return QY * (QX + 1) + HPV_MAXT * NTX * QX + HPV_MAXT * NTY * QY + QY * NTX + NTX * NTY + HPV_MAXT * NTY * QX + 32;
+    return QY * (QX + 1) + HPV_MAXT * NTX * QX + HPV_MAXT * NTY * QY + QY * NTX + NTX * NTY + HPV_MAXT * NTY * QX + 64;
 }
 
 // Projection (+ adjoint) of ONE element by a whole workgroup of PW_BLOCK threads; `sm` = its LDS scratch of
@@ -64,6 +72,7 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
     const double* __restrict__ edge_coef = pa.edge_coef;
     double* __restrict__ edge_gbar = pa.edge_gbar;
     constexpr int NWV = PW_BLOCK / 64;
+    static_assert(3 * NWV <= 64, "per-wave reduction scratch");
     constexpr int NQ = QX * QY, NR = NTX * NTY, LDG = QX + 1;
     constexpr int NIT = (NQ + PW_BLOCK - 1) / PW_BLOCK;
     double* G = sm;                              // [QY][LDG]
@@ -72,7 +81,7 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
     double* T = BYl + HPV_MAXT * NTY * QY;       // [QY][NTX]
     double* U = T + QY * NTX;                    // [NR]
     double* S = U + NR;                          // [HPV_MAXT][NTY][QX]
-    double* red = S + HPV_MAXT * NTY * QX;       // [32]
+    double* red = S + HPV_MAXT * NTY * QX;       // [64]: three arrays of one entry per wave (<= 16 waves)
     const long base = e * NQ;
     const int tid = threadIdx.x;
     const int nterms = pd.nterms, C = pd.C;
@@ -148,21 +157,37 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
             if (qd < NQ) G[(qd / QX) * LDG + (qd % QX)] = gv[t][it];
         }
         __syncthreads();
-        for (int o = tid; o < QY * NTX; o += PW_BLOCK) {
-            const int j = o / NTX, r = o % NTX;
-            double acc = 0.0;
+        // split-K: SPX adjacent lanes share one output and a shuffle tree adds their partial sums -- with few
+        // outputs (QY*NTX, then NR) and long contractions the phases are latency chains, not throughput
+        {
+            constexpr int SPX = pj_splitk(QY * NTX, QX, PW_BLOCK);
+            for (int o0 = 0; o0 < QY * NTX; o0 += PW_BLOCK / SPX) {
+                const int o = o0 + tid / SPX, part = tid % SPX;
+                const bool ok = o < QY * NTX;
+                const int j = ok ? o / NTX : 0, r = ok ? o % NTX : 0;
+                double acc = 0.0;
 #pragma unroll 8
-            for (int i = 0; i < QX; ++i) acc = fma(AXl[t * NTX * QX + r * QX + i], G[j * LDG + i], acc);
-            T[o] = acc;
+                for (int i = part; i < QX; i += SPX) acc = fma(AXl[t * NTX * QX + r * QX + i], G[j * LDG + i], acc);
+#pragma unroll
+                for (int m = SPX >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+                if (ok && part == 0) T[o] = acc;
+            }
         }
         __syncthreads();
         const double c = coef[(long)t * coef_stride + e] * (td.eps_mult ? eps : 1.0);
-        for (int o = tid; o < NR; o += PW_BLOCK) {
-            const int k = o / NTX, r = o % NTX;
-            double acc = 0.0;
+        {
+            constexpr int SPY = pj_splitk(NR, QY, PW_BLOCK);
+            for (int o0 = 0; o0 < NR; o0 += PW_BLOCK / SPY) {
+                const int o = o0 + tid / SPY, part = tid % SPY;
+                const bool ok = o < NR;
+                const int k = ok ? o / NTX : 0, r = ok ? o % NTX : 0;
+                double acc = 0.0;
 #pragma unroll 8
-            for (int j = 0; j < QY; ++j) acc = fma(BYl[t * NTY * QY + k * QY + j], T[j * NTX + r], acc);
-            U[o] = fma(c, acc, U[o]);
+                for (int j = part; j < QY; j += SPY) acc = fma(BYl[t * NTY * QY + k * QY + j], T[j * NTX + r], acc);
+#pragma unroll
+                for (int m = SPY >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+                if (ok && part == 0) U[o] = fma(c, acc, U[o]);
+            }
         }
     }
     __syncthreads();
@@ -251,11 +276,11 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
         sl = pj_wave_sum(sl);
         sr = pj_wave_sum(sr);
         __syncthreads();
-        if ((tid & 63) == 0) { red[tid >> 6] = sl; red[8 + (tid >> 6)] = sr; }
+        if ((tid & 63) == 0) { red[tid >> 6] = sl; red[NWV + (tid >> 6)] = sr; }
         __syncthreads();
         if (tid == 0) {
             double tl = 0.0, tr = 0.0;
-            for (int w = 0; w < NWV; ++w) { tl += red[w]; tr += red[8 + w]; }
+            for (int w = 0; w < NWV; ++w) { tl += red[w]; tr += red[NWV + w]; }
             edge_gbar[2 * e] = -edge_coef[e] * sc * tl;
             edge_gbar[2 * e + 1] = edge_coef[e] * sc * tr;
         }
@@ -263,9 +288,9 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
     if (pd.has_eps) {
         deps = pj_wave_sum(deps);
         __syncthreads();
-        if ((tid & 63) == 0) red[16 + (tid >> 6)] = deps;
+        if ((tid & 63) == 0) red[2 * NWV + (tid >> 6)] = deps;
         __syncthreads();
-        if (tid == 0) { double t = 0.0; for (int w = 0; w < NWV; ++w) t += red[16 + w]; deps_e[e] = t; }
+        if (tid == 0) { double t = 0.0; for (int w = 0; w < NWV; ++w) t += red[2 * NWV + w]; deps_e[e] = t; }
     }
 }
 

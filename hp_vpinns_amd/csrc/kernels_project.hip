@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : 1) 
     const int slot = lane / LPE, li = lane % LPE;
     const bool lane_ok = slot < EPW;
 
-    const int nterms = pd.nterms, C = pd.C;
+    const int nterms = pd.nterms;
     const double eps = eps_ptr ? eps_ptr[0] : 0.0;
     const double sc = 2.0 / (double)NR;
 
@@ -367,7 +367,7 @@ static bool launch_tp(const ProjDesc& pd, const double* OUT, double* GBAR, doubl
 // term's two tables staged in LDS, the integrand staged once in LDS from batched coalesced loads, and the
 // Poisson-1D element-edge term (P1:90) supported.
 // ------------------------------------------------------------------------------------------------
-#define PW_BLOCK 256
+#define PW_BLOCK 1024
 template <int QX, int QY, int NTX, int NTY>
 __global__ void __launch_bounds__(PW_BLOCK) k_project_wg(ProjArgs pa) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
