@@ -99,6 +99,7 @@ def main():
         model.h.sync()
         torch.cuda.synchronize()
 
+    model.prepare(args.warmup, args.steps)   # multi-GPU: communicator warm-up + graph capture outside the timed region
     model._step(args.warmup, False)
     barrier()
     t0 = time.perf_counter()

@@ -855,12 +855,11 @@ int hpv_step(hpv_handle h, int n_iters, double* loss3_after) {
     int rc;
     if (h->use_graph && h->own_stream && !h->timing && n_iters > 0 && h->cfg.scheme == HPV_SCHEME_VPINN) {
         if ((rc = check_ready(h))) return rc;
+        // both graphs are captured at the first call (so that no later, possibly timed, call pays for a capture)
         if (!h->g_step && (rc = build_step_graph(h, 1, &h->g_step))) return rc;
+        if (!h->g_stepK && (rc = build_step_graph(h, HPV_GRAPH_ITERS, &h->g_stepK))) return rc;
         int it = 0;
-        if (n_iters >= 2 * HPV_GRAPH_ITERS) {
-            if (!h->g_stepK && (rc = build_step_graph(h, HPV_GRAPH_ITERS, &h->g_stepK))) return rc;
-            for (; it + HPV_GRAPH_ITERS <= n_iters; it += HPV_GRAPH_ITERS) HIPCHK(h, hipGraphLaunch(h->g_stepK, h->stream));
-        }
+        for (; it + HPV_GRAPH_ITERS <= n_iters; it += HPV_GRAPH_ITERS) HIPCHK(h, hipGraphLaunch(h->g_stepK, h->stream));
         for (; it < n_iters; ++it) HIPCHK(h, hipGraphLaunch(h->g_step, h->stream));
     } else {
         for (int it = 0; it < n_iters; ++it)

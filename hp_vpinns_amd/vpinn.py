@@ -134,6 +134,23 @@ class _VPINNBase:
 
     _DIST_GRAPH_ITERS = 8
 
+    def prepare(self, *step_counts):
+        """Do every one-off set-up a later `_step(n)` would otherwise do lazily (multi-GPU: communicator warm-up through a
+        loss evaluation -- no parameter update -- and capture of the iteration graphs for the given step counts), so that
+        a timed region contains iterations only.  Single-GPU handles capture their graphs at the first step."""
+        if not self._dist or os.environ.get("HPV_DIST_GRAPH", "1") == "0":
+            return
+        if not self._dist_warm:
+            self.h.eval_loss()
+            self._reducer.allreduce()
+            self.h.forward_backward()      # lazily created device objects of the backward path (gradient not applied)
+            self.h.sync()
+            self._dist_warm = True
+        for n in step_counts:
+            if n >= 4:
+                k = n if n <= 16 else self._DIST_GRAPH_ITERS
+                self._dist_graph(k)
+
     def _dist_iter(self):
         """One multi-GPU iteration: partial sums of this shard -> one all-reduce of the packed buffer -> Adam."""
         self.h.forward_backward()
