@@ -1,4 +1,4 @@
-// Micro-benchmark: issue rate of v_mfma_f64_16x16x4_f64 and of v_fma_f64 on gfx950.
+// Micro-benchmark: issue rate of v_mfma_f64_16x16x4_f64, v_mfma_f64_4x4x4_4b_f64 and v_fma_f64 on gfx950.
 // Build: hipcc --offload-arch=gfx950 -O3 scripts/mfma_f64_peak.hip -o scripts/mfma_f64_peak.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -15,6 +15,19 @@ __global__ void __launch_bounds__(256) k_mfma(double* out, int iters, double a0)
     }
     double s = 0;
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_mfma4(double* out, int iters, double a0) {
+    double acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+    double a = a0 + threadIdx.x * 1e-9, b = 1.0 + threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -58,6 +71,21 @@ int main() {
             double cyc = (ms * 1e-3) * 2.4e9 / ((double)iters * nacc * blocks_per_cu);
             printf("mfma_f64_16x16x4 waves/SIMD=%d nacc=%d : %.3f ms  %.1f TFLOP/s  ~%.1f cyc/MFMA/SIMD @2.4GHz\n", blocks_per_cu, nacc, ms, tf, cyc);
         }
+    }
+    for (int blocks_per_cu = 1; blocks_per_cu <= 2; ++blocks_per_cu) {
+        int grid = 256 * blocks_per_cu;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_mfma4, dim3(grid), dim3(256), 0, 0, d, iters, 1.0);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+        }
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        double n = (double)grid * 4 * iters * 8;   // 4x4x4_4b instructions: 4 blocks x 4x4x4 x 2 = 512 flop each
+        double cyc = (ms * 1e-3) * 2.4e9 / ((double)iters * 8 * blocks_per_cu);
+        printf("mfma_f64_4x4x4_4b waves/SIMD=%d nacc=8 : %.3f ms  %.1f TFLOP/s  ~%.1f cyc/MFMA/SIMD @2.4GHz\n", blocks_per_cu, ms,
+               n * 512.0 / (ms * 1e-3) / 1e12, cyc);
     }
     for (int blocks_per_cu = 1; blocks_per_cu <= 4; blocks_per_cu *= 2) {
         int grid = 256 * blocks_per_cu;
