@@ -26,7 +26,7 @@ EXPORTS = [
     "hpv_reduce_buffer", "hpv_apply_adam", "hpv_eval_loss", "hpv_read_loss", "hpv_sync",
     "hpv_predict", "hpv_get_residuals", "hpv_backend_in_use", "hpv_enable_timing",
     "hpv_kernel_time_ms", "hpv_bench_projection", "hpv_debug_activation", "hpv_get_state", "hpv_set_state",
-    "hpv_assemble_rhs", "hpv_set_collocation",
+    "hpv_assemble_rhs", "hpv_set_collocation", "hpv_gll_rule", "hpv_test_tables",
 ]
 
 
@@ -96,6 +96,8 @@ def load():
     lib.hpv_get_state.argtypes = [h, _dp, C.c_size_t]
     lib.hpv_set_state.argtypes = [h, _dp, C.c_size_t]
     lib.hpv_assemble_rhs.argtypes = [h, _dp, C.c_size_t, _dp, C.c_size_t]
+    lib.hpv_gll_rule.argtypes = [h, C.c_int, _dp, _dp]
+    lib.hpv_test_tables.argtypes = [h, C.c_int, _dp, C.c_int, _dp]
     _lib = lib
     return lib
 
@@ -276,6 +278,19 @@ class Handle:
         out = np.empty(int(n_out))
         self._chk(self.lib.hpv_assemble_rhs(self._h, _p(f_quad), f_quad.size, _p(out), out.size))
         return out
+
+    def gll_rule(self, q):
+        """(nodes, weights) of the q-point Gauss-Lobatto-Legendre rule, computed on the device."""
+        xi, w = np.empty(int(q)), np.empty(int(q))
+        self._chk(self.lib.hpv_gll_rule(self._h, int(q), _p(xi), _p(w)))
+        return xi, w
+
+    def test_tables(self, ntest, xi):
+        """(3, ntest, q): phi, phi', phi'' of the Legendre-difference test functions at `xi`, computed on the device."""
+        xi = _c(xi).reshape(-1)
+        tab = np.empty((3, int(ntest), xi.size))
+        self._chk(self.lib.hpv_test_tables(self._h, int(ntest), _p(xi), xi.size, _p(tab)))
+        return tab
 
     def debug_activation(self, x):
         x = _c(x).reshape(-1)

@@ -952,6 +952,39 @@ int hpv_assemble_rhs(hpv_handle h, const double* f_quad, size_t n, double* F_out
     return rc;
 }
 
+// Table generation on the device: the Gauss-Lobatto-Legendre rule of the drivers
+// (GaussLobattoJacobiWeights(Q, 0, 0): P1:312, P2:355, P3:395) and the test-function tables (Test_fcn / dTest_fcn).
+int hpv_gll_rule(hpv_handle h, int q, double* xi, double* w) {
+    if (!h || !xi || !w || q < 2) return -1;
+    double* d = nullptr;
+    int rc = dalloc(h, &d, (size_t)2 * q);
+    if (rc) return rc;
+    launch_gll_rule(q, d, d + q, h->stream);
+    hipError_t e = hipMemcpyAsync(xi, d, (size_t)q * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(w, d + q, (size_t)q * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(h, -2, "hpv_gll_rule failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int hpv_test_tables(hpv_handle h, int ntest, const double* xi, int q, double* tab) {
+    if (!h || !xi || !tab || ntest < 1 || q < 1) return -1;
+    double* d = nullptr;
+    const size_t nt = (size_t)3 * ntest * q;
+    int rc = dalloc(h, &d, nt + q);
+    if (rc) return rc;
+    rc = upload(h, d + nt, xi, (size_t)q);
+    if (!rc) {
+        launch_test_tables(ntest, q, d + nt, d, h->stream);
+        hipError_t e = hipMemcpyAsync(tab, d, nt * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, -2, "hpv_test_tables failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
 int hpv_get_residuals(hpv_handle h, double* R, size_t n) {
     if (!h || !R) return -1;
     const size_t want = (size_t)h->n_elem * h->ntx * h->nty;

@@ -74,6 +74,8 @@ void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, i
 void launch_adam(const AdamArgs& ad, const double* RB, int P, int Ptot, hipStream_t s);
 int adam_state_doubles(int P);
 void launch_debug_act(int act, const double* x, int n, double* a, double* a1, double* ref, hipStream_t s);
+void launch_gll_rule(int Q, double* x, double* w, hipStream_t s);
+void launch_test_tables(int ntest, int q, const double* xi, double* tab, hipStream_t s);
 bool launch_project_tp(const ProjDesc& pd, const double* OUT, double* GBAR, double* R, const double* F, const double* coef,
                        long coef_stride, const double* wtx, const double* wty, const double* eps_ptr, double* loss_e,
                        double* deps_e, long N, long n_elem, int do_adjoint, hipStream_t s);

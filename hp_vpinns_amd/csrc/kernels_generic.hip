@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(BWD_BLOCK) k_mlp_bwd_generic(NetDesc nd, const
 void launch_mlp_bwd_generic(const NetDesc& nd, const double* theta, const double* X, const double* ACT,
                             const double* GBAR, double* GPART, int rows, long N, hipStream_t s) {
     if (N <= 0) return;
-    hipMemsetAsync(GPART, 0, (size_t)rows * nd.P * sizeof(double), s);
+    (void)hipMemsetAsync(GPART, 0, (size_t)rows * nd.P * sizeof(double), s);
     int blocks = rows / (BWD_BLOCK / WAVE);
     hipLaunchKernelGGL(k_mlp_bwd_generic, dim3(blocks), dim3(BWD_BLOCK), 0, s, nd, theta, X, ACT, GBAR, GPART, N);
 }
@@ -610,4 +610,72 @@ int pinn_residual_parts(int n) { int b = (n + 255) / 256; return b > 64 ? 64 : (
 void launch_pinn_residual(const double* OUT, const double* f, double* GBAR, double* part, long N, int n, int write_gbar,
                           hipStream_t s) {
     hipLaunchKernelGGL(k_pinn_residual, dim3(pinn_residual_parts(n)), dim3(256), 0, s, OUT, f, GBAR, part, N, n, write_gbar);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Driver-side table generation on the device: Jacobi polynomials by the three-term
+// recurrence (never expanded coefficients: those are off by 1e13 at n = 61), the Gauss-Lobatto-Legendre rule
+// (GaussLobattoJacobiWeights(Q, 0, 0), Q:47-61) by Newton from the Chebyshev-Gauss-Lobatto points, and the
+// test-function tables phi_n = P_{n+1} - P_{n-1} with their first two derivatives (Test_fcn / dTest_fcn,
+// P1:157-183).
+// ------------------------------------------------------------------------------------------------
+__device__ double dev_jacobi(int n, double a, double b, double x) {
+    if (n < 0) return 0.0;
+    double p0 = 1.0;
+    if (n == 0) return p0;
+    double p1 = 0.5 * ((a - b) + (a + b + 2.0) * x);
+    for (int k = 1; k < n; ++k) {
+        const double c = 2.0 * k + a + b;
+        const double a1 = 2.0 * (k + 1.0) * (k + a + b + 1.0) * c;
+        const double a2 = (c + 1.0) * (a * a - b * b);
+        const double a3 = c * (c + 1.0) * (c + 2.0);
+        const double a4 = 2.0 * (k + a) * (k + b) * (c + 2.0);
+        const double p2 = ((a2 + a3 * x) * p1 - a4 * p0) / a1;
+        p0 = p1;
+        p1 = p2;
+    }
+    return p1;
+}
+
+// interior GLL nodes = zeros of P'_{Q-1} = zeros of P_{Q-2}^{(1,1)}; weights 2 / (Q (Q-1) P_{Q-1}(x)^2)
+__global__ void k_gll_rule(int Q, double* __restrict__ x, double* __restrict__ w) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Q) return;
+    double xk;
+    if (k == 0) xk = -1.0;
+    else if (k == Q - 1) xk = 1.0;
+    else {
+        xk = -cos(3.14159265358979323846 * (double)k / (double)(Q - 1));
+        for (int it = 0; it < 50; ++it) {
+            const double p = dev_jacobi(Q - 2, 1.0, 1.0, xk);
+            const double dp = 0.5 * (Q + 1.0) * dev_jacobi(Q - 3, 2.0, 2.0, xk);   // d/dx P_n^{(1,1)} = (n+3)/2 P_{n-1}^{(2,2)}
+            const double dx = p / dp;
+            xk -= dx;
+            if (fabs(dx) < 1e-16) break;
+        }
+    }
+    const double pl = dev_jacobi(Q - 1, 0.0, 0.0, xk);
+    x[k] = xk;
+    w[k] = 2.0 / ((double)Q * (Q - 1.0) * pl * pl);
+}
+
+__global__ void k_test_tables(int ntest, int q, const double* __restrict__ xi, double* __restrict__ tab) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ntest * q) return;
+    const int n = idx / q + 1;
+    const double x = xi[idx % q];
+    const double t0 = dev_jacobi(n + 1, 0.0, 0.0, x) - dev_jacobi(n - 1, 0.0, 0.0, x);
+    double t1 = 0.5 * (n + 2.0) * dev_jacobi(n, 1.0, 1.0, x);
+    if (n >= 2) t1 -= 0.5 * n * dev_jacobi(n - 2, 1.0, 1.0, x);
+    double t2 = 0.25 * (n + 2.0) * (n + 3.0) * dev_jacobi(n - 1, 2.0, 2.0, x);
+    if (n >= 3) t2 -= 0.25 * n * (n + 1.0) * dev_jacobi(n - 3, 2.0, 2.0, x);
+    tab[idx] = t0;
+    tab[(long)ntest * q + idx] = t1;
+    tab[2L * ntest * q + idx] = t2;
+}
+void launch_gll_rule(int Q, double* x, double* w, hipStream_t s) {
+    hipLaunchKernelGGL(k_gll_rule, dim3((Q + 63) / 64), dim3(64), 0, s, Q, x, w);
+}
+void launch_test_tables(int ntest, int q, const double* xi, double* tab, hipStream_t s) {
+    hipLaunchKernelGGL(k_test_tables, dim3((ntest * q + 255) / 256), dim3(256), 0, s, ntest, q, xi, tab);
 }

@@ -126,6 +126,14 @@ int hpv_set_state(hpv_handle h, const double* buf, size_t n);
  * (element-major, q = j*qx+i, n = n_owned*qx*qy); F_out is [n_owned][nty][ntx]. */
 int hpv_assemble_rhs(hpv_handle h, const double* f_quad, size_t n, double* F_out, size_t n_out);
 
+/* Driver-side table generation on the device.  hpv_gll_rule: the Q-point Gauss-Lobatto-
+ * Legendre nodes and weights the drivers take from GaussLobattoJacobiWeights(Q, 0, 0) (Q:47-61; P1:312, P2:355,
+ * P3:395), Newton on the three-term recurrence.  hpv_test_tables: phi_n = P_{n+1} - P_{n-1}, phi'_n, phi''_n for
+ * n = 1..ntest at the nodes xi (VPINN.Test_fcn / dTest_fcn, P1:157-183) as [3][ntest][q], the layout
+ * hpv_set_tables takes per direction. */
+int hpv_gll_rule(hpv_handle h, int q, double* xi, double* w);
+int hpv_test_tables(hpv_handle h, int ntest, const double* xi, int q, double* tab);
+
 /* Introspection for tests / benchmarks. */
 int hpv_get_residuals(hpv_handle h, double* R, size_t n);   /* R of the owned elements [ne][nty][ntx] */
 int hpv_backend_in_use(hpv_handle h);                       /* HPV_BACKEND_GENERIC or HPV_BACKEND_MFMA */

@@ -293,6 +293,23 @@ def test_device_rhs_assembly_matches_reference_fixtures():
     assert rel(s["F_ext_total"], gold("poisson2d_cfg3")["F_ext_total"]) < 1e-13
 
 
+def test_device_gll_rule_and_test_function_tables_match_reference_fixtures():
+    """Row N1: Gauss-Lobatto-Legendre nodes/weights and the phi / phi' / phi'' tables generated on the device against the
+    fixtures produced by running the reference's quadrature module and VPINN.Test_fcn / dTest_fcn."""
+    from hp_vpinns_amd import _lib
+    h = _lib.Handle(_lib.PDE_POISSON2D, 1, _lib.ACT_TANH, [2, 20, 1])
+    gq, gt = gold("quadrature"), gold("testfcn")
+    for q in (5, 10, 20, 80):
+        x, w = h.gll_rule(q)
+        assert np.abs(x - gq[f"gll_x_{q}"]).max() < 2e-15 and rel(w, gq[f"gll_w_{q}"]) < 1e-13
+        assert abs(w.sum() - 2.0) < 1e-14
+    for nt, q in ((60, 80), (5, 10), (10, 20)):
+        tab = h.test_tables(nt, gq[f"gll_x_{q}"])
+        for d, name in enumerate(("phi", "dphi", "d2phi")):
+            ref = gt[f"{name}_{nt}_{q}"][:, :, 0]
+            assert rel(tab[d], ref) < 1e-12, (nt, q, name, rel(tab[d], ref))
+
+
 def test_checkpoint_resume_is_bit_exact_and_l2_error(tmp_path):
     """Row N4: save after 7 iterations, restore into a fresh model, continue: identical to 15 straight."""
     from hp_vpinns_amd.vpinn import VPINN2D
