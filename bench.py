@@ -63,8 +63,8 @@ def cpu_baseline(setup, theta, iters, vectorized=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--backend", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-residual-roofline", action="store_true")
@@ -120,6 +120,27 @@ def main():
     model.h.enable_timing(False)
     loss3 = model.loss()
 
+    # ---- weak-scaling probe (multi-GPU only, reported beside the headline number): every rank keeps a full
+    #      config-4 shard (256 elements), i.e. the job solves a 16 x 16N-element problem; shows what the exchange costs
+    #      when the per-GPU work is not shrunk to the latency floor ----
+    weak = None
+    if dist is not None and (world > 1 or os.environ.get("HPV_WEAK_PROBE") == "1"):
+        sw = poisson2d.setup(**dict(CFG4, N_el_y=CFG4["N_el_y"] * world), with_test_grid=False, assemble="device", device=local_rank)
+        mw = poisson2d.build_model(sw, LAYERS, var_form=1, init_params=theta, backend=args.backend, device=local_rank)
+        kw = min(args.steps, 1000)
+        mw.prepare(args.warmup, kw)
+        mw._step(args.warmup, False)
+        dist.barrier(); torch.cuda.synchronize()
+        tw = time.perf_counter()
+        mw._step(kw, False)
+        dist.barrier(); torch.cuda.synchronize()
+        tw = torch.tensor([time.perf_counter() - tw], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        weak = {"elements": 256 * world, "elements_per_gpu": 256, "steps": kw, "it_per_s": kw / float(tw.item()),
+                "element_iterations_per_s": 256 * world * kw / float(tw.item()),
+                "note": "not the headline metric: same kernels, problem grown with N (16 x 16N elements)"}
+        del mw
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -161,6 +182,8 @@ def main():
                              "kernel time; peak = fp64 datasheet (matrix = vector on MI355X); measured ubench ceilings on "
                              "this chip: 47 TFLOP/s v_mfma_f64_16x16x4, 62 TFLOP/s v_fma_f64, not additive"},
     }
+    if weak is not None:
+        out["weak_scaling_probe"] = weak
     if world == 1 and not args.no_residual_roofline:
         # the per-element projection (residual + adjoint) kernel on a batch larger than the 256 MB
         # Infinity Cache: 2^18 elements of the config-4 element shape, random channels

@@ -27,7 +27,7 @@ def f_ext(x, y):                                                 # P2:304-307
 
 
 def setup(N_el_x=4, N_el_y=4, N_test_x=5, N_test_y=5, N_quad=10, N_bound=80, N_residual=100, seed=1234,
-          with_test_grid=True, assemble="host"):
+          with_test_grid=True, assemble="host", device=0):
     np.random.seed(seed)                                         # P2:23
     ones = lambda a, v: np.full((len(a), 1), float(v))           # noqa: E731
     x_up = 2 * lhs(1, N_bound) - 1                               # P2:314-320
@@ -59,7 +59,7 @@ def setup(N_el_x=4, N_el_y=4, N_test_x=5, N_test_y=5, N_quad=10, N_bound=80, N_r
     F_ext_total = np.empty((NE_x, NE_y, N_test_y, N_test_x))
     if assemble == "device":                                     # same numbers from the projection kernel
         from ..rhs import assemble_F_ext_2d
-        F_ext_total = assemble_F_ext_2d(f_ext, grid_x, grid_y, N_test_x, N_test_y, N_quad)
+        F_ext_total = assemble_F_ext_2d(f_ext, grid_x, grid_y, N_test_x, N_test_y, N_quad, device=device)
     for ex in range(NE_x if assemble != "device" else 0):        # P2:386-411
         xq = grid_x[ex] + (grid_x[ex + 1] - grid_x[ex]) / 2 * (X_quad + 1)
         for ey in range(NE_y):

@@ -12,10 +12,10 @@ import numpy as np
 from . import _lib
 
 
-def assemble_F_ext_1d(f_ext, grid, N_test, N_quad):
+def assemble_F_ext_1d(f_ext, grid, N_test, N_quad, device=0):
     """-> (NE, N_test, 1) like P1:293-294."""
     grid = np.asarray(grid, dtype=np.float64)
-    h = _lib.Handle(_lib.PDE_POISSON1D, 1, _lib.ACT_SIN, [1, 1])
+    h = _lib.Handle(_lib.PDE_POISSON1D, 1, _lib.ACT_SIN, [1, 1], device=device)
     x, w = h.gll_rule(N_quad)
     h.set_quadrature(x, w)
     h.set_tables(h.test_tables(N_test, x))
@@ -27,10 +27,10 @@ def assemble_F_ext_1d(f_ext, grid, N_test, N_quad):
     return F.reshape(ne, N_test, 1)
 
 
-def assemble_F_ext_2d(f_ext, grid_x, grid_y, N_test_x, N_test_y, N_quad):
+def assemble_F_ext_2d(f_ext, grid_x, grid_y, N_test_x, N_test_y, N_quad, device=0):
     """-> (NE_x, NE_y, N_test_y, N_test_x) like P2:414."""
     grid_x, grid_y = np.asarray(grid_x, dtype=np.float64), np.asarray(grid_y, dtype=np.float64)
-    h = _lib.Handle(_lib.PDE_POISSON2D, 1, _lib.ACT_TANH, [2, 1])
+    h = _lib.Handle(_lib.PDE_POISSON2D, 1, _lib.ACT_TANH, [2, 1], device=device)
     x, w = h.gll_rule(N_quad)
     h.set_quadrature(x, w, x, w)
     h.set_tables(h.test_tables(N_test_x, x), h.test_tables(N_test_y, x))
