@@ -115,3 +115,44 @@ def test_vectorized_oracle_equals_structured():
     (l1, g1), (l2, g2) = o1.loss_and_grad(), o2.loss_and_grad()
     assert np.abs(np.array(l1) - np.array(l2)).max() < 1e-12 * abs(l1[0])
     assert np.abs(g1 - g2).max() < 1e-11 * np.abs(g1).max()
+
+
+# ---- consistency anchors of the restated variational forms against reference-produced data ---------------------
+# F_ext_total in the fixtures was assembled by the reference's own driver code from its f_ext; feeding the reference's
+# exact solution u_ext (instead of the network) into the restated loss graph must therefore make the variational
+# residual vanish -- to round-off for the strong form, to the quadrature error of the integration by parts for the weak
+# forms, decreasing under refinement.  A wrong sign, Jacobian factor or test-function derivative in the restatement
+# would leave an O(1) residual (as var_form 2 of the 2-D reference itself does for Jx != 1: it carries no 1/Jx^2).
+def _exact_1d(X):
+    return 1.0 * (0.1 * torch.sin(8 * np.pi * X) + torch.tanh(80 * X))          # P1:248-250 (amp 1, omega 8 pi, r1 80)
+
+
+def _exact_2d(X):
+    x, y = X[:, 0:1], X[:, 1:2]
+    return (0.1 * torch.sin(2 * np.pi * x) + torch.tanh(10 * x)) * torch.sin(2 * np.pi * y)   # P2:300-302
+
+
+@pytest.mark.parametrize("tag,vf,tol", [("poisson2d_default", 0, 1e-25), ("poisson2d_default", 1, 1e-6),
+                                        ("poisson2d_cfg3", 1, 1e-9), ("poisson2d_cfg4", 1, 1e-25)])
+def test_exact_solution_annihilates_the_2d_variational_residual(tag, vf, tol):
+    g = gold(tag)
+    a = p2_args(g, layers=[2, 5, 1])
+    o = O.OracleVPINN2D(*a, var_form=vf)
+    o.neural_net = lambda X, theta=None: _exact_2d(X)
+    o.vectorized = tag != "poisson2d_default"
+    loss, lossb, lossv = (float(v.detach()) for v in o.loss_parts())
+    zero_net = (g["F_ext_total"] ** 2).mean(axis=(2, 3)).sum()
+    assert lossv < tol * zero_net, (lossv, zero_net)
+    assert lossb < 1e-25                                        # the boundary fixtures are u_ext on the boundary
+
+
+@pytest.mark.parametrize("tag,vf", [("poisson1d_cfg2", 1), ("poisson1d_cfg2", 2), ("poisson1d_cfg2", 3)])
+def test_exact_solution_annihilates_the_1d_variational_residual(tag, vf):
+    g = gold(tag)
+    a = p1_args(g, layers=[1, 5, 1])
+    o = O.OracleVPINN1D(*a, var_form=vf)
+    o.neural_net = lambda X, theta=None: _exact_1d(X)
+    loss, lossb, lossv = (float(v.detach()) for v in o.loss_parts())
+    zero_net = (g["F_ext_total"] ** 2).mean(axis=(1, 2)).sum()
+    assert lossv < 1e-6 * zero_net, (vf, lossv, zero_net)
+    assert lossb < 1e-25
