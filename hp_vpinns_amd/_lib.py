@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HPV_LIBRARY") or os.path.join(_HERE, "libhpvpinn.so")   # (override: another build of the same library)
 
 HPV_MAX_LAYERS = 16
+HIST_CAP = 4096          # HPV_HIST_CAP of csrc/hpv_internal.h: loss-history entries the device keeps
 PDE_POISSON1D, PDE_POISSON2D, PDE_ADVDIFF = 0, 1, 2
 ACT_TANH, ACT_SIN = 0, 1
 BACKEND_AUTO, BACKEND_GENERIC, BACKEND_MFMA = 0, 1, 2
@@ -27,6 +28,7 @@ EXPORTS = [
     "hpv_predict", "hpv_get_residuals", "hpv_backend_in_use", "hpv_enable_timing",
     "hpv_kernel_time_ms", "hpv_bench_projection", "hpv_debug_activation", "hpv_get_state", "hpv_set_state",
     "hpv_assemble_rhs", "hpv_set_collocation", "hpv_gll_rule", "hpv_test_tables",
+    "hpv_step_record", "hpv_history_reset", "hpv_history_read",
 ]
 
 
@@ -97,6 +99,9 @@ def load():
     lib.hpv_set_state.argtypes = [h, _dp, C.c_size_t]
     lib.hpv_assemble_rhs.argtypes = [h, _dp, C.c_size_t, _dp, C.c_size_t]
     lib.hpv_gll_rule.argtypes = [h, C.c_int, _dp, _dp]
+    lib.hpv_step_record.argtypes = [h, C.c_int, _dp]
+    lib.hpv_history_reset.argtypes = [h]
+    lib.hpv_history_read.argtypes = [h, C.c_int, _dp]
     lib.hpv_test_tables.argtypes = [h, C.c_int, _dp, C.c_int, _dp]
     _lib = lib
     return lib
@@ -277,6 +282,20 @@ class Handle:
         f_quad = _c(f_quad).reshape(-1)
         out = np.empty(int(n_out))
         self._chk(self.lib.hpv_assemble_rhs(self._h, _p(f_quad), f_quad.size, _p(out), out.size))
+        return out
+
+    def step_record(self, n):
+        """n Adam iterations; (n, 3) array {loss, lossb, lossv} after each update (one extra forward pass in total)."""
+        out = np.empty((int(n), 3))
+        self._chk(self.lib.hpv_step_record(self._h, int(n), _p(out)))
+        return out
+
+    def history_reset(self):
+        self._chk(self.lib.hpv_history_reset(self._h))
+
+    def history_read(self, n):
+        out = np.empty((int(n), 3))
+        self._chk(self.lib.hpv_history_read(self._h, int(n), _p(out)))
         return out
 
     def gll_rule(self, q):

@@ -73,6 +73,8 @@ struct hpv_ctx {
     int n_data = 0;
     // parameters / optimizer
     double *d_theta = nullptr, *d_m = nullptr, *d_v = nullptr, *d_state = nullptr, *d_RB = nullptr;
+    double* d_hist = nullptr;   // [HPV_HIST_CAP][3] loss history (AdamArgs)
+    int* d_hist_idx = nullptr;
     // mfma path (one object per batch: quadrature points, boundary/data points, element edges)
     HpvMfma* mfma = nullptr;
     HpvMfma* mfma_data = nullptr;
@@ -300,7 +302,8 @@ int ensure_small_mfma(hpv_ctx* h, Batch& b, HpvMfma** m) {
 }
 
 AdamArgs adam_args(hpv_ctx* h) {
-    return AdamArgs{h->d_theta, h->d_m, h->d_v, h->d_state, h->cfg.lr, h->cfg.beta1, h->cfg.beta2, h->cfg.eps};
+    return AdamArgs{h->d_theta, h->d_m, h->d_v, h->d_state, h->cfg.lr, h->cfg.beta1, h->cfg.beta2, h->cfg.eps,
+                    h->d_hist, h->d_hist_idx, HPV_HIST_CAP};
 }
 
 int enqueue_pinn_pass(hpv_ctx* h, bool backward, bool fuse_adam);
@@ -557,6 +560,9 @@ int hpv_create(hpv_handle* out, const hpv_config* cfg) {
     rc |= dalloc(h, &h->d_m, (size_t)h->Ptot);
     rc |= dalloc(h, &h->d_v, (size_t)h->Ptot);
     rc |= dalloc(h, &h->d_state, (size_t)adam_state_doubles(h->P));
+    rc |= dalloc(h, &h->d_hist, (size_t)3 * HPV_HIST_CAP);
+    rc |= dalloc(h, &h->d_hist_idx, (size_t)1);
+    if (!rc) (void)hipMemset(h->d_hist_idx, 0, sizeof(int));
     rc |= dalloc(h, &h->d_RB, (size_t)h->Ptot + 4);
     rc |= dalloc(h, &h->d_data_part, 64);
     if (rc) { g_create_error = h->err; hpv_destroy(h); return -2; }
@@ -585,8 +591,9 @@ void hpv_destroy(hpv_handle h) {
     if (h->d_jac) (void)hipFree(h->d_jac);
     free_batch(h->var); free_batch(h->data); free_batch(h->edge); free_batch(h->pred);
     double* ptrs[] = {h->d_wtx, h->d_wty, h->d_edge_dphi, h->d_coef, h->d_edge_coef, h->d_F, h->d_R, h->d_loss_e,
-                      h->d_deps_e, h->d_udata, h->d_data_part, h->d_theta, h->d_m, h->d_v, h->d_state, h->d_RB};
+                      h->d_deps_e, h->d_udata, h->d_data_part, h->d_theta, h->d_m, h->d_v, h->d_state, h->d_RB, h->d_hist};
     for (double* p : ptrs) if (p) (void)hipFree(p);
+    if (h->d_hist_idx) (void)hipFree(h->d_hist_idx);
     for (auto& t : h->timers) for (auto e : t.ev) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -850,8 +857,8 @@ int hpv_loss_and_grad(hpv_handle h, double* loss3, double* grad) {
     return 0;
 }
 
-int hpv_step(hpv_handle h, int n_iters, double* loss3_after) {
-    if (!h) return -1;
+// n_iters training iterations enqueued on the handle's stream (graph replays where possible), no synchronisation
+static int enqueue_iterations(hpv_ctx* h, int n_iters) {
     int rc;
     if (h->use_graph && h->own_stream && !h->timing && n_iters > 0 && h->cfg.scheme == HPV_SCHEME_VPINN) {
         if ((rc = check_ready(h))) return rc;
@@ -865,11 +872,66 @@ int hpv_step(hpv_handle h, int n_iters, double* loss3_after) {
         for (int it = 0; it < n_iters; ++it)
             if ((rc = enqueue_pass(h, true, true))) return rc;
     }
+    return 0;
+}
+
+int hpv_step(hpv_handle h, int n_iters, double* loss3_after) {
+    if (!h) return -1;
+    int rc;
+    if ((rc = enqueue_iterations(h, n_iters))) return rc;
     if (loss3_after) {
         if ((rc = enqueue_pass(h, false))) return rc;
         if ((rc = hpv_read_loss(h, loss3_after))) return rc;
     } else {
         HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+// ---- loss history (the reference records the loss after every update with a second forward pass, P2:243-244; the
+//      forward pass of the NEXT iteration computes exactly that value, so the device keeps it) ----
+static void loss_triple(hpv_ctx* h, const double* raw, double* loss3) {
+    loss3[0] = raw[0] + raw[1];
+    loss3[1] = (h->cfg.pde == HPV_PDE_ADVDIFF) ? raw[1] : raw[2];  // P3:184 folds the weight into lossb
+    loss3[2] = raw[0];
+}
+
+int hpv_history_reset(hpv_handle h) {
+    if (!h) return -1;
+    HIPCHK(h, hipMemsetAsync(h->d_hist_idx, 0, sizeof(int), h->stream));
+    return 0;
+}
+
+int hpv_history_read(hpv_handle h, int n, double* loss3_hist) {
+    if (!h || !loss3_hist || n < 0) return -1;
+    if (n > HPV_HIST_CAP) return fail(h, -1, "history holds %d entries, %d requested", HPV_HIST_CAP, n);
+    int have = 0;
+    std::vector<double> raw((size_t)3 * n);
+    HIPCHK(h, hipMemcpyAsync(&have, h->d_hist_idx, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (n) HIPCHK(h, hipMemcpyAsync(raw.data(), h->d_hist, raw.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (have < n) return fail(h, -3, "only %d training iterations since hpv_history_reset, %d requested", have, n);
+    for (int i = 0; i < n; ++i) loss_triple(h, &raw[(size_t)3 * i], loss3_hist + 3 * i);
+    return 0;
+}
+
+int hpv_step_record(hpv_handle h, int n_iters, double* loss3_hist) {
+    if (!h || !loss3_hist || n_iters < 0) return -1;
+    int rc;
+    std::vector<double> chunk((size_t)3 * HPV_HIST_CAP);
+    for (int done = 0; done < n_iters;) {
+        const int c = std::min(HPV_HIST_CAP, n_iters - done);
+        if ((rc = hpv_history_reset(h))) return rc;
+        if ((rc = enqueue_iterations(h, c))) return rc;
+        if ((rc = hpv_history_read(h, c, chunk.data()))) return rc;
+        // entry j was computed by the forward pass that preceded update done+j+1, i.e. it is the loss after update done+j
+        for (int j = 0; j < c; ++j)
+            if (done + j >= 1) std::copy_n(&chunk[(size_t)3 * j], 3, loss3_hist + (size_t)3 * (done + j - 1));
+        done += c;
+    }
+    if (n_iters > 0) {   // the loss after the last update: one forward pass
+        if ((rc = enqueue_pass(h, false))) return rc;
+        if ((rc = hpv_read_loss(h, loss3_hist + (size_t)3 * (n_iters - 1)))) return rc;
     }
     return 0;
 }

@@ -53,7 +53,13 @@ static inline size_t hpv_proj_lds_bytes(const ProjDesc& pd) {
 struct AdamArgs {
     double *theta, *m, *v, *state;   // theta == nullptr: no update
     double lr, b1, b2, eps;
+    // loss history: every training iteration appends the raw loss triple {lossv, w*lossb, mean sq} of ITS forward pass
+    // (= the loss after the previous update) at hist[3 * (*hist_idx)++]; entries beyond hist_cap are dropped
+    double* hist;
+    int* hist_idx;
+    int hist_cap;
 };
+#define HPV_HIST_CAP 4096
 
 // ---- kernel launchers (kernels_generic.hip) ----
 void launch_mlp_fwd_generic(const NetDesc& nd, const double* theta, const double* X, double* ACT, double* OUT, long N,

@@ -530,7 +530,14 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
             RB[P] = de;
             if (ad.theta) adam_update(ad, P, de, ad.state[0], ad.state[1]);   // the trainable epsilon (P3:63)
         }
-        if (ad.theta) { ad.state[0] *= ad.b1; ad.state[1] *= ad.b2; }
+        if (ad.theta) {
+            ad.state[0] *= ad.b1; ad.state[1] *= ad.b2;
+            if (ad.hist) {   // single-GPU training iteration: record this forward pass's loss (see AdamArgs)
+                const int i = *ad.hist_idx;
+                if (i < ad.hist_cap) { ad.hist[3 * i] = lv; ad.hist[3 * i + 1] = lossb_weight * msq; ad.hist[3 * i + 2] = msq; }
+                *ad.hist_idx = i + 1;
+            }
+        }
         RB[Ptot + 0] = lv;
         RB[Ptot + 1] = lossb_weight * msq;
         RB[Ptot + 2] = msq;
@@ -560,6 +567,11 @@ int adam_state_doubles(int P) { return 2 * ((P + FIN_COLS - 1) / FIN_COLS + 1); 
 __global__ void __launch_bounds__(1024) k_adam(AdamArgs ad, const double* __restrict__ g, int Ptot, int ncopies) {
     const double b1p = ad.state[0], b2p = ad.state[1];
     for (int i = threadIdx.x; i < Ptot; i += blockDim.x) adam_update(ad, i, g[i], b1p, b2p);
+    if (threadIdx.x == 0 && ad.hist) {   // multi-GPU iteration: g is the all-reduced packed buffer, the losses follow the gradient
+        const int i = *ad.hist_idx;
+        if (i < ad.hist_cap) { ad.hist[3 * i] = g[Ptot]; ad.hist[3 * i + 1] = g[Ptot + 1]; ad.hist[3 * i + 2] = g[Ptot + 2]; }
+        *ad.hist_idx = i + 1;
+    }
     __syncthreads();
     for (int c = threadIdx.x; c < ncopies; c += blockDim.x) {   // advance every replicated copy
         ad.state[2 * c] *= ad.b1;

@@ -185,6 +185,26 @@ class _VPINNBase:
         self._dist_graphs[k] = g
         return g
 
+    def _step_record(self, n):
+        """n Adam iterations; (n, 3) array {loss, lossb, lossv} AFTER each update.  The loss after update k is what the
+        forward pass of iteration k+1 computes anyway, and the device keeps a history of it (hpv_step_record /
+        hpv_history_*): per-iteration recording costs one extra forward pass per call instead of one per iteration."""
+        if not self._dist:
+            return self.h.step_record(n)
+        out = np.empty((n, 3))
+        done = 0
+        while done < n:
+            c = min(_lib.HIST_CAP, n - done)
+            self.h.history_reset()
+            self._step(c, False)
+            hist = self.h.history_read(c)      # entry j: forward pass before update done+j+1 = loss after update done+j
+            lo = 1 if done == 0 else 0
+            out[done + lo - 1:done + c - 1] = hist[lo:]
+            done += c
+        if n > 0:
+            out[n - 1] = self.loss()
+        return out
+
     def loss_and_grad(self):
         """({loss, lossb, lossv}, d loss / d theta) at the current parameters (global over ranks)."""
         if not self._dist:
@@ -346,16 +366,23 @@ class VPINN2D(_VPINNBase):
         start_time = time.time()
         it = 0
         while it < nIter:
-            n = min(record_every, nIter - it)
-            loss3 = self._step(n, True)
+            if record_every == 1:      # every update recorded: device-side loss history, one read-back per chunk
+                n = min(self._RECORD_CHUNK, nIter - it)
+                losses = self._step_record(n)[:, 0]
+            else:
+                n = min(record_every, nIter - it)
+                losses = [float(self._step(n, True)[0])]
+            for k, loss_value in enumerate(losses):
+                i = it + (k if record_every == 1 else n - 1)        # index of the iteration this value belongs to
+                self.loss_his.append(float(loss_value))
+                if i % 100 == 0 and self.rank == 0:
+                    elapsed = time.time() - start_time
+                    print('It: %d, Loss: %.3e, Time: %.2f' % (i, loss_value, elapsed))
+                    start_time = time.time()
             it += n
-            loss_value = float(loss3[0])
-            self.loss_his.append(loss_value)
-            if (it - 1) % 100 == 0 and self.rank == 0:
-                elapsed = time.time() - start_time
-                print('It: %d, Loss: %.3e, Time: %.2f' % (it - 1, loss_value, elapsed))
-                start_time = time.time()
         self.h.sync()
+
+    _RECORD_CHUNK = 1000
 
 
 class VPINNAdvDiff(_VPINNBase):

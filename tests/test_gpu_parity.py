@@ -250,6 +250,13 @@ def test_reduce_buffer_is_a_zero_copy_torch_view():
             assert m2._dist_graphs.get(8) is not None, "multi-GPU iteration graph was not captured"
             assert abs(l3[0] - float(o2.loss_parts()[0])) < TRAJ_TOL * abs(l3[0])
             assert rel(m2.get_params(), o2.get_params()) < TRAJ_TOL
+            o3, m3 = _pair_2d("poisson2d_small", 1, layers=[2, 20, 20, 20, 1])
+            hist = m3._step_record(21)           # loss history through the multi-GPU path (k_adam records the reduced buffer)
+            lo3 = []
+            for _ in range(8):
+                o3.adam_step()
+                lo3.append(float(o3.loss_parts()[0]))
+            assert rel(hist[:8, 0], lo3) < TRAJ_TOL and np.all(np.diff(hist[:, 0]) < 0)
             l3b = m2._step(11, True)             # a second size: 11-iteration graph
             for _ in range(11):
                 o2.adam_step()
@@ -308,6 +315,32 @@ def test_device_gll_rule_and_test_function_tables_match_reference_fixtures():
         for d, name in enumerate(("phi", "dphi", "d2phi")):
             ref = gt[f"{name}_{nt}_{q}"][:, :, 0]
             assert rel(tab[d], ref) < 1e-12, (nt, q, name, rel(tab[d], ref))
+
+
+def test_loss_history_equals_a_forward_pass_after_every_update():
+    """P2:243-244 records the loss after every update with a second forward pass per iteration; the device-side history
+    (hpv_step_record) must give the same values (the next iteration's forward pass computes them anyway) and leave the
+    parameters bit-identical -- also across the history capacity and against the oracle's per-iteration losses."""
+    from hp_vpinns_amd import _lib
+    o, m1 = _pair_2d("poisson2d_small", 1, layers=[2, 20, 20, 20, 1])
+    _, m2 = _pair_2d("poisson2d_small", 1, layers=[2, 20, 20, 20, 1])
+    ref = np.array([m1._step(1, True) for _ in range(25)])
+    hist = m2._step_record(25)
+    assert hist.shape == (25, 3) and rel(hist, ref) < 1e-13
+    assert np.array_equal(m1.get_params(), m2.get_params())
+    lo = []
+    for _ in range(10):
+        o.adam_step()
+        lo.append(float(o.loss_parts()[0]))
+    assert rel(hist[:10, 0], lo) < TRAJ_TOL
+    n = _lib.HIST_CAP + 37                       # more iterations than the history holds: read back in chunks
+    ref2 = m1._step(n, True)
+    hist2 = m2._step_record(n)
+    assert hist2.shape == (n, 3) and rel(hist2[-1], ref2) < 1e-13 and np.array_equal(m1.get_params(), m2.get_params())
+    m3 = _pair_2d("poisson2d_small", 1, layers=[2, 20, 20, 20, 1])[1]
+    m3.loss_his = []
+    m3.train(30)                                 # the class's own loop (record_every = 1) goes through the history
+    assert rel(m3.loss_his[:25], ref[:, 0]) < 1e-13 and len(m3.loss_his) == 30
 
 
 def test_checkpoint_resume_is_bit_exact_and_l2_error(tmp_path):
