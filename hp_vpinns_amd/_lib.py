@@ -99,9 +99,9 @@ def load():
     lib.hpv_set_state.argtypes = [h, _dp, C.c_size_t]
     lib.hpv_assemble_rhs.argtypes = [h, _dp, C.c_size_t, _dp, C.c_size_t]
     lib.hpv_gll_rule.argtypes = [h, C.c_int, _dp, _dp]
-    lib.hpv_step_record.argtypes = [h, C.c_int, _dp]
+    lib.hpv_step_record.argtypes = [h, C.c_int, _dp, _dp]
     lib.hpv_history_reset.argtypes = [h]
-    lib.hpv_history_read.argtypes = [h, C.c_int, _dp]
+    lib.hpv_history_read.argtypes = [h, C.c_int, _dp, _dp]
     lib.hpv_test_tables.argtypes = [h, C.c_int, _dp, C.c_int, _dp]
     _lib = lib
     return lib
@@ -285,18 +285,19 @@ class Handle:
         return out
 
     def step_record(self, n):
-        """n Adam iterations; (n, 3) array {loss, lossb, lossv} after each update (one extra forward pass in total)."""
-        out = np.empty((int(n), 3))
-        self._chk(self.lib.hpv_step_record(self._h, int(n), _p(out)))
-        return out
+        """n Adam iterations; ((n, 3) array {loss, lossb, lossv}, (n,) epsilon) after each update (one extra forward pass
+        in total)."""
+        out, eps = np.empty((int(n), 3)), np.empty(int(n))
+        self._chk(self.lib.hpv_step_record(self._h, int(n), _p(out), _p(eps)))
+        return out, eps
 
     def history_reset(self):
         self._chk(self.lib.hpv_history_reset(self._h))
 
     def history_read(self, n):
-        out = np.empty((int(n), 3))
-        self._chk(self.lib.hpv_history_read(self._h, int(n), _p(out)))
-        return out
+        out, eps = np.empty((int(n), 3)), np.empty(int(n))
+        self._chk(self.lib.hpv_history_read(self._h, int(n), _p(out), _p(eps)))
+        return out, eps
 
     def gll_rule(self, q):
         """(nodes, weights) of the q-point Gauss-Lobatto-Legendre rule, computed on the device."""

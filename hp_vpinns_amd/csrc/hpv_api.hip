@@ -73,7 +73,7 @@ struct hpv_ctx {
     int n_data = 0;
     // parameters / optimizer
     double *d_theta = nullptr, *d_m = nullptr, *d_v = nullptr, *d_state = nullptr, *d_RB = nullptr;
-    double* d_hist = nullptr;   // [HPV_HIST_CAP][3] loss history (AdamArgs)
+    double* d_hist = nullptr;   // [HPV_HIST_CAP][4] loss / epsilon history (AdamArgs)
     int* d_hist_idx = nullptr;
     // mfma path (one object per batch: quadrature points, boundary/data points, element edges)
     HpvMfma* mfma = nullptr;
@@ -560,7 +560,7 @@ int hpv_create(hpv_handle* out, const hpv_config* cfg) {
     rc |= dalloc(h, &h->d_m, (size_t)h->Ptot);
     rc |= dalloc(h, &h->d_v, (size_t)h->Ptot);
     rc |= dalloc(h, &h->d_state, (size_t)adam_state_doubles(h->P));
-    rc |= dalloc(h, &h->d_hist, (size_t)3 * HPV_HIST_CAP);
+    rc |= dalloc(h, &h->d_hist, (size_t)4 * HPV_HIST_CAP);
     rc |= dalloc(h, &h->d_hist_idx, (size_t)1);
     if (!rc) (void)hipMemset(h->d_hist_idx, 0, sizeof(int));
     rc |= dalloc(h, &h->d_RB, (size_t)h->Ptot + 4);
@@ -902,36 +902,49 @@ int hpv_history_reset(hpv_handle h) {
     return 0;
 }
 
-int hpv_history_read(hpv_handle h, int n, double* loss3_hist) {
+int hpv_history_read(hpv_handle h, int n, double* loss3_hist, double* eps_hist) {
     if (!h || !loss3_hist || n < 0) return -1;
     if (n > HPV_HIST_CAP) return fail(h, -1, "history holds %d entries, %d requested", HPV_HIST_CAP, n);
     int have = 0;
-    std::vector<double> raw((size_t)3 * n);
+    std::vector<double> raw((size_t)4 * n);
     HIPCHK(h, hipMemcpyAsync(&have, h->d_hist_idx, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (n) HIPCHK(h, hipMemcpyAsync(raw.data(), h->d_hist, raw.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (have < n) return fail(h, -3, "only %d training iterations since hpv_history_reset, %d requested", have, n);
-    for (int i = 0; i < n; ++i) loss_triple(h, &raw[(size_t)3 * i], loss3_hist + 3 * i);
+    for (int i = 0; i < n; ++i) {
+        loss_triple(h, &raw[(size_t)4 * i], loss3_hist + 3 * i);
+        if (eps_hist) eps_hist[i] = raw[(size_t)4 * i + 3];
+    }
     return 0;
 }
 
-int hpv_step_record(hpv_handle h, int n_iters, double* loss3_hist) {
+int hpv_step_record(hpv_handle h, int n_iters, double* loss3_hist, double* eps_hist) {
     if (!h || !loss3_hist || n_iters < 0) return -1;
     int rc;
-    std::vector<double> chunk((size_t)3 * HPV_HIST_CAP);
+    std::vector<double> chunk((size_t)3 * HPV_HIST_CAP), ceps(HPV_HIST_CAP);
     for (int done = 0; done < n_iters;) {
         const int c = std::min(HPV_HIST_CAP, n_iters - done);
         if ((rc = hpv_history_reset(h))) return rc;
         if ((rc = enqueue_iterations(h, c))) return rc;
-        if ((rc = hpv_history_read(h, c, chunk.data()))) return rc;
-        // entry j was computed by the forward pass that preceded update done+j+1, i.e. it is the loss after update done+j
+        if ((rc = hpv_history_read(h, c, chunk.data(), ceps.data()))) return rc;
+        // entry j was computed by the forward pass that preceded update done+j+1, i.e. it belongs to the state after update done+j
         for (int j = 0; j < c; ++j)
-            if (done + j >= 1) std::copy_n(&chunk[(size_t)3 * j], 3, loss3_hist + (size_t)3 * (done + j - 1));
+            if (done + j >= 1) {
+                std::copy_n(&chunk[(size_t)3 * j], 3, loss3_hist + (size_t)3 * (done + j - 1));
+                if (eps_hist) eps_hist[done + j - 1] = ceps[j];
+            }
         done += c;
     }
-    if (n_iters > 0) {   // the loss after the last update: one forward pass
+    if (n_iters > 0) {   // the state after the last update: one forward pass
         if ((rc = enqueue_pass(h, false))) return rc;
         if ((rc = hpv_read_loss(h, loss3_hist + (size_t)3 * (n_iters - 1)))) return rc;
+        if (eps_hist) {
+            eps_hist[n_iters - 1] = 0.0;
+            if (h->has_eps) {
+                HIPCHK(h, hipMemcpyAsync(eps_hist + n_iters - 1, h->d_theta + h->P, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+            }
+        }
     }
     return 0;
 }

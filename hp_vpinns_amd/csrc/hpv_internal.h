@@ -53,8 +53,8 @@ static inline size_t hpv_proj_lds_bytes(const ProjDesc& pd) {
 struct AdamArgs {
     double *theta, *m, *v, *state;   // theta == nullptr: no update
     double lr, b1, b2, eps;
-    // loss history: every training iteration appends the raw loss triple {lossv, w*lossb, mean sq} of ITS forward pass
-    // (= the loss after the previous update) at hist[3 * (*hist_idx)++]; entries beyond hist_cap are dropped
+    // loss history: every training iteration appends {lossv, w*lossb, mean sq, epsilon} of ITS forward pass (= the loss
+    // and the trainable coefficient after the previous update) at hist[4 * (*hist_idx)++]; entries beyond hist_cap are dropped
     double* hist;
     int* hist_idx;
     int hist_cap;

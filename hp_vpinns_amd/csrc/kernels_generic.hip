@@ -526,6 +526,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
     sq = block_sum(sq, red);
     if (threadIdx.x == 0) {
         const double msq = n_data > 0 ? sq / (double)n_data : 0.0;
+        const double eps_now = (has_eps && ad.theta) ? ad.theta[P] : 0.0;   // the coefficient this forward pass used
         if (has_eps && write_grad) {
             RB[P] = de;
             if (ad.theta) adam_update(ad, P, de, ad.state[0], ad.state[1]);   // the trainable epsilon (P3:63)
@@ -534,7 +535,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
             ad.state[0] *= ad.b1; ad.state[1] *= ad.b2;
             if (ad.hist) {   // single-GPU training iteration: record this forward pass's loss (see AdamArgs)
                 const int i = *ad.hist_idx;
-                if (i < ad.hist_cap) { ad.hist[3 * i] = lv; ad.hist[3 * i + 1] = lossb_weight * msq; ad.hist[3 * i + 2] = msq; }
+                if (i < ad.hist_cap) { ad.hist[4 * i] = lv; ad.hist[4 * i + 1] = lossb_weight * msq; ad.hist[4 * i + 2] = msq; ad.hist[4 * i + 3] = eps_now; }
                 *ad.hist_idx = i + 1;
             }
         }
@@ -564,14 +565,18 @@ int adam_state_doubles(int P) { return 2 * ((P + FIN_COLS - 1) / FIN_COLS + 1); 
 //   theta -= lr_t m / (sqrt(v) + eps)      -- eps OUTSIDE the bias correction, unlike torch.optim.Adam.
 // state = {beta1^t, beta2^t} kept as running products exactly like TF's beta*_power variables.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_adam(AdamArgs ad, const double* __restrict__ g, int Ptot, int ncopies) {
+__global__ void __launch_bounds__(1024) k_adam(AdamArgs ad, const double* __restrict__ g, int P, int Ptot, int ncopies) {
     const double b1p = ad.state[0], b2p = ad.state[1];
-    for (int i = threadIdx.x; i < Ptot; i += blockDim.x) adam_update(ad, i, g[i], b1p, b2p);
     if (threadIdx.x == 0 && ad.hist) {   // multi-GPU iteration: g is the all-reduced packed buffer, the losses follow the gradient
         const int i = *ad.hist_idx;
-        if (i < ad.hist_cap) { ad.hist[3 * i] = g[Ptot]; ad.hist[3 * i + 1] = g[Ptot + 1]; ad.hist[3 * i + 2] = g[Ptot + 2]; }
+        if (i < ad.hist_cap) {
+            ad.hist[4 * i] = g[Ptot]; ad.hist[4 * i + 1] = g[Ptot + 1]; ad.hist[4 * i + 2] = g[Ptot + 2];
+            ad.hist[4 * i + 3] = Ptot > P ? ad.theta[P] : 0.0;   // epsilon before this update
+        }
         *ad.hist_idx = i + 1;
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Ptot; i += blockDim.x) adam_update(ad, i, g[i], b1p, b2p);
     __syncthreads();
     for (int c = threadIdx.x; c < ncopies; c += blockDim.x) {   // advance every replicated copy
         ad.state[2 * c] *= ad.b1;
@@ -580,7 +585,7 @@ __global__ void __launch_bounds__(1024) k_adam(AdamArgs ad, const double* __rest
 }
 
 void launch_adam(const AdamArgs& ad, const double* RB, int P, int Ptot, hipStream_t s) {
-    hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, s, ad, RB, Ptot, adam_state_doubles(P) / 2);
+    hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, s, ad, RB, P, Ptot, adam_state_doubles(P) / 2);
 }
 
 // ------------------------------------------------------------------------------------------------

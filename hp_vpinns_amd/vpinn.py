@@ -186,24 +186,48 @@ class _VPINNBase:
         return g
 
     def _step_record(self, n):
-        """n Adam iterations; (n, 3) array {loss, lossb, lossv} AFTER each update.  The loss after update k is what the
-        forward pass of iteration k+1 computes anyway, and the device keeps a history of it (hpv_step_record /
-        hpv_history_*): per-iteration recording costs one extra forward pass per call instead of one per iteration."""
+        """n Adam iterations; ((n, 3) array {loss, lossb, lossv}, (n,) epsilon) AFTER each update.  The loss after update
+        k is what the forward pass of iteration k+1 computes anyway, and the device keeps a history of it
+        (hpv_step_record / hpv_history_*): per-iteration recording costs one extra forward pass per call instead of one
+        per iteration."""
         if not self._dist:
             return self.h.step_record(n)
-        out = np.empty((n, 3))
+        out, eps = np.empty((n, 3)), np.zeros(n)
         done = 0
         while done < n:
             c = min(_lib.HIST_CAP, n - done)
             self.h.history_reset()
             self._step(c, False)
-            hist = self.h.history_read(c)      # entry j: forward pass before update done+j+1 = loss after update done+j
+            hist, he = self.h.history_read(c)  # entry j: forward pass before update done+j+1 = state after update done+j
             lo = 1 if done == 0 else 0
             out[done + lo - 1:done + c - 1] = hist[lo:]
+            eps[done + lo - 1:done + c - 1] = he[lo:]
             done += c
         if n > 0:
             out[n - 1] = self.loss()
-        return out
+            if self._n_extra:
+                eps[n - 1] = self.h.get_params()[-1]
+        return out, eps
+
+    _RECORD_CHUNK = 1000
+
+    def _recorded_run(self, it, n, tresh, every=10):
+        """Iterations it .. it+n-1 in one device run; returns ([(iteration, loss3, epsilon)] for the recording iterations
+        (index % every == 0), stop) where stop is the first recorded iteration whose loss is below `tresh` (the
+        reference leaves its loop there, P1:215 / P3:320) or None.  On such a stop the state saved before the run is
+        restored and the run repeated up to exactly that iteration, so the parameters are those the reference ends with."""
+        state = self.h.get_state() if tresh > 0 else None
+        hist, eps = self._step_record(n)
+        recs, stop = [], None
+        for k in range((-it) % every, n, every):
+            recs.append((it + k, hist[k], eps[k]))
+            if hist[k][0] < tresh:
+                stop = it + k
+                break
+        if stop is not None and stop < it + n - 1:
+            self.h.set_state(state)
+            self._step(stop - it + 1, False)
+        return recs, stop
 
     def loss_and_grad(self):
         """({loss, lossb, lossv}, d loss / d theta) at the current parameters (global over ranks)."""
@@ -295,20 +319,21 @@ class VPINN1D(_VPINNBase):
         start_time = time.time()
         it = 0
         while it < nIter:
-            n, rec = _next_chunk(it, nIter)
-            last = it + n - 1
-            loss3 = self._step(n, rec)
+            n = min(self._RECORD_CHUNK, nIter - it)
+            recs, stop = self._recorded_run(it, n, tresh)
             it += n
-            if rec:
+            for last, loss3, _ in recs:
                 loss_value, loss_valueb, loss_valuev = float(loss3[0]), float(loss3[1]), float(loss3[2])
                 self.total_record.append(np.array([last, loss_value]))
-                if loss_value < tresh:
+                if last == stop:
                     print('It: %d, Loss: %.3e' % (last, loss_value))
                     break
                 if last % 100 == 0 and self.rank == 0:
                     elapsed = time.time() - start_time
                     print('It: %d, Lossb: %.3e, Lossv: %.3e, Time: %.2f' % (last, loss_valueb, loss_valuev, elapsed))
                     start_time = time.time()
+            if stop is not None:
+                break
         self.h.sync()
 
 
@@ -368,7 +393,7 @@ class VPINN2D(_VPINNBase):
         while it < nIter:
             if record_every == 1:      # every update recorded: device-side loss history, one read-back per chunk
                 n = min(self._RECORD_CHUNK, nIter - it)
-                losses = self._step_record(n)[:, 0]
+                losses = self._step_record(n)[0][:, 0]
             else:
                 n = min(record_every, nIter - it)
                 losses = [float(self._step(n, True)[0])]
@@ -381,8 +406,6 @@ class VPINN2D(_VPINNBase):
                     start_time = time.time()
             it += n
         self.h.sync()
-
-    _RECORD_CHUNK = 1000
 
 
 class VPINNAdvDiff(_VPINNBase):
@@ -431,6 +454,28 @@ class VPINNAdvDiff(_VPINNBase):
         loss_value, start_time = None, time.time()
         it = 0
         while it < nIter:
+            if it + self._RECORD_CHUNK - 1 <= 0.9 * nIter:
+                # outside the last tenth of the run (where new minima snapshot the prediction, P3:324-326) the records come
+                # from the device-side loss / epsilon history: one read-back per chunk instead of one per 10 iterations
+                n = min(self._RECORD_CHUNK, nIter - it)
+                t0 = time.time()
+                recs, stop = self._recorded_run(it, n, tresh)
+                total_time_train += time.time() - t0
+                it += n
+                for last, loss3, eps in recs:
+                    loss_value, epsilon_value = float(loss3[0]), np.array([eps])
+                    total_records.append(np.array([last, loss_value, epsilon_value, 1], dtype=object))
+                    if last == stop:
+                        print('It: %d, Loss: %.3e' % (last, loss_value))
+                        break
+                    if last % 100 == 0 and self.rank == 0:
+                        elapsed = time.time() - start_time
+                        print('It: %d, Lossv: %.3e, Lossp: %.3e, Lossb: %.3e, Time: %.2f, epsilon: %.4f'
+                              % (last, loss3[2], 1, loss3[1], elapsed, float(eps)))
+                        start_time = time.time()
+                if stop is not None:
+                    break
+                continue
             n, rec = _next_chunk(it, nIter)
             last = it + n - 1
             t0 = time.time()

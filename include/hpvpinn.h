@@ -105,12 +105,13 @@ int hpv_step(hpv_handle h, int n_iters, double* loss3_after);
 /* n_iters Adam iterations with the loss after EVERY update recorded -- what VPINN.train of the 2-D script does with a
  * second forward pass per iteration (P2:243-244).  The loss after update k is the value the forward pass of
  * iteration k+1 computes anyway; every training iteration appends it to a device-side history, so only the loss after
- * the last update costs a forward pass.  loss3_hist is [n_iters][3] = {loss, lossb, lossv} after update 1..n_iters.
- * hpv_history_reset / hpv_history_read expose the history to callers that drive the iterations themselves (multi-GPU:
- * entry i = loss computed by the i-th forward pass since the reset, global after the all-reduce). */
-int hpv_step_record(hpv_handle h, int n_iters, double* loss3_hist);
+ * the last update costs a forward pass.  loss3_hist is [n_iters][3] = {loss, lossb, lossv} after update 1..n_iters;
+ * eps_hist (may be NULL) is [n_iters], the trainable diffusion coefficient after each update (P3:318, 0 for the Poisson
+ * problems).  hpv_history_reset / hpv_history_read expose the history to callers that drive the iterations themselves
+ * (multi-GPU: entry i = loss / epsilon seen by the i-th forward pass since the reset, global after the all-reduce). */
+int hpv_step_record(hpv_handle h, int n_iters, double* loss3_hist, double* eps_hist);
 int hpv_history_reset(hpv_handle h);
-int hpv_history_read(hpv_handle h, int n, double* loss3_hist);
+int hpv_history_read(hpv_handle h, int n, double* loss3_hist, double* eps_hist);
 
 /* Pieces of hpv_step for the multi-GPU path (one process per GPU): enqueue forward + backward
  * into the packed device buffer [grad (P) | lossv | lossb | pad] (all partial sums of this
