@@ -87,6 +87,8 @@ struct hpv_ctx {
     double *d_fcol = nullptr, *d_col_part = nullptr;
     int n_col = 0;
     double* d_jac = nullptr;   // |J_e| of the owned elements (RHS assembly, hpv_assemble_rhs)
+    double* d_upart = nullptr; // partial residual sums of the row-split projection (few tall elements)
+    int proj_split = 1;        // workgroups per element there; loss_e / deps_e hold n_elem * proj_split entries
     // timing
     bool timing = false;
     TimerClass timers[3];
@@ -361,7 +363,7 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
                                 eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->stream) &&
              !launch_project_wg(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
                                 eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT,
-                                h->d_edge_dphi, h->d_edge_coef, h->edge.GBAR, h->stream)))
+                                h->d_edge_dphi, h->d_edge_coef, h->edge.GBAR, h->stream, h->d_upart)))
             launch_project(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
                            h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi,
                            h->d_edge_coef, h->edge.GBAR, h->stream);
@@ -397,8 +399,8 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
     const AdamArgs ad = adam_args(h);
     launch_finalize(backward && h->var.N > 0 ? h->var.GPART : nullptr, h->var.rows,
                     backward && h->n_data > 0 && !h->merged ? h->data.GPART : nullptr, h->data.rows,
-                    backward && h->pd.edge && h->edge.N > 0 ? h->edge.GPART : nullptr, h->edge.rows, h->d_loss_e, h->n_elem,
-                    h->d_deps_e, h->d_data_part, ndp, h->cfg.lossb_weight, h->n_data, h->P, h->has_eps, h->d_RB,
+                    backward && h->pd.edge && h->edge.N > 0 ? h->edge.GPART : nullptr, h->edge.rows, h->d_loss_e,
+                    (long)h->n_elem * h->proj_split, h->d_deps_e, h->d_data_part, ndp, h->cfg.lossb_weight, h->n_data, h->P, h->has_eps, h->d_RB,
                     backward ? 1 : 0, (backward && fuse_adam) ? &ad : nullptr, h->stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, -2, "kernel launch failed: %s", hipGetErrorString(e));
@@ -589,6 +591,7 @@ void hpv_destroy(hpv_handle h) {
     if (h->d_fcol) (void)hipFree(h->d_fcol);
     if (h->d_col_part) (void)hipFree(h->d_col_part);
     if (h->d_jac) (void)hipFree(h->d_jac);
+    if (h->d_upart) (void)hipFree(h->d_upart);
     free_batch(h->var); free_batch(h->data); free_batch(h->edge); free_batch(h->pred);
     double* ptrs[] = {h->d_wtx, h->d_wty, h->d_edge_dphi, h->d_coef, h->d_edge_coef, h->d_F, h->d_R, h->d_loss_e,
                       h->d_deps_e, h->d_udata, h->d_data_part, h->d_theta, h->d_m, h->d_v, h->d_state, h->d_RB, h->d_hist};
@@ -714,13 +717,16 @@ int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* g
     if ((rc = dalloc(h, &h->d_jac, jac.size()))) return rc;
     if (ne > 0 && (rc = upload(h, h->d_jac, jac.data(), jac.size()))) return rc;
     if ((rc = dalloc(h, &h->d_R, (size_t)ne * h->ntx * h->nty))) return rc;
-    if ((rc = dalloc(h, &h->d_loss_e, (size_t)ne))) return rc;
-    if ((rc = dalloc(h, &h->d_deps_e, (size_t)ne))) return rc;
+    h->proj_split = project_row_split(h->pd, ne, h->cfg.backend == HPV_BACKEND_GENERIC);
+    const size_t nred = (size_t)ne * h->proj_split;
+    if ((rc = dalloc(h, &h->d_loss_e, nred))) return rc;
+    if ((rc = dalloc(h, &h->d_deps_e, nred))) return rc;
+    if ((rc = dalloc(h, &h->d_upart, h->proj_split > 1 ? nred * h->ntx * h->nty : 0))) return rc;
     h->Xq_host = X;
     h->batch_dirty = true;
     if (N > 0) {
         if ((rc = upload(h, h->d_coef, coef.data(), coef.size()))) return rc;
-        HIPCHK(h, hipMemsetAsync(h->d_deps_e, 0, (size_t)ne * sizeof(double), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_deps_e, 0, nred * sizeof(double), h->stream));
     }
     if (h->pd.edge) {
         if ((rc = alloc_batch(h, h->edge, h->nd_val, 2 * ne, true))) return rc;

@@ -91,4 +91,5 @@ void launch_pinn_residual(const double* OUT, const double* f, double* GBAR, doub
 bool launch_project_wg(const ProjDesc& pd, const double* OUT, double* GBAR, double* R, const double* F, const double* coef,
                        long coef_stride, const double* wtx, const double* wty, const double* eps_ptr, double* loss_e,
                        double* deps_e, long N, long n_elem, int do_adjoint, const double* edge_u, const double* edge_dphi,
-                       const double* edge_coef, double* edge_gbar, hipStream_t s);
+                       const double* edge_coef, double* edge_gbar, hipStream_t s, double* upart = nullptr);
+int project_row_split(const ProjDesc& pd, long n_elem, int backend_generic);   // workgroups per element of the row-split projection

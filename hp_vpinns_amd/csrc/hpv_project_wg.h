@@ -294,3 +294,193 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Row-split projection for FEW, TALL elements (AdvDiff with the 80x80 rule: 8 elements of 6 400 points would
+// otherwise keep 8 CUs busy for 25 us).  PJ_SPLIT workgroups per element, workgroup (e, c) owns the QY/PJ_SPLIT rows
+// j0 .. j0+RB-1 of the element:
+//   phase A  k_project_rows_fwd : its rows' integrands, x-contraction, PARTIAL y-contraction
+//                                 Upart[e][c][k][r] = sum_t m_t c_t sum_{j in chunk} BY_t[k][j] sum_i AX_t[r][i] G_t[j][i]
+//   phase B  k_project_rows_adj : U = sum_c Upart - F (every workgroup, 25..100 values), R / loss_e by chunk 0, then the
+//                                 adjoint of its own rows: GBAR and the chunk's share of d loss / d epsilon.
+// loss_e / deps_e are written per (e, c) (zeros where a chunk has nothing to add); the finalize kernel sums
+// n_elem * PJ_SPLIT entries in a fixed order.
+// ------------------------------------------------------------------------------------------------
+#define PJ_SPLIT 8
+#define PJ_RBLOCK 512
+
+template <int QX, int QY, int NTX, int NTY>
+constexpr int project_rows_lds_doubles() {
+    constexpr int RB = QY / PJ_SPLIT;
+    return RB * (QX + 1) + HPV_MAXT * NTX * QX + HPV_MAXT * NTY * RB + RB * NTX + NTX * NTY + HPV_MAXT * NTY * QX + 64;
+}
+
+template <int QX, int QY, int NTX, int NTY>
+__global__ void __launch_bounds__(PJ_RBLOCK) k_project_rows_fwd(ProjArgs pa, double* __restrict__ Upart) {
+    static_assert(QY % PJ_SPLIT == 0, "rows per chunk");
+    constexpr int RB = QY / PJ_SPLIT, NR = NTX * NTY, LDG = QX + 1, NP = RB * QX;
+    constexpr int NIT = (NP + PJ_RBLOCK - 1) / PJ_RBLOCK;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* G = sm;                              // [RB][LDG]
+    double* AXl = G + RB * LDG;                  // [HPV_MAXT][NTX][QX]
+    double* BYl = AXl + HPV_MAXT * NTX * QX;     // [HPV_MAXT][NTY][RB]   columns j0..j0+RB-1 of w_y phi^(dy)
+    double* T = BYl + HPV_MAXT * NTY * RB;       // [RB][NTX]
+    double* U = T + RB * NTX;                    // [NR]
+    const ProjDesc& pd = pa.pd;
+    const long e = blockIdx.x / PJ_SPLIT;
+    const int c = blockIdx.x % PJ_SPLIT, j0 = c * RB, tid = threadIdx.x;
+    const long base = e * (long)(QX * QY) + (long)j0 * QX;
+    const int nterms = pd.nterms, C = pd.C;
+    const double eps = pa.eps_ptr ? pa.eps_ptr[0] : 0.0;
+    // all global reads up front: tables and every term's integrand at this thread's points
+    double gv[HPV_MAXT][NIT];
+#pragma unroll
+    for (int t = 0; t < HPV_MAXT; ++t) {
+        const int dx = t < nterms ? pd.t[t].dx : 0, dy = t < nterms ? pd.t[t].dy : 0;
+        for (int i = tid; i < NTX * QX; i += PJ_RBLOCK) AXl[t * NTX * QX + i] = pa.wtx[(long)dx * NTX * QX + i];
+        for (int i = tid; i < NTY * RB; i += PJ_RBLOCK) BYl[t * NTY * RB + i] = pa.wty[(long)dy * NTY * QY + (i / RB) * QY + j0 + i % RB];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) gv[t][it] = 0.0;
+        if (t < nterms) {
+#pragma unroll
+            for (int ch = 0; ch < HPV_MAXC; ++ch) {
+                const double al = (ch < C) ? pd.t[t].a0[ch] + eps * pd.t[t].a1[ch] : 0.0;
+                if (al != 0.0) {     // block-uniform: whole channels are skipped
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int qd = it * PJ_RBLOCK + tid;
+                        gv[t][it] = fma(al, pa.OUT[(long)ch * pa.N + base + (qd < NP ? qd : NP - 1)], gv[t][it]);
+                    }
+                }
+            }
+        }
+    }
+    for (int o = tid; o < NR; o += PJ_RBLOCK) U[o] = 0.0;
+#pragma unroll
+    for (int t = 0; t < HPV_MAXT; ++t) {
+        if (t >= nterms) break;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int qd = it * PJ_RBLOCK + tid;
+            if (qd < NP) G[(qd / QX) * LDG + (qd % QX)] = gv[t][it];
+        }
+        __syncthreads();
+        {
+            constexpr int SPX = pj_splitk(RB * NTX, QX, PJ_RBLOCK);
+            for (int o0 = 0; o0 < RB * NTX; o0 += PJ_RBLOCK / SPX) {
+                const int o = o0 + tid / SPX, part = tid % SPX;
+                const bool ok = o < RB * NTX;
+                const int j = ok ? o / NTX : 0, r = ok ? o % NTX : 0;
+                double acc = 0.0;
+#pragma unroll 8
+                for (int i = part; i < QX; i += SPX) acc = fma(AXl[t * NTX * QX + r * QX + i], G[j * LDG + i], acc);
+#pragma unroll
+                for (int m = SPX >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+                if (ok && part == 0) T[o] = acc;
+            }
+        }
+        __syncthreads();
+        const double cf = pa.coef[(long)t * pa.coef_stride + e] * (pd.t[t].eps_mult ? eps : 1.0);
+        for (int o = tid; o < NR; o += PJ_RBLOCK) {
+            const int k = o / NTX, r = o % NTX;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < RB; ++j) acc = fma(BYl[t * NTY * RB + k * RB + j], T[j * NTX + r], acc);
+            U[o] = fma(cf, acc, U[o]);
+        }
+    }
+    __syncthreads();
+    for (int o = tid; o < NR; o += PJ_RBLOCK) Upart[(long)blockIdx.x * NR + o] = U[o];
+}
+
+template <int QX, int QY, int NTX, int NTY>
+__global__ void __launch_bounds__(PJ_RBLOCK) k_project_rows_adj(ProjArgs pa, const double* __restrict__ Upart) {
+    constexpr int RB = QY / PJ_SPLIT, NR = NTX * NTY, NP = RB * QX, NWV = PJ_RBLOCK / 64;
+    constexpr int NIT = (NP + PJ_RBLOCK - 1) / PJ_RBLOCK;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* AXl = sm;                            // [HPV_MAXT][NTX][QX]
+    double* BYl = AXl + HPV_MAXT * NTX * QX;     // [HPV_MAXT][NTY][RB]
+    double* U = BYl + HPV_MAXT * NTY * RB;       // [NR]
+    double* S = U + NR;                          // [HPV_MAXT][NTY][QX]
+    double* red = S + HPV_MAXT * NTY * QX;       // [64]
+    const ProjDesc& pd = pa.pd;
+    const long e = blockIdx.x / PJ_SPLIT;
+    const int c = blockIdx.x % PJ_SPLIT, j0 = c * RB, tid = threadIdx.x;
+    const long base = e * (long)(QX * QY) + (long)j0 * QX;
+    const int nterms = pd.nterms, C = pd.C;
+    const double eps = pa.eps_ptr ? pa.eps_ptr[0] : 0.0;
+    for (int t = 0; t < nterms; ++t) {
+        for (int i = tid; i < NTX * QX; i += PJ_RBLOCK) AXl[t * NTX * QX + i] = pa.wtx[(long)pd.t[t].dx * NTX * QX + i];
+        for (int i = tid; i < NTY * RB; i += PJ_RBLOCK)
+            BYl[t * NTY * RB + i] = pa.wty[(long)pd.t[t].dy * NTY * QY + (i / RB) * QY + j0 + i % RB];
+    }
+    double sq = 0.0;
+    for (int o = tid; o < NR; o += PJ_RBLOCK) {
+        double u = pa.F ? -pa.F[e * NR + o] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < PJ_SPLIT; ++cc) u += Upart[(e * PJ_SPLIT + cc) * (long)NR + o];   // fixed order: every chunk agrees
+        U[o] = u;
+        if (c == 0) { pa.R[e * NR + o] = u; sq = fma(u, u, sq); }
+    }
+    sq = pj_wave_sum(sq);
+    if ((tid & 63) == 0) red[tid >> 6] = sq;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int w = 0; w < NWV; ++w) t += red[w]; pa.loss_e[blockIdx.x] = c == 0 ? t / (double)NR : 0.0; }
+    if (!pa.do_adjoint) return;
+    const double sc = 2.0 / (double)NR;
+    for (int t = 0; t < nterms; ++t)
+        for (int o = tid; o < NTY * QX; o += PJ_RBLOCK) {
+            const int k = o / QX, i = o % QX;
+            double acc = 0.0;
+#pragma unroll
+            for (int r = 0; r < NTX; ++r) acc = fma(AXl[t * NTX * QX + r * QX + i], U[k * NTX + r], acc);
+            S[t * NTY * QX + o] = acc * sc;
+        }
+    __syncthreads();
+    double deps = 0.0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int qd = it * PJ_RBLOCK + tid;
+        double o[HPV_MAXC];
+        if (pd.has_eps) {
+#pragma unroll
+            for (int ch = 0; ch < HPV_MAXC; ++ch) o[ch] = pa.OUT[(long)(ch < C ? ch : 0) * pa.N + base + (qd < NP ? qd : NP - 1)];
+        }
+        if (qd < NP) {
+            const int j = qd / QX, i = qd % QX;
+            double gb[HPV_MAXC];
+#pragma unroll
+            for (int ch = 0; ch < HPV_MAXC; ++ch) gb[ch] = 0.0;
+            for (int t = 0; t < nterms; ++t) {
+                const TermDesc& td = pd.t[t];
+                double gh = 0.0;
+#pragma unroll
+                for (int k = 0; k < NTY; ++k) gh = fma(BYl[t * NTY * RB + k * RB + j], S[t * NTY * QX + k * QX + i], gh);
+                gh *= pa.coef[(long)t * pa.coef_stride + e];
+                const double m = td.eps_mult ? eps : 1.0;
+                double g1 = 0.0, gt = 0.0;
+#pragma unroll
+                for (int ch = 0; ch < HPV_MAXC; ++ch) {
+                    const double al = td.a0[ch] + eps * td.a1[ch];
+                    gb[ch] = fma(al, m * gh, gb[ch]);
+                    if (pd.has_eps) {
+                        g1 = fma(td.a1[ch], o[ch], g1);
+                        gt = fma(al, o[ch], gt);
+                    }
+                }
+                deps = fma(gh, m * g1 + (td.eps_mult ? gt : 0.0), deps);
+            }
+#pragma unroll
+            for (int ch = 0; ch < HPV_MAXC; ++ch)
+                if (ch < C) pa.GBAR[(long)ch * pa.N + base + qd] = gb[ch];
+        }
+    }
+    if (pd.has_eps) {
+        deps = pj_wave_sum(deps);
+        __syncthreads();
+        if ((tid & 63) == 0) red[16 + (tid >> 6)] = deps;
+        __syncthreads();
+        if (tid == 0) { double t = 0.0; for (int w = 0; w < NWV; ++w) t += red[16 + w]; pa.deps_e[blockIdx.x] = t; }
+    }
+}

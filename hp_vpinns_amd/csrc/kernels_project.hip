@@ -391,11 +391,38 @@ static bool launch_wg(const ProjDesc& pd, const double* OUT, double* GBAR, doubl
     return true;
 }
 
+// Workgroups per element of the row-split projection (1: not applicable); loss_e / deps_e then hold n_elem * split entries.
+int project_row_split(const ProjDesc& pd, long n_elem, int backend_generic) {
+    if (backend_generic || pd.edge || n_elem <= 0 || n_elem * PJ_SPLIT > 4096) return 1;
+    if (pd.qx == 80 && pd.qy == 80 && pd.ntx == 5 && pd.nty == 5) return PJ_SPLIT;
+    return 1;
+}
+
+template <int QX, int QY, int NTX, int NTY>
+static void launch_rows(const ProjArgs& pa, long n_elem, double* upart, hipStream_t s) {
+    constexpr size_t lds = (size_t)project_rows_lds_doubles<QX, QY, NTX, NTY>() * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_project_rows_fwd<QX, QY, NTX, NTY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_project_rows_adj<QX, QY, NTX, NTY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const unsigned blocks = (unsigned)(n_elem * PJ_SPLIT);
+    hipLaunchKernelGGL((k_project_rows_fwd<QX, QY, NTX, NTY>), dim3(blocks), dim3(PJ_RBLOCK), lds, s, pa, upart);
+    hipLaunchKernelGGL((k_project_rows_adj<QX, QY, NTX, NTY>), dim3(blocks), dim3(PJ_RBLOCK), lds, s, pa, upart);
+}
+
 bool launch_project_wg(const ProjDesc& pd, const double* OUT, double* GBAR, double* R, const double* F, const double* coef,
                        long coef_stride, const double* wtx, const double* wty, const double* eps_ptr, double* loss_e,
                        double* deps_e, long N, long n_elem, int do_adjoint, const double* edge_u, const double* edge_dphi,
-                       const double* edge_coef, double* edge_gbar, hipStream_t s) {
+                       const double* edge_coef, double* edge_gbar, hipStream_t s, double* upart) {
     if (n_elem <= 0) return false;
+    if (upart && project_row_split(pd, n_elem, 0) > 1) {   // few tall elements: PJ_SPLIT workgroups per element, two phases
+        ProjArgs pa{pd, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, N, do_adjoint, nullptr, nullptr,
+                    nullptr, nullptr};
+        launch_rows<80, 80, 5, 5>(pa, n_elem, upart, s);
+        return true;
+    }
 #define HPV_WG(QX_, QY_, NTX_, NTY_)                                                                                \
     if (pd.qx == QX_ && pd.qy == QY_ && pd.ntx == NTX_ && pd.nty == NTY_)                                            \
         return launch_wg<QX_, QY_, NTX_, NTY_>(pd, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, N, \
