@@ -26,7 +26,7 @@ def test_zero_network_loss_1d(tag, lv):
     g = gold(tag)
     a = p1_args(g)
     o = O.OracleVPINN1D(*a, init_params=np.zeros(O.n_params(a[8])))
-    loss, lossb, lossv = (float(v) for v in o.loss_parts())
+    loss, lossb, lossv = (float(v.detach()) for v in o.loss_parts())
     F = g["F_ext_total"]
     assert abs(lossv - (F ** 2).mean(axis=(1, 2)).sum()) < 1e-9
     assert abs(lossv - lv) < 1e-8 and abs(lossb - 1.0) < 1e-12 and abs(loss - lv - 1.0) < 1e-8
@@ -36,7 +36,7 @@ def test_zero_network_loss_2d():
     g = gold("poisson2d_default")
     a = p2_args(g)
     o = O.OracleVPINN2D(*a, init_params=np.zeros(O.n_params(a[13])))
-    loss, lossb, lossv = (float(v) for v in o.loss_parts())
+    loss, lossb, lossv = (float(v.detach()) for v in o.loss_parts())
     assert abs(lossv - 60.15859233615944) < 1e-9 and abs(lossb - 0.24711041894014868) < 1e-12
     assert abs(loss - (10 * lossb + lossv)) < 1e-12        # P2:127
 
