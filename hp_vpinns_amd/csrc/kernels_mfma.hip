@@ -163,9 +163,9 @@ __global__ void __launch_bounds__(BLK, BLK == 256 ? 2 : 1) k_fwd_mfma(MfmaArgs g
     // LDS, lane-major (conflict-free ds_read_b64), shared by the block's waves: frees ~60 VGPRs per wave
     extern __shared__ __attribute__((aligned(16))) double fl[];
     // Output neurons 0..15 go through one 16-row MFMA tile; neurons 16..19 (the would-be second tile, 3/4
-    // padding) are computed on the VALU from WR = W[in = 4s+q][16+a] plus a 3-move reduce-scatter.  fp64 MFMA
-    // and fp64 VALU share one execution resource on gfx950 (measured: no additive throughput), so dropping
-    // the padded tile is a net saving of FP64 issue slots.
+    // padding) through v_mfma_f64_4x4x4_4b with the A operand WR = W[in = 4s+q][16+a] (see the layer loop).
+    // fp64 MFMA and fp64 VALU share one execution resource on gfx950 (measured: no additive throughput), so a
+    // padded tile -- or the same products on the VALU -- would be a net loss of FP64 issue slots.
     double* WT = fl;                                   // [(L-1)][MF_KS][64]
     double* BH = fl + (L > 1 ? L - 1 : 0) * MF_KS * 64;       // [(L-1)][MF_KS][64]
     double* WR = BH + (L > 1 ? L - 1 : 0) * MF_KS * 64;       // [(L-1)][MF_KS][4 (q)][4 (a)]
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES == 8 || (1 + NT1 + NT2) * L
     }
     // gradient accumulators (per wave, over all its tiles)
     // dW of a hidden->hidden layer = one 16x16 MFMA tile (in, out < 16) + two 4x16 strips on v_mfma_f64_4x4x4_4b
-    // (4 blocks of 4x4x4, no padding: a 16x16x4 tile there would be 3/4 zeros) + the 4x4 corner on the VALU
+    // (4 blocks of 4x4x4, no padding: a 16x16x4 tile there would be 3/4 zeros) + the 4x4 corner (one more 4x4x4_4b)
     v4d dWacc[LH];
     double dS10[LH], dS01[LH];   // lane (q,pt): dW[in = 16+q][out = pt]  and  dW[in = pt][out = 16+q]
 #pragma unroll
