@@ -567,6 +567,38 @@ def test_full_size_config4_properties():
     assert rel(acc, g) < 1e-11
 
 
+def test_large_grid_known_answer_and_shards():
+    """Maximum sizes: the config-4 element shape on a 64x64-element grid (1.6 M quadrature points, 1.8 GB activation
+    store): zero-network known answer, and the gradient of two half-domain shards sums to the whole (index widths,
+    grid-stride loops, the fused kernel with more workgroups than CUs)."""
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    s = poisson2d.setup(N_el_x=64, N_el_y=64, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False, assemble="device")
+    L = [2, 20, 20, 20, 1]
+    m0 = poisson2d.build_model(s, L, init_params=np.zeros(921))
+    z3 = m0.loss()
+    assert abs(z3[2] - (s["F_ext_total"] ** 2).mean(axis=(2, 3)).sum()) < 1e-10 * z3[2]
+    del m0
+    th = xavier_init(L, 3)
+    m = poisson2d.build_model(s, L, init_params=th)
+    l3, g = m.loss_and_grad()
+    del m
+    half = poisson2d.setup(N_el_x=64, N_el_y=64, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False, assemble="device")
+    acc_l, acc_g = 0.0, 0.0
+    for sl in (slice(0, 32), slice(32, 64)):     # the two x-halves as separate problems on their own grids
+        hs = dict(half)
+        hs["grid_x"] = half["grid_x"][sl.start:sl.stop + 1]
+        hs["F_ext_total"] = half["F_ext_total"][sl]
+        hs["N_testfcn_total"] = [half["N_testfcn_total"][0][sl], half["N_testfcn_total"][1]]
+        if sl.start:                             # boundary term only once
+            hs["X_u_train"], hs["u_train"] = half["X_u_train"][:0], half["u_train"][:0]
+        mh = poisson2d.build_model(hs, L, init_params=th)
+        lh, gh = mh.loss_and_grad()
+        acc_l, acc_g = acc_l + lh[0], acc_g + gh
+        del mh
+    assert abs(acc_l - l3[0]) < 1e-11 * abs(l3[0]) and rel(acc_g, g) < 1e-10
+
+
 @pytest.mark.parametrize("vf", [1, 2, 3])
 def test_tall_element_projection_1d(vf):
     """(80 quad, 60 test) 1-D elements go through the workgroup-per-element projection kernel, incl. the edge
