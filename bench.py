@@ -162,8 +162,32 @@ def main():
         # element-block mode: the per-element projection (+ adjoint) runs at the head of the reverse kernel; its
         # sum-factorised flops (2 terms x 2 x (20*10*20 + 10*10*20) x 2 = 48 kflop per element) belong to that launch
         flops["mlp_bwd"] += 48000 * (N_local // 400)
+    # Algorithmic HBM bytes per launch: the activation store is 140 doubles per point at config 4
+    # (s of layer 1; s, z_x, z_y of layers 2 and 3), written once by the forward and read once by the reverse kernel.
+    slots, d_in, C_u, n_res_local = 20 * (1 + 3 + 3), 2, 2, (model.Nelementx * model.Nelementy * 100) // world
+    n_data_local = 320 if rank == 0 else 0
+    npt = N_local + n_data_local
+    abytes = {"mlp_fwd": 8 * npt * (slots + d_in + C),                                   # read X, write slots + channels
+              "mlp_bwd": 8 * npt * (slots + d_in + C) + (8 * N_local * 2 * C_u + 16 * n_res_local if proj_fused else 0)}
+    # (reverse: read slots, X, adjoint channels; fused projection: read C_u channels + F, write C_u adjoint channels + R)
     dom = max(("mlp_fwd", "mlp_bwd"), key=lambda k: ktime[k])
-    ach = flops[dom] / (ktime[dom] * 1e-3) / 1e12 if ktime[dom] > 0 else 0.0
+
+    def roof(k):
+        t = ktime[k] * 1e-3
+        tf = flops[k] / t / 1e12 if t > 0 else 0.0
+        gbs = abytes[k] / t / 1e9 if t > 0 else 0.0
+        t_mfma, t_hbm = flops[k] / (PEAK_FP64_TFLOPS * 1e12), abytes[k] / (PEAK_HBM_GBS * 1e9)
+        hbm_bound = t_hbm >= t_mfma        # the ceiling that takes longer at peak rate is the one that bounds the kernel
+        r = {"kernel": k, "bound": "hbm" if hbm_bound else "mfma",
+             "achieved": gbs if hbm_bound else tf, "peak": PEAK_HBM_GBS if hbm_bound else PEAK_FP64_TFLOPS,
+             "unit": "GB/s" if hbm_bound else "TFLOP/s",
+             "frac": gbs / PEAK_HBM_GBS if hbm_bound else tf / PEAK_FP64_TFLOPS,
+             "traffic": traffic_tab.get(k) if world == 1 else None,
+             "bytes_per_launch": abytes[k], "flops_per_launch": flops[k], "avg_ms": ktime[k],
+             "other_ceiling": {"bound": "mfma" if hbm_bound else "hbm", "achieved": tf if hbm_bound else gbs,
+                               "unit": "TFLOP/s" if hbm_bound else "GB/s",
+                               "frac": tf / PEAK_FP64_TFLOPS if hbm_bound else gbs / PEAK_HBM_GBS}}
+        return r
     out = {
         "metric": "variational-loss iterations/sec", "value": args.steps / dt, "unit": "it/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -174,13 +198,13 @@ def main():
                    "parallelism": "element-sharded dp%d" % world},
         "loss_after": float(loss3[0]),
         "kernel_ms": ktime,
-        "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                     "frac": ach / PEAK_FP64_TFLOPS,
-                     "traffic": traffic_tab.get(dom) if world == 1 else None,
-                     "flops_per_launch": flops[dom], "avg_ms": ktime[dom], "projection_fused_into_reverse": proj_fused,
-                     "note": "algorithmic fp64 flops of the layer products (2*C*G*N, C=3 channels, G=1720/row) / hipEvent "
-                             "kernel time; peak = fp64 datasheet (matrix = vector on MI355X); measured ubench ceilings on "
-                             "this chip: 47 TFLOP/s v_mfma_f64_16x16x4, 62 TFLOP/s v_fma_f64, not additive"},
+        "roofline": dict(roof(dom), projection_fused_into_reverse=proj_fused,
+                         note="dominant kernel; algorithmic bytes = activation store (1120 B/point) + coordinates + channels "
+                              "(+ the fused projection's channels, F, R); algorithmic flops = 2*C*G*N of the layer products "
+                              "(C=3, G=1720/row); the bound is the ceiling with the larger time at peak rate; traffic = PMC HBM "
+                              "bytes (profiles/traffic.json); fp64 ubench ceilings on this chip: 47 TFLOP/s v_mfma_f64_16x16x4, "
+                              "72 v_mfma_f64_4x4x4_4b, 62 v_fma_f64, not additive"),
+        "roofline_other_kernel": roof("mlp_fwd" if dom == "mlp_bwd" else "mlp_bwd"),
     }
     if weak is not None:
         out["weak_scaling_probe"] = weak

@@ -63,8 +63,10 @@ tj = {}
 fe, wr = pmc("pmc_fetch"), pmc("pmc_write")
 for k in set(fe) | set(wr):
     b = (2 * fe.get(k, {}).get("FETCH_SIZE", 0.0) + wr.get(k, {}).get("WRITE_SIZE", 0.0)) * 1024
-    if "k_bwd_mfma" in k: tj["mlp_bwd"] = b
-    if "k_fwd_mfma" in k: tj["mlp_fwd"] = b
+    # (several instantiations may appear -- e.g. the forward kernel without activation store for the loss read-back:
+    #  the training iteration's kernel is the one that moves the most bytes)
+    if "k_bwd_mfma" in k: tj["mlp_bwd"] = max(b, tj.get("mlp_bwd", 0.0))
+    if "k_fwd_mfma" in k: tj["mlp_fwd"] = max(b, tj.get("mlp_fwd", 0.0))
     if "k_project" in k: tj["project"] = b
 fe, wr = pmc("pmc_fetch_proj"), pmc("pmc_write_proj")
 for k in set(fe) | set(wr):
