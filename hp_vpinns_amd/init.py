@@ -37,3 +37,32 @@ def unpack(theta, layers):
         ws.append(theta[o:o + i * j].reshape(i, j)); o += i * j
         bs.append(theta[o:o + j].reshape(1, j)); o += j
     return ws, bs, theta[o:]
+
+
+MFMA_WIDTH = 20   # hidden width of the MFMA kernels (csrc/kernels_mfma.hip)
+
+
+def pad_plan(layers, extra=0, width=MFMA_WIDTH, max_hidden=4):
+    """Zero-padding of a narrow network onto the `width`-wide kernels.  Returns (padded_layers, index) with
+    theta_padded[index] = theta, or None when the network is not eligible (already `width` wide, wider, too deep).
+
+    The padding is exact, not an approximation: a padded neuron has zero incoming weights and bias, so it outputs
+    act(0) = 0 (tanh and sin) with zero tangents, its outgoing weights are zero, and every gradient entry that belongs
+    to padding is exactly zero (h_pad = 0 kills dW rows, hbar_pad = 0 kills dW columns and db) -- TF1 Adam leaves them
+    at zero.  Sums only gain exact-zero terms."""
+    hidden = layers[1:-1]
+    if not (1 <= len(hidden) <= max_hidden) or layers[-1] != 1 or layers[0] > 2:
+        return None
+    if any(w > width for w in hidden) or all(w == width for w in hidden):
+        return None
+    padded = [layers[0]] + [width] * len(hidden) + [1]
+    idx, o = [], 0
+    for l in range(len(layers) - 1):
+        i, j = layers[l], layers[l + 1]
+        I, J = padded[l], padded[l + 1]
+        idx += [o + r * J + c for r in range(i) for c in range(j)]
+        o += I * J
+        idx += [o + c for c in range(j)]
+        o += J
+    idx += [o + k for k in range(extra)]
+    return padded, np.asarray(idx, dtype=np.int64)

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _lib
 from .dist import Reducer, dist_info, shard_range
-from .init import n_params, xavier_init
+from .init import n_params, pad_plan, xavier_init
 from .testfcn import dTest_fcn, tables_1d
 
 
@@ -85,7 +85,12 @@ class _VPINNBase:
         self.device = device
         bk = {"auto": _lib.BACKEND_AUTO, "generic": _lib.BACKEND_GENERIC, "mfma": _lib.BACKEND_MFMA,
               "hip": _lib.BACKEND_AUTO}[backend]
-        self.h = _lib.Handle(self._pde, var_form, self._act, self.layers, lr=LR, lossb_weight=lossb_weight,
+        # Narrow networks (the reference defaults are 5 wide: P2:280, P3:46) are zero-padded onto the 20-wide MFMA kernels
+        # -- exact (init.pad_plan) -- unless the generic kernels are asked for; the library then sees a 20-wide network
+        # and this class maps parameters / gradients between the two layouts.
+        plan = None if backend == "generic" else pad_plan(self.layers, self._n_extra)
+        self._dev_layers, self._pad_idx = (plan if plan is not None else (self.layers, None))
+        self.h = _lib.Handle(self._pde, var_form, self._act, self._dev_layers, lr=LR, lossb_weight=lossb_weight,
                              V=V, device=device, backend=bk, scheme=scheme)
         if init_params is None:
             init_params = xavier_init(self.layers, seed, extra=[1.0] * self._n_extra)
@@ -100,8 +105,20 @@ class _VPINNBase:
             torch.cuda.set_device(device)
             self.h.set_stream(torch.cuda.current_stream().cuda_stream)
 
+    def _to_dev(self, theta):
+        """user parameter layout -> the layout the library holds (zero-padded for narrow networks)."""
+        theta = np.asarray(theta, dtype=np.float64).reshape(-1)
+        if self._pad_idx is None:
+            return theta
+        out = np.zeros(n_params(self._dev_layers, self._n_extra))
+        out[self._pad_idx] = theta
+        return out
+
+    def _from_dev(self, v):
+        return v if self._pad_idx is None else np.ascontiguousarray(np.asarray(v)[self._pad_idx])
+
     def _finish(self):
-        self.h.set_params(self._init_params)
+        self.h.set_params(self._to_dev(self._init_params))
         self.h.backend_in_use()   # assembles the device batches; raises if a requested backend is unavailable
         if self._dist:
             ptr, n = self.h.reduce_buffer()
@@ -232,11 +249,12 @@ class _VPINNBase:
     def loss_and_grad(self):
         """({loss, lossb, lossv}, d loss / d theta) at the current parameters (global over ranks)."""
         if not self._dist:
-            return self.h.loss_and_grad(True)
+            loss3, g = self.h.loss_and_grad(True)
+            return loss3, self._from_dev(g)
         self.h.forward_backward()
         t = self._reducer.allreduce()
         loss3 = self.h.read_loss()
-        return loss3, t[: self.h.num_params()].cpu().numpy()
+        return loss3, self._from_dev(t[: self.h.num_params()].cpu().numpy())
 
     def loss(self):
         if not self._dist:
@@ -246,10 +264,10 @@ class _VPINNBase:
         return self.h.read_loss()
 
     def get_params(self):
-        return self.h.get_params()
+        return self._from_dev(self.h.get_params())
 
     def set_params(self, theta):
-        self.h.set_params(theta)
+        self.h.set_params(self._to_dev(theta))
 
     def backend(self):
         return {_lib.BACKEND_GENERIC: "generic", _lib.BACKEND_MFMA: "mfma"}[self.h.backend_in_use()]
@@ -262,12 +280,15 @@ class _VPINNBase:
 
     def save_checkpoint(self, path):
         """Parameters + Adam moments + beta powers (.npz); the reference never saves weights."""
-        np.savez(path, state=self.h.get_state(), layers=np.asarray(self.layers), cls=type(self).__name__)
+        np.savez(path, state=self.h.get_state(), layers=np.asarray(self.layers), dev_layers=np.asarray(self._dev_layers),
+                 cls=type(self).__name__)
 
     def load_checkpoint(self, path):
         d = np.load(path, allow_pickle=False)
         if list(d["layers"]) != list(self.layers) or str(d["cls"]) != type(self).__name__:
             raise ValueError("checkpoint was written by a different model")
+        if "dev_layers" in d and list(d["dev_layers"]) != list(self._dev_layers):
+            raise ValueError("checkpoint was written with a different device layout (backend='generic' vs padded MFMA)")
         self.h.set_state(d["state"])
 
     def _predict(self, X):

@@ -193,7 +193,7 @@ def test_mfma_equals_generic_on_device():
 def test_mfma_unavailable_shape_raises():
     from hp_vpinns_amd import _lib
     with pytest.raises(_lib.HpvError):
-        _pair_2d("poisson2d_small", 1, layers=[2, 8, 8, 1], backend="mfma")
+        _pair_2d("poisson2d_small", 1, layers=[2, 24, 24, 1], backend="mfma")   # wider than the MFMA kernels
 
 
 def test_device_tanh_accuracy():
@@ -485,9 +485,19 @@ def test_reference_default_networks():
     assert a[13] == [2, 5, 5, 5, 1]
     th = theta0(a[13], 2)
     o, m = OracleVPINN2D(*a, init_params=th), VPINN2D(*a, init_params=th)
-    assert m.backend() == "generic"
+    assert m.backend() == "mfma" and m._dev_layers == [2, 20, 20, 20, 1]   # 5-wide net zero-padded onto the MFMA kernels
     _check_loss_grad(o, m)
     _check_traj(o, m, n=5)
+    mg = VPINN2D(*a, init_params=th, backend="generic")      # the same network on the generic kernels, unpadded
+    assert mg.backend() == "generic"
+    l3p, gp = VPINN2D(*a, init_params=th).loss_and_grad()
+    l3g, gg = mg.loss_and_grad()
+    assert gp.shape == gg.shape == th.shape and rel(gp, gg) < 1e-12 and rel(l3p, l3g) < 1e-13
+    m.h.step(40, False)                                      # padding stays exactly zero under training
+    full = m.h.get_params()
+    pad = np.ones(full.size, bool)
+    pad[m._pad_idx] = False
+    assert pad.sum() > 0 and np.all(full[pad] == 0.0)
     a = p3_args(gold("advdiff_default"))
     th = theta0(a[12], 3, extra=[1.0])
     o, m = OracleVPINNAdvDiff(*a, init_params=th), VPINNAdvDiff(*a, init_params=th)
