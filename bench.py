@@ -78,14 +78,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # (test hook: HPV_BENCH_ONE_GPU=1 runs every rank on cuda:0 with a gloo group -- the whole multi-rank flow, incl. the
+    #  in-library exchange, on a single-GPU box; throughput is then meaningless)
+    one_gpu = os.environ.get("HPV_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    red_dev = "cpu" if one_gpu else "cuda"
     if world > 1 or ("RANK" in os.environ and os.environ.get("HPV_FORCE_DIST") == "1"):
         # one process per GPU over RCCL; HPV_FORCE_DIST=1 under a 1-process torchrun exercises the same path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from hp_vpinns_amd.drivers import poisson2d
     from hp_vpinns_amd.init import xavier_init
@@ -107,7 +116,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -134,7 +143,7 @@ def main():
         tw = time.perf_counter()
         mw._step(kw, False)
         dist.barrier(); torch.cuda.synchronize()
-        tw = torch.tensor([time.perf_counter() - tw], dtype=torch.float64, device="cuda")
+        tw = torch.tensor([time.perf_counter() - tw], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         weak = {"elements": 256 * world, "elements_per_gpu": 256, "steps": kw, "it_per_s": kw / float(tw.item()),
                 "element_iterations_per_s": 256 * world * kw / float(tw.item()),
@@ -195,7 +204,9 @@ def main():
         "config": {"workload": "Poisson-2D hp-VPINN, 16x16 elements, 20x20 GLL quad/elem, 10x10 test fcns/elem, "
                                "MLP [2,20,20,20,1] tanh, var_form 1, 320 boundary pts, TF1 Adam (BASELINE config 4)",
                    "points": 102400, "residuals": 25600, "params": 921, "backend": model.backend(),
-                   "parallelism": "element-sharded dp%d" % world},
+                   "parallelism": "element-sharded dp%d" % world,
+                   "exchange": ("in-library p2p mailboxes over xGMI" if getattr(model, "_p2p", False)
+                                else ("rccl all-reduce (torch.distributed)" if world > 1 else "none"))},
         "loss_after": float(loss3[0]),
         "kernel_ms": ktime,
         "roofline": dict(roof(dom), projection_fused_into_reverse=proj_fused,

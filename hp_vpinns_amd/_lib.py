@@ -29,6 +29,7 @@ EXPORTS = [
     "hpv_kernel_time_ms", "hpv_bench_projection", "hpv_debug_activation", "hpv_get_state", "hpv_set_state",
     "hpv_assemble_rhs", "hpv_set_collocation", "hpv_gll_rule", "hpv_test_tables",
     "hpv_step_record", "hpv_history_reset", "hpv_history_read",
+    "hpv_p2p_export", "hpv_p2p_connect", "hpv_p2p_selftest", "hpv_p2p_disconnect",
 ]
 
 
@@ -101,6 +102,10 @@ def load():
     lib.hpv_gll_rule.argtypes = [h, C.c_int, _dp, _dp]
     lib.hpv_step_record.argtypes = [h, C.c_int, _dp, _dp]
     lib.hpv_history_reset.argtypes = [h]
+    lib.hpv_p2p_export.argtypes = [h, C.c_int, C.c_int, C.c_char_p]
+    lib.hpv_p2p_connect.argtypes = [h, C.c_char_p]
+    lib.hpv_p2p_selftest.argtypes = [h, _dp, C.c_size_t, C.POINTER(C.c_int)]
+    lib.hpv_p2p_disconnect.argtypes = [h]
     lib.hpv_history_read.argtypes = [h, C.c_int, _dp, _dp]
     lib.hpv_test_tables.argtypes = [h, C.c_int, _dp, C.c_int, _dp]
     _lib = lib
@@ -298,6 +303,22 @@ class Handle:
         out, eps = np.empty((int(n), 3)), np.empty(int(n))
         self._chk(self.lib.hpv_history_read(self._h, int(n), _p(out), _p(eps)))
         return out, eps
+
+    def p2p_export(self, world, rank):
+        buf = C.create_string_buffer(128)
+        self._chk(self.lib.hpv_p2p_export(self._h, int(world), int(rank), buf))
+        return buf.raw
+
+    def p2p_connect(self, handles):
+        self._chk(self.lib.hpv_p2p_connect(self._h, bytes(handles)))
+
+    def p2p_selftest(self, n):
+        out, flag = np.empty(int(n)), C.c_int(0)
+        self._chk(self.lib.hpv_p2p_selftest(self._h, _p(out), out.size, C.byref(flag)))
+        return out, int(flag.value)
+
+    def p2p_disconnect(self):
+        self._chk(self.lib.hpv_p2p_disconnect(self._h))
 
     def gll_rule(self, q):
         """(nodes, weights) of the q-point Gauss-Lobatto-Legendre rule, computed on the device."""

@@ -87,6 +87,14 @@ struct hpv_ctx {
     double *d_fcol = nullptr, *d_col_part = nullptr;
     int n_col = 0;
     double* d_jac = nullptr;   // |J_e| of the owned elements (RHS assembly, hpv_assemble_rhs)
+    // in-library exchange of the packed buffer between the ranks of a node (hpv_p2p_*)
+    P2PArgs pp{};
+    bool p2p_on = false;
+    double* d_inbox = nullptr;
+    unsigned long long* d_flag = nullptr;
+    unsigned long long* d_p2p_counter = nullptr;
+    int* d_p2p_err = nullptr;
+    void* p2p_maps[2 * HPV_P2P_MAX] = {};
     double* d_upart = nullptr; // partial residual sums of the row-split projection (few tall elements)
     int proj_split = 1;        // workgroups per element there; loss_e / deps_e hold n_elem * proj_split entries
     // timing
@@ -100,6 +108,8 @@ struct hpv_ctx {
     hipGraphExec_t g_step = nullptr;
     hipGraphExec_t g_stepK = nullptr;    // HPV_GRAPH_ITERS iterations per replay (fewer inter-graph gaps)
 };
+
+static void p2p_release(hpv_ctx* h);
 
 namespace {
 
@@ -454,6 +464,19 @@ int enqueue_pinn_pass(hpv_ctx* h, bool backward, bool fuse_adam) {
     return 0;
 }
 
+// A pass whose packed buffer is made global: with the in-library exchange connected the reduced buffer (and, for a
+// training iteration, the Adam update) follows the finalize kernel on the same stream; otherwise the plain pass.
+int enqueue_pass_x(hpv_ctx* h, bool backward, bool fuse_adam) {
+    if (!h->p2p_on) return enqueue_pass(h, backward, fuse_adam);
+    int rc = enqueue_pass(h, backward, false);
+    if (rc) return rc;
+    const AdamArgs ad = adam_args(h);
+    launch_p2p_exchange(h->pp, h->d_RB, (backward && fuse_adam) ? &ad : nullptr, h->P, h->Ptot, h->stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, -2, "exchange launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 #define HPV_GRAPH_ITERS 8
 void drop_graph(hpv_ctx* h) {
     if (h->g_step) { (void)hipGraphExecDestroy(h->g_step); h->g_step = nullptr; }
@@ -470,7 +493,7 @@ int build_step_graph(hpv_ctx* h, int iters, hipGraphExec_t* out) {
     hipGraph_t graph = nullptr;
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     h->side_active = true;
-    for (int k = 0; k < iters && !rc; ++k) rc = enqueue_pass(h, true, true);   // forward .. finalize (+ fused Adam)
+    for (int k = 0; k < iters && !rc; ++k) rc = enqueue_pass_x(h, true, true);   // forward .. finalize (+ fused Adam / exchange)
     h->side_active = false;
     hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -592,6 +615,7 @@ void hpv_destroy(hpv_handle h) {
     if (h->d_col_part) (void)hipFree(h->d_col_part);
     if (h->d_jac) (void)hipFree(h->d_jac);
     if (h->d_upart) (void)hipFree(h->d_upart);
+    p2p_release(h);
     free_batch(h->var); free_batch(h->data); free_batch(h->edge); free_batch(h->pred);
     double* ptrs[] = {h->d_wtx, h->d_wty, h->d_edge_dphi, h->d_coef, h->d_edge_coef, h->d_F, h->d_R, h->d_loss_e,
                       h->d_deps_e, h->d_udata, h->d_data_part, h->d_theta, h->d_m, h->d_v, h->d_state, h->d_RB, h->d_hist};
@@ -853,7 +877,7 @@ int hpv_read_loss(hpv_handle h, double* loss3) {
 
 int hpv_loss_and_grad(hpv_handle h, double* loss3, double* grad) {
     if (!h) return -1;
-    int rc = grad ? enqueue_pass(h, true) : enqueue_pass(h, false);
+    int rc = enqueue_pass_x(h, grad != nullptr, false);
     if (rc) return rc;
     if (loss3 && (rc = hpv_read_loss(h, loss3))) return rc;
     if (grad) {
@@ -876,8 +900,17 @@ static int enqueue_iterations(hpv_ctx* h, int n_iters) {
         for (; it < n_iters; ++it) HIPCHK(h, hipGraphLaunch(h->g_step, h->stream));
     } else {
         for (int it = 0; it < n_iters; ++it)
-            if ((rc = enqueue_pass(h, true, true))) return rc;
+            if ((rc = enqueue_pass_x(h, true, true))) return rc;
     }
+    return 0;
+}
+
+// after a synchronisation point: did an exchange give up waiting for a peer?
+static int p2p_check(hpv_ctx* h) {
+    if (!h->p2p_on) return 0;
+    int err = 0;
+    HIPCHK(h, hipMemcpy(&err, h->d_p2p_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) return fail(h, -5, "in-library exchange: a peer did not arrive (rank %d of %d)", h->pp.rank, h->pp.world);
     return 0;
 }
 
@@ -886,12 +919,12 @@ int hpv_step(hpv_handle h, int n_iters, double* loss3_after) {
     int rc;
     if ((rc = enqueue_iterations(h, n_iters))) return rc;
     if (loss3_after) {
-        if ((rc = enqueue_pass(h, false))) return rc;
+        if ((rc = enqueue_pass_x(h, false, false))) return rc;
         if ((rc = hpv_read_loss(h, loss3_after))) return rc;
     } else {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
-    return 0;
+    return p2p_check(h);
 }
 
 // ---- loss history (the reference records the loss after every update with a second forward pass, P2:243-244; the
@@ -942,7 +975,7 @@ int hpv_step_record(hpv_handle h, int n_iters, double* loss3_hist, double* eps_h
         done += c;
     }
     if (n_iters > 0) {   // the state after the last update: one forward pass
-        if ((rc = enqueue_pass(h, false))) return rc;
+        if ((rc = enqueue_pass_x(h, false, false))) return rc;
         if ((rc = hpv_read_loss(h, loss3_hist + (size_t)3 * (n_iters - 1)))) return rc;
         if (eps_hist) {
             eps_hist[n_iters - 1] = 0.0;
@@ -1064,6 +1097,89 @@ int hpv_test_tables(hpv_handle h, int ntest, const double* xi, int q, double* ta
     }
     (void)hipFree(d);
     return rc;
+}
+
+// ---- in-library exchange (multi-GPU, one process per GPU on one node) ----
+static void p2p_release(hpv_ctx* h) {
+    for (void*& m : h->p2p_maps) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
+    if (h->d_inbox) (void)hipFree(h->d_inbox);
+    if (h->d_flag) (void)hipFree(h->d_flag);
+    if (h->d_p2p_counter) (void)hipFree(h->d_p2p_counter);
+    if (h->d_p2p_err) (void)hipFree(h->d_p2p_err);
+    h->d_inbox = nullptr; h->d_flag = nullptr; h->d_p2p_counter = nullptr; h->d_p2p_err = nullptr;
+    h->p2p_on = false;
+}
+
+int hpv_p2p_export(hpv_handle h, int world, int rank, void* handles128) {
+    if (!h || !handles128 || world < 1 || world > HPV_P2P_MAX || rank < 0 || rank >= world) return -1;
+    if (!h->have_params) return fail(h, -3, "hpv_set_params has not been called");
+    p2p_release(h);
+    drop_graph(h);
+    const int n = h->Ptot + 4;
+    const size_t nb = (size_t)2 * world * n * sizeof(double), fb = (size_t)2 * world * sizeof(unsigned long long);
+    // uncached (fine-grained) device memory: peers write it over xGMI while this rank polls it
+    if (hipExtMallocWithFlags((void**)&h->d_inbox, nb, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); HIPCHK(h, hipMalloc((void**)&h->d_inbox, nb)); }
+    if (hipExtMallocWithFlags((void**)&h->d_flag, fb, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); HIPCHK(h, hipMalloc((void**)&h->d_flag, fb)); }
+    HIPCHK(h, hipMalloc((void**)&h->d_p2p_counter, sizeof(unsigned long long)));
+    HIPCHK(h, hipMalloc((void**)&h->d_p2p_err, sizeof(int)));
+    HIPCHK(h, hipMemset(h->d_inbox, 0, nb));
+    HIPCHK(h, hipMemset(h->d_flag, 0, fb));
+    HIPCHK(h, hipMemset(h->d_p2p_counter, 0, sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(h->d_p2p_err, 0, sizeof(int)));
+    HIPCHK(h, hipDeviceSynchronize());
+    hipIpcMemHandle_t hi, hf;
+    HIPCHK(h, hipIpcGetMemHandle(&hi, h->d_inbox));
+    HIPCHK(h, hipIpcGetMemHandle(&hf, h->d_flag));
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    memcpy(handles128, &hi, 64);
+    memcpy((char*)handles128 + 64, &hf, 64);
+    h->pp = P2PArgs{};
+    h->pp.world = world; h->pp.rank = rank; h->pp.n = n;
+    h->pp.counter = h->d_p2p_counter; h->pp.err = h->d_p2p_err;
+    return 0;
+}
+
+int hpv_p2p_connect(hpv_handle h, const void* handles) {
+    if (!h || !handles || !h->d_inbox) return -1;
+    const int W = h->pp.world, me = h->pp.rank;
+    for (int r = 0; r < W; ++r) {
+        if (r == me) { h->pp.inbox[r] = h->d_inbox; h->pp.flag[r] = h->d_flag; continue; }
+        hipIpcMemHandle_t hi, hf;
+        memcpy(&hi, (const char*)handles + (size_t)r * 128, 64);
+        memcpy(&hf, (const char*)handles + (size_t)r * 128 + 64, 64);
+        void *pi = nullptr, *pf = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&pi, hi, hipIpcMemLazyEnablePeerAccess);
+        if (e == hipSuccess) e = hipIpcOpenMemHandle(&pf, hf, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { (void)hipGetLastError(); p2p_release(h); return fail(h, -2, "hipIpcOpenMemHandle (rank %d): %s", r, hipGetErrorString(e)); }
+        h->p2p_maps[2 * r] = pi; h->p2p_maps[2 * r + 1] = pf;
+        h->pp.inbox[r] = (double*)pi; h->pp.flag[r] = (unsigned long long*)pf;
+    }
+    drop_graph(h);
+    h->p2p_on = true;
+    return 0;
+}
+
+int hpv_p2p_disconnect(hpv_handle h) {
+    if (!h) return -1;
+    (void)hipStreamSynchronize(h->stream);
+    drop_graph(h);
+    p2p_release(h);
+    return 0;
+}
+
+// Known-answer exchange: RB[i] = (rank + 1) + 1e-3 i on every rank -> out[i] = W (W + 1) / 2 + W 1e-3 i; status = the
+// device-side timeout flag.  Collective: every rank must call it the same number of times.
+int hpv_p2p_selftest(hpv_handle h, double* out, size_t n, int* timed_out) {
+    if (!h || !out || !timed_out || !h->p2p_on || n != (size_t)h->pp.n) return -1;
+    std::vector<double> v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = (double)(h->pp.rank + 1) + 1e-3 * (double)i;
+    int rc = upload(h, h->d_RB, v.data(), n);
+    if (rc) return rc;
+    launch_p2p_exchange(h->pp, h->d_RB, nullptr, h->P, h->Ptot, h->stream);
+    HIPCHK(h, hipMemcpyAsync(out, h->d_RB, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(timed_out, h->d_p2p_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
 }
 
 int hpv_get_residuals(hpv_handle h, double* R, size_t n) {

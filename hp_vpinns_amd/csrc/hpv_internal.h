@@ -61,6 +61,18 @@ struct AdamArgs {
 };
 #define HPV_HIST_CAP 4096
 
+// One-shot exchange of the packed buffer between the ranks of one node (multi-GPU path without a collective library
+// in the iteration): every rank owns a mailbox [2 parities][world][n] doubles + arrival counters [2][world], mapped
+// into every peer through hipIpc; see k_p2p_exchange (kernels_generic.hip).
+#define HPV_P2P_MAX 8
+struct P2PArgs {
+    double* inbox[HPV_P2P_MAX];                 // inbox[r] = rank r's mailbox as mapped here (own rank: the local pointer)
+    unsigned long long* flag[HPV_P2P_MAX];      // flag[r]  = rank r's arrival counters
+    unsigned long long* counter;                // exchanges done so far (local)
+    int* err;                                   // set to 1 when a peer did not arrive within the spin budget
+    int world, rank, n;
+};
+
 // ---- kernel launchers (kernels_generic.hip) ----
 void launch_mlp_fwd_generic(const NetDesc& nd, const double* theta, const double* X, double* ACT, double* OUT, long N,
                             int save_act, hipStream_t s);
@@ -78,6 +90,7 @@ void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, i
                      int n_data_part, double lossb_weight, int n_data, int P, int has_eps, double* RB, int write_grad,
                      const AdamArgs* fused_adam, hipStream_t s);
 void launch_adam(const AdamArgs& ad, const double* RB, int P, int Ptot, hipStream_t s);
+void launch_p2p_exchange(const P2PArgs& pp, double* RB, const AdamArgs* adam_or_null, int P, int Ptot, hipStream_t s);
 int adam_state_doubles(int P);
 void launch_debug_act(int act, const double* x, int n, double* a, double* a1, double* ref, hipStream_t s);
 void launch_gll_rule(int Q, double* x, double* w, hipStream_t s);

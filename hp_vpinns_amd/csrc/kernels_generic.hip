@@ -584,6 +584,70 @@ __global__ void __launch_bounds__(1024) k_adam(AdamArgs ad, const double* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One-shot all-reduce(sum) of the packed buffer over peer-mapped mailboxes, fused with the TF1 Adam update
+// (multi-GPU iteration = forward, reverse, finalize, THIS; no collective library call inside the iteration).
+//   exchange k, parity p = k & 1:   write RB into inbox[r][p][rank] of every rank r (own included),
+//   system-scope fence, release-store k+1 into flag[r][p][rank]; wait until own flag[p][r] >= k+1 for every r;
+//   RB = sum over r of inbox[own][p][r] in rank order (identical bits on every rank).
+// Two parities make the mailbox safe: a rank can only start exchange k+2 after every peer has contributed to k+1,
+// i.e. after every peer has finished reading exchange k.  The wait is bounded (err flag instead of a hang).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_p2p_exchange(P2PArgs pp, double* __restrict__ RB, AdamArgs ad, int P, int Ptot,
+                                                      int ncopies) {
+    const unsigned long long k = *pp.counter;
+    const int par = (int)(k & 1ULL), W = pp.world, n = pp.n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double v = RB[i];
+        for (int r = 0; r < W; ++r)
+            __hip_atomic_store(pp.inbox[r] + ((long)par * W + pp.rank) * n + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if ((int)threadIdx.x < W)
+        __hip_atomic_store(pp.flag[threadIdx.x] + par * W + pp.rank, k + 1ULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((int)threadIdx.x < W) {
+        const unsigned long long* f = pp.flag[pp.rank] + par * W + threadIdx.x;
+        long spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < k + 1ULL) {
+            if (++spins > (1L << 24)) { *pp.err = 1; break; }    // ~ a second: a peer is gone; do not hang the device
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    const double* mine = pp.inbox[pp.rank] + (long)par * W * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double sum = 0.0;
+        for (int r = 0; r < W; ++r) sum += __hip_atomic_load(mine + (long)r * n + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        RB[i] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *pp.counter = k + 1ULL;
+    if (!ad.theta) return;
+    // ---- TF1 Adam on the reduced gradient (same as k_adam) ----
+    const double b1p = ad.state[0], b2p = ad.state[1];
+    if (threadIdx.x == 0 && ad.hist) {
+        const int i = *ad.hist_idx;
+        if (i < ad.hist_cap) {
+            ad.hist[4 * i] = RB[Ptot]; ad.hist[4 * i + 1] = RB[Ptot + 1]; ad.hist[4 * i + 2] = RB[Ptot + 2];
+            ad.hist[4 * i + 3] = Ptot > P ? ad.theta[P] : 0.0;
+        }
+        *ad.hist_idx = i + 1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Ptot; i += blockDim.x) adam_update(ad, i, RB[i], b1p, b2p);
+    __syncthreads();
+    for (int c = threadIdx.x; c < ncopies; c += blockDim.x) {
+        ad.state[2 * c] *= ad.b1;
+        ad.state[2 * c + 1] *= ad.b2;
+    }
+}
+void launch_p2p_exchange(const P2PArgs& pp, double* RB, const AdamArgs* adam_or_null, int P, int Ptot, hipStream_t s) {
+    AdamArgs ad{};
+    if (adam_or_null) ad = *adam_or_null;
+    hipLaunchKernelGGL(k_p2p_exchange, dim3(1), dim3(1024), 0, s, pp, RB, ad, P, Ptot, adam_state_doubles(P) / 2);
+}
+
 void launch_adam(const AdamArgs& ad, const double* RB, int P, int Ptot, hipStream_t s) {
     hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, s, ad, RB, P, Ptot, adam_state_doubles(P) / 2);
 }

@@ -100,10 +100,11 @@ class _VPINNBase:
         self._reducer = None
         self._dist_warm = False
         self._dist_graphs = {}
+        self._p2p = False      # in-library exchange connected (multi-GPU without a collective call per iteration)
+        self._coll = False     # multi-GPU through torch.distributed collectives (the fallback)
         if self._dist:
             import torch
             torch.cuda.set_device(device)
-            self.h.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def _to_dev(self, theta):
         """user parameter layout -> the layout the library holds (zero-padded for narrow networks)."""
@@ -121,13 +122,57 @@ class _VPINNBase:
         self.h.set_params(self._to_dev(self._init_params))
         self.h.backend_in_use()   # assembles the device batches; raises if a requested backend is unavailable
         if self._dist:
-            ptr, n = self.h.reduce_buffer()
-            self._reducer = Reducer(ptr, n, self.device, force=True)
+            if os.environ.get("HPV_P2P", "1") != "0" and 1 < self.world <= 8:
+                self._p2p = self._connect_p2p()
+            if not self._p2p:
+                import torch
+                self._coll = True
+                self.h.set_stream(torch.cuda.current_stream().cuda_stream)
+                ptr, n = self.h.reduce_buffer()
+                self._reducer = Reducer(ptr, n, self.device, force=True)
+
+    def _connect_p2p(self):
+        """Set up the in-library exchange (include/hpvpinn.h, hpv_p2p_*): all-gather the ranks' IPC mailbox handles,
+        map them, and verify three known-answer exchanges on every rank.  Any failure on any rank -- no peer access,
+        IPC refused, a peer not arriving -- makes every rank fall back to the torch.distributed all-reduce."""
+        import torch.distributed as dist
+
+        def agree(flag):
+            flags = [None] * self.world
+            dist.all_gather_object(flags, bool(flag))
+            return all(flags)
+
+        try:
+            mine = self.h.p2p_export(self.world, self.rank)
+        except _lib.HpvError:
+            mine = None
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine)
+        ok = all(hd is not None for hd in handles)
+        if ok:
+            try:
+                self.h.p2p_connect(b"".join(handles))
+            except _lib.HpvError:
+                ok = False
+        if not agree(ok):
+            if mine is not None:
+                self.h.p2p_disconnect()
+            return False
+        n = self.h.reduce_buffer()[1]
+        expect = self.world * (self.world + 1) / 2 + self.world * 1e-3 * np.arange(n)
+        good = True
+        for _ in range(3):                      # both mailbox parities and a re-use
+            out, timed_out = self.h.p2p_selftest(n)
+            good = good and not timed_out and np.abs(out - expect).max() < 1e-12
+        if not agree(good):
+            self.h.p2p_disconnect()
+            return False
+        return True
 
     # -- iteration pieces -----------------------------------------------------------------
     def _step(self, n, read_loss):
         """n Adam iterations; returns loss3 evaluated after the last update if read_loss."""
-        if not self._dist:
+        if not self._coll:
             return self.h.step(n, read_loss)
         left = n
         if n >= 4 and os.environ.get("HPV_DIST_GRAPH", "1") != "0":
@@ -155,7 +200,7 @@ class _VPINNBase:
         """Do every one-off set-up a later `_step(n)` would otherwise do lazily (multi-GPU: communicator warm-up through a
         loss evaluation -- no parameter update -- and capture of the iteration graphs for the given step counts), so that
         a timed region contains iterations only.  Single-GPU handles capture their graphs at the first step."""
-        if not self._dist or os.environ.get("HPV_DIST_GRAPH", "1") == "0":
+        if not self._coll or os.environ.get("HPV_DIST_GRAPH", "1") == "0":
             return
         if not self._dist_warm:
             self.h.eval_loss()
@@ -207,7 +252,7 @@ class _VPINNBase:
         k is what the forward pass of iteration k+1 computes anyway, and the device keeps a history of it
         (hpv_step_record / hpv_history_*): per-iteration recording costs one extra forward pass per call instead of one
         per iteration."""
-        if not self._dist:
+        if not self._coll:
             return self.h.step_record(n)
         out, eps = np.empty((n, 3)), np.zeros(n)
         done = 0
@@ -248,7 +293,7 @@ class _VPINNBase:
 
     def loss_and_grad(self):
         """({loss, lossb, lossv}, d loss / d theta) at the current parameters (global over ranks)."""
-        if not self._dist:
+        if not self._coll:
             loss3, g = self.h.loss_and_grad(True)
             return loss3, self._from_dev(g)
         self.h.forward_backward()
@@ -257,7 +302,7 @@ class _VPINNBase:
         return loss3, self._from_dev(t[: self.h.num_params()].cpu().numpy())
 
     def loss(self):
-        if not self._dist:
+        if not self._coll:
             return self.h.loss_and_grad(False)[0]
         self.h.eval_loss()
         self._reducer.allreduce()

@@ -120,6 +120,18 @@ int hpv_history_read(hpv_handle h, int n, double* loss3_hist, double* eps_hist);
 int hpv_forward_backward(hpv_handle h);
 int hpv_reduce_buffer(hpv_handle h, void** dev_ptr, size_t* n_doubles);
 int hpv_apply_adam(hpv_handle h);
+/* In-library exchange for the multi-GPU path (one process per GPU on one node), instead of handing the packed buffer to a
+ * collective library every iteration: each rank owns a mailbox that every peer maps through hipIpc; one kernel per
+ * iteration writes the buffer into all mailboxes over xGMI, waits for the peers' contributions (bounded), sums them in
+ * rank order -- bitwise identical on all ranks -- and applies the Adam update.  After hpv_p2p_connect, hpv_step /
+ * hpv_step_record / hpv_loss_and_grad are collective calls: every rank must issue the same sequence.
+ *   hpv_p2p_export  : allocate the mailbox, return its two 64-byte IPC handles (handles128);
+ *   hpv_p2p_connect : handles = [world][128], the exports of all ranks in rank order (all-gathered by the caller);
+ *   hpv_p2p_selftest: known-answer exchange (collective); out[i] must equal W(W+1)/2 + W*1e-3*i, *timed_out 0. */
+int hpv_p2p_export(hpv_handle h, int world, int rank, void* handles128);
+int hpv_p2p_connect(hpv_handle h, const void* handles);
+int hpv_p2p_selftest(hpv_handle h, double* out, size_t n, int* timed_out);
+int hpv_p2p_disconnect(hpv_handle h);
 int hpv_eval_loss(hpv_handle h);            /* forward only -> same packed buffer slots [P], [P+1] */
 int hpv_read_loss(hpv_handle h, double* loss3); /* sync + copy {loss, lossb, lossv} from the buffer   */
 int hpv_sync(hpv_handle h);

@@ -658,3 +658,54 @@ def test_fused_projection_reverse_config4_element_shape(nex, ney):
     for _ in range(2):                # duplicate projections by the workgroups of an element: results must be reproducible
         l3b, gb = m.loss_and_grad()
         assert np.array_equal(gb, gf) and np.array_equal(l3b, l3f)
+
+
+def _p2p_worker(rank, world, port, out_path):
+    """One rank of the in-library exchange test: its own process, both ranks on cuda:0 (IPC works within a device)."""
+    import os
+    import pickle
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hp_vpinns_amd.drivers import poisson2d
+        from hp_vpinns_amd.init import xavier_init
+        s = poisson2d.setup(N_el_x=4, N_el_y=6, N_test_x=10, N_test_y=10, N_quad=20, N_bound=13, with_test_grid=False)
+        L = [2, 20, 20, 20, 1]
+        m = poisson2d.build_model(s, L, init_params=xavier_init(L, 5), device=0)
+        res = {"p2p": m._p2p, "world": m.world}
+        if m._p2p:
+            l3, g = m.loss_and_grad()
+            hist = m._step_record(9)[0]
+            l3b = m._step(13, True)
+            res.update(l3=l3, g=g, hist=hist, l3b=l3b, theta=m.get_params())
+            m._step(1500, False)                 # many back-to-back exchanges (graph replays, both mailbox parities)
+            res.update(l3c=m.loss(), theta_long=m.get_params())
+        with open(f"{out_path}.{rank}", "wb") as f:
+            pickle.dump(res, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_in_library_exchange_two_ranks_on_one_gpu(tmp_path):
+    """The multi-GPU iteration without a collective library call: two processes (two element shards) exchange the packed
+    buffer through IPC-mapped mailboxes and apply Adam in the same kernel.  Both ranks must hold bit-identical
+    parameters, and losses / gradient / trajectory must equal the single-process model (up to the summation order)."""
+    import pickle
+    import torch.multiprocessing as mp
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    out = str(tmp_path / "p2p")
+    mp.spawn(_p2p_worker, args=(2, 29541, out), nprocs=2, join=True)
+    r0, r1 = (pickle.load(open(f"{out}.{r}", "rb")) for r in (0, 1))
+    assert r0["p2p"] and r1["p2p"] and r0["world"] == 2, "the in-library exchange did not connect"
+    assert np.array_equal(r0["theta"], r1["theta"]) and np.array_equal(r0["hist"], r1["hist"]) and np.array_equal(r0["g"], r1["g"])
+    assert np.array_equal(r0["theta_long"], r1["theta_long"]) and np.array_equal(r0["l3c"], r1["l3c"]) and np.all(np.isfinite(r0["theta_long"]))
+    s = poisson2d.setup(N_el_x=4, N_el_y=6, N_test_x=10, N_test_y=10, N_quad=20, N_bound=13, with_test_grid=False)
+    L = [2, 20, 20, 20, 1]
+    m = poisson2d.build_model(s, L, init_params=xavier_init(L, 5))
+    l3, g = m.loss_and_grad()
+    hist = m._step_record(9)[0]
+    l3b = m._step(13, True)
+    assert rel(r0["l3"], l3) < 1e-12 and rel(r0["g"], g) < 1e-11
+    assert rel(r0["hist"], hist) < 1e-9 and rel(r0["l3b"], l3b) < 1e-9 and rel(r0["theta"], m.get_params()) < 1e-9
