@@ -156,3 +156,47 @@ def test_exact_solution_annihilates_the_1d_variational_residual(tag, vf):
     zero_net = (g["F_ext_total"] ** 2).mean(axis=(1, 2)).sum()
     assert lossv < 1e-6 * zero_net, (vf, lossv, zero_net)
     assert lossb < 1e-25
+
+
+# ---- two independent restatements: autograd double-backward vs closed-form Taylor channels + hand-derived
+#      reverse pass (oracle/closed_form.py, the mathematics of the HIP kernels) must agree to round-off ----
+def _rel(a, b):
+    a, b = np.asarray(a, float).ravel(), np.asarray(b, float).ravel()
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("vf", [0, 1, 2])
+def test_closed_form_equals_autograd_poisson2d(vf):
+    from oracle import closed_form as CF
+    a = p2_args(gold("poisson2d_small"))
+    L = a[13]
+    th = theta0(L, 5)
+    l3, g = O.OracleVPINN2D(*a, var_form=vf, init_params=th).loss_and_grad()
+    q = int(round(np.sqrt(a[4].shape[0])))
+    l3c, gc = CF.loss_and_grad_2d(th, L, "poisson2d", vf, a[4][:q, 0], a[5][:q, 0], a[8], a[9], a[10][0][0], a[10][1][0],
+                                  a[7], a[0], a[1], 10.0)
+    assert _rel(l3c, l3) < 1e-13 and _rel(gc, g) < 1e-12
+
+
+@pytest.mark.parametrize("vf", [1, 2, 3])
+def test_closed_form_equals_autograd_poisson1d(vf):
+    from oracle import closed_form as CF
+    a = p1_args(gold("poisson1d_small"))
+    L = a[8]
+    th = theta0(L, 11)
+    l3, g = O.OracleVPINN1D(*a, var_form=vf, init_params=th).loss_and_grad()
+    l3c, gc = CF.loss_and_grad_1d(th, L, vf, a[2][:, 0], a[3][:, 0], a[5], a[4].shape[1], a[4], a[0], a[1], 1.0)
+    assert _rel(l3c, l3) < 1e-13 and _rel(gc, g) < 1e-11
+
+
+@pytest.mark.parametrize("vf", [0, 1])
+def test_closed_form_equals_autograd_advdiff(vf):
+    from oracle import closed_form as CF
+    a = p3_args(gold("advdiff_small"))
+    L = a[12]
+    th = theta0(L, 9, extra=[0.7])
+    l3, g = O.OracleVPINNAdvDiff(*a, var_form=vf, init_params=th).loss_and_grad()
+    q = int(a[5].size)
+    l3c, gc = CF.loss_and_grad_2d(th, L, "advdiff", vf, a[3][:q, 0], a[4][:q, 0], a[7], a[8], a[9][0][0], a[9][1][0], None,
+                                  a[0], a[1], 10.0, V=1.0)
+    assert _rel(l3c, l3) < 1e-13 and _rel(gc, g) < 1e-12          # the last entry is d loss / d epsilon
