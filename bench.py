@@ -128,6 +128,13 @@ def main():
     ktime = {name: model.h.kernel_time_ms(i)[0] for i, name in enumerate(("mlp_fwd", "project", "mlp_bwd"))}
     model.h.enable_timing(False)
     loss3 = model.loss()
+    # the L2-error half of the metric, on a 101 x 101 grid of the exact solution, at the parameters reached after all the
+    # iterations above (a few thousand Adam steps from the Xavier start: far from converged, see profiles/r01_convergence.txt)
+    import numpy as np
+    gx = np.linspace(-1, 1, 101)
+    Xt = np.stack(np.meshgrid(gx, gx), -1).reshape(-1, 2)
+    rel_l2 = model.rel_l2_error(Xt, poisson2d.u_ext(Xt[:, 0:1], Xt[:, 1:2]))
+    n_its_done = args.warmup + args.steps + nt
 
     # ---- weak-scaling probe (multi-GPU only, reported beside the headline number): every rank keeps a full
     #      config-4 shard (256 elements), i.e. the job solves a 16 x 16N-element problem; shows what the exchange costs
@@ -208,6 +215,8 @@ def main():
                    "exchange": ("in-library p2p mailboxes over xGMI" if getattr(model, "_p2p", False)
                                 else ("rccl all-reduce (torch.distributed)" if world > 1 else "none"))},
         "loss_after": float(loss3[0]),
+        "rel_l2_error": {"value": rel_l2, "after_iterations": n_its_done, "grid": "101x101",
+                         "note": "50 001 iterations reach 4.6e-3 (profiles/r01_convergence.txt)"},
         "kernel_ms": ktime,
         "roofline": dict(roof(dom), projection_fused_into_reverse=proj_fused,
                          note="dominant kernel; algorithmic bytes = activation store (1120 B/point) + coordinates + channels "
