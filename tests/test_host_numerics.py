@@ -116,3 +116,27 @@ def test_advdiff_driver_setup_matches_reference(tag, kw):
     X, T = np.meshgrid(g["uext_x"], g["uext_t"])
     _close(advdiff.u_ext(X, T), g["uext_grid"], 1e-13)     # the 801-term Fourier series (P3:416-445)
     assert abs(advdiff.epsilon - float(g["epsilon_exact"])) < 1e-16
+
+
+def test_zero_padding_of_a_narrow_network_is_exact():
+    """init.pad_plan: a 5-wide network (reference default, P2:280) zero-padded onto 20-wide layers has the same loss, and
+    its gradient restricted to the original entries equals the original gradient while every padding entry is exactly 0
+    (checked with the CPU oracle; on the GPU the classes use this to run narrow networks on the MFMA kernels)."""
+    from cases import gold, p2_args, theta0
+    from hp_vpinns_amd.init import n_params, pad_plan
+    from oracle import vpinn_oracle as O
+    a = list(p2_args(gold("poisson2d_small"), layers=[2, 5, 7, 1]))
+    th = theta0(a[13], 3)
+    padded_layers, idx = pad_plan(a[13])
+    assert padded_layers == [2, 20, 20, 1] and idx.size == th.size == n_params(a[13])
+    thp = np.zeros(n_params(padded_layers))
+    thp[idx] = th
+    l3, g = O.OracleVPINN2D(*a, init_params=th).loss_and_grad()
+    a[13] = padded_layers
+    l3p, gp = O.OracleVPINN2D(*a, init_params=thp).loss_and_grad()
+    assert np.abs(np.array(l3p) - np.array(l3)).max() < 1e-13 * abs(l3[0])
+    assert np.abs(gp[idx] - g).max() < 1e-13 * np.abs(g).max()
+    pad = np.ones(thp.size, bool)
+    pad[idx] = False
+    assert pad.sum() == thp.size - th.size and np.all(gp[pad] == 0.0)
+    assert pad_plan([2, 20, 20, 1]) is None and pad_plan([2, 24, 1]) is None and pad_plan([2, 5, 5, 5, 5, 5, 1]) is None
