@@ -140,3 +140,38 @@ def test_zero_padding_of_a_narrow_network_is_exact():
     pad[idx] = False
     assert pad.sum() == thp.size - th.size and np.all(gp[pad] == 0.0)
     assert pad_plan([2, 20, 20, 1]) is None and pad_plan([2, 24, 1]) is None and pad_plan([2, 5, 5, 5, 5, 5, 1]) is None
+
+
+def test_recorded_run_indices_and_stop_without_a_device():
+    """vpinn._VPINNBase._recorded_run: which iterations of a chunk are recording iterations (index % 10 == 0), where the
+    run stops (first recorded loss below the threshold) and that the state is rolled back and re-run to exactly that
+    iteration -- with the device replaced by a stub."""
+    from hp_vpinns_amd.vpinn import _VPINNBase
+
+    class Stub(_VPINNBase):
+        def __init__(self, losses):
+            self.losses, self.calls = np.asarray(losses, float), []
+
+            class H:
+                def get_state(s):
+                    return "state"
+
+                def set_state(s, st):
+                    self.calls.append(("set_state", st))
+            self.h = H()
+
+        def _step_record(self, n):
+            self.calls.append(("record", n))
+            return np.stack([self.losses[:n], 0 * self.losses[:n], self.losses[:n]], 1), np.zeros(n)
+
+        def _step(self, n, read_loss):
+            self.calls.append(("step", n))
+
+    m = Stub(np.linspace(10, 1, 30))
+    recs, stop = m._recorded_run(7, 30, 0.0)                 # iterations 7..36: recording ones are 10, 20, 30
+    assert [r[0] for r in recs] == [10, 20, 30] and stop is None and m.calls == [("record", 30)]
+    assert [float(r[1][0]) for r in recs] == [float(m.losses[k]) for k in (3, 13, 23)]
+    m = Stub(np.linspace(10, 1, 30))
+    recs, stop = m._recorded_run(0, 30, 6.5)                 # losses at iterations 0, 10, 20: 10, 6.9, 3.8 -> stop at 20
+    assert [r[0] for r in recs] == [0, 10, 20] and stop == 20
+    assert m.calls == [("record", 30), ("set_state", "state"), ("step", 21)]
