@@ -89,3 +89,76 @@ def test_world2_gloo_allreduce_matches_unsharded():
         assert abs(out[P] + out[P + 1] - loss) < 1e-12 * abs(loss)
         assert abs(out[P + 2] - lossb) < 1e-14
     assert np.array_equal(res[0][2], res[1][2])   # bitwise identical on both ranks -> replicas stay in sync
+
+
+def _p2p_logic_worker(rank, world, port, q):
+    """The agreement / fallback logic of VPINN._connect_p2p with the device replaced by a stub (3 scenarios)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hp_vpinns_amd import _lib
+    from hp_vpinns_amd.vpinn import _VPINNBase
+
+    class Stub(_VPINNBase):
+        def __init__(self, export_fails=False, wrong_answer=False, timeout=False):
+            outer = self
+            self.rank, self.world, self.log = rank, world, []
+
+            class H:
+                def p2p_export(s, w, r):
+                    if export_fails:
+                        raise _lib.HpvError("no ipc")
+                    return bytes([r]) * 128
+
+                def p2p_connect(s, handles):
+                    outer.log.append(("connect", len(handles)))
+
+                def reduce_buffer(s):
+                    return 0, 10
+
+                def p2p_selftest(s, n):
+                    v = world * (world + 1) / 2 + world * 1e-3 * np.arange(n)
+                    return (v + (1.0 if wrong_answer else 0.0)), int(timeout)
+
+                def p2p_disconnect(s):
+                    outer.log.append("disconnect")
+            self.h = H()
+
+    out = []
+    m = Stub()
+    out.append((m._connect_p2p(), m.log))                                   # everything works
+    m = Stub(export_fails=(rank == 1))
+    out.append((m._connect_p2p(), m.log))                                   # one rank cannot export
+    m = Stub(wrong_answer=(rank == 0))
+    out.append((m._connect_p2p(), m.log))                                   # one rank reads a wrong sum
+    m = Stub(timeout=(rank == 1))
+    out.append((m._connect_p2p(), m.log))                                   # one rank's peer never arrives
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_in_library_exchange_setup_agrees_on_fallback():
+    """Every rank must reach the same decision -- use the in-library exchange or fall back to the collective path --
+    whichever rank the failure happens on, and a rank that exported a mailbox must release it on fallback."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_p2p_logic_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        ok, log = res[rank][0]
+        assert ok is True and log == [("connect", 256)]
+        ok, log = res[rank][1]
+        assert ok is False and ("disconnect" in log) == (rank == 0) and ("connect", 256) not in log
+        for scenario in (2, 3):
+            ok, log = res[rank][scenario]
+            assert ok is False and log == [("connect", 256), "disconnect"]
