@@ -159,6 +159,16 @@ __global__ void __launch_bounds__(BLK, BLK == 256 ? 2 : 1) k_fwd_mfma(MfmaArgs g
         b1[s] = th[g.boff[0] + j];
         wo[s] = th[g.woff[L] + j];
     }
+    // the coordinates of the NEXT tile are fetched while this one computes (2 doubles per lane): otherwise every
+    // tile starts with a full HBM round trip in front of a ~10 us dependent chain.  The first tile's request is issued
+    // here, before the weight staging, so that it overlaps that round trip.
+    double xn[D];
+    {
+        long p0 = wave * 16 + pt;
+        p0 = p0 < g.N ? p0 : g.N - 1;
+#pragma unroll
+        for (int c = 0; c < D; ++c) xn[c] = g.X[(long)c * g.N + p0];
+    }
     // A-operand fragments W^T[out = 16t+pt][in = 4s+q] and bias fragments of the hidden->hidden layers live in
     // LDS, lane-major (conflict-free ds_read_b64), shared by the block's waves: frees ~60 VGPRs per wave
     extern __shared__ __attribute__((aligned(16))) double fl[];
@@ -169,30 +179,37 @@ __global__ void __launch_bounds__(BLK, BLK == 256 ? 2 : 1) k_fwd_mfma(MfmaArgs g
     double* WT = fl;                                   // [(L-1)][MF_KS][64]
     double* BH = fl + (L > 1 ? L - 1 : 0) * MF_KS * 64;       // [(L-1)][MF_KS][64]
     double* WR = BH + (L > 1 ? L - 1 : 0) * MF_KS * 64;       // [(L-1)][MF_KS][4 (q)][4 (a)]
-    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += BLK) {
-        const int ln = f & 63, s_ = (f >> 6) % MF_KS, i_ = f / (64 * MF_KS) + 1;
-        WT[f] = th[g.woff[i_] + (4 * s_ + (ln >> 4)) * MF_H + (ln & 15)];
-    }
-    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 16; f += BLK) {
-        const int a_ = f & 3, q_ = (f >> 2) & 3, s_ = (f >> 4) % MF_KS, i_ = f / (16 * MF_KS) + 1;
-        WR[f] = th[g.woff[i_] + (4 * s_ + q_) * MF_H + 16 + a_];
-    }
-    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += BLK) {
-        const int ln = f & 63, s_ = (f >> 6) % MF_KS, i_ = f / (64 * MF_KS) + 1;
-        BH[f] = th[g.boff[i_] + 4 * s_ + (ln >> 4)];
+    {   // all global reads of the staging are issued before the first LDS store (one round trip instead of three)
+        constexpr int NW = (L - 1) * MF_KS * 64, NR_ = (L - 1) * MF_KS * 16;
+        constexpr int ITW = (NW + BLK - 1) / BLK, ITR = (NR_ + BLK - 1) / BLK;
+        double vw[ITW > 0 ? ITW : 1], vb[ITW > 0 ? ITW : 1], vr[ITR > 0 ? ITR : 1];
+#pragma unroll
+        for (int it = 0; it < ITW; ++it) {
+            const int f = it * BLK + threadIdx.x, fc = f < NW ? f : 0;
+            const int ln = fc & 63, s_ = (fc >> 6) % MF_KS, i_ = fc / (64 * MF_KS) + 1;
+            vw[it] = th[g.woff[i_] + (4 * s_ + (ln >> 4)) * MF_H + (ln & 15)];
+            vb[it] = th[g.boff[i_] + 4 * s_ + (ln >> 4)];
+        }
+#pragma unroll
+        for (int it = 0; it < ITR; ++it) {
+            const int f = it * BLK + threadIdx.x, fc = f < NR_ ? f : 0;
+            const int a_ = fc & 3, q_ = (fc >> 2) & 3, s_ = (fc >> 4) % MF_KS, i_ = fc / (16 * MF_KS) + 1;
+            vr[it] = th[g.woff[i_] + (4 * s_ + q_) * MF_H + 16 + a_];
+        }
+#pragma unroll
+        for (int it = 0; it < ITW; ++it) {
+            const int f = it * BLK + threadIdx.x;
+            if (f < NW) { WT[f] = vw[it]; BH[f] = vb[it]; }
+        }
+#pragma unroll
+        for (int it = 0; it < ITR; ++it) {
+            const int f = it * BLK + threadIdx.x;
+            if (f < NR_) WR[f] = vr[it];
+        }
     }
     __syncthreads();
     const double bo = th[g.boff[L]];
 
-    // the coordinates of the NEXT tile are fetched while this one computes (2 doubles per lane): otherwise every
-    // tile starts with a full HBM round trip in front of a ~10 us dependent chain
-    double xn[D];
-    {
-        long p0 = wave * 16 + pt;
-        p0 = p0 < g.N ? p0 : g.N - 1;
-#pragma unroll
-        for (int c = 0; c < D; ++c) xn[c] = g.X[(long)c * g.N + p0];
-    }
     for (long tile = wave; tile < tile_end; tile += nwaves) {
         const long p = tile * 16 + pt;
         const bool valid = p < g.N;
