@@ -610,7 +610,7 @@ __global__ void __launch_bounds__(1024) k_p2p_exchange(P2PArgs pp, double* __res
         const unsigned long long* f = pp.flag[pp.rank] + par * W + threadIdx.x;
         long spins = 0;
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < k + 1ULL) {
-            if (++spins > (1L << 24)) { *pp.err = 1; break; }    // ~ a second: a peer is gone; do not hang the device
+            if (++spins > (1L << 27)) { *pp.err = 1; break; }    // several seconds (ranks may be skewed by host work): a peer is gone; do not hang the device
             __builtin_amdgcn_s_sleep(2);
         }
     }
