@@ -10,3 +10,11 @@ from .testfcn import Test_fcn, dTest_fcn  # noqa: F401
 
 __all__ = ["Jacobi", "DJacobi", "GaussJacobiWeights", "GaussLobattoJacobiWeights",
            "Test_fcn", "dTest_fcn"]
+
+
+def __getattr__(name):
+    """`from hp_vpinns_amd import VPINN2D` without importing torch / the HIP library at package import."""
+    if name in ("VPINN1D", "VPINN2D", "VPINNAdvDiff"):
+        from . import vpinn
+        return getattr(vpinn, name)
+    raise AttributeError(f"module 'hp_vpinns_amd' has no attribute {name!r}")
