@@ -407,20 +407,38 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES == 8 || (1 + NT1 + NT2) * L
     // per-lane weight fragments
     // first-layer and head weights of this lane's neurons: lane-major in LDS, re-read per tile (not 30 resident VGPRs)
     double* W1O = WRB + (L > 1 ? L - 1 : 0) * MF_KS * 16;    // [(D+1)][MF_KS][64]
-    for (int f = threadIdx.x; f < (D + 1) * MF_KS * 64; f += (WAVES * 64)) {
-        const int ln = f & 63, s_ = (f >> 6) % MF_KS, c_ = f / (64 * MF_KS);
-        const int j = 4 * s_ + (ln >> 4);
-        W1O[f] = c_ < D ? th[g.woff[0] + c_ * MF_H + j] : th[g.woff[L] + j];
-    }
-    // A operand of hbar_in^T = W zbar^T : W[in = 16t+pt][out = 4s+q], kept in LDS (not registers) so that
-    // two waves per SIMD fit; every wave of the block reads the same lane-major fragments, conflict-free
-    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 64; f += (WAVES * 64)) {
-        const int ln = f & 63, s_ = (f >> 6) % MF_KS, i_ = f / (64 * MF_KS) + 1;
-        WN[f] = th[g.woff[i_] + (ln & 15) * MF_H + 4 * s_ + (ln >> 4)];
-    }
-    for (int f = threadIdx.x; f < (L - 1) * MF_KS * 16; f += (WAVES * 64)) {
-        const int a_ = f & 3, q_ = (f >> 2) & 3, s_ = (f >> 4) % MF_KS, i_ = f / (16 * MF_KS) + 1;
-        WRB[f] = th[g.woff[i_] + (16 + a_) * MF_H + 4 * s_ + q_];
+    {   // all global reads of the weight staging are issued before the first LDS store (one round trip instead of three)
+        constexpr int BT = WAVES * 64;
+        constexpr int N1 = (D + 1) * MF_KS * 64, NW = (L - 1) * MF_KS * 64, NRB = (L - 1) * MF_KS * 16;
+        constexpr int IT1 = (N1 + BT - 1) / BT, ITW = (NW + BT - 1) / BT, ITR = (NRB + BT - 1) / BT;
+        double v1[IT1], vw[ITW > 0 ? ITW : 1], vr[ITR > 0 ? ITR : 1];
+#pragma unroll
+        for (int it = 0; it < IT1; ++it) {
+            const int f = it * BT + threadIdx.x, fc = f < N1 ? f : 0;
+            const int ln = fc & 63, s_ = (fc >> 6) % MF_KS, c_ = fc / (64 * MF_KS);
+            const int j = 4 * s_ + (ln >> 4);
+            v1[it] = c_ < D ? th[g.woff[0] + c_ * MF_H + j] : th[g.woff[L] + j];
+        }
+        // A operand of hbar_in^T = W zbar^T : W[in = 16t+pt][out = 4s+q], kept in LDS (not registers) so that
+        // two waves per SIMD fit; every wave of the block reads the same lane-major fragments, conflict-free
+#pragma unroll
+        for (int it = 0; it < ITW; ++it) {
+            const int f = it * BT + threadIdx.x, fc = f < NW ? f : 0;
+            const int ln = fc & 63, s_ = (fc >> 6) % MF_KS, i_ = fc / (64 * MF_KS) + 1;
+            vw[it] = th[g.woff[i_] + (ln & 15) * MF_H + 4 * s_ + (ln >> 4)];
+        }
+#pragma unroll
+        for (int it = 0; it < ITR; ++it) {
+            const int f = it * BT + threadIdx.x, fc = f < NRB ? f : 0;
+            const int a_ = fc & 3, q_ = (fc >> 2) & 3, s_ = (fc >> 4) % MF_KS, i_ = fc / (16 * MF_KS) + 1;
+            vr[it] = th[g.woff[i_] + (16 + a_) * MF_H + 4 * s_ + q_];
+        }
+#pragma unroll
+        for (int it = 0; it < IT1; ++it) { const int f = it * BT + threadIdx.x; if (f < N1) W1O[f] = v1[it]; }
+#pragma unroll
+        for (int it = 0; it < ITW; ++it) { const int f = it * BT + threadIdx.x; if (f < NW) WN[f] = vw[it]; }
+#pragma unroll
+        for (int it = 0; it < ITR; ++it) { const int f = it * BT + threadIdx.x; if (f < NRB) WRB[f] = vr[it]; }
     }
     __syncthreads();
     if constexpr (PQX > 0) {
