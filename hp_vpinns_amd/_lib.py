@@ -30,6 +30,7 @@ EXPORTS = [
     "hpv_assemble_rhs", "hpv_set_collocation", "hpv_gll_rule", "hpv_test_tables",
     "hpv_step_record", "hpv_history_reset", "hpv_history_read",
     "hpv_p2p_export", "hpv_p2p_connect", "hpv_p2p_selftest", "hpv_p2p_disconnect",
+    "hpv_eval_channels",
 ]
 
 
@@ -108,6 +109,7 @@ def load():
     lib.hpv_p2p_disconnect.argtypes = [h]
     lib.hpv_history_read.argtypes = [h, C.c_int, _dp, _dp]
     lib.hpv_test_tables.argtypes = [h, C.c_int, _dp, C.c_int, _dp]
+    lib.hpv_eval_channels.argtypes = [h, _dp, C.c_size_t]
     _lib = lib
     return lib
 
@@ -118,6 +120,14 @@ def _p(a):
 
 def _c(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _points(X, dim, what):
+    """(n, dim) float64 C-contiguous point array -- the C side reads n*dim doubles, so the row length is checked here."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    if X.ndim != 2 or X.shape[1] != dim:
+        raise ValueError(f"{what} must have shape (n, {dim}), got {X.shape}")
+    return X
 
 
 class Handle:
@@ -194,13 +204,19 @@ class Handle:
         self._chk(self.lib.hpv_set_rhs(self._h, _p(F), 0 if F is None else F.size))
 
     def set_collocation(self, X, f):
-        X, f = _c(X), _c(f).reshape(-1)
+        X, f = _points(X, self.layers[0], "collocation points"), _c(f).reshape(-1)
+        if f.size != X.shape[0]:
+            raise ValueError("one right-hand-side value per collocation point")
         self._chk(self.lib.hpv_set_collocation(self._h, _p(X), _p(f), X.shape[0]))
 
     def set_data(self, X, u):
-        X, u = _c(X), _c(u)
-        n = 0 if X is None else X.shape[0]
-        self._chk(self.lib.hpv_set_data(self._h, _p(X), _p(u), n))
+        if X is None:
+            self._chk(self.lib.hpv_set_data(self._h, None, None, 0))
+            return
+        X, u = _points(X, self.layers[0], "data points"), _c(u).reshape(-1)
+        if u.size != X.shape[0]:
+            raise ValueError("one target value per data point")
+        self._chk(self.lib.hpv_set_data(self._h, _p(X), _p(u), X.shape[0]))
 
     # ---- parameters ---------------------------------------------------------------------
     def num_params(self):
@@ -250,9 +266,16 @@ class Handle:
         self._chk(self.lib.hpv_sync(self._h))
 
     def predict(self, X):
-        X = _c(X)
+        X = _points(X, self.layers[0], "prediction points")
         out = np.empty(X.shape[0])
         self._chk(self.lib.hpv_predict(self._h, _p(X), X.shape[0], _p(out)))
+        return out
+
+    def channels(self, n_points, n_channels):
+        """(C, n_points): the network value and its input-derivative channels at this handle's quadrature points,
+        element-major (one forward launch; hpv_eval_channels)."""
+        out = np.empty((int(n_channels), int(n_points)))
+        self._chk(self.lib.hpv_eval_channels(self._h, _p(out), out.size))
         return out
 
     def residuals(self, n):

@@ -343,14 +343,8 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
         tstart(h, 0);
         MfmaDataTerm dt{h->data_off, h->merged ? h->n_data : 0, h->d_udata, h->var.GBAR, h->d_data_part,
                         h->n_data > 0 ? -2.0 * h->cfg.lossb_weight / (double)h->n_data : 0.0, backward ? 1 : 0};
-        bool fused = false;
-        if (use_mfma && !h->timing) {   // timing mode keeps the kernels separate so each class can be measured
-            ProjArgs pa{h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
-                        h->d_loss_e, h->d_deps_e, h->var.N, backward ? 1 : 0, nullptr, nullptr, nullptr, nullptr};
-            fused = hpv_mfma_forward_fused(h->mfma, h->d_theta, h->var.X, h->var.OUT, backward ? 1 : 0, h->stream, &dt, pa, h->n_elem);
-        }
-        if (fused) { /* forward + projection done */ }
-        else if (use_mfma) hpv_mfma_forward(h->mfma, h->d_theta, h->var.X, h->var.OUT, backward ? 1 : 0, h->stream, &dt);
+        const bool fused = false;
+        if (use_mfma) hpv_mfma_forward(h->mfma, h->d_theta, h->var.X, h->var.OUT, backward ? 1 : 0, h->stream, &dt);
         else run_fwd(h, h->var, nullptr, backward ? 1 : 0);
         tstop(h, 0);
         if (h->pd.edge) run_fwd(h, h->edge, h->mfma_edge, backward ? 1 : 0);
@@ -1136,6 +1130,11 @@ int hpv_p2p_export(hpv_handle h, int world, int rank, void* handles128) {
     h->pp = P2PArgs{};
     h->pp.world = world; h->pp.rank = rank; h->pp.n = n;
     h->pp.counter = h->d_p2p_counter; h->pp.err = h->d_p2p_err;
+    {   // wall-clock budget of one exchange wait (ranks may be skewed by host work); HPV_P2P_TIMEOUT_MS overrides
+        double ms = 20000.0;
+        if (const char* e = getenv("HPV_P2P_TIMEOUT_MS")) { const double v = atof(e); if (v > 0.0) ms = v; }
+        h->pp.timeout_ticks = (unsigned long long)(ms * 1e5);
+    }
     return 0;
 }
 
@@ -1187,6 +1186,24 @@ int hpv_get_residuals(hpv_handle h, double* R, size_t n) {
     const size_t want = (size_t)h->n_elem * h->ntx * h->nty;
     if (n != want) return fail(h, -1, "R buffer has %zu entries, expected %zu", n, want);
     HIPCHK(h, hipMemcpyAsync(R, h->d_R, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int hpv_eval_channels(hpv_handle h, double* out, size_t n) {
+    if (!h || !out) return -1;
+    if (h->cfg.scheme != HPV_SCHEME_VPINN) return fail(h, -1, "hpv_eval_channels belongs to the variational scheme");
+    int rc = check_ready(h);
+    if (rc) return rc;
+    const int C = h->nd_var.C;
+    if (n != (size_t)C * h->Nq) return fail(h, -1, "channel buffer has %zu entries, expected %zu", n, (size_t)C * h->Nq);
+    if (h->Nq == 0) return 0;
+    if (h->mfma && h->backend == HPV_BACKEND_MFMA) hpv_mfma_forward(h->mfma, h->d_theta, h->var.X, h->var.OUT, 0, h->stream);
+    else run_fwd(h, h->var, nullptr, 0);
+    HIPCHK(h, hipGetLastError());
+    for (int ch = 0; ch < C; ++ch)     // the device batch may carry padding / data points behind the quadrature points
+        HIPCHK(h, hipMemcpyAsync(out + (size_t)ch * h->Nq, h->var.OUT + (size_t)ch * h->var.N, (size_t)h->Nq * sizeof(double),
+                                 hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }

@@ -69,9 +69,11 @@ struct P2PArgs {
     double* inbox[HPV_P2P_MAX];                 // inbox[r] = rank r's mailbox as mapped here (own rank: the local pointer)
     unsigned long long* flag[HPV_P2P_MAX];      // flag[r]  = rank r's arrival counters
     unsigned long long* counter;                // exchanges done so far (local)
-    int* err;                                   // set to 1 when a peer did not arrive within the spin budget
+    int* err;                                   // set to 1 when a peer did not arrive in time (sticky; the exchange then is a no-op)
     int world, rank, n;
+    unsigned long long timeout_ticks;           // wait budget in s_memrealtime ticks (100 MHz)
 };
+#define HPV_P2P_POISON 0xFFFFFFFFFFFFFFFFULL     // arrival-counter value a rank publishes after giving up
 
 // ---- kernel launchers (kernels_generic.hip) ----
 void launch_mlp_fwd_generic(const NetDesc& nd, const double* theta, const double* X, double* ACT, double* OUT, long N,

@@ -10,7 +10,7 @@
 #include <hip/hip_runtime.h>
 
 __device__ __forceinline__ double hpv_tanh(double x) {
-    const double ax = fmin(fabs(x), 32.0);
+    const double ax = fabs(x) < 32.0 ? fabs(x) : (x != x ? x : 32.0);   // NaN propagates (fmin would drop it)
     const double y = -2.0 * ax;
     const double k = rint(y * 1.4426950408889634);
     double r = fma(-k, 6.93147180369123816490e-01, y);

@@ -25,12 +25,6 @@ void hpv_mfma_forward(HpvMfma* m, const double* theta, const double* X, double* 
 void hpv_mfma_backward(HpvMfma* m, const double* theta, const double* X, const double* GBAR, double* GPART, int* rows,
                        hipStream_t s);
 struct ProjArgs;
-bool hpv_mfma_forward_fused(HpvMfma* m, const double* theta, const double* X, double* OUT, int save_act, hipStream_t s,
-                            const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem);
 bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, const double* GBAR, double* GPART, int* rows,
                              hipStream_t s, const ProjArgs& pa, long n_elem);
 int hpv_mfma_max_rows(HpvMfma* m, long n_elem);
-bool hpv_mfma_has_projection(HpvMfma* m);
-void hpv_mfma_project(HpvMfma* m, const ProjDesc& pd, const double* OUT, double* GBAR, double* R, const double* F,
-                      const double* coef, long coef_stride, const double* wtx, const double* wty, const double* eps_ptr,
-                      double* loss_e, double* deps_e, long N, long n_elem, int do_adjoint, hipStream_t s);

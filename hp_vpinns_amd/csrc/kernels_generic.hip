@@ -535,8 +535,10 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
             ad.state[0] *= ad.b1; ad.state[1] *= ad.b2;
             if (ad.hist) {   // single-GPU training iteration: record this forward pass's loss (see AdamArgs)
                 const int i = *ad.hist_idx;
-                if (i < ad.hist_cap) { ad.hist[4 * i] = lv; ad.hist[4 * i + 1] = lossb_weight * msq; ad.hist[4 * i + 2] = msq; ad.hist[4 * i + 3] = eps_now; }
-                *ad.hist_idx = i + 1;
+                if (i >= 0 && i < ad.hist_cap) {   // the index saturates at hist_cap (it never wraps)
+                    ad.hist[4 * i] = lv; ad.hist[4 * i + 1] = lossb_weight * msq; ad.hist[4 * i + 2] = msq; ad.hist[4 * i + 3] = eps_now;
+                    *ad.hist_idx = i + 1;
+                }
             }
         }
         RB[Ptot + 0] = lv;
@@ -569,11 +571,11 @@ __global__ void __launch_bounds__(1024) k_adam(AdamArgs ad, const double* __rest
     const double b1p = ad.state[0], b2p = ad.state[1];
     if (threadIdx.x == 0 && ad.hist) {   // multi-GPU iteration: g is the all-reduced packed buffer, the losses follow the gradient
         const int i = *ad.hist_idx;
-        if (i < ad.hist_cap) {
+        if (i >= 0 && i < ad.hist_cap) {   // saturating index
             ad.hist[4 * i] = g[Ptot]; ad.hist[4 * i + 1] = g[Ptot + 1]; ad.hist[4 * i + 2] = g[Ptot + 2];
             ad.hist[4 * i + 3] = Ptot > P ? ad.theta[P] : 0.0;   // epsilon before this update
+            *ad.hist_idx = i + 1;
         }
-        *ad.hist_idx = i + 1;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < Ptot; i += blockDim.x) adam_update(ad, i, g[i], b1p, b2p);
@@ -595,6 +597,10 @@ __global__ void __launch_bounds__(1024) k_adam(AdamArgs ad, const double* __rest
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_p2p_exchange(P2PArgs pp, double* __restrict__ RB, AdamArgs ad, int P, int Ptot,
                                                       int ncopies) {
+    __shared__ int s_fail;
+    if (threadIdx.x == 0) s_fail = *pp.err;      // sticky: once an exchange has failed, every later one is a no-op
+    __syncthreads();
+    if (s_fail) return;
     const unsigned long long k = *pp.counter;
     const int par = (int)(k & 1ULL), W = pp.world, n = pp.n;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -607,14 +613,28 @@ __global__ void __launch_bounds__(1024) k_p2p_exchange(P2PArgs pp, double* __res
     if ((int)threadIdx.x < W)
         __hip_atomic_store(pp.flag[threadIdx.x] + par * W + pp.rank, k + 1ULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((int)threadIdx.x < W) {
+        // Bounded by WALL CLOCK (s_memrealtime counts at 100 MHz), not by a spin count.  A peer that gave up publishes
+        // HPV_P2P_POISON instead of its arrival count, so that every rank aborts the same exchange.
         const unsigned long long* f = pp.flag[pp.rank] + par * W + threadIdx.x;
-        long spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < k + 1ULL) {
-            if (++spins > (1L << 27)) { *pp.err = 1; break; }    // several seconds (ranks may be skewed by host work): a peer is gone; do not hang the device
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            const unsigned long long v = __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (v == HPV_P2P_POISON) { atomicExch(&s_fail, 1); break; }
+            if (v >= k + 1ULL) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > pp.timeout_ticks) { atomicExch(&s_fail, 1); break; }
             __builtin_amdgcn_s_sleep(2);
         }
     }
     __syncthreads();
+    if (s_fail) {
+        // leave RB, theta, m, v, the beta powers and the exchange counter untouched; tell the host and the peers
+        if (threadIdx.x == 0) *pp.err = 1;
+        if ((int)threadIdx.x < W) {
+            __hip_atomic_store(pp.flag[threadIdx.x] + 0 * W + pp.rank, HPV_P2P_POISON, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pp.flag[threadIdx.x] + 1 * W + pp.rank, HPV_P2P_POISON, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     const double* mine = pp.inbox[pp.rank] + (long)par * W * n;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         double sum = 0.0;
@@ -628,11 +648,11 @@ __global__ void __launch_bounds__(1024) k_p2p_exchange(P2PArgs pp, double* __res
     const double b1p = ad.state[0], b2p = ad.state[1];
     if (threadIdx.x == 0 && ad.hist) {
         const int i = *ad.hist_idx;
-        if (i < ad.hist_cap) {
+        if (i >= 0 && i < ad.hist_cap) {   // saturating index
             ad.hist[4 * i] = RB[Ptot]; ad.hist[4 * i + 1] = RB[Ptot + 1]; ad.hist[4 * i + 2] = RB[Ptot + 2];
             ad.hist[4 * i + 3] = Ptot > P ? ad.theta[P] : 0.0;
+            *ad.hist_idx = i + 1;
         }
-        *ad.hist_idx = i + 1;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < Ptot; i += blockDim.x) adam_update(ad, i, RB[i], b1p, b2p);

@@ -58,7 +58,7 @@ struct MfmaArgs {
     double* data_part;    // [data tiles] partial sums of (u_d - u)^2
     double data_scale;    // -2 w / n_data
     int data_write_gbar;
-    // fused forward + projection (element-block mode): blocks [0, proj_n_elem) own one element each
+    // element-block mode of the reverse kernel (projection fused in): blocks own the elements [0, proj_n_elem)
     long proj_n_elem;
     int proj_split;       // workgroups per element in the reverse kernel's element-block mode (1, 2, 4 or 8)
     ProjArgs pa;
@@ -74,12 +74,11 @@ struct HpvMfma {
     MfmaArgs base;
     void (*fwd)(const MfmaArgs&, int, hipStream_t) = nullptr;
     void (*bwd)(const MfmaArgs&, int, hipStream_t) = nullptr;
-    void (*fwd_fused)(const MfmaArgs&, int, hipStream_t) = nullptr; // forward + projection (kept for A/B: HPV_FUSE=fwd)
     void (*bwd_fused)(const MfmaArgs&, int, hipStream_t) = nullptr; // projection + reverse, element-block mode
     int occ_fwd = 1, occ_bwd = 1;   // resident 256-thread blocks per CU
     int n_cus = 256;                // compute units of the device
     int max_rows = 0;               // gradient rows the caller allocated (>= every launch mode's row count)
-    bool fuse_bwd = true, fuse_fwd = false;   // HPV_FUSE=n / f at creation (A/B switches; default: projection fused into the reverse kernel)
+    bool fuse_bwd = true;   // HPV_FUSE=n at creation: separate projection and reverse launches (A/B switch)
 };
 
 template <int ACT>
@@ -114,16 +113,12 @@ struct SlotCount {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-// BLK threads per workgroup.  PQX > 0 selects the FUSED forward+projection mode for elements of PQX x PQY
-// points (a multiple of 16) with PNTX x PNTY test functions: workgroup b < proj_n_elem runs all tiles of element
-// b and then, after a workgroup barrier, projects it (project_element_wg) -- the per-element projection no
-// longer is a separate, latency-bound launch on a fraction of the CUs; later workgroups take the data tiles.
 // SAVE: the activation store for the reverse pass is a compile-time choice -- a run-time flag put a scalar branch
 // around every store, which cut each layer's activation math into one basic block per value (no interleaving of
 // the five independent tanh chains of a lane).
-template <int D, int NT1, int NT2, int ACT, int L, int BLK = MF_BLOCK, int PQX = 0, int PQY = 0, int PNTX = 0, int PNTY = 0,
-          bool SAVE = true>
-__global__ void __launch_bounds__(BLK, BLK == 256 ? 2 : 1) k_fwd_mfma(MfmaArgs g) {
+template <int D, int NT1, int NT2, int ACT, int L, bool SAVE = true>
+__global__ void __launch_bounds__(MF_BLOCK, 2) k_fwd_mfma(MfmaArgs g) {
+    constexpr int BLK = MF_BLOCK;
     constexpr int C = 1 + NT1 + NT2;
     constexpr int NS = SlotCount<ACT, NT1, NT2>::value;
     constexpr int SA1 = 1;                                   // slot of A1 (sin only)
@@ -131,22 +126,9 @@ __global__ void __launch_bounds__(BLK, BLK == 256 ? 2 : 1) k_fwd_mfma(MfmaArgs g
     constexpr int SZCC = SZC + NT1;
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, pt = lane & 15;
-    long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-    long tile_end = g.ntiles;
-    if constexpr (PQX > 0) {
-        constexpr long TPE = (PQX * PQY) / 16;   // tiles per element
-        constexpr int WPB = BLK / 64;
-        const int wvi = threadIdx.x >> 6;
-        if ((long)blockIdx.x < g.proj_n_elem) {
-            wave = (long)blockIdx.x * TPE + wvi;
-            nwaves = WPB;
-            tile_end = ((long)blockIdx.x + 1) * TPE;
-        } else {
-            wave = g.proj_n_elem * TPE + ((long)blockIdx.x - g.proj_n_elem) * WPB + wvi;
-            nwaves = ((long)gridDim.x - g.proj_n_elem) * WPB;
-        }
-    }
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const long tile_end = g.ntiles;
     const double* __restrict__ th = g.theta;
 
     // per-lane weight fragments
@@ -329,14 +311,6 @@ __global__ void __launch_bounds__(BLK, BLK == 256 ? 2 : 1) k_fwd_mfma(MfmaArgs g
                 sq += __shfl_xor(sq, 8, 64);
                 if (lane == 0) g.data_part[tile - g.data_off / 16] = sq;
             }
-        }
-    }
-    if constexpr (PQX > 0) {
-        __threadfence_block();
-        __syncthreads();     // the element's output channels (written by this workgroup) are complete
-        if ((long)blockIdx.x < g.proj_n_elem) {
-            double* psm = fl + (L > 1 ? L - 1 : 0) * (2 * MF_KS * 64 + MF_KS * 16);
-            project_element_wg<PQX, PQY, PNTX, PNTY, BLK>(g.pa, (long)blockIdx.x, psm);
         }
     }
 }
@@ -744,8 +718,7 @@ static void run_fwd(const MfmaArgs& a, int blocks, hipStream_t s) {
     if (a.save_act)
         hipLaunchKernelGGL((k_fwd_mfma<D, NT1, NT2, ACT, L>), dim3(blocks), dim3(MF_BLOCK), fwd_lds_bytes(L), s, a);
     else
-        hipLaunchKernelGGL((k_fwd_mfma<D, NT1, NT2, ACT, L, MF_BLOCK, 0, 0, 0, 0, false>), dim3(blocks), dim3(MF_BLOCK),
-                           fwd_lds_bytes(L), s, a);
+        hipLaunchKernelGGL((k_fwd_mfma<D, NT1, NT2, ACT, L, false>), dim3(blocks), dim3(MF_BLOCK), fwd_lds_bytes(L), s, a);
 }
 static size_t bwd_lds_bytes(int P, int L, int C, int waves);
 template <int D, int NT1, int NT2, int ACT, int L, int QX, int QY, int NTX, int NTY>
@@ -761,13 +734,6 @@ static void run_bwd_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
     hipLaunchKernelGGL((k_bwd_mfma<D, NT1, NT2, ACT, L, QX, QY, NTX, NTY, FW>), dim3(blocks), dim3(FW * 64), lds, s, a);
 }
 
-#define FZ_BLK 512
-template <int D, int NT1, int NT2, int ACT, int L, int QX, int QY, int NTX, int NTY>
-static void run_fwd_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
-    const size_t lds = fwd_lds_bytes(L) + (size_t)project_wg_lds_doubles<QX, QY, NTX, NTY>() * sizeof(double);
-    hipLaunchKernelGGL((k_fwd_mfma<D, NT1, NT2, ACT, L, FZ_BLK, QX, QY, NTX, NTY>), dim3(blocks), dim3(FZ_BLK), lds, s, a);
-}
-
 template <int D, int NT1, int NT2, int ACT, int L>
 static void run_bwd(const MfmaArgs& a, int blocks, hipStream_t s) {
     size_t lds = bwd_lds_bytes(a.P, L, 1 + NT1 + NT2);
@@ -779,8 +745,6 @@ static bool pick(HpvMfma* m) {
     m->fwd = run_fwd<D, NT1, NT2, ACT, L>;
     m->bwd = run_bwd<D, NT1, NT2, ACT, L>;
     if constexpr (D == 2 && NT1 == 2 && NT2 == 0 && ACT == HPV_ACT_TANH)   // BASELINE config 4 (Poisson-2D var_form 1)
-        m->fwd_fused = run_fwd_fused<D, NT1, NT2, ACT, L, 20, 20, 10, 10>;
-    if constexpr (D == 2 && NT1 == 2 && NT2 == 0 && ACT == HPV_ACT_TANH)
         m->bwd_fused = run_bwd_fused<D, NT1, NT2, ACT, L, 20, 20, 10, 10>;
     size_t lds = bwd_lds_bytes(m->nd.P, L, 1 + NT1 + NT2);
     int of = 1, ob = 1;
@@ -846,8 +810,7 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
     m->bwd_blocks = (int)std::min<long>(want, (long)cus * std::max(1, m->occ_bwd));
     {
         const char* e = getenv("HPV_FUSE");
-        m->fuse_bwd = !(e && (e[0] == 'n' || e[0] == 'f'));
-        m->fuse_fwd = e && e[0] == 'f';
+        m->fuse_bwd = !(e && e[0] == 'n');
     }
     MfmaArgs& a = m->base;
     a = MfmaArgs{};
@@ -900,31 +863,6 @@ void hpv_mfma_backward(HpvMfma* m, const double* theta, const double* X, const d
     if (rows) *rows = hpv_mfma_grad_rows(m);
 }
 
-// Forward with the per-element projection fused in (element-block mode).  Returns false when this object /
-// element shape has no fused instantiation; the caller then runs forward and projection separately.
-bool hpv_mfma_forward_fused(HpvMfma* m, const double* theta, const double* X, double* OUT, int save_act, hipStream_t s,
-                            const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem) {
-    const ProjDesc& pd = pa.pd;
-    if (!m->fwd_fused || pd.edge || n_elem <= 0 || !save_act) return false;   // (the fused instantiation always stores)
-    if (!(pd.qx == 20 && pd.qy == 20 && pd.ntx == 10 && pd.nty == 10)) return false;
-    const long tpe = (20 * 20) / 16;
-    if (n_elem * tpe > m->ntiles) return false;
-    if (!m->fuse_fwd) return false;   // A/B only
-    MfmaArgs a = m->base;
-    a.theta = theta; a.X = X; a.OUT = OUT; a.save_act = save_act;
-    a.data_off = -1;
-    if (dt && dt->n_data > 0) {
-        a.data_off = dt->data_off; a.ud = dt->ud; a.gbar0 = dt->gbar0; a.data_part = dt->data_part;
-        a.data_scale = dt->scale; a.data_write_gbar = dt->write_gbar;
-    }
-    a.proj_n_elem = n_elem;
-    a.pa = pa;
-    const long rest = m->ntiles - n_elem * tpe;                 // pad + data tiles
-    const int extra = (int)((rest + (FZ_BLK / 64) - 1) / (FZ_BLK / 64));
-    m->fwd_fused(a, (int)n_elem + extra, s);
-    return true;
-}
-
 // Reverse pass with the per-element projection fused in front (element-block mode).  Returns false when not
 // applicable; the caller then launches projection and reverse pass separately.
 bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, const double* GBAR, double* GPART, int* rows,
@@ -948,6 +886,3 @@ bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, c
     return true;
 }
 
-bool hpv_mfma_has_projection(HpvMfma*) { return false; }
-void hpv_mfma_project(HpvMfma*, const ProjDesc&, const double*, double*, double*, const double*, const double*, long,
-                      const double*, const double*, const double*, double*, double*, long, long, int, hipStream_t) {}

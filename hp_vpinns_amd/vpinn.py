@@ -32,14 +32,19 @@ def _group_ready():
 
 
 def _tensor_rule(X_quad, W_quad):
-    """Recover the 1-D rules from the flattened tensor-product arrays of P2:355-360 (x fastest)."""
+    """Recover the 1-D rules from the flattened tensor-product arrays of P2:355-360 (x fastest); the x and y rules may
+    have different lengths (the C ABI takes qx and qy separately)."""
     X_quad, W_quad = np.asarray(X_quad, dtype=np.float64), np.asarray(W_quad, dtype=np.float64)
+    if X_quad.ndim != 2 or X_quad.shape[1] != 2 or W_quad.shape != X_quad.shape:
+        raise ValueError("X_quad and W_quad must both have shape (Qx*Qy, 2)")
     nq = X_quad.shape[0]
-    q = int(round(np.sqrt(nq)))
-    if q * q != nq:
-        raise ValueError("X_quad is not a Q x Q tensor-product rule")
-    xi, yi = X_quad[:q, 0].copy(), X_quad[::q, 1].copy()
-    wx, wy = W_quad[:q, 0].copy(), W_quad[::q, 1].copy()
+    qx = 1                                    # x runs fastest: the first row ends where y changes for the first time
+    while qx < nq and X_quad[qx, 1] == X_quad[0, 1]:
+        qx += 1
+    if nq % qx:
+        raise ValueError("X_quad is not a Qx x Qy tensor-product rule")
+    xi, yi = X_quad[:qx, 0].copy(), X_quad[::qx, 1].copy()
+    wx, wy = W_quad[:qx, 0].copy(), W_quad[::qx, 1].copy()
     xx, yy = np.meshgrid(xi, yi)
     wxx, wyy = np.meshgrid(wx, wy)
     ok = (np.array_equal(xx.flatten(), X_quad[:, 0]) and np.array_equal(yy.flatten(), X_quad[:, 1])
@@ -312,6 +317,8 @@ class _VPINNBase:
         return self._from_dev(self.h.get_params())
 
     def set_params(self, theta):
+        """New parameters; the Adam moments and beta powers are RESET (a fresh optimizer, as after `initialize_NN`).
+        Use `load_checkpoint` / `h.set_state` to continue a run."""
         self.h.set_params(self._to_dev(theta))
 
     def backend(self):
@@ -323,13 +330,20 @@ class _VPINNBase:
         u_exact = np.asarray(u_exact, dtype=np.float64).reshape(-1, 1)
         return float(np.linalg.norm(u_exact - self._predict(X), 2) / np.linalg.norm(u_exact, 2))
 
+    @staticmethod
+    def _ckpt_path(path):
+        path = os.fspath(path)
+        return path if path.endswith(".npz") else path + ".npz"     # what np.savez would write
+
     def save_checkpoint(self, path):
-        """Parameters + Adam moments + beta powers (.npz); the reference never saves weights."""
-        np.savez(path, state=self.h.get_state(), layers=np.asarray(self.layers), dev_layers=np.asarray(self._dev_layers),
-                 cls=type(self).__name__)
+        """Parameters + Adam moments + beta powers (.npz appended when missing, for saving and loading alike); the
+        reference never saves weights."""
+        np.savez(self._ckpt_path(path), state=self.h.get_state(), layers=np.asarray(self.layers),
+                 dev_layers=np.asarray(self._dev_layers), cls=type(self).__name__)
 
     def load_checkpoint(self, path):
-        d = np.load(path, allow_pickle=False)
+        """Restores parameters AND optimizer state (unlike `set_params`, which resets the Adam moments and beta powers)."""
+        d = np.load(self._ckpt_path(path), allow_pickle=False)
         if list(d["layers"]) != list(self.layers) or str(d["cls"]) != type(self).__name__:
             raise ValueError("checkpoint was written by a different model")
         if "dev_layers" in d and list(d["dev_layers"]) != list(self._dev_layers):

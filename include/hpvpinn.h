@@ -160,6 +160,10 @@ int hpv_test_tables(hpv_handle h, int ntest, const double* xi, int q, double* ta
 /* Introspection for tests / benchmarks. */
 int hpv_get_residuals(hpv_handle h, double* R, size_t n);   /* R of the owned elements [ne][nty][ntx] */
 int hpv_backend_in_use(hpv_handle h);                       /* HPV_BACKEND_GENERIC or HPV_BACKEND_MFMA */
+/* The network value and its input-derivative channels at the owned quadrature points, [C][n_owned*qx*qy]
+ * (channel order: u, then d/dx, d/dy (d/dt), then the second derivatives the variational form integrates) --
+ * what net_u / net_du / net_dxu / net_dyu / net_dtu return (P1:140-148, P2:171-185, P3:232-245).  One forward launch. */
+int hpv_eval_channels(hpv_handle h, double* out, size_t n);
 /* Test hook: the device activation s(x), s'(x) (cfg.act) and the ROCm math library's s(x) for the same
  * inputs, so tests can bound the error of the hand-written fp64 tanh (replaces tf.tanh, P2:165). */
 int hpv_debug_activation(hpv_handle h, const double* x, int n, double* a, double* a1, double* ref);

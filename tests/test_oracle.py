@@ -105,16 +105,40 @@ def test_advdiff_epsilon_moves_and_5tuple():
     assert float(o.get_params()[-1]) != 1.0
 
 
-def test_vectorized_oracle_equals_structured():
-    """The batched/einsum variant timed as CPU baseline B computes the same loss and gradient."""
-    a = p2_args(gold("poisson2d_small"))
-    th = theta0(a[13], 17)
-    o1 = O.OracleVPINN2D(*a, init_params=th)
-    o2 = O.OracleVPINN2D(*a, init_params=th)
+def _same(o1, o2):
     o2.vectorized = True
     (l1, g1), (l2, g2) = o1.loss_and_grad(), o2.loss_and_grad()
-    assert np.abs(np.array(l1) - np.array(l2)).max() < 1e-12 * abs(l1[0])
+    assert np.abs(np.array(l1) - np.array(l2)).max() < 1e-12 * abs(l1[0]), (l1, l2)
     assert np.abs(g1 - g2).max() < 1e-11 * np.abs(g1).max()
+    for _ in range(3):          # and the Adam trajectories stay together
+        o1.adam_step(); o2.adam_step()
+    assert np.abs(o1.get_params() - o2.get_params()).max() < 1e-12
+
+
+@pytest.mark.parametrize("vf", [0, 1, 2])
+def test_vectorized_oracle_equals_structured_2d(vf):
+    """The batched/einsum variant (CPU baseline B; the checker of the full-size GPU parity tests) computes the same
+    loss and gradient as the reference-structured element loop, for every var_form."""
+    a = p2_args(gold("poisson2d_small"))
+    th = theta0(a[13], 17)
+    _same(O.OracleVPINN2D(*a, var_form=vf, init_params=th), O.OracleVPINN2D(*a, var_form=vf, init_params=th))
+
+
+@pytest.mark.parametrize("tag,vf", [("poisson1d_small", 1), ("poisson1d_small", 2), ("poisson1d_small", 3), ("poisson1d_ne3", 3)])
+def test_vectorized_oracle_equals_structured_1d(tag, vf):
+    a = p1_args(gold(tag))
+    th = theta0(a[8], 18)
+    # non-zero first bias: with zero biases the sin network is odd, d loss / d b_out cancels to round-off and Adam
+    # (which normalises by sqrt(v) + 1e-8) would amplify that noise into an O(lr) difference of one parameter
+    th[a[8][1]: 2 * a[8][1]] = 0.1 * np.arange(a[8][1])
+    _same(O.OracleVPINN1D(*a, var_form=vf, init_params=th), O.OracleVPINN1D(*a, var_form=vf, init_params=th))
+
+
+@pytest.mark.parametrize("vf", [0, 1])
+def test_vectorized_oracle_equals_structured_advdiff(vf):
+    a = p3_args(gold("advdiff_small"))
+    th = theta0(a[12], 19, extra=[0.6])
+    _same(O.OracleVPINNAdvDiff(*a, var_form=vf, init_params=th), O.OracleVPINNAdvDiff(*a, var_form=vf, init_params=th))
 
 
 # ---- consistency anchors of the restated variational forms against reference-produced data ---------------------
@@ -200,3 +224,22 @@ def test_closed_form_equals_autograd_advdiff(vf):
     l3c, gc = CF.loss_and_grad_2d(th, L, "advdiff", vf, a[3][:q, 0], a[4][:q, 0], a[7], a[8], a[9][0][0], a[9][1][0], None,
                                   a[0], a[1], 10.0, V=1.0)
     assert _rel(l3c, l3) < 1e-13 and _rel(gc, g) < 1e-12          # the last entry is d loss / d epsilon
+
+
+# ---- the C / OpenMP restatement (CPU baseline B of BASELINE.md section 3) pinned to the autograd oracle ------------
+@pytest.mark.parametrize("tag,threads", [("poisson2d_small", 1), ("poisson2d_small", 3), ("poisson2d_cfg3", 4)])
+def test_c_closed_form_baseline_equals_the_autograd_oracle(tag, threads):
+    from oracle.cpu_baseline import CPoisson2D
+    a = p2_args(gold(tag), layers=[2, 20, 20, 20, 1])
+    th = theta0(a[13], 21)
+    o = O.OracleVPINN2D(*a, var_form=1, init_params=th)
+    o.vectorized = True
+    c = CPoisson2D(a[0], a[1], a[4], a[5], a[7], a[8], a[9], a[13], th, threads=threads)
+    (lo, go), (lc, gc) = o.loss_and_grad(), c.loss_and_grad()
+    assert np.abs(np.array(lo) - lc).max() < 1e-12 * abs(lo[0]), (lo, lc)
+    assert np.linalg.norm(go - gc) < 1e-10 * np.linalg.norm(go)
+    hist = c.train(5)                       # TF1 Adam in C == the oracle's adam_step
+    for k in range(5):
+        l3 = o.adam_step()
+        assert abs(l3[0] - hist[k, 0]) < 1e-10 * abs(l3[0])
+    assert np.abs(o.get_params() - c.theta).max() < 1e-10
