@@ -4,10 +4,10 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-for f in kernels_generic kernels_mfma kernels_project hpv_api; do
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ hpv_internal.h -nt $f.o ] || [ hpv_mfma.h -nt $f.o ] || [ ../../include/hpvpinn.h -nt $f.o ]; then
+for f in kernels_generic kernels_mfma kernels_fused kernels_project hpv_api; do
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ hpv_internal.h -nt $f.o ] || [ hpv_mfma.h -nt $f.o ] || [ hpv_mfma_dev.h -nt $f.o ] || [ hpv_project_wg.h -nt $f.o ] || [ hpv_math.h -nt $f.o ] || [ ../../include/hpvpinn.h -nt $f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o $f.o
   fi
 done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libhpvpinn.so kernels_generic.o kernels_mfma.o kernels_project.o hpv_api.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libhpvpinn.so kernels_generic.o kernels_mfma.o kernels_fused.o kernels_project.o hpv_api.o
 echo "built $(cd .. && pwd)/libhpvpinn.so"

@@ -340,46 +340,55 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
     }
     // --- variational term on this shard's quadrature batch ---
     if (h->var.N > 0) {
-        tstart(h, 0);
         MfmaDataTerm dt{h->data_off, h->merged ? h->n_data : 0, h->d_udata, h->var.GBAR, h->d_data_part,
                         h->n_data > 0 ? -2.0 * h->cfg.lossb_weight / (double)h->n_data : 0.0, backward ? 1 : 0};
-        const bool fused = false;
-        if (use_mfma) hpv_mfma_forward(h->mfma, h->d_theta, h->var.X, h->var.OUT, backward ? 1 : 0, h->stream, &dt);
-        else run_fwd(h, h->var, nullptr, backward ? 1 : 0);
-        tstop(h, 0);
-        if (h->pd.edge) run_fwd(h, h->edge, h->mfma_edge, backward ? 1 : 0);
-        // projection: fused into the reverse kernel (element-block mode) when that applies, otherwise its own launch
-        bool bfused = false;
-        if (backward && use_mfma && !fused) {
-            ProjArgs pa{h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
-                        h->d_loss_e, h->d_deps_e, h->var.N, 1, nullptr, nullptr, nullptr, nullptr};
-            tstart(h, 2);   // timed as the reverse-pass class (the projection is ~1 % of its flops)
-            bfused = hpv_mfma_backward_fused(h->mfma, h->d_theta, h->var.X, h->var.GBAR, h->var.GPART, &h->var.rows, h->stream,
-                                             pa, h->n_elem);
-            if (bfused) tstop(h, 2);   // (otherwise nothing was launched; the start event is re-recorded below)
-        }
-        if (!(fused || bfused)) tstart(h, 1);
-        // specialised tensor-product kernel for the hot element shapes unless the generic backend is forced
-        // (needs GBAR's unused channels pre-zeroed: true for every batch, see alloc_batch)
-        if (fused || bfused) {
-        } else if (h->cfg.backend == HPV_BACKEND_GENERIC ||
-            (!launch_project_tp(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
-                                eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->stream) &&
-             !launch_project_wg(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
-                                eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT,
-                                h->d_edge_dphi, h->d_edge_coef, h->edge.GBAR, h->stream, h->d_upart)))
-            launch_project(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
-                           h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi,
-                           h->d_edge_coef, h->edge.GBAR, h->stream);
-        if (!(fused || bfused)) tstop(h, 1);
-        if (backward && !bfused) {
+        ProjArgs pa{h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
+                    h->d_loss_e, h->d_deps_e, h->var.N, backward ? 1 : 0, nullptr, nullptr, nullptr, nullptr};
+        // (1) element-resident whole-iteration kernel: forward, projection and reverse pass in one launch, no activation
+        //     store (kernels_fused.hip); timed as the reverse-pass class
+        bool ifused = false;
+        if (backward && use_mfma) {
             tstart(h, 2);
-            if (use_mfma) hpv_mfma_backward(h->mfma, h->d_theta, h->var.X, h->var.GBAR, h->var.GPART, &h->var.rows, h->stream);
-            else run_bwd(h, h->var, nullptr);
-            tstop(h, 2);
+            ifused = hpv_mfma_iter_fused(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
+            if (ifused) tstop(h, 2);   // (otherwise nothing was launched; the start event is re-recorded below)
         }
-        if (backward) {
-            if (h->pd.edge) run_bwd(h, h->edge, h->mfma_edge);
+        if (!ifused) {
+            tstart(h, 0);
+            if (use_mfma) hpv_mfma_forward(h->mfma, h->d_theta, h->var.X, h->var.OUT, backward ? 1 : 0, h->stream, &dt);
+            else run_fwd(h, h->var, nullptr, backward ? 1 : 0);
+            tstop(h, 0);
+            if (h->pd.edge) run_fwd(h, h->edge, h->mfma_edge, backward ? 1 : 0);
+            // (2) projection fused into the reverse kernel (element-block mode; small shards split an element over
+            //     several workgroups) when that applies, otherwise (3) its own launch
+            bool bfused = false;
+            if (backward && use_mfma) {
+                tstart(h, 2);   // timed as the reverse-pass class (the projection is ~1 % of its flops)
+                bfused = hpv_mfma_backward_fused(h->mfma, h->d_theta, h->var.X, h->var.GBAR, h->var.GPART, &h->var.rows, h->stream,
+                                                 pa, h->n_elem);
+                if (bfused) tstop(h, 2);
+            }
+            if (!bfused) {
+                tstart(h, 1);
+                // specialised tensor-product kernel for the hot element shapes unless the generic backend is forced
+                // (needs GBAR's unused channels pre-zeroed: true for every batch, see alloc_batch)
+                if (h->cfg.backend == HPV_BACKEND_GENERIC ||
+                    (!launch_project_tp(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
+                                        eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->stream) &&
+                     !launch_project_wg(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
+                                        eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT,
+                                        h->d_edge_dphi, h->d_edge_coef, h->edge.GBAR, h->stream, h->d_upart)))
+                    launch_project(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
+                                   h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi,
+                                   h->d_edge_coef, h->edge.GBAR, h->stream);
+                tstop(h, 1);
+                if (backward) {
+                    tstart(h, 2);
+                    if (use_mfma) hpv_mfma_backward(h->mfma, h->d_theta, h->var.X, h->var.GBAR, h->var.GPART, &h->var.rows, h->stream);
+                    else run_bwd(h, h->var, nullptr);
+                    tstop(h, 2);
+                }
+            }
+            if (backward && h->pd.edge) run_bwd(h, h->edge, h->mfma_edge);
         }
     }
     // --- boundary / data term ---

@@ -27,4 +27,8 @@ void hpv_mfma_backward(HpvMfma* m, const double* theta, const double* X, const d
 struct ProjArgs;
 bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, const double* GBAR, double* GPART, int* rows,
                              hipStream_t s, const ProjArgs& pa, long n_elem);
+// Element-resident whole-iteration kernel (kernels_fused.hip): forward, projection and reverse pass of the shard in ONE
+// launch, no activation store.  Returns false when not applicable (shape, variational form, small shard).
+bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
+                         const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem);
 int hpv_mfma_max_rows(HpvMfma* m, long n_elem);

@@ -1,0 +1,93 @@
+// Device-side definitions shared by the MFMA kernels (kernels_mfma.hip: forward / reverse; kernels_fused.hip: the
+// element-resident whole-iteration kernel): argument block, lane layout constants, activation helpers.
+#pragma once
+#include "hpv_mfma.h"
+#include "hpv_math.h"
+#include "hpv_project_wg.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+#define MF_H 20
+#define MF_KS 5        // k-steps of 4 over the 20 inputs
+#define MF_LD 17       // padded leading dimension of the LDS transpose tiles
+#define MF_TRB 20      // rows of a transpose tile of k_bwd_mfma (20 neurons; every fragment row is in range)
+#define MF_BLOCK 256
+#define MF_WAVES (MF_BLOCK / 64)
+
+struct MfmaArgs {
+    const double* theta;
+    const double* X;      // [d][N]
+    double* OUT;          // [C][N]
+    const double* GBAR;   // [C][N]
+    double* ACTS;         // [tile][layer][slot][5][64]
+    double* GPART;        // [block][P]
+    long N;
+    long ntiles;
+    int save_act;
+    int woff[HPV_MAX_LAYERS];
+    int boff[HPV_MAX_LAYERS];
+    int t1dim[2];
+    int t2idx[2];
+    int P;
+    // boundary/data term folded into the forward kernel (tiles at and beyond data_off; -1: none)
+    long data_off;
+    const double* ud;     // [n_data] target values
+    double* gbar0;        // adjoint row of the value channel (written when data_write_gbar)
+    double* data_part;    // [data tiles] partial sums of (u_d - u)^2
+    double data_scale;    // -2 w / n_data
+    int data_write_gbar;
+    // element-block mode of the reverse kernel (projection fused in): blocks own the elements [0, proj_n_elem)
+    long proj_n_elem;
+    int proj_split;       // workgroups per element in the reverse kernel's element-block mode (1, 2, 4 or 8)
+    ProjArgs pa;
+};
+
+struct HpvMfma {
+    NetDesc nd;
+    long N, ntiles;
+    int L;
+    int ns;            // saved slots per layer
+    double* ACTS = nullptr;
+    int fwd_blocks, bwd_blocks;
+    MfmaArgs base;
+    void (*fwd)(const MfmaArgs&, int, hipStream_t) = nullptr;
+    void (*bwd)(const MfmaArgs&, int, hipStream_t) = nullptr;
+    void (*bwd_fused)(const MfmaArgs&, int, hipStream_t) = nullptr; // projection + reverse, element-block mode
+    int occ_fwd = 1, occ_bwd = 1;   // resident 256-thread blocks per CU
+    int n_cus = 256;                // compute units of the device
+    int max_rows = 0;               // gradient rows the caller allocated (>= every launch mode's row count)
+    // A/B switches read at creation (HPV_FUSE): default = the element-resident whole-iteration kernel where it applies,
+    // 'b' = forward + (projection fused into the reverse kernel), 'n' = forward, projection, reverse as separate launches
+    // 'i' = the whole-iteration kernel also for shards too small to fill the chip with one workgroup per element (tests)
+    bool fuse_bwd = true, iter_fused_ok = true, iter_fused_force = false;
+};
+
+template <int ACT>
+__device__ __forceinline__ void act_fwd(double z, double& a, double& a1, double& a2) {
+    if constexpr (ACT == HPV_ACT_TANH) {
+        a = hpv_tanh(z);
+        a1 = 1.0 - a * a;
+        a2 = -2.0 * a * a1;
+    } else {
+        sincos(z, &a, &a1);
+        a2 = -a;
+    }
+}
+template <int ACT>
+__device__ __forceinline__ void act_saved(double a, double a1s, double& a1, double& a2, double& a3) {
+    if constexpr (ACT == HPV_ACT_TANH) {
+        a1 = 1.0 - a * a;
+        a2 = -2.0 * a * a1;
+        a3 = -2.0 * a1 * (1.0 - 3.0 * a * a);
+    } else {
+        a1 = a1s;
+        a2 = -a;
+        a3 = -a1s;
+    }
+}
+
+template <int ACT, int NT1, int NT2>
+struct SlotCount {
+    static constexpr int value = 1 + (ACT == HPV_ACT_SIN ? 1 : 0) + NT1 + NT2;
+};
+

@@ -1,0 +1,534 @@
+// Element-resident whole-iteration kernel for the BASELINE config-4 shape (Poisson-2D var_form 1 and every other
+// two-term "one-hot" form on 20x20-point / 10x10-test elements, [2,20,...,20,1] tanh networks):
+//
+//   ONE workgroup (4 wavefronts, one per SIMD, up to 512 registers each) owns ONE element and runs the whole
+//   iteration for it without touching HBM in between:
+//     phase F  Taylor-mode forward of the element's 25 16-point tiles (7,6,6,6 per wave; one wave also takes one of the
+//              boundary/data tiles).  Only s = tanh(z) of every hidden layer is kept -- 15 doubles per lane and tile,
+//              IN REGISTERS (the compiler parks them in the AGPR half of the unified register file) -- and the two
+//              integrated channels u_x, u_y go to LDS.
+//     phase P  projection of the element from LDS (sum-factorised, P2:98-105), residual R = U - F, element loss
+//              (P2:117-120), adjoint of u_x, u_y back into the same LDS array.
+//     phase R  reverse pass of the same tiles: the tangent pre-activations z_x, z_y are RECOMPUTED from s on the MFMA
+//              pipe (2 channels x (L-1) layer products), then the hand-derived reverse pass of kernels_mfma.hip.
+//   The activation store of the two-kernel path (1 120 B/point written by the forward and read by the reverse kernel,
+//   248 MB of HBM traffic per iteration at config 4) does not exist here: per iteration the kernel reads the
+//   coordinates twice (L2-resident), F, the parameters, and writes R, the element losses and one gradient row per
+//   workgroup.
+//
+// Lane layout, MFMA formulation and the 16 + 4 split of a 20-wide layer are those of kernels_mfma.hip.
+#include <cstdlib>
+
+#include "hpv_mfma_dev.h"
+
+#define FZ_WAVES 4
+#define FZ_BLOCK (FZ_WAVES * 64)
+#define FZ_MAXT 7          // tiles per wave: ceil(25 / 4), or 6 + one boundary/data tile
+#define FZ_QX 20
+#define FZ_QY 20
+#define FZ_NTX 10
+#define FZ_NTY 10
+#define FZ_NQ (FZ_QX * FZ_QY)
+#define FZ_NR (FZ_NTX * FZ_NTY)
+#define FZ_TPE (FZ_NQ / 16)
+#define FZ_C 3             // u, u_x, u_y
+
+template <int L>
+struct FzLds {
+    static constexpr int LH = L > 1 ? L - 1 : 0;
+    static constexpr int WT = 0;                           // [LH][5][64]  forward A fragments  W[4s+q][out = pt]
+    static constexpr int BH = WT + LH * MF_KS * 64;        // [LH][5][64]  bias fragments       b[4s+q]
+    static constexpr int WR = BH + LH * MF_KS * 64;        // [LH][5][16]  W[4s+q][16+a]
+    static constexpr int WN = WR + LH * MF_KS * 16;        // [LH][5][64]  reverse A fragments  W[in = pt][out = 4s+q]
+    static constexpr int WRB = WN + LH * MF_KS * 64;       // [LH][5][16]  W[16+a][4s+q]
+    static constexpr int W1O = WRB + LH * MF_KS * 16;      // [4][5][64]   W1[0][4s+q], W1[1][4s+q], Wo[4s+q], b1[4s+q]
+    static constexpr int CH = W1O + 4 * MF_KS * 64;        // [2][400]     u_x, u_y of the element -> their adjoints
+    static constexpr int AX = CH + 2 * FZ_NQ;              // [2][NTX][QX] w_x phi^(dx_t)
+    static constexpr int BY = AX + 2 * FZ_NTX * FZ_QX;     // [2][NTY][QY] w_y phi^(dy_t)
+    static constexpr int T = BY + 2 * FZ_NTY * FZ_QY;      // [2][QY][NTX]
+    static constexpr int UP = T + 2 * FZ_QY * FZ_NTX;      // [2][NR]      per-term partial of U
+    static constexpr int U = UP + 2 * FZ_NR;               // [NR]
+    static constexpr int S = U + FZ_NR;                    // [2][NTY][QX]
+    static constexpr int RED = S + 2 * FZ_NTY * FZ_QX;     // [16]
+    static constexpr int TR = RED + 16;                    // per-wave transpose tiles | epilogue gradient rows
+    static constexpr int TR_WAVE = FZ_C * 2 * MF_TRB * MF_LD;
+    static constexpr int total(int P) { return TR + (FZ_WAVES * TR_WAVE > FZ_WAVES * P ? FZ_WAVES * TR_WAVE : FZ_WAVES * P); }
+};
+
+// hidden -> hidden product of one channel: z^T = W^T h^T (+ bias fragment for the value channel), 16 + 4 split
+template <bool BIAS>
+__device__ __forceinline__ void fz_layer(const double* WTl, const double* WRl, const double* BHl, int lofs,
+                                         const double (&h)[MF_KS], double (&z)[MF_KS]) {
+    v4d acc = BIAS ? v4d{BHl[lofs], BHl[64 + lofs], BHl[128 + lofs], BHl[192 + lofs]} : v4d{0.0, 0.0, 0.0, 0.0};
+    double z16 = BIAS ? BHl[256 + lofs] : 0.0;
+    const double* wrl = WRl + (lofs >> 4) * 4 + (lofs & 3);
+#pragma unroll
+    for (int s = 0; s < MF_KS; ++s) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(WTl[s * 64 + lofs], h[s], acc, 0, 0, 0);
+        z16 = __builtin_amdgcn_mfma_f64_4x4x4f64(wrl[s * 16], h[s], z16, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) z[s] = acc[s];
+    z[4] = z16;
+}
+
+template <int L>
+__global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
+    using M = FzLds<L>;
+    constexpr int LH = L > 1 ? L - 1 : 1;
+    constexpr int NSV = L * MF_KS;                 // saved doubles per lane and tile
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int q = lane >> 4, pt = lane & 15;
+    const long e = blockIdx.x;
+    const double* __restrict__ th = g.theta;
+    const ProjArgs& pa = g.pa;
+
+    // ---- stage every weight fragment and the projection tables (one global round trip) ----
+    {
+        constexpr int NW = (L - 1) * MF_KS * 64, NRW = (L - 1) * MF_KS * 16, N1 = 4 * MF_KS * 64;
+        for (int f = tid; f < NW; f += FZ_BLOCK) {
+            const int ln = f & 63, s_ = (f >> 6) % MF_KS, i_ = f / (64 * MF_KS) + 1;
+            lds[M::WT + f] = th[g.woff[i_] + (4 * s_ + (ln >> 4)) * MF_H + (ln & 15)];
+            lds[M::BH + f] = th[g.boff[i_] + 4 * s_ + (ln >> 4)];
+            lds[M::WN + f] = th[g.woff[i_] + (ln & 15) * MF_H + 4 * s_ + (ln >> 4)];
+        }
+        for (int f = tid; f < NRW; f += FZ_BLOCK) {
+            const int a_ = f & 3, q_ = (f >> 2) & 3, s_ = (f >> 4) % MF_KS, i_ = f / (16 * MF_KS) + 1;
+            lds[M::WR + f] = th[g.woff[i_] + (4 * s_ + q_) * MF_H + 16 + a_];
+            lds[M::WRB + f] = th[g.woff[i_] + (16 + a_) * MF_H + 4 * s_ + q_];
+        }
+        for (int f = tid; f < N1; f += FZ_BLOCK) {
+            const int ln = f & 63, s_ = (f >> 6) % MF_KS, c_ = f / (64 * MF_KS);
+            const int j = 4 * s_ + (ln >> 4);
+            lds[M::W1O + f] = c_ < 2 ? th[g.woff[0] + c_ * MF_H + j] : (c_ == 2 ? th[g.woff[L] + j] : th[g.boff[0] + j]);
+        }
+        for (int f = tid; f < 2 * FZ_NTX * FZ_QX; f += FZ_BLOCK) {
+            const int t = f / (FZ_NTX * FZ_QX), i = f % (FZ_NTX * FZ_QX);
+            lds[M::AX + f] = pa.wtx[(long)pa.pd.t[t].dx * FZ_NTX * FZ_QX + i];
+            lds[M::BY + f] = pa.wty[(long)pa.pd.t[t].dy * FZ_NTY * FZ_QY + i];
+        }
+    }
+    const double bo = th[g.boff[L]];
+    __syncthreads();
+
+    // ---- tile list of this wave: element tiles wv, wv+4, ..; wave 1 adopts boundary/data tile `dtile` ----
+    const int n_el = (FZ_TPE - wv + FZ_WAVES - 1) / FZ_WAVES;
+    const long dtile = g.proj_n_elem * FZ_TPE + blockIdx.x;
+    const bool has_d = (wv == 1) && dtile < g.ntiles;
+    const int n_own = n_el + (has_d ? 1 : 0);
+    auto tile_of = [&](int k) -> long { return k < n_el ? e * FZ_TPE + wv + (long)k * FZ_WAVES : dtile; };
+
+    double S[FZ_MAXT][NSV];      // s = tanh(z) of every hidden layer, every tile of this wave (registers / AGPRs)
+    double gdat = 0.0;           // adjoint of u at the data tile's point (boundary term, P2:122)
+
+    // =============================================================================================
+    // phase F: forward
+    // =============================================================================================
+    double xn[2];
+    {
+        long p0 = tile_of(0) * 16 + pt;
+        p0 = p0 < g.N ? p0 : g.N - 1;
+        xn[0] = g.X[p0]; xn[1] = g.X[g.N + p0];
+    }
+#pragma unroll 1
+    for (int k = 0; k < n_own; ++k) {
+        const long tile = tile_of(k);
+        const long p = tile * 16 + pt;
+        const bool valid = p < g.N;
+        const double x0 = valid ? xn[0] : 0.0, x1 = valid ? xn[1] : 0.0;
+        if (k + 1 < n_own) {
+            long pn = tile_of(k + 1) * 16 + pt;
+            pn = pn < g.N ? pn : g.N - 1;
+            xn[0] = g.X[pn]; xn[1] = g.X[g.N + pn];
+        }
+        int lofs = lane;
+        asm volatile("" : "+v"(lofs));       // opaque: the LDS fragment reads stay inside the loop
+        double h[FZ_C][MF_KS], sv[NSV];
+        // layer 1 (VALU)
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            const double w0 = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs], w1 = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
+            const double z = lds[M::W1O + (3 * MF_KS + s) * 64 + lofs] + x0 * w0 + x1 * w1;
+            double a, a1, a2;
+            act_fwd<HPV_ACT_TANH>(z, a, a1, a2);
+            sv[s] = a;
+            h[0][s] = a; h[1][s] = a1 * w0; h[2][s] = a1 * w1;
+        }
+#pragma unroll
+        for (int i = 1; i < L; ++i) {
+            double z[FZ_C][MF_KS];
+            fz_layer<true>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, lds + M::BH + (i - 1) * MF_KS * 64, lofs, h[0], z[0]);
+            fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[1], z[1]);
+            fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[2], z[2]);
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                double a, a1, a2;
+                act_fwd<HPV_ACT_TANH>(z[0][s], a, a1, a2);
+                sv[i * MF_KS + s] = a;
+                h[0][s] = a; h[1][s] = a1 * z[1][s]; h[2][s] = a1 * z[2][s];
+            }
+        }
+        // linear head
+        double o[FZ_C];
+#pragma unroll
+        for (int ch = 0; ch < FZ_C; ++ch) {
+            double v = 0.0;
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) v += h[ch][s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            o[ch] = v;
+        }
+        o[0] += bo;
+        if (k < n_el) {
+            if (q == 0) {
+                const int lp = (wv + k * FZ_WAVES) * 16 + pt;     // point index inside the element
+                lds[M::CH + lp] = o[1];
+                lds[M::CH + FZ_NQ + lp] = o[2];
+            }
+        } else {
+            // lossb = w mean((u_d - u)^2) (P2:122,127): adjoint of u kept in a register, per-tile partial sum to memory
+            const double dd = valid ? g.ud[p - g.data_off] - o[0] : 0.0;
+            gdat = g.data_scale * dd;
+            double sq = dd * dd;
+            sq += __shfl_xor(sq, 1, 64);
+            sq += __shfl_xor(sq, 2, 64);
+            sq += __shfl_xor(sq, 4, 64);
+            sq += __shfl_xor(sq, 8, 64);
+            if (lane == 0) g.data_part[tile - g.data_off / 16] = sq;
+        }
+        switch (k) {      // wave-uniform: every case moves this tile's s values into its own registers
+#define FZ_STASH(K) case K: _Pragma("unroll") for (int j = 0; j < NSV; ++j) S[K][j] = sv[j]; break;
+            FZ_STASH(0) FZ_STASH(1) FZ_STASH(2) FZ_STASH(3) FZ_STASH(4) FZ_STASH(5) FZ_STASH(6)
+#undef FZ_STASH
+        }
+    }
+    __syncthreads();
+
+    // =============================================================================================
+    // phase P: projection of the element from LDS (two one-hot terms: term t integrates channel 1 + t)
+    // =============================================================================================
+    {
+        const double* G = lds + M::CH;
+        // T_t[j][r] = sum_i AX_t[r][i] G_t[j][i]
+        for (int o = tid; o < 2 * FZ_QY * FZ_NTX; o += FZ_BLOCK) {
+            const int t = o / (FZ_QY * FZ_NTX), j = (o / FZ_NTX) % FZ_QY, r = o % FZ_NTX;
+            const double* ax = lds + M::AX + (t * FZ_NTX + r) * FZ_QX;
+            const double* gr = G + t * FZ_NQ + j * FZ_QX;
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < FZ_QX; ++i) acc = fma(ax[i], gr[i], acc);
+            lds[M::T + o] = acc;
+        }
+        __syncthreads();
+        // per-term partial of U[k][r] = c_t sum_j BY_t[k][j] T_t[j][r]
+        if (tid < 2 * FZ_NR) {
+            const int t = tid / FZ_NR, o = tid % FZ_NR, kk = o / FZ_NTX, r = o % FZ_NTX;
+            const double* by = lds + M::BY + (t * FZ_NTY + kk) * FZ_QY;
+            const double* tt = lds + M::T + t * FZ_QY * FZ_NTX + r;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < FZ_QY; ++j) acc = fma(by[j], tt[j * FZ_NTX], acc);
+            lds[M::UP + tid] = pa.coef[(long)t * pa.coef_stride + e] * acc;
+        }
+        __syncthreads();
+        double sq = 0.0;
+        if (tid < FZ_NR) {
+            const double u = (lds[M::UP + tid] + lds[M::UP + FZ_NR + tid]) - (pa.F ? pa.F[e * FZ_NR + tid] : 0.0);
+            lds[M::U + tid] = u;
+            pa.R[e * FZ_NR + tid] = u;
+            sq = u * u;
+        }
+        if (wv < 2) {
+            sq = pj_wave_sum(sq);
+            if (lane == 0) lds[M::RED + wv] = sq;
+        }
+        __syncthreads();
+        if (tid == 0) pa.loss_e[e] = (lds[M::RED] + lds[M::RED + 1]) / (double)FZ_NR;
+        // adjoint: S_t[k][i] = (2/NR) c_t sum_r AX_t[r][i] U[k][r];  Gbar_t[j][i] = sum_k BY_t[k][j] S_t[k][i]
+        const double sc = 2.0 / (double)FZ_NR;
+        for (int o = tid; o < 2 * FZ_NTY * FZ_QX; o += FZ_BLOCK) {
+            const int t = o / (FZ_NTY * FZ_QX), kk = (o / FZ_QX) % FZ_NTY, i = o % FZ_QX;
+            const double* ax = lds + M::AX + t * FZ_NTX * FZ_QX + i;
+            const double* ur = lds + M::U + kk * FZ_NTX;
+            double acc = 0.0;
+#pragma unroll
+            for (int r = 0; r < FZ_NTX; ++r) acc = fma(ax[r * FZ_QX], ur[r], acc);
+            lds[M::S + o] = acc * sc * pa.coef[(long)t * pa.coef_stride + e];
+        }
+        __syncthreads();
+        for (int o = tid; o < 2 * FZ_NQ; o += FZ_BLOCK) {
+            const int t = o / FZ_NQ, j = (o / FZ_QX) % FZ_QY, i = o % FZ_QX;
+            const double* by = lds + M::BY + t * FZ_NTY * FZ_QY + j;
+            const double* sr = lds + M::S + t * FZ_NTY * FZ_QX + i;
+            double acc = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < FZ_NTY; ++kk) acc = fma(by[kk * FZ_QY], sr[kk * FZ_QX], acc);
+            lds[M::CH + o] = acc;
+        }
+        __syncthreads();
+    }
+
+    // =============================================================================================
+    // phase R: reverse pass (tangent pre-activations recomputed from s)
+    // =============================================================================================
+    double* TAB = lds + M::TR + wv * M::TR_WAVE;
+    v4d dWacc[LH];
+    double dS10[LH], dS01[LH], accC[LH];
+#pragma unroll
+    for (int i = 0; i < LH; ++i) { dWacc[i] = v4d{0.0, 0.0, 0.0, 0.0}; dS10[i] = 0.0; dS01[i] = 0.0; accC[i] = 0.0; }
+    double db[L][MF_KS], dW1[2][MF_KS], dWo[MF_KS], dbo = 0.0;
+#pragma unroll
+    for (int s = 0; s < MF_KS; ++s) {
+        dWo[s] = 0.0; dW1[0][s] = 0.0; dW1[1][s] = 0.0;
+#pragma unroll
+        for (int i = 0; i < L; ++i) db[i][s] = 0.0;
+    }
+
+#pragma unroll 1
+    for (int k = 0; k < n_own; ++k) {
+        const long tile = tile_of(k);
+        const long p = tile * 16 + pt;
+        const bool valid = p < g.N;
+        const double x0 = valid ? g.X[p] : 0.0, x1 = valid ? g.X[g.N + p] : 0.0;
+        int lofs = lane;
+        asm volatile("" : "+v"(lofs));
+        double sv[NSV];
+        switch (k) {
+#define FZ_FETCH(K) case K: _Pragma("unroll") for (int j = 0; j < NSV; ++j) sv[j] = S[K][j]; break;
+            FZ_FETCH(0) FZ_FETCH(1) FZ_FETCH(2) FZ_FETCH(3) FZ_FETCH(4) FZ_FETCH(5) FZ_FETCH(6)
+#undef FZ_FETCH
+            default:
+#pragma unroll
+                for (int j = 0; j < NSV; ++j) sv[j] = 0.0;
+        }
+        double gb[FZ_C];
+        if (k < n_el) {
+            const int lp = (wv + k * FZ_WAVES) * 16 + pt;
+            gb[0] = 0.0; gb[1] = lds[M::CH + lp]; gb[2] = lds[M::CH + FZ_NQ + lp];
+        } else {
+            gb[0] = gdat; gb[1] = 0.0; gb[2] = 0.0;
+        }
+        // tangent pre-activations of every hidden layer: layer 0 has z_c = W1[c,:]; layer i: z_c = (sigma'(z_{i-1}) z_c,{i-1}) W_i
+        double zc[L][2][MF_KS];
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            zc[0][0][s] = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs];
+            zc[0][1][s] = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
+        }
+#pragma unroll
+        for (int i = 1; i < L; ++i) {
+            double hx[MF_KS], hy[MF_KS];
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                const double a = sv[(i - 1) * MF_KS + s], a1 = 1.0 - a * a;
+                hx[s] = a1 * zc[i - 1][0][s]; hy[s] = a1 * zc[i - 1][1][s];
+            }
+            fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, hx, zc[i][0]);
+            fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, hy, zc[i][1]);
+        }
+
+        double hbar[FZ_C][MF_KS], zbar[FZ_C][MF_KS];
+        // ---- linear head ----
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            const double a = sv[(L - 1) * MF_KS + s], a1 = 1.0 - a * a;
+            const double wo = lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
+            dWo[s] = fma(a, gb[0], dWo[s]);
+            dWo[s] = fma(a1 * zc[L - 1][0][s], gb[1], dWo[s]);
+            dWo[s] = fma(a1 * zc[L - 1][1][s], gb[2], dWo[s]);
+            hbar[0][s] = gb[0] * wo; hbar[1][s] = gb[1] * wo; hbar[2][s] = gb[2] * wo;
+        }
+        if (q == 0) dbo += gb[0];
+
+        // ---- hidden layers, last to first ----
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                const double a = sv[i * MF_KS + s];
+                const double a1 = 1.0 - a * a, a2 = -2.0 * a * a1;
+                zbar[1][s] = hbar[1][s] * a1;
+                zbar[2][s] = hbar[2][s] * a1;
+                const double zb = hbar[0][s] * a1 + a2 * (hbar[1][s] * zc[i][0][s] + hbar[2][s] * zc[i][1][s]);
+                zbar[0][s] = zb;
+                db[i][s] += zb;
+            }
+            if (i == 0) {
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+                    dW1[0][s] += x0 * zbar[0][s] + zbar[1][s];
+                    dW1[1][s] += x1 * zbar[0][s] + zbar[2][s];
+                }
+            } else {
+                // weight gradient dW_i[in][out] = sum_pt sum_ch h_{i-1,ch}[pt][in] zbar_ch[pt][out]: the operands are needed
+                // point-major -> per-wave LDS transpose tiles, all channels written first (one wave-level sync)
+                pj_wave_sync();
+#pragma unroll
+                for (int ch = 0; ch < FZ_C; ++ch) {
+                    double* TA = TAB + (2 * ch) * (MF_TRB * MF_LD);
+                    double* TB = TA + MF_TRB * MF_LD;
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s) {
+                        const double a = sv[(i - 1) * MF_KS + s], a1 = 1.0 - a * a;
+                        const double hv = ch == 0 ? a : a1 * zc[i - 1][ch - 1][s];
+                        TA[(4 * s + q) * MF_LD + pt] = hv;
+                        TB[(4 * s + q) * MF_LD + pt] = zbar[ch][s];
+                    }
+                }
+                pj_wave_sync();
+#pragma unroll
+                for (int ch = 0; ch < FZ_C; ++ch) {
+                    const double* TA = TAB + (2 * ch) * (MF_TRB * MF_LD);
+                    const double* TB = TA + MF_TRB * MF_LD;
+                    double aF[4], bF[4], aS[4], bS[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        aF[kk] = TA[pt * MF_LD + 4 * kk + q];
+                        bF[kk] = TB[pt * MF_LD + 4 * kk + q];
+                        aS[kk] = TA[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                        bS[kk] = TB[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        dWacc[i - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[kk], bF[kk], dWacc[i - 1], 0, 0, 0);
+                        dS10[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(aS[kk], bF[kk], dS10[i - 1], 0, 0, 0);
+                        dS01[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(bS[kk], aF[kk], dS01[i - 1], 0, 0, 0);
+                    }
+                    accC[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(TA[(16 + (lane & 3)) * MF_LD + (pt & 12) + q],
+                                                                   TB[(16 + (lane & 3)) * MF_LD + (pt & 12) + q], accC[i - 1], 0, 0, 0);
+                }
+                // hbar_{i-1}^T = W_i zbar^T
+#pragma unroll
+                for (int ch = 0; ch < FZ_C; ++ch) {
+                    v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
+                    double h4 = 0.0;
+                    const double* wrl = lds + M::WRB + (i - 1) * MF_KS * 16 + q * 4 + (lane & 3);
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s) {
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[M::WN + ((i - 1) * MF_KS + s) * 64 + lofs], zbar[ch][s], acc, 0, 0, 0);
+                        h4 = __builtin_amdgcn_mfma_f64_4x4x4f64(wrl[s * 16], zbar[ch][s], h4, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) hbar[ch][s] = acc[s];
+                    hbar[ch][4] = h4;
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: per-wave partials -> LDS -> one gradient row per workgroup ----
+    __syncthreads();
+    double* WP = lds + M::TR + (long)wv * g.P;
+    for (int idx = lane; idx < g.P; idx += 64) WP[idx] = 0.0;
+    pj_wave_sync();
+#pragma unroll
+    for (int i = 1; i < L; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) WP[g.woff[i] + (4 * r + q) * MF_H + pt] = dWacc[i - 1][r];
+        WP[g.woff[i] + (16 + q) * MF_H + pt] = dS10[i - 1];
+        WP[g.woff[i] + pt * MF_H + 16 + q] = dS01[i - 1];
+    }
+#pragma unroll
+    for (int i = 1; i < L; ++i) {
+        double t = accC[i - 1];
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        if (pt < 4) WP[g.woff[i] + (16 + q) * MF_H + 16 + pt] = t;
+    }
+#pragma unroll
+    for (int s = 0; s < MF_KS; ++s) {
+        const int j = 4 * s + q;
+        double v[L + 3];
+#pragma unroll
+        for (int i = 0; i < L; ++i) v[i] = db[i][s];
+        v[L] = dW1[0][s]; v[L + 1] = dW1[1][s]; v[L + 2] = dWo[s];
+#pragma unroll
+        for (int kq = 0; kq < L + 3; ++kq) {
+            double t = v[kq];
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 4, 64);
+            t += __shfl_xor(t, 8, 64);
+            v[kq] = t;
+        }
+        if (pt == 0) {
+#pragma unroll
+            for (int i = 0; i < L; ++i) WP[g.boff[i] + j] = v[i];
+            WP[g.woff[0] + j] = v[L];
+            WP[g.woff[0] + MF_H + j] = v[L + 1];
+            WP[g.woff[L] + j] = v[L + 2];
+        }
+    }
+    {
+        double t = dbo;
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        if (lane == 0) WP[g.boff[L]] = t;
+    }
+    __syncthreads();
+    const double* W0 = lds + M::TR;
+    double* row = g.GPART + (long)blockIdx.x * g.P;
+    for (int idx = tid; idx < g.P; idx += FZ_BLOCK) {
+        double acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < FZ_WAVES; ++w) acc += W0[(long)w * g.P + idx];
+        row[idx] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <int L>
+static void launch_iter_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
+    const size_t bytes = (size_t)FzLds<L>::total(a.P) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_iter_fused<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_iter_fused<L>), dim3(blocks), dim3(FZ_BLOCK), bytes, s, a);
+}
+
+// Whole training pass (forward, projection, reverse) of a shard of 20x20 / 10x10 elements in one launch.  Returns false
+// when the shape / variational form / shard is not covered; the caller then runs the separate kernels.
+bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
+                         const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem) {
+    const ProjDesc& pd = pa.pd;
+    const NetDesc& nd = m->nd;
+    if (!m->iter_fused_ok) return false;
+    if (!(nd.d == 2 && nd.nT1 == 2 && nd.nT2 == 0 && nd.act == HPV_ACT_TANH) || m->L < 2 || m->L > 3) return false;
+    if (!(pd.qx == FZ_QX && pd.qy == FZ_QY && pd.ntx == FZ_NTX && pd.nty == FZ_NTY) || pd.edge || pd.has_eps) return false;
+    if (pd.nterms != 2) return false;
+    for (int t = 0; t < 2; ++t)          // one-hot: term t integrates exactly channel 1 + t with weight 1
+        for (int ch = 0; ch < HPV_MAXC; ++ch)
+            if (pd.t[t].a0[ch] != (ch == 1 + t ? 1.0 : 0.0) || pd.t[t].a1[ch] != 0.0 || pd.t[t].eps_mult) return false;
+    if (n_elem <= 0) return false;
+    if (n_elem * 2 <= m->n_cus && !m->iter_fused_force) return false;   // small shards: the split-element reverse kernel fills the chip
+    const long rest = m->ntiles - n_elem * FZ_TPE;                  // pad + boundary/data tiles: at most one per workgroup
+    if (rest < 0 || rest > n_elem) return false;
+    if (n_elem > hpv_mfma_grad_rows(m) && n_elem > m->max_rows) return false;
+    MfmaArgs a = m->base;
+    a.theta = theta; a.X = X; a.GPART = GPART;
+    a.data_off = -1;
+    if (dt && dt->n_data > 0) {
+        a.data_off = dt->data_off; a.ud = dt->ud; a.gbar0 = dt->gbar0; a.data_part = dt->data_part;
+        a.data_scale = dt->scale; a.data_write_gbar = dt->write_gbar;
+    } else if (rest > 0) {
+        return false;    // tiles behind the elements but no data term: not a layout this kernel knows
+    }
+    a.proj_n_elem = n_elem;
+    a.proj_split = 1;
+    a.pa = pa;
+    switch (m->L) {
+        case 2: launch_iter_fused<2>(a, (int)n_elem, s); break;
+        case 3: launch_iter_fused<3>(a, (int)n_elem, s); break;
+        default: return false;
+    }
+    if (rows) *rows = (int)n_elem;
+    return true;
+}

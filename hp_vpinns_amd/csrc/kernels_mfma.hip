@@ -23,92 +23,7 @@
 // First layer (d -> 20) and linear head (20 -> 1) are VALU work (K = 1..2 and M = 1 are no MFMA shapes).
 #include <cstdlib>
 
-#include "hpv_mfma.h"
-#include "hpv_math.h"
-#include "hpv_project_wg.h"
-
-typedef double v4d __attribute__((ext_vector_type(4)));
-
-#define MF_H 20
-#define MF_KS 5        // k-steps of 4 over the 20 inputs
-#define MF_LD 17       // padded leading dimension of the LDS transpose tiles
-#define MF_TRB 20      // rows of a transpose tile of k_bwd_mfma (20 neurons; every fragment row is in range)
-#define MF_BLOCK 256
-#define MF_WAVES (MF_BLOCK / 64)
-
-struct MfmaArgs {
-    const double* theta;
-    const double* X;      // [d][N]
-    double* OUT;          // [C][N]
-    const double* GBAR;   // [C][N]
-    double* ACTS;         // [tile][layer][slot][5][64]
-    double* GPART;        // [block][P]
-    long N;
-    long ntiles;
-    int save_act;
-    int woff[HPV_MAX_LAYERS];
-    int boff[HPV_MAX_LAYERS];
-    int t1dim[2];
-    int t2idx[2];
-    int P;
-    // boundary/data term folded into the forward kernel (tiles at and beyond data_off; -1: none)
-    long data_off;
-    const double* ud;     // [n_data] target values
-    double* gbar0;        // adjoint row of the value channel (written when data_write_gbar)
-    double* data_part;    // [data tiles] partial sums of (u_d - u)^2
-    double data_scale;    // -2 w / n_data
-    int data_write_gbar;
-    // element-block mode of the reverse kernel (projection fused in): blocks own the elements [0, proj_n_elem)
-    long proj_n_elem;
-    int proj_split;       // workgroups per element in the reverse kernel's element-block mode (1, 2, 4 or 8)
-    ProjArgs pa;
-};
-
-struct HpvMfma {
-    NetDesc nd;
-    long N, ntiles;
-    int L;
-    int ns;            // saved slots per layer
-    double* ACTS = nullptr;
-    int fwd_blocks, bwd_blocks;
-    MfmaArgs base;
-    void (*fwd)(const MfmaArgs&, int, hipStream_t) = nullptr;
-    void (*bwd)(const MfmaArgs&, int, hipStream_t) = nullptr;
-    void (*bwd_fused)(const MfmaArgs&, int, hipStream_t) = nullptr; // projection + reverse, element-block mode
-    int occ_fwd = 1, occ_bwd = 1;   // resident 256-thread blocks per CU
-    int n_cus = 256;                // compute units of the device
-    int max_rows = 0;               // gradient rows the caller allocated (>= every launch mode's row count)
-    bool fuse_bwd = true;   // HPV_FUSE=n at creation: separate projection and reverse launches (A/B switch)
-};
-
-template <int ACT>
-__device__ __forceinline__ void act_fwd(double z, double& a, double& a1, double& a2) {
-    if constexpr (ACT == HPV_ACT_TANH) {
-        a = hpv_tanh(z);
-        a1 = 1.0 - a * a;
-        a2 = -2.0 * a * a1;
-    } else {
-        sincos(z, &a, &a1);
-        a2 = -a;
-    }
-}
-template <int ACT>
-__device__ __forceinline__ void act_saved(double a, double a1s, double& a1, double& a2, double& a3) {
-    if constexpr (ACT == HPV_ACT_TANH) {
-        a1 = 1.0 - a * a;
-        a2 = -2.0 * a * a1;
-        a3 = -2.0 * a1 * (1.0 - 3.0 * a * a);
-    } else {
-        a1 = a1s;
-        a2 = -a;
-        a3 = -a1s;
-    }
-}
-
-template <int ACT, int NT1, int NT2>
-struct SlotCount {
-    static constexpr int value = 1 + (ACT == HPV_ACT_SIN ? 1 : 0) + NT1 + NT2;
-};
+#include "hpv_mfma_dev.h"
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -235,6 +150,7 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) k_fwd_mfma(MfmaArgs g) {
         for (int i = 1; i < L; ++i) {
             v4d acc[C];
             const double* bhl = BH + (i - 1) * MF_KS * 64 + lofs;
+            double z16[C];
 #pragma unroll
             for (int ch = 0; ch < C; ++ch)
                 acc[ch] = (ch == 0) ? v4d{bhl[0], bhl[64], bhl[128], bhl[192]} : v4d{0.0, 0.0, 0.0, 0.0};
@@ -247,7 +163,6 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) k_fwd_mfma(MfmaArgs g) {
             // four groups of 4 points; no padding).  A[i'][k] = W[4s+k][16+i'] (lane: k = q, i' = lane&3, same for every
             // block), B_b[k][j] = h[4s+k][pt = 4b+j] = this lane's own h[ch][s]; D lane (q,pt) = neuron 16+q at point pt,
             // i.e. exactly the lane's fifth value.
-            double z16[C];
             {
                 const double* wrl = WR + (i - 1) * MF_KS * 16 + (lofs >> 4) * 4 + (lofs & 3);
                 double wr[MF_KS];
@@ -811,6 +726,8 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
     {
         const char* e = getenv("HPV_FUSE");
         m->fuse_bwd = !(e && e[0] == 'n');
+        m->iter_fused_ok = !(e && (e[0] == 'n' || e[0] == 'b'));
+        m->iter_fused_force = e && e[0] == 'i';
     }
     MfmaArgs& a = m->base;
     a = MfmaArgs{};

@@ -658,6 +658,48 @@ def test_fused_projection_reverse_config4_element_shape(nex, ney):
     for _ in range(2):                # duplicate projections by the workgroups of an element: results must be reproducible
         l3b, gb = m.loss_and_grad()
         assert np.array_equal(gb, gf) and np.array_equal(l3b, l3f)
+    # the element-resident whole-iteration kernel (forced also for these small shards) against the separate launches
+    os.environ["HPV_FUSE"] = "i"
+    try:
+        m3 = poisson2d.build_model(s, L, init_params=th)
+        l3i, gi = m3.loss_and_grad()
+        r_i = m3.h.residuals(nex * ney * 100)
+        for _ in range(2):
+            l3b, gb = m3.loss_and_grad()
+            assert np.array_equal(gb, gi) and np.array_equal(l3b, l3i)
+        m3._step(5, False)
+        m2._step(5, False)
+        assert rel(m3.get_params(), m2.get_params()) < 1e-11
+    finally:
+        del os.environ["HPV_FUSE"]
+    assert rel(gi, g) < 1e-12 and rel(l3i, l3) < 1e-13 and rel(r_i, r_u) < 1e-12
+
+
+@pytest.mark.parametrize("nhid", [2, 3])
+def test_whole_iteration_kernel_depths_and_forms(nhid):
+    """kernels_fused.hip on the config-4 element shape: 2 and 3 hidden layers, against the oracle (small grid, forced) --
+    loss, gradient, residuals, a short Adam trajectory; var_form 2 is a two-term form that is NOT one-hot and must fall
+    back to the separate kernels with identical results."""
+    import os
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    from oracle.vpinn_oracle import OracleVPINN2D
+    s = poisson2d.setup(N_el_x=2, N_el_y=2, N_test_x=10, N_test_y=10, N_quad=20, N_bound=9, with_test_grid=False)
+    L = [2] + [20] * nhid + [1]
+    th = xavier_init(L, 8)
+    os.environ["HPV_FUSE"] = "i"
+    try:
+        for vf in (1, 2):
+            m = poisson2d.build_model(s, L, var_form=vf, init_params=th)
+            o = OracleVPINN2D(s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"], s["WXY_quad_train"],
+                              None, s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"], None, None, L,
+                              var_form=vf, init_params=th)
+            o.vectorized = True
+            _check_loss_grad(o, m)
+            assert rel(m.h.residuals(400), o.last["R"].reshape(-1)) < TOL
+            _check_traj(o, m, n=5)
+    finally:
+        del os.environ["HPV_FUSE"]
 
 
 def _p2p_worker(rank, world, port, out_path):
