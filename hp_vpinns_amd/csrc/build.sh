@@ -6,6 +6,11 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 for f in kernels_generic kernels_mfma kernels_fused kernels_project hpv_api; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ hpv_internal.h -nt $f.o ] || [ hpv_mfma.h -nt $f.o ] || [ hpv_mfma_dev.h -nt $f.o ] || [ hpv_project_wg.h -nt $f.o ] || [ hpv_math.h -nt $f.o ] || [ ../../include/hpvpinn.h -nt $f.o ]; then
+    if [ $f = kernels_fused ]; then   # the whole-iteration kernel parks live values in AGPRs by hand: verify the compiler stays clear
+      $HIPCC $FLAGS -S --cuda-device-only $f.hip -o $f.s 2>/dev/null
+      python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi3 76
+      python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi2 136
+    fi
     $HIPCC $FLAGS -c $f.hip -o $f.o
   fi
 done

@@ -5,7 +5,7 @@
 //   iteration for it without touching HBM in between:
 //     phase F  Taylor-mode forward of the element's 25 16-point tiles (7,6,6,6 per wave; one wave also takes one of the
 //              boundary/data tiles).  Only s = tanh(z) of every hidden layer is kept -- 15 doubles per lane and tile,
-//              IN REGISTERS (the compiler parks them in the AGPR half of the unified register file) -- and the two
+//              IN REGISTERS (hand-placed in the AGPR half of the unified register file; one tile per wave in LDS) -- and the two
 //              integrated channels u_x, u_y go to LDS.
 //     phase P  projection of the element from LDS (sum-factorised, P2:98-105), residual R = U - F, element loss
 //              (P2:117-120), adjoint of u_x, u_y back into the same LDS array.
@@ -50,10 +50,38 @@ struct FzLds {
     static constexpr int U = UP + 2 * FZ_NR;               // [NR]
     static constexpr int S = U + FZ_NR;                    // [2][NTY][QX]
     static constexpr int RED = S + 2 * FZ_NTY * FZ_QX;     // [16]
-    static constexpr int TR = RED + 16;                    // per-wave transpose tiles | epilogue gradient rows
+    static constexpr int PK = RED + 16;                    // [waves][L*5][64]  s of each wave's FIRST tile (the other tiles' s live in registers)
+    static constexpr int TR = PK + FZ_WAVES * L * MF_KS * 64;   // per-wave transpose tiles | epilogue gradient rows
     static constexpr int TR_WAVE = FZ_C * 2 * MF_TRB * MF_LD;
     static constexpr int total(int P) { return TR + (FZ_WAVES * TR_WAVE > FZ_WAVES * P ? FZ_WAVES * TR_WAVE : FZ_WAVES * P); }
 };
+
+// ---- explicit AGPR stash -------------------------------------------------------------------------------------------
+// At one wave per SIMD a wave owns 512 registers: 256 architectural VGPRs + 256 accumulation registers (AGPRs).  The s
+// values of the wave's tiles 1..6 (6 x L x 5 doubles per lane) are parked in the TOP AGPRs a[FZ_ABASE..255] by hand
+// (v_accvgpr_write/read through inline asm): left to the register allocator, the same values end up behind PHI copies
+// that move hundreds of registers per tile.  The compiler does not know these registers hold live values -- it only sees
+// that a255 is clobbered, which makes the kernel descriptor reserve all 256 AGPRs -- so csrc/build.sh runs
+// scripts/check_agpr.py on the generated assembly: the build FAILS if compiler-generated code touches a[FZ_ABASE..255].
+template <int IDX>
+__device__ __forceinline__ void acc_put(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    asm volatile("v_accvgpr_write_b32 a[%2], %0\n\tv_accvgpr_write_b32 a[%3], %1" ::"v"(lo), "v"(hi), "n"(IDX), "n"(IDX + 1));
+}
+template <int IDX>
+__device__ __forceinline__ double acc_get() {
+    int lo, hi;
+    asm volatile("v_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]" : "=v"(lo), "=v"(hi) : "n"(IDX), "n"(IDX + 1));
+    return __hiloint2double(hi, lo);
+}
+template <int BASE, int N, int J = 0>
+__device__ __forceinline__ void acc_put_all(const double (&sv)[N]) {
+    if constexpr (J < N) { acc_put<BASE + 2 * J>(sv[J]); acc_put_all<BASE, N, J + 1>(sv); }
+}
+template <int BASE, int N, int J = 0>
+__device__ __forceinline__ void acc_get_all(double (&sv)[N]) {
+    if constexpr (J < N) { sv[J] = acc_get<BASE + 2 * J>(); acc_get_all<BASE, N, J + 1>(sv); }
+}
 
 // hidden -> hidden product of one channel: z^T = W^T h^T (+ bias fragment for the value channel), 16 + 4 split
 template <bool BIAS>
@@ -78,7 +106,8 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     constexpr int LH = L > 1 ? L - 1 : 1;
     constexpr int NSV = L * MF_KS;                 // saved doubles per lane and tile
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): tile counts and branches on it stay scalar
     const int q = lane >> 4, pt = lane & 15;
     const long e = blockIdx.x;
     const double* __restrict__ th = g.theta;
@@ -119,7 +148,11 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     const int n_own = n_el + (has_d ? 1 : 0);
     auto tile_of = [&](int k) -> long { return k < n_el ? e * FZ_TPE + wv + (long)k * FZ_WAVES : dtile; };
 
-    double S[FZ_MAXT][NSV];      // s = tanh(z) of every hidden layer, every tile of this wave (registers / AGPRs)
+    // s = tanh(z) of every hidden layer: tile 0's go to LDS (what is left of it), the tiles 1..6 of this wave to the top
+    // AGPRs a[ABASE + (k-1) * 2 NSV ..] (see acc_put)
+    constexpr int ABASE = 256 - (FZ_MAXT - 1) * 2 * NSV;
+    asm volatile("" ::: "a255");       // the kernel owns all 256 AGPRs
+    double* PKw = lds + M::PK + wv * (NSV * 64) + lane;
     double gdat = 0.0;           // adjoint of u at the data tile's point (boundary term, P2:122)
 
     // =============================================================================================
@@ -199,8 +232,12 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             if (lane == 0) g.data_part[tile - g.data_off / 16] = sq;
         }
         switch (k) {      // wave-uniform: every case moves this tile's s values into its own registers
-#define FZ_STASH(K) case K: _Pragma("unroll") for (int j = 0; j < NSV; ++j) S[K][j] = sv[j]; break;
-            FZ_STASH(0) FZ_STASH(1) FZ_STASH(2) FZ_STASH(3) FZ_STASH(4) FZ_STASH(5) FZ_STASH(6)
+            case 0:
+#pragma unroll
+                for (int j = 0; j < NSV; ++j) PKw[j * 64] = sv[j];
+                break;
+#define FZ_STASH(K) case K: acc_put_all<ABASE + (K - 1) * 2 * NSV, NSV>(sv); break;
+            FZ_STASH(1) FZ_STASH(2) FZ_STASH(3) FZ_STASH(4) FZ_STASH(5) FZ_STASH(6)
 #undef FZ_STASH
         }
     }
@@ -296,8 +333,12 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         asm volatile("" : "+v"(lofs));
         double sv[NSV];
         switch (k) {
-#define FZ_FETCH(K) case K: _Pragma("unroll") for (int j = 0; j < NSV; ++j) sv[j] = S[K][j]; break;
-            FZ_FETCH(0) FZ_FETCH(1) FZ_FETCH(2) FZ_FETCH(3) FZ_FETCH(4) FZ_FETCH(5) FZ_FETCH(6)
+            case 0:
+#pragma unroll
+                for (int j = 0; j < NSV; ++j) sv[j] = PKw[j * 64];
+                break;
+#define FZ_FETCH(K) case K: acc_get_all<ABASE + (K - 1) * 2 * NSV, NSV>(sv); break;
+            FZ_FETCH(1) FZ_FETCH(2) FZ_FETCH(3) FZ_FETCH(4) FZ_FETCH(5) FZ_FETCH(6)
 #undef FZ_FETCH
             default:
 #pragma unroll
@@ -311,19 +352,15 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             gb[0] = gdat; gb[1] = 0.0; gb[2] = 0.0;
         }
         // tangent pre-activations of every hidden layer: layer 0 has z_c = W1[c,:]; layer i: z_c = (sigma'(z_{i-1}) z_c,{i-1}) W_i
-        double zc[L][2][MF_KS];
-#pragma unroll
-        for (int s = 0; s < MF_KS; ++s) {
-            zc[0][0][s] = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs];
-            zc[0][1][s] = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
-        }
+        double zc[L][2][MF_KS];      // (entry 0 is never materialised: ZC(0, c, s) re-reads the LDS fragment)
+#define ZC(I, CC, SS) ((I) == 0 ? lds[M::W1O + ((CC) * MF_KS + (SS)) * 64 + lofs] : zc[(I)][(CC)][(SS)])
 #pragma unroll
         for (int i = 1; i < L; ++i) {
             double hx[MF_KS], hy[MF_KS];
 #pragma unroll
             for (int s = 0; s < MF_KS; ++s) {
                 const double a = sv[(i - 1) * MF_KS + s], a1 = 1.0 - a * a;
-                hx[s] = a1 * zc[i - 1][0][s]; hy[s] = a1 * zc[i - 1][1][s];
+                hx[s] = a1 * ZC(i - 1, 0, s); hy[s] = a1 * ZC(i - 1, 1, s);
             }
             fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, hx, zc[i][0]);
             fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, hy, zc[i][1]);
@@ -351,7 +388,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                 const double a1 = 1.0 - a * a, a2 = -2.0 * a * a1;
                 zbar[1][s] = hbar[1][s] * a1;
                 zbar[2][s] = hbar[2][s] * a1;
-                const double zb = hbar[0][s] * a1 + a2 * (hbar[1][s] * zc[i][0][s] + hbar[2][s] * zc[i][1][s]);
+                const double zb = hbar[0][s] * a1 + a2 * (hbar[1][s] * ZC(i, 0, s) + hbar[2][s] * ZC(i, 1, s));
                 zbar[0][s] = zb;
                 db[i][s] += zb;
             }
@@ -372,10 +409,25 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
 #pragma unroll
                     for (int s = 0; s < MF_KS; ++s) {
                         const double a = sv[(i - 1) * MF_KS + s], a1 = 1.0 - a * a;
-                        const double hv = ch == 0 ? a : a1 * zc[i - 1][ch - 1][s];
+                        const double hv = ch == 0 ? a : a1 * ZC(i - 1, ch - 1, s);
                         TA[(4 * s + q) * MF_LD + pt] = hv;
                         TB[(4 * s + q) * MF_LD + pt] = zbar[ch][s];
                     }
+                }
+                // hbar_{i-1}^T = W_i zbar^T  (independent of the transposes: issued while the LDS writes above land)
+#pragma unroll
+                for (int ch = 0; ch < FZ_C; ++ch) {
+                    v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
+                    double h4 = 0.0;
+                    const double* wrl = lds + M::WRB + (i - 1) * MF_KS * 16 + q * 4 + (lane & 3);
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s) {
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[M::WN + ((i - 1) * MF_KS + s) * 64 + lofs], zbar[ch][s], acc, 0, 0, 0);
+                        h4 = __builtin_amdgcn_mfma_f64_4x4x4f64(wrl[s * 16], zbar[ch][s], h4, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) hbar[ch][s] = acc[s];
+                    hbar[ch][4] = h4;
                 }
                 pj_wave_sync();
 #pragma unroll
@@ -399,25 +451,11 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                     accC[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(TA[(16 + (lane & 3)) * MF_LD + (pt & 12) + q],
                                                                    TB[(16 + (lane & 3)) * MF_LD + (pt & 12) + q], accC[i - 1], 0, 0, 0);
                 }
-                // hbar_{i-1}^T = W_i zbar^T
-#pragma unroll
-                for (int ch = 0; ch < FZ_C; ++ch) {
-                    v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
-                    double h4 = 0.0;
-                    const double* wrl = lds + M::WRB + (i - 1) * MF_KS * 16 + q * 4 + (lane & 3);
-#pragma unroll
-                    for (int s = 0; s < MF_KS; ++s) {
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[M::WN + ((i - 1) * MF_KS + s) * 64 + lofs], zbar[ch][s], acc, 0, 0, 0);
-                        h4 = __builtin_amdgcn_mfma_f64_4x4x4f64(wrl[s * 16], zbar[ch][s], h4, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) hbar[ch][s] = acc[s];
-                    hbar[ch][4] = h4;
-                }
             }
         }
     }
 
+#undef ZC
     // ---- epilogue: per-wave partials -> LDS -> one gradient row per workgroup ----
     __syncthreads();
     double* WP = lds + M::TR + (long)wv * g.P;
