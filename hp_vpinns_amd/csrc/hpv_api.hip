@@ -1217,6 +1217,11 @@ int hpv_eval_channels(hpv_handle h, double* out, size_t n) {
     return 0;
 }
 
+// (undeclared debug hook of the -DHPV_FZ_TIMING build: raw read of the channel buffer the fused kernel stamps)
+int hpv_debug_read_out(hpv_handle h, double* out, size_t n) {
+    if (!h || !out || !h->var.OUT) return -1;
+    return hipMemcpy(out, h->var.OUT, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
 int hpv_backend_in_use(hpv_handle h) {
     if (!h) return -1;
     if (h->cfg.scheme == HPV_SCHEME_VPINN && h->have_quad && h->have_tables && h->have_elems && h->batch_dirty) {

@@ -33,6 +33,14 @@
 #define FZ_TPE (FZ_NQ / 16)
 #define FZ_C 3             // u, u_x, u_y
 
+// Build with -DHPV_FZ_TIMING to make the kernel record the duration of its phases (staging, forward, barrier wait,
+// projection, reverse, barrier wait, epilogue) per wave into MfmaArgs::OUT; scripts/fz_timing.py prints them.
+#ifdef HPV_FZ_TIMING
+#define FZ_STAMP(I) fz_t[I] = clock64()
+#else
+#define FZ_STAMP(I)
+#endif
+
 template <int L>
 struct FzLds {
     static constexpr int LH = L > 1 ? L - 1 : 0;
@@ -43,16 +51,18 @@ struct FzLds {
     static constexpr int WRB = WN + LH * MF_KS * 64;       // [LH][5][16]  W[16+a][4s+q]
     static constexpr int W1O = WRB + LH * MF_KS * 16;      // [4][5][64]   W1[0][4s+q], W1[1][4s+q], Wo[4s+q], b1[4s+q]
     static constexpr int CH = W1O + 4 * MF_KS * 64;        // [2][400]     u_x, u_y of the element -> their adjoints
-    static constexpr int AX = CH + 2 * FZ_NQ;              // [2][NTX][QX] w_x phi^(dx_t)
+    static constexpr int PK = CH + 2 * FZ_NQ;              // [6][L*5][64] parked s: slot w = tile 0 of wave w, slots 4, 5 = tile 1 of waves 0, 1
+    static constexpr int TR = PK + 6 * L * MF_KS * 64;     // phase P: projection scratch | phase R: per-wave transpose tiles | epilogue rows
+    static constexpr int TR_WAVE = FZ_C * 2 * MF_TRB * MF_LD;
+    // projection scratch inside the TR region
+    static constexpr int AX = TR;                          // [2][NTX][QX] w_x phi^(dx_t)
     static constexpr int BY = AX + 2 * FZ_NTX * FZ_QX;     // [2][NTY][QY] w_y phi^(dy_t)
     static constexpr int T = BY + 2 * FZ_NTY * FZ_QY;      // [2][QY][NTX]
     static constexpr int UP = T + 2 * FZ_QY * FZ_NTX;      // [2][NR]      per-term partial of U
     static constexpr int U = UP + 2 * FZ_NR;               // [NR]
     static constexpr int S = U + FZ_NR;                    // [2][NTY][QX]
     static constexpr int RED = S + 2 * FZ_NTY * FZ_QX;     // [16]
-    static constexpr int PK = RED + 16;                    // [waves][L*5][64]  s of each wave's FIRST tile (the other tiles' s live in registers)
-    static constexpr int TR = PK + FZ_WAVES * L * MF_KS * 64;   // per-wave transpose tiles | epilogue gradient rows
-    static constexpr int TR_WAVE = FZ_C * 2 * MF_TRB * MF_LD;
+    static_assert(RED + 16 - TR <= FZ_WAVES * TR_WAVE, "projection scratch fits the transpose region");
     static constexpr int total(int P) { return TR + (FZ_WAVES * TR_WAVE > FZ_WAVES * P ? FZ_WAVES * TR_WAVE : FZ_WAVES * P); }
 };
 
@@ -81,6 +91,22 @@ __device__ __forceinline__ void acc_put_all(const double (&sv)[N]) {
 template <int BASE, int N, int J = 0>
 __device__ __forceinline__ void acc_get_all(double (&sv)[N]) {
     if constexpr (J < N) { sv[J] = acc_get<BASE + 2 * J>(); acc_get_all<BASE, N, J + 1>(sv); }
+}
+
+// sum over the 16 lanes of a DPP row (= the 16 points of a neuron group), result in every lane: quad butterflies,
+// then row_half_mirror and row_mirror -- VALU only (a __shfl_xor tree is two ds_bpermute per step and double)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum16(double v) {
+    v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);   // row_half_mirror
+    v += dpp_move<0x140>(v);   // row_mirror
+    return v;
 }
 
 // hidden -> hidden product of one channel: z^T = W^T h^T (+ bias fragment for the value channel), 16 + 4 split
@@ -112,6 +138,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     const long e = blockIdx.x;
     const double* __restrict__ th = g.theta;
     const ProjArgs& pa = g.pa;
+#ifdef HPV_FZ_TIMING
+    long long fz_t[8];
+#endif
 
     // ---- stage every weight fragment and the projection tables (one global round trip) ----
     {
@@ -139,7 +168,12 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         }
     }
     const double bo = th[g.boff[L]];
+    // the element's projection constants, requested now so that no global latency sits inside phase P
+    const double pc0 = pa.coef[e], pc1 = pa.coef[pa.coef_stride + e];
+    const double pF = (pa.F && tid < FZ_NR) ? pa.F[e * FZ_NR + tid] : 0.0;
+    FZ_STAMP(0);
     __syncthreads();
+    FZ_STAMP(1);
 
     // ---- tile list of this wave: element tiles wv, wv+4, ..; wave 1 adopts boundary/data tile `dtile` ----
     const int n_el = (FZ_TPE - wv + FZ_WAVES - 1) / FZ_WAVES;
@@ -150,9 +184,12 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
 
     // s = tanh(z) of every hidden layer: tile 0's go to LDS (what is left of it), the tiles 1..6 of this wave to the top
     // AGPRs a[ABASE + (k-1) * 2 NSV ..] (see acc_put)
-    constexpr int ABASE = 256 - (FZ_MAXT - 1) * 2 * NSV;
+    constexpr int NREG = FZ_MAXT - 2;  // tiles whose s live in AGPRs; the first one (waves 0, 1: two) of a wave is parked in LDS
+    constexpr int ABASE = 256 - NREG * 2 * NSV;
     asm volatile("" ::: "a255");       // the kernel owns all 256 AGPRs
+    const int n_lds = wv <= 1 ? 2 : 1;
     double* PKw = lds + M::PK + wv * (NSV * 64) + lane;
+    double* PKw2 = lds + M::PK + (4 + (wv & 1)) * (NSV * 64) + lane;
     double gdat = 0.0;           // adjoint of u at the data tile's point (boundary term, P2:122)
 
     // =============================================================================================
@@ -225,23 +262,24 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             const double dd = valid ? g.ud[p - g.data_off] - o[0] : 0.0;
             gdat = g.data_scale * dd;
             double sq = dd * dd;
-            sq += __shfl_xor(sq, 1, 64);
-            sq += __shfl_xor(sq, 2, 64);
-            sq += __shfl_xor(sq, 4, 64);
-            sq += __shfl_xor(sq, 8, 64);
+            sq = row_sum16(sq);
             if (lane == 0) g.data_part[tile - g.data_off / 16] = sq;
         }
-        switch (k) {      // wave-uniform: every case moves this tile's s values into its own registers
-            case 0:
+        if (k < n_lds) {     // wave-uniform
+            double* pk = k == 0 ? PKw : PKw2;
 #pragma unroll
-                for (int j = 0; j < NSV; ++j) PKw[j * 64] = sv[j];
-                break;
-#define FZ_STASH(K) case K: acc_put_all<ABASE + (K - 1) * 2 * NSV, NSV>(sv); break;
-            FZ_STASH(1) FZ_STASH(2) FZ_STASH(3) FZ_STASH(4) FZ_STASH(5) FZ_STASH(6)
+            for (int j = 0; j < NSV; ++j) pk[j * 64] = sv[j];
+        } else {
+            switch (k - n_lds) {
+#define FZ_STASH(K) case K: acc_put_all<ABASE + K * 2 * NSV, NSV>(sv); break;
+                FZ_STASH(0) FZ_STASH(1) FZ_STASH(2) FZ_STASH(3) FZ_STASH(4)
 #undef FZ_STASH
+            }
         }
     }
+    FZ_STAMP(2);
     __syncthreads();
+    FZ_STAMP(3);
 
     // =============================================================================================
     // phase P: projection of the element from LDS (two one-hot terms: term t integrates channel 1 + t)
@@ -267,12 +305,12 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < FZ_QY; ++j) acc = fma(by[j], tt[j * FZ_NTX], acc);
-            lds[M::UP + tid] = pa.coef[(long)t * pa.coef_stride + e] * acc;
+            lds[M::UP + tid] = (t == 0 ? pc0 : pc1) * acc;
         }
         __syncthreads();
         double sq = 0.0;
         if (tid < FZ_NR) {
-            const double u = (lds[M::UP + tid] + lds[M::UP + FZ_NR + tid]) - (pa.F ? pa.F[e * FZ_NR + tid] : 0.0);
+            const double u = (lds[M::UP + tid] + lds[M::UP + FZ_NR + tid]) - pF;
             lds[M::U + tid] = u;
             pa.R[e * FZ_NR + tid] = u;
             sq = u * u;
@@ -292,7 +330,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             double acc = 0.0;
 #pragma unroll
             for (int r = 0; r < FZ_NTX; ++r) acc = fma(ax[r * FZ_QX], ur[r], acc);
-            lds[M::S + o] = acc * sc * pa.coef[(long)t * pa.coef_stride + e];
+            lds[M::S + o] = acc * sc * (t == 0 ? pc0 : pc1);
         }
         __syncthreads();
         for (int o = tid; o < 2 * FZ_NQ; o += FZ_BLOCK) {
@@ -310,6 +348,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     // =============================================================================================
     // phase R: reverse pass (tangent pre-activations recomputed from s)
     // =============================================================================================
+    FZ_STAMP(4);
     double* TAB = lds + M::TR + wv * M::TR_WAVE;
     v4d dWacc[LH];
     double dS10[LH], dS01[LH], accC[LH];
@@ -332,17 +371,19 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         int lofs = lane;
         asm volatile("" : "+v"(lofs));
         double sv[NSV];
-        switch (k) {
-            case 0:
+        if (k < n_lds) {
+            const double* pk = k == 0 ? PKw : PKw2;
 #pragma unroll
-                for (int j = 0; j < NSV; ++j) sv[j] = PKw[j * 64];
-                break;
-#define FZ_FETCH(K) case K: acc_get_all<ABASE + (K - 1) * 2 * NSV, NSV>(sv); break;
-            FZ_FETCH(1) FZ_FETCH(2) FZ_FETCH(3) FZ_FETCH(4) FZ_FETCH(5) FZ_FETCH(6)
+            for (int j = 0; j < NSV; ++j) sv[j] = pk[j * 64];
+        } else {
+            switch (k - n_lds) {
+#define FZ_FETCH(K) case K: acc_get_all<ABASE + K * 2 * NSV, NSV>(sv); break;
+                FZ_FETCH(0) FZ_FETCH(1) FZ_FETCH(2) FZ_FETCH(3) FZ_FETCH(4)
 #undef FZ_FETCH
-            default:
+                default:
 #pragma unroll
-                for (int j = 0; j < NSV; ++j) sv[j] = 0.0;
+                    for (int j = 0; j < NSV; ++j) sv[j] = 0.0;
+            }
         }
         double gb[FZ_C];
         if (k < n_el) {
@@ -352,8 +393,13 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             gb[0] = gdat; gb[1] = 0.0; gb[2] = 0.0;
         }
         // tangent pre-activations of every hidden layer: layer 0 has z_c = W1[c,:]; layer i: z_c = (sigma'(z_{i-1}) z_c,{i-1}) W_i
-        double zc[L][2][MF_KS];      // (entry 0 is never materialised: ZC(0, c, s) re-reads the LDS fragment)
-#define ZC(I, CC, SS) ((I) == 0 ? lds[M::W1O + ((CC) * MF_KS + (SS)) * 64 + lofs] : zc[(I)][(CC)][(SS)])
+        double zc[L][2][MF_KS];
+#define ZC(I, CC, SS) zc[(I)][(CC)][(SS)]
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            zc[0][0][s] = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs];
+            zc[0][1][s] = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
+        }
 #pragma unroll
         for (int i = 1; i < L; ++i) {
             double hx[MF_KS], hy[MF_KS];
@@ -456,11 +502,11 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     }
 
 #undef ZC
+    FZ_STAMP(5);
     // ---- epilogue: per-wave partials -> LDS -> one gradient row per workgroup ----
     __syncthreads();
-    double* WP = lds + M::TR + (long)wv * g.P;
-    for (int idx = lane; idx < g.P; idx += 64) WP[idx] = 0.0;
-    pj_wave_sync();
+    FZ_STAMP(6);
+    double* WP = lds + M::TR + (long)wv * g.P;     // every one of the P entries is written below
 #pragma unroll
     for (int i = 1; i < L; ++i) {
 #pragma unroll
@@ -483,14 +529,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         for (int i = 0; i < L; ++i) v[i] = db[i][s];
         v[L] = dW1[0][s]; v[L + 1] = dW1[1][s]; v[L + 2] = dWo[s];
 #pragma unroll
-        for (int kq = 0; kq < L + 3; ++kq) {
-            double t = v[kq];
-            t += __shfl_xor(t, 1, 64);
-            t += __shfl_xor(t, 2, 64);
-            t += __shfl_xor(t, 4, 64);
-            t += __shfl_xor(t, 8, 64);
-            v[kq] = t;
-        }
+        for (int kq = 0; kq < L + 3; ++kq) v[kq] = row_sum16(v[kq]);
         if (pt == 0) {
 #pragma unroll
             for (int i = 0; i < L; ++i) WP[g.boff[i] + j] = v[i];
@@ -500,11 +539,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         }
     }
     {
-        double t = dbo;
-        t += __shfl_xor(t, 1, 64);
-        t += __shfl_xor(t, 2, 64);
-        t += __shfl_xor(t, 4, 64);
-        t += __shfl_xor(t, 8, 64);
+        const double t = row_sum16(dbo);
         if (lane == 0) WP[g.boff[L]] = t;
     }
     __syncthreads();
@@ -516,6 +551,14 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         for (int w = 0; w < FZ_WAVES; ++w) acc += W0[(long)w * g.P + idx];
         row[idx] = acc;
     }
+#ifdef HPV_FZ_TIMING
+    if (lane == 0 && g.OUT) {   // phase durations in shader cycles: [block][wave][8]
+        FZ_STAMP(7);
+        double* o = g.OUT + ((long)blockIdx.x * 4 + wv) * 8;
+        for (int i = 0; i < 7; ++i) o[i] = (double)(fz_t[i + 1] - fz_t[i]);
+        o[7] = (double)(fz_t[7] - fz_t[0]);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -552,6 +595,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     if (n_elem > hpv_mfma_grad_rows(m) && n_elem > m->max_rows) return false;
     MfmaArgs a = m->base;
     a.theta = theta; a.X = X; a.GPART = GPART;
+    a.OUT = const_cast<double*>(pa.OUT);   // (only written by the -DHPV_FZ_TIMING build)
     a.data_off = -1;
     if (dt && dt->n_data > 0) {
         a.data_off = dt->data_off; a.ud = dt->ud; a.gbar0 = dt->gbar0; a.data_part = dt->data_part;

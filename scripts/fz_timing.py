@@ -1,0 +1,18 @@
+import os, sys, ctypes as C
+sys.path.insert(0, "/root/repo")
+# needs a library built with HPV_EXTRA_FLAGS=-DHPV_FZ_TIMING bash hp_vpinns_amd/csrc/build.sh
+import numpy as np
+from hp_vpinns_amd.drivers import poisson2d
+from hp_vpinns_amd.init import xavier_init
+LAYERS = [2, 20, 20, 20, 1]
+s = poisson2d.setup(N_el_x=16, N_el_y=16, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
+m = poisson2d.build_model(s, LAYERS, var_form=1, init_params=xavier_init(LAYERS, 1234))
+m.h.step(50, False)
+out = np.empty(256 * 4 * 8)
+m.h.lib.hpv_debug_read_out.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t]
+m.h.lib.hpv_debug_read_out(m.h._h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size)
+t = out.reshape(256, 4, 8)
+names = ["stage-sync", "fwd", "wait-after-fwd", "proj", "rev", "wait-after-rev", "epilogue", "total"]
+print("clock64 ticks (100 MHz?) mean over blocks, per wave:")
+for w in range(4):
+    print("wave", w, {n: round(float(t[:, w, i].mean()), 1) for i, n in enumerate(names)})
