@@ -30,7 +30,8 @@ EXPORTS = [
     "hpv_assemble_rhs", "hpv_set_collocation", "hpv_gll_rule", "hpv_test_tables",
     "hpv_step_record", "hpv_history_reset", "hpv_history_read",
     "hpv_p2p_export", "hpv_p2p_connect", "hpv_p2p_selftest", "hpv_p2p_disconnect",
-    "hpv_eval_channels",
+    "hpv_eval_channels", "hpv_bench_residual",
+    "hpv_set_collocation_shard", "hpv_rccl_unique_id", "hpv_rccl_connect", "hpv_rccl_selftest", "hpv_rccl_disconnect", "hpv_exchange_in_use",
 ]
 
 
@@ -110,6 +111,13 @@ def load():
     lib.hpv_history_read.argtypes = [h, C.c_int, _dp, _dp]
     lib.hpv_test_tables.argtypes = [h, C.c_int, _dp, C.c_int, _dp]
     lib.hpv_eval_channels.argtypes = [h, _dp, C.c_size_t]
+    lib.hpv_bench_residual.argtypes = [h, C.c_long, C.c_int, C.c_int, _dp, _dp]
+    lib.hpv_set_collocation_shard.argtypes = [h, _dp, _dp, C.c_int, C.c_long]
+    lib.hpv_rccl_unique_id.argtypes = [h, C.c_char_p]
+    lib.hpv_rccl_connect.argtypes = [h, C.c_int, C.c_int, C.c_char_p]
+    lib.hpv_rccl_selftest.argtypes = [h, _dp, C.c_size_t]
+    lib.hpv_rccl_disconnect.argtypes = [h]
+    lib.hpv_exchange_in_use.argtypes = [h]
     _lib = lib
     return lib
 
@@ -203,11 +211,13 @@ class Handle:
         F = _c(F)
         self._chk(self.lib.hpv_set_rhs(self._h, _p(F), 0 if F is None else F.size))
 
-    def set_collocation(self, X, f):
+    def set_collocation(self, X, f, n_total=None):
+        """X, f: this handle's collocation points; n_total: their number over all shards (default: these are all)."""
         X, f = _points(X, self.layers[0], "collocation points"), _c(f).reshape(-1)
         if f.size != X.shape[0]:
             raise ValueError("one right-hand-side value per collocation point")
-        self._chk(self.lib.hpv_set_collocation(self._h, _p(X), _p(f), X.shape[0]))
+        self._chk(self.lib.hpv_set_collocation_shard(self._h, _p(X), _p(f), X.shape[0],
+                                                     X.shape[0] if n_total is None else int(n_total)))
 
     def set_data(self, X, u):
         if X is None:
@@ -327,6 +337,25 @@ class Handle:
         self._chk(self.lib.hpv_history_read(self._h, int(n), _p(out), _p(eps)))
         return out, eps
 
+    def rccl_unique_id(self):
+        buf = C.create_string_buffer(128)
+        self._chk(self.lib.hpv_rccl_unique_id(self._h, buf))
+        return buf.raw
+
+    def rccl_connect(self, world, rank, uid):
+        self._chk(self.lib.hpv_rccl_connect(self._h, int(world), int(rank), bytes(uid)))
+
+    def rccl_selftest(self, n):
+        out = np.empty(int(n))
+        self._chk(self.lib.hpv_rccl_selftest(self._h, _p(out), out.size))
+        return out
+
+    def rccl_disconnect(self):
+        self._chk(self.lib.hpv_rccl_disconnect(self._h))
+
+    def exchange_in_use(self):
+        return {0: "none", 1: "rccl", 2: "p2p"}[int(self.lib.hpv_exchange_in_use(self._h))]
+
     def p2p_export(self, world, rank):
         buf = C.create_string_buffer(128)
         self._chk(self.lib.hpv_p2p_export(self._h, int(world), int(rank), buf))
@@ -362,7 +391,7 @@ class Handle:
         self._chk(self.lib.hpv_debug_activation(self._h, _p(x), x.size, _p(a), _p(a1), _p(ref)))
         return a, a1, ref
 
-    def bench_projection(self, n_elem, reps=10):
+    def bench_projection(self, n_elem, reps=10, do_adjoint=True):
         ms, by = C.c_double(), C.c_double()
-        self._chk(self.lib.hpv_bench_projection(self._h, int(n_elem), int(reps), C.byref(ms), C.byref(by)))
+        self._chk(self.lib.hpv_bench_residual(self._h, int(n_elem), int(reps), 1 if do_adjoint else 0, C.byref(ms), C.byref(by)))
         return ms.value, by.value

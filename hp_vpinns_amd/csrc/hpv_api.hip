@@ -1,5 +1,8 @@
 // C-ABI of libhpvpinn.so (include/hpvpinn.h): host orchestration of one hp-VPINN training
 // handle = one GPU's shard of elements + a replica of the network parameters.
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is dlopen'ed on first multi-GPU use (no link-time dependency)
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -86,6 +89,7 @@ struct hpv_ctx {
     HpvMfma* mfma_colloc = nullptr;
     double *d_fcol = nullptr, *d_col_part = nullptr;
     int n_col = 0;
+    long n_col_total = 0;      // collocation points of ALL shards (the mean of P2:124 runs over them)
     double* d_jac = nullptr;   // |J_e| of the owned elements (RHS assembly, hpv_assemble_rhs)
     // in-library exchange of the packed buffer between the ranks of a node (hpv_p2p_*)
     P2PArgs pp{};
@@ -95,6 +99,10 @@ struct hpv_ctx {
     unsigned long long* d_p2p_counter = nullptr;
     int* d_p2p_err = nullptr;
     void* p2p_maps[2 * HPV_P2P_MAX] = {};
+    // in-library RCCL all-reduce of the packed buffer (hpv_rccl_*): the multi-GPU default
+    ncclComm_t rccl_comm = nullptr;
+    bool rccl_on = false;
+    int rccl_world = 1, rccl_rank = 0;
     double* d_upart = nullptr; // partial residual sums of the row-split projection (few tall elements)
     int proj_split = 1;        // workgroups per element there; loss_e / deps_e hold n_elem * proj_split entries
     // timing
@@ -105,13 +113,43 @@ struct hpv_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_active = false;            // true only while capturing
     bool use_graph = true;
-    hipGraphExec_t g_step = nullptr;
     hipGraphExec_t g_stepK = nullptr;    // HPV_GRAPH_ITERS iterations per replay (fewer inter-graph gaps)
+    hipGraphExec_t g_rem[8] = {};        // g_rem[r]: r iterations (the remainder of a call), captured at first use
 };
 
 static void p2p_release(hpv_ctx* h);
+static void rccl_release(hpv_ctx* h);
 
 namespace {
+
+// RCCL entry points resolved at run time.  A copy that is already loaded (torch ships one) is reused, so that one
+// process never runs two collective libraries.
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+RcclApi& rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!api.lib) return api;
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy && api.GetErrorString;
+    return api;
+}
 
 int fail(hpv_ctx* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -447,7 +485,8 @@ int enqueue_pinn_pass(hpv_ctx* h, bool backward, bool fuse_adam) {
         if ((rc = ensure_small_mfma(h, h->data, &h->mfma_data))) return rc;
     }
     run_fwd(h, h->colloc, h->mfma_colloc, backward ? 1 : 0);
-    launch_pinn_residual(h->colloc.OUT, h->d_fcol, h->colloc.GBAR, h->d_col_part, h->colloc.N, h->n_col, backward ? 1 : 0, h->stream);
+    launch_pinn_residual(h->colloc.OUT, h->d_fcol, h->colloc.GBAR, h->d_col_part, h->colloc.N, h->n_col, h->n_col_total,
+                         backward ? 1 : 0, h->stream);
     if (backward) run_bwd(h, h->colloc, h->mfma_colloc);
     int ndp = 0;
     if (h->n_data > 0) {
@@ -470,6 +509,19 @@ int enqueue_pinn_pass(hpv_ctx* h, bool backward, bool fuse_adam) {
 // A pass whose packed buffer is made global: with the in-library exchange connected the reduced buffer (and, for a
 // training iteration, the Adam update) follows the finalize kernel on the same stream; otherwise the plain pass.
 int enqueue_pass_x(hpv_ctx* h, bool backward, bool fuse_adam) {
+    if (h->rccl_on) {
+        // ONE collective per iteration: ncclAllReduce(sum) of [grad | d eps | lossv | w*lossb | msq | pad] over
+        // xGMI, on the handle's stream (captured into the iteration graphs like the kernels), then the identical TF1 Adam
+        // update on every rank
+        int rc = enqueue_pass(h, backward, false);
+        if (rc) return rc;
+        ncclResult_t r = rccl_api().AllReduce(h->d_RB, h->d_RB, (size_t)h->Ptot + 4, ncclDouble, ncclSum, h->rccl_comm, h->stream);
+        if (r != ncclSuccess) return fail(h, -6, "ncclAllReduce failed: %s", rccl_api().GetErrorString(r));
+        if (backward && fuse_adam) launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(h, -2, "adam launch failed: %s", hipGetErrorString(e));
+        return 0;
+    }
     if (!h->p2p_on) return enqueue_pass(h, backward, fuse_adam);
     int rc = enqueue_pass(h, backward, false);
     if (rc) return rc;
@@ -482,8 +534,8 @@ int enqueue_pass_x(hpv_ctx* h, bool backward, bool fuse_adam) {
 
 #define HPV_GRAPH_ITERS 8
 void drop_graph(hpv_ctx* h) {
-    if (h->g_step) { (void)hipGraphExecDestroy(h->g_step); h->g_step = nullptr; }
     if (h->g_stepK) { (void)hipGraphExecDestroy(h->g_stepK); h->g_stepK = nullptr; }
+    for (hipGraphExec_t& g : h->g_rem) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
 }
 
 // Capture `iters` whole training iterations (incl. the Adam updates) into an executable graph.
@@ -619,6 +671,7 @@ void hpv_destroy(hpv_handle h) {
     if (h->d_jac) (void)hipFree(h->d_jac);
     if (h->d_upart) (void)hipFree(h->d_upart);
     p2p_release(h);
+    rccl_release(h);
     free_batch(h->var); free_batch(h->data); free_batch(h->edge); free_batch(h->pred);
     double* ptrs[] = {h->d_wtx, h->d_wty, h->d_edge_dphi, h->d_coef, h->d_edge_coef, h->d_F, h->d_R, h->d_loss_e,
                       h->d_deps_e, h->d_udata, h->d_data_part, h->d_theta, h->d_m, h->d_v, h->d_state, h->d_RB, h->d_hist};
@@ -804,9 +857,13 @@ int hpv_set_data(hpv_handle h, const double* X, const double* u, int n) {
 }
 
 int hpv_set_collocation(hpv_handle h, const double* X, const double* f, int n) {
+    return hpv_set_collocation_shard(h, X, f, n, (long)n);
+}
+
+int hpv_set_collocation_shard(hpv_handle h, const double* X, const double* f, int n, long n_total) {
     if (!h) return -1;
     if (h->cfg.scheme != HPV_SCHEME_PINN) return fail(h, -1, "collocation points belong to scheme PINNs");
-    if (n < 1 || !X || !f) return fail(h, -1, "bad collocation arguments");
+    if (n < 1 || !X || !f || n_total < n) return fail(h, -1, "bad collocation arguments");
     drop_graph(h);
     int rc;
     if (h->mfma_colloc) { hpv_mfma_destroy(h->mfma_colloc); h->mfma_colloc = nullptr; }
@@ -816,6 +873,7 @@ int hpv_set_collocation(hpv_handle h, const double* X, const double* f, int n) {
     if ((rc = upload(h, h->d_fcol, f, (size_t)n))) return rc;
     if ((rc = dalloc(h, &h->d_col_part, 64))) return rc;
     h->n_col = n;
+    h->n_col_total = n_total;
     return 0;
 }
 
@@ -895,12 +953,28 @@ static int enqueue_iterations(hpv_ctx* h, int n_iters) {
     int rc;
     if (h->use_graph && h->own_stream && !h->timing && n_iters > 0 && h->cfg.scheme == HPV_SCHEME_VPINN) {
         if ((rc = check_ready(h))) return rc;
-        // both graphs are captured at the first call (so that no later, possibly timed, call pays for a capture)
-        if (!h->g_step && (rc = build_step_graph(h, 1, &h->g_step))) return rc;
-        if (!h->g_stepK && (rc = build_step_graph(h, HPV_GRAPH_ITERS, &h->g_stepK))) return rc;
+        // n = a * HPV_GRAPH_ITERS + r: a replays of the K-iteration graph and ONE replay of an r-iteration graph (captured
+        // the first time a call leaves that remainder -- callers that time a call run it once untimed before)
+        static_assert(HPV_GRAPH_ITERS <= 8, "g_rem size");
+        if (n_iters >= HPV_GRAPH_ITERS && !h->g_stepK && (rc = build_step_graph(h, HPV_GRAPH_ITERS, &h->g_stepK))) {
+            if (!h->rccl_on) return rc;
+            // a collective that refuses stream capture must not stop the run: eager launches from here on
+            h->use_graph = false;
+            h->err.clear();
+            return enqueue_iterations(h, n_iters);
+        }
         int it = 0;
         for (; it + HPV_GRAPH_ITERS <= n_iters; it += HPV_GRAPH_ITERS) HIPCHK(h, hipGraphLaunch(h->g_stepK, h->stream));
-        for (; it < n_iters; ++it) HIPCHK(h, hipGraphLaunch(h->g_step, h->stream));
+        const int rem = n_iters - it;
+        if (rem > 0) {
+            if (!h->g_rem[rem] && (rc = build_step_graph(h, rem, &h->g_rem[rem]))) {
+                if (!h->rccl_on) return rc;
+                h->use_graph = false;
+                h->err.clear();
+                return enqueue_iterations(h, rem);
+            }
+            HIPCHK(h, hipGraphLaunch(h->g_rem[rem], h->stream));
+        }
     } else {
         for (int it = 0; it < n_iters; ++it)
             if ((rc = enqueue_pass_x(h, true, true))) return rc;
@@ -1190,6 +1264,64 @@ int hpv_p2p_selftest(hpv_handle h, double* out, size_t n, int* timed_out) {
     return 0;
 }
 
+// ---- in-library RCCL all-reduce (multi-GPU default: one process per GPU, communicator owned by the handle) ----
+static void rccl_release(hpv_ctx* h) {
+    if (h->rccl_comm) { (void)rccl_api().CommDestroy(h->rccl_comm); h->rccl_comm = nullptr; }
+    h->rccl_on = false;
+}
+
+int hpv_rccl_unique_id(hpv_handle h, void* id128) {
+    if (!h || !id128) return -1;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    if (!rccl_api().ok) return fail(h, -6, "librccl.so could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+    ncclUniqueId id;
+    ncclResult_t r = rccl_api().GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(h, -6, "ncclGetUniqueId failed: %s", rccl_api().GetErrorString(r));
+    memcpy(id128, &id, 128);
+    return 0;
+}
+
+int hpv_rccl_connect(hpv_handle h, int world, int rank, const void* id128) {
+    if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return -1;
+    if (!rccl_api().ok) return fail(h, -6, "librccl.so could not be loaded");
+    if (!h->have_params) return fail(h, -3, "hpv_set_params has not been called");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    drop_graph(h);
+    rccl_release(h);
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclResult_t r = rccl_api().CommInitRank(&h->rccl_comm, world, id, rank);
+    if (r != ncclSuccess) { h->rccl_comm = nullptr; return fail(h, -6, "ncclCommInitRank failed: %s", rccl_api().GetErrorString(r)); }
+    h->rccl_world = world; h->rccl_rank = rank;
+    h->rccl_on = true;
+    return 0;
+}
+
+int hpv_rccl_disconnect(hpv_handle h) {
+    if (!h) return -1;
+    (void)hipStreamSynchronize(h->stream);
+    drop_graph(h);
+    rccl_release(h);
+    return 0;
+}
+
+// Known-answer all-reduce: RB[i] = (rank + 1) + 1e-3 i on every rank -> out[i] = W (W + 1) / 2 + W 1e-3 i.  Collective.
+int hpv_rccl_selftest(hpv_handle h, double* out, size_t n) {
+    if (!h || !out || !h->rccl_on || n != (size_t)h->Ptot + 4) return -1;
+    std::vector<double> v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = (double)(h->rccl_rank + 1) + 1e-3 * (double)i;
+    int rc = upload(h, h->d_RB, v.data(), n);
+    if (rc) return rc;
+    ncclResult_t r = rccl_api().AllReduce(h->d_RB, h->d_RB, n, ncclDouble, ncclSum, h->rccl_comm, h->stream);
+    if (r != ncclSuccess) return fail(h, -6, "ncclAllReduce failed: %s", rccl_api().GetErrorString(r));
+    HIPCHK(h, hipMemcpyAsync(out, h->d_RB, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int hpv_exchange_in_use(hpv_handle h) { return !h ? -1 : (h->rccl_on ? 1 : (h->p2p_on ? 2 : 0)); }
+
 int hpv_get_residuals(hpv_handle h, double* R, size_t n) {
     if (!h || !R) return -1;
     const size_t want = (size_t)h->n_elem * h->ntx * h->nty;
@@ -1269,6 +1401,10 @@ int hpv_kernel_time_ms(hpv_handle h, int which, double* avg_ms, long* launches) 
 }
 
 int hpv_bench_projection(hpv_handle h, long n_elem, int reps, double* avg_ms, double* bytes_per_launch) {
+    return hpv_bench_residual(h, n_elem, reps, 1, avg_ms, bytes_per_launch);
+}
+
+int hpv_bench_residual(hpv_handle h, long n_elem, int reps, int do_adjoint, double* avg_ms, double* bytes_per_launch) {
     if (!h) return -1;
     if (!h->have_quad || !h->have_tables) return fail(h, -3, "set quadrature and tables first");
     if (n_elem < 1 || reps < 1) return fail(h, -1, "bad arguments");
@@ -1300,8 +1436,8 @@ int hpv_bench_projection(hpv_handle h, long n_elem, int reps, double* avg_ms, do
         (void)hipMemset(GB, 0, (size_t)C * N * sizeof(double));
         auto go = [&]() {
             if (h->cfg.backend == HPV_BACKEND_GENERIC ||
-                !launch_project_tp(p2, OUT, GB, R, F, coef, n_elem, h->d_wtx, h->d_wty, eps_ptr, le, de, N, n_elem, 1, h->stream))
-                launch_project(p2, OUT, GB, R, F, coef, n_elem, h->d_wtx, h->d_wty, eps_ptr, le, de, N, n_elem, 1, nullptr, nullptr, nullptr, nullptr, h->stream);
+                !launch_project_tp(p2, OUT, GB, R, F, coef, n_elem, h->d_wtx, h->d_wty, eps_ptr, le, de, N, n_elem, do_adjoint ? 1 : 0, h->stream))
+                launch_project(p2, OUT, GB, R, F, coef, n_elem, h->d_wtx, h->d_wty, eps_ptr, le, de, N, n_elem, do_adjoint ? 1 : 0, nullptr, nullptr, nullptr, nullptr, h->stream);
         };
         go();
         (void)hipEventRecord(e0, h->stream);
@@ -1314,10 +1450,11 @@ int hpv_bench_projection(hpv_handle h, long n_elem, int reps, double* avg_ms, do
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = fail(h, -2, "projection bench failed: %s", hipGetErrorString(e));
     }
-    // algorithmic bytes: read the integrated channels + F, write the adjoint channels + R
+    // algorithmic bytes: read the integrated channels + F, write R (8 (C_u N + 2 N_R)); with the adjoint
+    // also write the adjoint channels
     int cu = 0;
     for (int ch = 0; ch < C; ++ch) { bool used = false; for (int t = 0; t < pd.nterms; ++t) if (pd.t[t].a0[ch] != 0.0 || pd.t[t].a1[ch] != 0.0) used = true; cu += used; }
-    if (bytes_per_launch) *bytes_per_launch = 8.0 * (2.0 * cu * (double)N + 2.0 * (double)n_elem * NR);
+    if (bytes_per_launch) *bytes_per_launch = 8.0 * ((do_adjoint ? 2.0 : 1.0) * cu * (double)N + 2.0 * (double)n_elem * NR);
     double* ptrs[] = {OUT, GB, R, F, coef, le, de};
     for (double* p : ptrs) if (p) (void)hipFree(p);
     return rc;

@@ -101,8 +101,8 @@ bool launch_project_tp(const ProjDesc& pd, const double* OUT, double* GBAR, doub
                        long coef_stride, const double* wtx, const double* wty, const double* eps_ptr, double* loss_e,
                        double* deps_e, long N, long n_elem, int do_adjoint, hipStream_t s);
 int pinn_residual_parts(int n);
-void launch_pinn_residual(const double* OUT, const double* f, double* GBAR, double* part, long N, int n, int write_gbar,
-                          hipStream_t s);
+void launch_pinn_residual(const double* OUT, const double* f, double* GBAR, double* part, long N, int n, long n_total,
+                          int write_gbar, hipStream_t s);
 bool launch_project_wg(const ProjDesc& pd, const double* OUT, double* GBAR, double* R, const double* F, const double* coef,
                        long coef_stride, const double* wtx, const double* wty, const double* eps_ptr, double* loss_e,
                        double* deps_e, long N, long n_elem, int do_adjoint, const double* edge_u, const double* edge_dphi,

@@ -695,22 +695,23 @@ void launch_debug_act(int act, const double* x, int n, double* a, double* a1, do
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_pinn_residual(const double* __restrict__ OUT, const double* __restrict__ f,
                                                       double* __restrict__ GBAR, double* __restrict__ part, long N,
-                                                      int n, int write_gbar) {
+                                                      int n, long n_total, int write_gbar) {
+    // n points of THIS shard; the mean of P2:124 runs over the n_total collocation points of all shards
     __shared__ double red[16];
     double sq = 0.0;
-    const double sc = 2.0 / (double)n;
+    const double sc = 2.0 / (double)n_total;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
         const double r = OUT[3 * N + p] + OUT[4 * N + p] - f[p];
         sq += r * r;
         if (write_gbar) { GBAR[3 * N + p] = sc * r; GBAR[4 * N + p] = sc * r; }
     }
     sq = block_sum(sq, red);
-    if (threadIdx.x == 0) part[blockIdx.x] = sq / (double)n;
+    if (threadIdx.x == 0) part[blockIdx.x] = sq / (double)n_total;
 }
 int pinn_residual_parts(int n) { int b = (n + 255) / 256; return b > 64 ? 64 : (b < 1 ? 1 : b); }
-void launch_pinn_residual(const double* OUT, const double* f, double* GBAR, double* part, long N, int n, int write_gbar,
-                          hipStream_t s) {
-    hipLaunchKernelGGL(k_pinn_residual, dim3(pinn_residual_parts(n)), dim3(256), 0, s, OUT, f, GBAR, part, N, n, write_gbar);
+void launch_pinn_residual(const double* OUT, const double* f, double* GBAR, double* part, long N, int n, long n_total,
+                          int write_gbar, hipStream_t s) {
+    hipLaunchKernelGGL(k_pinn_residual, dim3(pinn_residual_parts(n)), dim3(256), 0, s, OUT, f, GBAR, part, N, n, n_total, write_gbar);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -105,7 +105,8 @@ class _VPINNBase:
         self._reducer = None
         self._dist_warm = False
         self._dist_graphs = {}
-        self._p2p = False      # in-library exchange connected (multi-GPU without a collective call per iteration)
+        self._rccl = False     # in-library ncclAllReduce connected (the multi-GPU default)
+        self._p2p = False      # in-library mailbox exchange connected (opt-in: HPV_EXCHANGE=p2p)
         self._coll = False     # multi-GPU through torch.distributed collectives (the fallback)
         if self._dist:
             import torch
@@ -127,14 +128,69 @@ class _VPINNBase:
         self.h.set_params(self._to_dev(self._init_params))
         self.h.backend_in_use()   # assembles the device batches; raises if a requested backend is unavailable
         if self._dist:
-            if os.environ.get("HPV_P2P", "1") != "0" and 1 < self.world <= 8:
+            # Exchange of the packed buffer, in order of preference (every rank takes the same decision):
+            #   "rccl"  (default) ncclAllReduce issued by the library on its own stream, inside its iteration graphs;
+            #   "p2p"   (HPV_EXCHANGE=p2p) peer-mapped mailboxes, no collective-library call in the iteration;
+            #   "torch" torch.distributed all_reduce on torch's stream -- the fallback when the others cannot be set up.
+            want = os.environ.get("HPV_EXCHANGE", "rccl")
+            if os.environ.get("HPV_P2P") == "0" and want == "p2p":
+                want = "rccl"
+            if want == "p2p" and 1 < self.world <= 8:
                 self._p2p = self._connect_p2p()
-            if not self._p2p:
+            if not self._p2p and want in ("rccl", "p2p"):
+                self._rccl = self._connect_rccl()
+            if not (self._p2p or self._rccl):
                 import torch
                 self._coll = True
                 self.h.set_stream(torch.cuda.current_stream().cuda_stream)
                 ptr, n = self.h.reduce_buffer()
                 self._reducer = Reducer(ptr, n, self.device, force=True)
+
+    def exchange(self):
+        """'none' | 'rccl' (in-library ncclAllReduce) | 'p2p' (peer-mapped mailboxes) | 'torch' (torch.distributed)."""
+        return "torch" if self._coll else ("p2p" if self._p2p else ("rccl" if self._rccl else "none"))
+
+    def _connect_rccl(self):
+        """In-library RCCL communicator (include/hpvpinn.h, hpv_rccl_*): rank 0 creates the unique id, every rank joins, a
+        known-answer all-reduce runs on every rank and all ranks agree on the outcome; any failure anywhere sends every
+        rank to the torch.distributed fallback."""
+        import torch.distributed as dist
+
+        def agree(flag):
+            flags = [None] * self.world
+            dist.all_gather_object(flags, bool(flag))
+            return all(flags)
+
+        uid = None
+        if self.rank == 0:
+            try:
+                uid = self.h.rccl_unique_id()
+            except _lib.HpvError:
+                uid = None
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)
+        ok = box[0] is not None
+        if ok:
+            try:
+                self.h.rccl_connect(self.world, self.rank, box[0])
+            except _lib.HpvError:
+                ok = False
+        if not agree(ok):
+            if ok:
+                self.h.rccl_disconnect()
+            return False
+        n = self.h.reduce_buffer()[1]
+        expect = self.world * (self.world + 1) / 2 + self.world * 1e-3 * np.arange(n)
+        good = True
+        try:
+            for _ in range(2):
+                good = good and np.abs(self.h.rccl_selftest(n) - expect).max() < 1e-12
+        except _lib.HpvError:
+            good = False
+        if not agree(good):
+            self.h.rccl_disconnect()
+            return False
+        return True
 
     def _connect_p2p(self):
         """Set up the in-library exchange (include/hpvpinn.h, hpv_p2p_*): all-gather the ranks' IPC mailbox handles,
@@ -447,9 +503,13 @@ class VPINN2D(_VPINNBase):
                      scheme=_lib.SCHEME_PINN if scheme == "PINNs" else _lib.SCHEME_VPINN)
         if scheme == "PINNs":
             # strong-form branch (P2:128-129): loss = 10 lossb + mean((u_xx+u_yy-f)^2) at X_f_train
-            if self.world > 1:
-                raise NotImplementedError("the PINN branch is single-GPU")
-            self.h.set_collocation(np.asarray(X_f_train, dtype=np.float64), np.asarray(f_train, dtype=np.float64))
+            # multi-GPU: the collocation points shard over the ranks in contiguous blocks (lossp is a mean of independent
+            # point-wise terms), the boundary term stays on rank 0, one all-reduce of the packed buffer per iteration
+            Xf, ff = np.asarray(X_f_train, dtype=np.float64), np.asarray(f_train, dtype=np.float64).reshape(-1)
+            if Xf.shape[0] < self.world:
+                raise ValueError("fewer collocation points than ranks")
+            cb, ce = shard_range(Xf.shape[0], self.rank, self.world)
+            self.h.set_collocation(Xf[cb:ce], ff[cb:ce], n_total=Xf.shape[0])
         else:
             xi, wx, yi, wy = _tensor_rule(X_quad, W_quad)
             self.h.set_quadrature(xi, wx, yi, wy)

@@ -88,6 +88,9 @@ int hpv_set_data(hpv_handle h, const double* X, const double* u, int n);
 /* Collocation points of the strong-form PINN branch (`scheme == 'PINNs'`, P2:124-129,
  * 187-194): lossp = mean((u_xx + u_yy - f)^2) over X_f [n][2] replaces the variational term.  Poisson-2D only. */
 int hpv_set_collocation(hpv_handle h, const double* X, const double* f, int n);
+/* One rank's shard of the collocation set (multi-GPU PINN branch): n points here, n_total over all ranks -- lossp is the
+ * mean over all n_total points (P2:124), the partial sums are made global by the iteration's all-reduce. */
+int hpv_set_collocation_shard(hpv_handle h, const double* X, const double* f, int n, long n_total);
 
 size_t hpv_num_params(hpv_handle h);
 int hpv_set_params(hpv_handle h, const double* theta, size_t n); /* also resets Adam state (P1:107) */
@@ -120,8 +123,22 @@ int hpv_history_read(hpv_handle h, int n, double* loss3_hist, double* eps_hist);
 int hpv_forward_backward(hpv_handle h);
 int hpv_reduce_buffer(hpv_handle h, void** dev_ptr, size_t* n_doubles);
 int hpv_apply_adam(hpv_handle h);
-/* In-library exchange for the multi-GPU path (one process per GPU on one node), instead of handing the packed buffer to a
- * collective library every iteration: each rank owns a mailbox that every peer maps through hipIpc; one kernel per
+/* Multi-GPU default: the all-reduce issued by the library itself.  One process per GPU; the handle owns an RCCL
+ * communicator and every training iteration of hpv_step / hpv_step_record is forward+backward -> ONE
+ * ncclAllReduce(sum) of the packed buffer [grad (P) | d eps | lossv | w*lossb | msq | pad] over xGMI -> TF1 Adam, all
+ * enqueued on the handle's stream and captured into its iteration graphs.  After hpv_rccl_connect,
+ * hpv_step / hpv_step_record / hpv_loss_and_grad are collective calls: every rank issues the same sequence.
+ *   hpv_rccl_unique_id: rank 0 creates the 128-byte ncclUniqueId; the caller distributes it to all ranks;
+ *   hpv_rccl_connect  : ncclCommInitRank (collective);
+ *   hpv_rccl_selftest : known-answer all-reduce (collective); out[i] must equal W(W+1)/2 + W*1e-3*i;
+ *   hpv_exchange_in_use: 0 none (single GPU or caller-driven pieces above), 1 RCCL, 2 peer-mapped mailboxes (below). */
+int hpv_rccl_unique_id(hpv_handle h, void* id128);
+int hpv_rccl_connect(hpv_handle h, int world, int rank, const void* id128);
+int hpv_rccl_selftest(hpv_handle h, double* out, size_t n);
+int hpv_rccl_disconnect(hpv_handle h);
+int hpv_exchange_in_use(hpv_handle h);
+/* Opt-in alternative (HPV_EXCHANGE=p2p in the Python classes): in-library exchange over peer-mapped mailboxes instead of
+ * a collective-library call every iteration: each rank owns a mailbox that every peer maps through hipIpc; one kernel per
  * iteration writes the buffer into all mailboxes over xGMI, waits for the peers' contributions (bounded), sums them in
  * rank order -- bitwise identical on all ranks -- and applies the Adam update.  After hpv_p2p_connect, hpv_step /
  * hpv_step_record / hpv_loss_and_grad are collective calls: every rank must issue the same sequence.
@@ -177,6 +194,9 @@ int hpv_kernel_time_ms(hpv_handle h, int which, double* avg_ms, long* launches);
  * SURVEY.md section 8(d).  n_elem elements of the handle's (qx,qy,ntx,nty) shape; returns the
  * average kernel time over `reps` launches. */
 int hpv_bench_projection(hpv_handle h, long n_elem, int reps, double* avg_ms, double* bytes_per_launch);
+/* Same with the adjoint half switchable: do_adjoint = 0 is the residual-only launch whose algorithmic bytes are
+ * SURVEY.md 8(d)'s 8 (C_u N + 2 N_R) (read the integrated channels and F, write R). */
+int hpv_bench_residual(hpv_handle h, long n_elem, int reps, int do_adjoint, double* avg_ms, double* bytes_per_launch);
 
 #ifdef __cplusplus
 }

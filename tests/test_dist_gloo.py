@@ -162,3 +162,74 @@ def test_in_library_exchange_setup_agrees_on_fallback():
         for scenario in (2, 3):
             ok, log = res[rank][scenario]
             assert ok is False and log == [("connect", 256), "disconnect"]
+
+
+def _rccl_logic_worker(rank, world, port, q):
+    """The agreement / fallback logic of VPINN._connect_rccl with the device replaced by a stub."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hp_vpinns_amd import _lib
+    from hp_vpinns_amd.vpinn import _VPINNBase
+
+    class Stub(_VPINNBase):
+        def __init__(self, no_library=False, init_fails=False, wrong_answer=False):
+            outer = self
+            self.rank, self.world, self.log = rank, world, []
+
+            class H:
+                def rccl_unique_id(s):
+                    if no_library:
+                        raise _lib.HpvError("librccl.so could not be loaded")
+                    return b"\x07" * 128
+
+                def rccl_connect(s, w, r, uid):
+                    if init_fails:
+                        raise _lib.HpvError("ncclCommInitRank failed")
+                    outer.log.append(("connect", w, r, len(uid)))
+
+                def reduce_buffer(s):
+                    return 0, 10
+
+                def rccl_selftest(s, n):
+                    return world * (world + 1) / 2 + world * 1e-3 * np.arange(n) + (1.0 if wrong_answer else 0.0)
+
+                def rccl_disconnect(s):
+                    outer.log.append("disconnect")
+            self.h = H()
+
+    out = []
+    for kw in ({}, {"no_library": True}, {"init_fails": rank == 1}, {"wrong_answer": rank == 0}):
+        m = Stub(**kw)
+        out.append((m._connect_rccl(), m.log))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_in_library_rccl_setup_agrees_on_fallback():
+    """The multi-GPU default: rank 0's ncclUniqueId reaches every rank, every rank joins and checks a known answer; a
+    failure on ANY rank (library missing, communicator refused, wrong sum) makes EVERY rank fall back, and ranks that had
+    joined leave the communicator."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_logic_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        ok, log = res[rank][0]
+        assert ok is True and log == [("connect", 2, rank, 128)]
+        ok, log = res[rank][1]
+        assert ok is False and log == []                                   # no id: nobody even tries to join
+        ok, log = res[rank][2]
+        assert ok is False and log == ([("connect", 2, 0, 128), "disconnect"] if rank == 0 else [])
+        ok, log = res[rank][3]
+        assert ok is False and log == [("connect", 2, rank, 128), "disconnect"]

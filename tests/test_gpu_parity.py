@@ -238,8 +238,34 @@ def test_reduce_buffer_is_a_zero_copy_torch_view():
         # forced on with a 1-rank RCCL group: must reproduce the single-process trajectory
         os.environ["HPV_FORCE_DIST"] = "1"
         try:
+            # default multi-GPU exchange: ncclAllReduce issued by the library inside its own iteration graphs
+            o1, m1 = _pair_2d("poisson2d_small", 1, layers=[2, 20, 20, 20, 1])
+            assert m1._dist and m1.exchange() == "rccl" and m1.h.exchange_in_use() == "rccl"
+            _check_loss_grad(o1, m1)
+            _check_traj(o1, m1, n=4)
+            for _ in range(27):
+                o1.adam_step()
+            l3 = m1._step(27, True)           # 3 replays of the 8-iteration graph + one 3-iteration graph, all-reduce captured
+            assert abs(l3[0] - float(o1.loss_parts()[0])) < TRAJ_TOL * abs(l3[0])
+            assert rel(m1.get_params(), o1.get_params()) < TRAJ_TOL
+            hist = m1._step_record(9)[0]
+            for _ in range(9):
+                o1.adam_step()
+            assert abs(hist[-1, 0] - float(o1.loss_parts()[0])) < TRAJ_TOL * abs(hist[-1, 0])
+            # the strong-form PINN branch through the same exchange (collocation points shard over the ranks)
+            from hp_vpinns_amd.vpinn import VPINN2D
+            from oracle.vpinn_oracle import OracleVPINN2D
+            ap = p2_args(gold("poisson2d_small"), layers=[2, 20, 20, 20, 1])
+            thp = theta0(ap[13], 31)
+            op, mp_ = OracleVPINN2D(*ap, scheme="PINNs", init_params=thp), VPINN2D(*ap, scheme="PINNs", init_params=thp)
+            assert mp_.exchange() == "rccl"
+            _check_loss_grad(op, mp_)
+            _check_traj(op, mp_, n=4)
+            del m1, mp_
+            # the fallback: torch.distributed all_reduce on torch's stream (HPV_EXCHANGE=torch)
+            os.environ["HPV_EXCHANGE"] = "torch"
             o2, m2 = _pair_2d("poisson2d_small", 1, layers=[2, 20, 20, 20, 1])
-            assert m2._dist and m2._reducer.active
+            assert m2._dist and m2._reducer.active and m2.exchange() == "torch"
             _check_loss_grad(o2, m2)
             _check_traj(o2, m2, n=6)
             # 27 iterations in one call: 1 eager + 3 replays of the captured 8-iteration graph
@@ -264,6 +290,7 @@ def test_reduce_buffer_is_a_zero_copy_torch_view():
             assert abs(l3b[0] - float(o2.loss_parts()[0])) < TRAJ_TOL * abs(l3b[0])
         finally:
             del os.environ["HPV_FORCE_DIST"]
+            os.environ.pop("HPV_EXCHANGE", None)
     finally:
         dist.destroy_process_group()
 
@@ -708,6 +735,8 @@ def _p2p_worker(rank, world, port, out_path):
     import pickle
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["HPV_EXCHANGE"] = "p2p"            # (the default, in-library RCCL, needs one GPU per rank)
+    os.environ["HPV_P2P_TIMEOUT_MS"] = "1500"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from hp_vpinns_amd.drivers import poisson2d
@@ -723,6 +752,21 @@ def _p2p_worker(rank, world, port, out_path):
             res.update(l3=l3, g=g, hist=hist, l3b=l3b, theta=m.get_params())
             m._step(1500, False)                 # many back-to-back exchanges (graph replays, both mailbox parities)
             res.update(l3c=m.loss(), theta_long=m.get_params())
+            # a peer that does not arrive: rank 1 stays away for longer than the wait budget.  Rank 0 must report the
+            # failure with its replica (parameters, Adam state) UNTOUCHED, and the late rank must fail as well (poisoned
+            # arrival counters) instead of applying an update its peer never made.
+            import time
+            from hp_vpinns_amd import _lib
+            dist.barrier()
+            state0 = m.h.get_state()
+            if rank == 1:
+                time.sleep(4.0)
+            try:
+                m._step(2, False)
+                res["timeout_raised"] = False
+            except _lib.HpvError as e:
+                res["timeout_raised"] = "peer did not arrive" in str(e)
+            res["state_untouched"] = bool(np.array_equal(m.h.get_state(), state0))
         with open(f"{out_path}.{rank}", "wb") as f:
             pickle.dump(res, f)
     finally:
@@ -751,3 +795,5 @@ def test_in_library_exchange_two_ranks_on_one_gpu(tmp_path):
     l3b = m._step(13, True)
     assert rel(r0["l3"], l3) < 1e-12 and rel(r0["g"], g) < 1e-11
     assert rel(r0["hist"], hist) < 1e-9 and rel(r0["l3b"], l3b) < 1e-9 and rel(r0["theta"], m.get_params()) < 1e-9
+    for r in (r0, r1):
+        assert r["timeout_raised"] is True and r["state_untouched"] is True, (r["timeout_raised"], r["state_untouched"])
