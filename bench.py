@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- variational-loss iterations/sec of the hp-VPINN hot path on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One step = one full training iteration of BASELINE.json config 4 (Poisson-2D, 16x16 elements,
-20x20 GLL points and 10x10 test functions per element, MLP [2,20,20,20,1] tanh, var_form 1):
-Taylor-mode MLP forward at all 102 400 quadrature points, per-element projection + residual,
-adjoint, reverse pass, boundary term (320 points), TF1 Adam update.  Inputs are synthetic of that
-shape (the driver's exact right-hand side, seeded boundary points, seeded Xavier init) and are
-resident in HBM before the timed region.  N>1 shards the 256 elements over the ranks (strong
-scaling: total work fixed) with one RCCL all-reduce of the packed gradient/loss buffer per step.
+One step = one full training iteration of BASELINE.json config 4 (Poisson-2D, 16x16 elements, 20x20 GLL points and
+10x10 test functions per element, MLP [2,20,20,20,1] tanh, var_form 1): Taylor-mode MLP forward at all 102 400
+quadrature points, per-element projection + residual, adjoint, reverse pass, boundary term (320 points), TF1 Adam
+update.  Inputs are synthetic of that shape (the driver's exact right-hand side, seeded boundary points, seeded Xavier
+init) and are resident in HBM before the timed region.
 
-Rank 0 prints ONE JSON line (see the contract in DESIGN.md section "Measurement").
+N > 1: `python bench.py --gpus N` re-executes itself under `python -m torch.distributed.run --nproc-per-node N` (when it
+is not already running under it), one rank per GPU; the 256 elements shard over the ranks (strong scaling: total work
+fixed) with ONE RCCL all-reduce of the packed gradient/loss buffer per step, issued by the library inside its
+iteration graphs.
+
+Timing: W untimed warm-up steps, one untimed window of K steps (captures the iteration graphs for exactly this K), then
+5 windows of EXACTLY K steps each, every window bracketed by barrier + synchronize on both sides and reduced with MAX
+over ranks; `value` = K / median window.  Rank 0 prints ONE JSON line (contract: DESIGN.md section 6).
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -28,36 +34,77 @@ CFG4 = dict(N_el_x=16, N_el_y=16, N_test_x=10, N_test_y=10, N_quad=20, N_bound=8
 LAYERS = [2, 20, 20, 20, 1]
 PEAK_FP64_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (datasheet; half the 157.3 TF FP32 rate of MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+N_WINDOWS = 5
 
 
 def gemm_flops_per_row(layers):
     return 2 * sum(layers[l] * layers[l + 1] for l in range(len(layers) - 1))
 
 
-def cpu_baseline(setup, theta, iters, vectorized=False):
-    """The oracle (reference-structured torch-fp64 restatement, or its vectorised variant) timed on this host."""
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (oracle/ is test infrastructure: imported ONLY inside these functions, never by the product)
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline_A(setup, theta, iters, windows=1):
+    """Baseline A of BASELINE.md section 3: the reference-structured oracle (per-element Python loop, one reduction per
+    test-function pair, autograd double backward -- the op granularity of the TF1 graph), torch CPU fp64."""
     import torch
-    # tiny-op graphs get slower with many threads (128 threads: 26 s/iter vs 4 s/iter at 8 on the
-    # same box class), so the baseline is pinned to 8 threads -- stated in "cores"
+    # tiny-op graphs get slower with many threads (128 threads: 26 s/iter vs 2.2 s/iter at 8 on this box class)
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     from oracle.vpinn_oracle import OracleVPINN2D
     s = setup
     o = OracleVPINN2D(s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"],
                       s["WXY_quad_train"], None, s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"],
                       s["X_u_train"], s["u_train"], LAYERS, init_params=theta)
-    o.vectorized = vectorized
     o.adam_step()  # warm-up (allocations, thread pool)
-    t0 = time.time()
-    for _ in range(iters):
-        o.adam_step()
-    dt = time.time() - t0
-    how = ("vectorised oracle (all elements batched, projection as one einsum; the strong CPU baseline B of BASELINE.md)"
-           if vectorized else
-           "reference-structured oracle (per-element Python loop, one reduction per test-function pair, autograd double "
-           "backward; baseline A of BASELINE.md)")
-    return {"value": iters / dt, "unit": "it/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "%d full iterations of the same config-4 workload, %s, host has %d logical cpus"
-                      % (iters, how, os.cpu_count())}
+    rates = []
+    for _ in range(windows):
+        t0 = time.time()
+        for _ in range(iters):
+            o.adam_step()
+        rates.append(iters / (time.time() - t0))
+    return {"value": _median(rates), "unit": "it/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "windows": [round(r, 4) for r in rates],
+            "sample": "%d window(s) of %d full iterations of the same config-4 workload; reference-structured oracle "
+                      "(per-element Python loop, one reduction per test-function pair, autograd double backward: baseline A "
+                      "of BASELINE.md), torch CPU fp64; host has %d logical cpus" % (windows, iters, os.cpu_count())}
+
+
+def cpu_baseline_B(setup, theta, iters, windows=1, sweep=(8, 32, 64, 128)):
+    """Baseline B of BASELINE.md section 3: closed-form C / OpenMP restatement (oracle/cpu_closed_form.c), all elements in
+    parallel; thread sweep, best reported."""
+    from oracle.cpu_baseline import CPoisson2D
+    s = setup
+    ncpu = os.cpu_count() or 1
+    best, table = None, {}
+    for nt in sorted({min(t, ncpu) for t in sweep}):
+        c = CPoisson2D(s["X_u_train"], s["u_train"], s["XY_quad_train"], s["WXY_quad_train"], s["F_ext_total"], s["grid_x"],
+                       s["grid_y"], LAYERS, theta, threads=nt)
+        c.train(3)
+        rates = []
+        for _ in range(windows):
+            t0 = time.time()
+            c.train(iters)
+            rates.append(iters / (time.time() - t0))
+        table[str(nt)] = round(_median(rates), 3)
+        if best is None or _median(rates) > best[1]:
+            best = (nt, _median(rates))
+    return {"value": best[1], "unit": "it/s", "cores": best[0], "kind": "port", "thread_sweep_it_per_s": table,
+            "sample": "%d window(s) of %d full iterations per thread count, closed-form C/OpenMP restatement "
+                      "(oracle/cpu_closed_form.c, gcc -O3 -march=x86-64-v3, pinned to the autograd oracle in tests/test_oracle.py: "
+                      "baseline B of BASELINE.md); host has %d logical cpus" % (windows, iters, ncpu)}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -68,26 +115,37 @@ def main():
     ap.add_argument("--backend", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-residual-roofline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-extras", action="store_true", help="skip the L2-error tail, the scaled problems and the alternative exchange")
+    ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="BASELINE.md section 3 protocol: A 5 x 20, B 5 x 200 iterations, median of the windows (minutes)")
+    ap.add_argument("--l2-iters", type=int, default=20000, help="total Adam iterations before the L2 error is evaluated")
     ap.add_argument("--residual-elems", type=int, default=1 << 18)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # the driver's plain `python bench.py --gpus N`: become N ranks, one per GPU, over RCCL
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                   "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
+                  + sys.argv[1:])
 
     import torch
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # (test hook: HPV_BENCH_ONE_GPU=1 runs every rank on cuda:0 with a gloo group -- the whole multi-rank flow, incl. the
-    #  in-library exchange, on a single-GPU box; throughput is then meaningless)
+    # (test hook: HPV_BENCH_ONE_GPU=1 runs every rank on cuda:0 with a gloo group -- the whole multi-rank flow on a
+    #  single-GPU box; throughput is then meaningless)
     one_gpu = os.environ.get("HPV_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
+        os.environ.setdefault("HPV_EXCHANGE", "p2p")
     torch.cuda.set_device(local_rank)
     dist = None
     red_dev = "cpu" if one_gpu else "cuda"
     if world > 1 or ("RANK" in os.environ and os.environ.get("HPV_FORCE_DIST") == "1"):
-        # one process per GPU over RCCL; HPV_FORCE_DIST=1 under a 1-process torchrun exercises the same path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -100,25 +158,36 @@ def main():
     from hp_vpinns_amd.init import xavier_init
     s = poisson2d.setup(**CFG4, with_test_grid=False)
     theta = xavier_init(LAYERS, 1234)
-    model = poisson2d.build_model(s, LAYERS, var_form=1, init_params=theta, backend=args.backend, device=local_rank)
 
-    def barrier():
+    def barrier(m):
         if dist is not None:
             dist.barrier()
-        model.h.sync()
+        m.h.sync()
         torch.cuda.synchronize()
 
-    model.prepare(args.warmup, args.steps)   # multi-GPU: communicator warm-up + graph capture outside the timed region
-    model._step(args.warmup, False)
-    barrier()
-    t0 = time.perf_counter()
-    model._step(args.steps, False)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_windows(m, warmup, steps, windows=N_WINDOWS):
+        """-> list of window times (s), MAX over ranks each."""
+        m.prepare(warmup, steps)      # torch-collective fallback: communicator warm-up + graph capture outside the timed region
+        m._step(warmup, False)
+        m._step(steps, False)         # untimed: captures the graphs this K needs (whole replays + one remainder graph)
+        out = []
+        for _ in range(windows):
+            barrier(m)
+            t0 = time.perf_counter()
+            m._step(steps, False)
+            barrier(m)
+            dt = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            out.append(dt)
+        return out
+
+    model = poisson2d.build_model(s, LAYERS, var_form=1, init_params=theta, backend=args.backend, device=local_rank)
+    wins = timed_windows(model, args.warmup, args.steps)
+    dt = _median(wins)
+    n_its_done = args.warmup + (1 + N_WINDOWS) * args.steps
 
     # ---- per-kernel device times (hipEvents on the stream the kernels run on), untimed extra pass ----
     nt = min(args.steps, 100)
@@ -127,83 +196,93 @@ def main():
     model.h.sync()
     ktime = {name: model.h.kernel_time_ms(i)[0] for i, name in enumerate(("mlp_fwd", "project", "mlp_bwd"))}
     model.h.enable_timing(False)
+    n_its_done += nt
     loss3 = model.loss()
-    # the L2-error half of the metric, on a 101 x 101 grid of the exact solution, at the parameters reached after all the
-    # iterations above (a few thousand Adam steps from the Xavier start: far from converged, see profiles/r01_convergence.txt)
-    import numpy as np
-    gx = np.linspace(-1, 1, 101)
-    Xt = np.stack(np.meshgrid(gx, gx), -1).reshape(-1, 2)
-    rel_l2 = model.rel_l2_error(Xt, poisson2d.u_ext(Xt[:, 0:1], Xt[:, 1:2]))
-    n_its_done = args.warmup + args.steps + nt
 
-    # ---- weak-scaling probe (multi-GPU only, reported beside the headline number): every rank keeps a full
-    #      config-4 shard (256 elements), i.e. the job solves a 16 x 16N-element problem; shows what the exchange costs
-    #      when the per-GPU work is not shrunk to the latency floor ----
-    weak = None
-    if dist is not None and (world > 1 or os.environ.get("HPV_WEAK_PROBE") == "1"):
-        sw = poisson2d.setup(**dict(CFG4, N_el_y=CFG4["N_el_y"] * world), with_test_grid=False, assemble="device", device=local_rank)
-        mw = poisson2d.build_model(sw, LAYERS, var_form=1, init_params=theta, backend=args.backend, device=local_rank)
-        kw = min(args.steps, 1000)
-        mw.prepare(args.warmup, kw)
-        mw._step(args.warmup, False)
-        dist.barrier(); torch.cuda.synchronize()
-        tw = time.perf_counter()
-        mw._step(kw, False)
-        dist.barrier(); torch.cuda.synchronize()
-        tw = torch.tensor([time.perf_counter() - tw], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        weak = {"elements": 256 * world, "elements_per_gpu": 256, "steps": kw, "it_per_s": kw / float(tw.item()),
-                "element_iterations_per_s": 256 * world * kw / float(tw.item()),
-                "note": "not the headline metric: same kernels, problem grown with N (16 x 16N elements)"}
-        del mw
+    # ---- the L2-error half of the metric: train on to a fixed total iteration count, then ||u - u_NN|| / ||u|| on a grid ----
+    rel_l2 = None
+    if not args.no_extras:
+        tail = max(0, args.l2_iters - n_its_done)
+        model._step(tail, False)
+        n_its_done += tail
+        gx = np.linspace(-1, 1, 101)
+        Xt = np.stack(np.meshgrid(gx, gx), -1).reshape(-1, 2)
+        rel_l2 = {"value": model.rel_l2_error(Xt, poisson2d.u_ext(Xt[:, 0:1], Xt[:, 1:2])), "after_iterations": n_its_done,
+                  "grid": "101x101", "loss": float(model.loss()[0]),
+                  "note": "seeded Xavier start (1234), Adam lr 1e-3; tests/test_gpu_convergence.py asserts <= 1e-2 after 30 000"}
+    exchange = model.exchange() if world > 1 or dist is not None else "none"
+
+    # ---- extras on a multi-GPU job (reported beside the headline number; the same kernels on larger problems) ----
+    extras = {}
+    if dist is not None and not args.no_extras and (world > 1 or os.environ.get("HPV_WEAK_PROBE") == "1"):
+        k2 = min(args.steps, 400)
+
+        def run_problem(nex, ney):
+            sw = poisson2d.setup(**dict(CFG4, N_el_x=nex, N_el_y=ney), with_test_grid=False, assemble="device", device=local_rank)
+            mw = poisson2d.build_model(sw, LAYERS, var_form=1, init_params=theta, backend=args.backend, device=local_rank)
+            w = timed_windows(mw, min(args.warmup, 40), k2, windows=3)
+            ex = mw.exchange()
+            del mw
+            return k2 / _median(w), ex
+        r, ex = run_problem(16, 16 * world)
+        extras["weak_scaling_probe"] = {"elements": 256 * world, "elements_per_gpu": 256, "steps": k2, "it_per_s": r,
+                                        "element_iterations_per_s": 256 * world * r, "exchange": ex,
+                                        "note": "not the headline metric: every rank keeps a full config-4 shard (16 x 16N elements)"}
+        r, ex = run_problem(64, 64)
+        npt = 64 * 64 * 400
+        extras["scaled_strong_64x64"] = {"elements": 4096, "points": npt, "steps": k2, "it_per_s": r, "exchange": ex,
+                                         "point_iterations_per_s": npt * r,
+                                         "per_rank_tflops_algorithmic": 3 * 3 * gemm_flops_per_row(LAYERS) * npt * r / world / 1e12,
+                                         "per_rank_frac_of_fp64_peak": 3 * 3 * gemm_flops_per_row(LAYERS) * npt * r / world / 1e12 / PEAK_FP64_TFLOPS,
+                                         "note": "SURVEY.md 7.3 scaled synthetic batch: the config-4 element shape on a 64x64-element "
+                                                 "grid, strong scaling (4096 / N elements per GPU)"}
+        if world > 1 and os.environ.get("HPV_BENCH_ALT_EXCHANGE", "1") == "1":
+            # the same config-4 job through the other in-library exchange (peer-mapped mailboxes), for comparison
+            alt = "p2p" if exchange != "p2p" else "rccl"
+            os.environ["HPV_EXCHANGE"] = alt
+            try:
+                ma = poisson2d.build_model(s, LAYERS, var_form=1, init_params=theta, backend=args.backend, device=local_rank)
+                wa = timed_windows(ma, min(args.warmup, 40), k2, windows=3)
+                extras["exchange_alt"] = {"exchange": ma.exchange(), "requested": alt, "steps": k2, "it_per_s": k2 / _median(wa)}
+                del ma
+            except Exception as e:  # noqa: BLE001 -- never let the comparison run take the headline line down
+                extras["exchange_alt"] = {"requested": alt, "error": str(e)[:200]}
+            finally:
+                os.environ.pop("HPV_EXCHANGE", None)
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json,
-    # produced by scripts/gpu_round.sh on this hardware; FETCH_SIZE corrected x2 as the microarch guide says)
-    traffic = None
+    # ---- roofline of the dominant kernel (SURVEY.md 8d definitions) ----
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             traffic_tab = json.load(f)
     except Exception:
         traffic_tab = {}
-    N_local = (model.Nelementx * model.Nelementy * 400) // world  # points per rank
+    n_elem_local = (model.Nelementx * model.Nelementy) // world
+    N_local = n_elem_local * 400                 # points per rank
     C, G = 3, gemm_flops_per_row(LAYERS)
-    flops = {"mlp_fwd": C * G * N_local, "mlp_bwd": 2 * C * G * N_local}
-    proj_fused = ktime["project"] == 0.0
-    if proj_fused:
-        # element-block mode: the per-element projection (+ adjoint) runs at the head of the reverse kernel; its
-        # sum-factorised flops (2 terms x 2 x (20*10*20 + 10*10*20) x 2 = 48 kflop per element) belong to that launch
-        flops["mlp_bwd"] += 48000 * (N_local // 400)
-    # Algorithmic HBM bytes per launch: the activation store is 140 doubles per point at config 4
-    # (s of layer 1; s, z_x, z_y of layers 2 and 3), written once by the forward and read once by the reverse kernel.
-    slots, d_in, C_u, n_res_local = 20 * (1 + 3 + 3), 2, 2, (model.Nelementx * model.Nelementy * 100) // world
-    n_data_local = 320 if rank == 0 else 0
-    npt = N_local + n_data_local
-    abytes = {"mlp_fwd": 8 * npt * (slots + d_in + C),                                   # read X, write slots + channels
-              "mlp_bwd": 8 * npt * (slots + d_in + C) + (8 * N_local * 2 * C_u + 16 * n_res_local if proj_fused else 0)}
-    # (reverse: read slots, X, adjoint channels; fused projection: read C_u channels + F, write C_u adjoint channels + R)
-    dom = max(("mlp_fwd", "mlp_bwd"), key=lambda k: ktime[k])
+    proj_flops = 48000 * n_elem_local            # sum-factorised: 2 terms x 2 x (20*10*20 + 10*10*20) x 2 flop per element
+    whole_iter_fused = ktime["mlp_fwd"] == 0.0 and ktime["project"] == 0.0
+    if whole_iter_fused:
+        kernels = {"iteration (forward+projection+reverse, element-resident)": (ktime["mlp_bwd"], 3 * C * G * N_local + proj_flops)}
+    else:
+        proj_in_bwd = ktime["project"] == 0.0
+        kernels = {"mlp_fwd": (ktime["mlp_fwd"], C * G * N_local),
+                   "mlp_bwd": (ktime["mlp_bwd"], 2 * C * G * N_local + (proj_flops if proj_in_bwd else 0))}
+    dom = max(kernels, key=lambda k: kernels[k][0])
 
     def roof(k):
-        t = ktime[k] * 1e-3
-        tf = flops[k] / t / 1e12 if t > 0 else 0.0
-        gbs = abytes[k] / t / 1e9 if t > 0 else 0.0
-        t_mfma, t_hbm = flops[k] / (PEAK_FP64_TFLOPS * 1e12), abytes[k] / (PEAK_HBM_GBS * 1e9)
-        hbm_bound = t_hbm >= t_mfma        # the ceiling that takes longer at peak rate is the one that bounds the kernel
-        r = {"kernel": k, "bound": "hbm" if hbm_bound else "mfma",
-             "achieved": gbs if hbm_bound else tf, "peak": PEAK_HBM_GBS if hbm_bound else PEAK_FP64_TFLOPS,
-             "unit": "GB/s" if hbm_bound else "TFLOP/s",
-             "frac": gbs / PEAK_HBM_GBS if hbm_bound else tf / PEAK_FP64_TFLOPS,
-             "traffic": traffic_tab.get(k) if world == 1 else None,
-             "bytes_per_launch": abytes[k], "flops_per_launch": flops[k], "avg_ms": ktime[k],
-             "other_ceiling": {"bound": "mfma" if hbm_bound else "hbm", "achieved": tf if hbm_bound else gbs,
-                               "unit": "TFLOP/s" if hbm_bound else "GB/s",
-                               "frac": tf / PEAK_FP64_TFLOPS if hbm_bound else gbs / PEAK_HBM_GBS}}
-        return r
+        ms, fl = kernels[k]
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        key = "iter_fused" if whole_iter_fused else k
+        return {"kernel": k, "bound": "mfma", "achieved": tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / PEAK_FP64_TFLOPS, "traffic": traffic_tab.get(key) if world == 1 else None,
+                "flops_per_launch": fl, "avg_ms": ms}
+    # whole-iteration algorithmic HBM bytes (fused ideal): coordinates in, F in, Adam state in/out
+    ideal_bytes = 8 * (2 * N_local + n_elem_local * 100 + 7 * 921)
     out = {
         "metric": "variational-loss iterations/sec", "value": args.steps / dt, "unit": "it/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -212,35 +291,46 @@ def main():
                                "MLP [2,20,20,20,1] tanh, var_form 1, 320 boundary pts, TF1 Adam (BASELINE config 4)",
                    "points": 102400, "residuals": 25600, "params": 921, "backend": model.backend(),
                    "parallelism": "element-sharded dp%d" % world,
-                   "exchange": ("in-library p2p mailboxes over xGMI" if getattr(model, "_p2p", False)
-                                else ("rccl all-reduce (torch.distributed)" if world > 1 else "none"))},
+                   "exchange": {"rccl": "in-library ncclAllReduce of the packed buffer, captured in the iteration graphs",
+                                "p2p": "in-library peer-mapped mailboxes over xGMI", "torch": "torch.distributed all_reduce (RCCL)",
+                                "none": "none"}[exchange]},
+        "timing": {"windows": N_WINDOWS, "window_it_per_s": [round(args.steps / w, 1) for w in wins],
+                   "value_is": "steps / median window; every window = exactly `steps` iterations between barrier+synchronize"},
         "loss_after": float(loss3[0]),
-        "rel_l2_error": {"value": rel_l2, "after_iterations": n_its_done, "grid": "101x101",
-                         "note": "50 001 iterations reach 4.6e-3 (profiles/r01_convergence.txt)"},
+        "rel_l2_error": rel_l2,
         "kernel_ms": ktime,
-        "roofline": dict(roof(dom), projection_fused_into_reverse=proj_fused,
-                         note="dominant kernel; algorithmic bytes = activation store (1120 B/point) + coordinates + channels "
-                              "(+ the fused projection's channels, F, R); algorithmic flops = 2*C*G*N of the layer products "
-                              "(C=3, G=1720/row); the bound is the ceiling with the larger time at peak rate; traffic = PMC HBM "
-                              "bytes (profiles/traffic.json); fp64 ubench ceilings on this chip: 47 TFLOP/s v_mfma_f64_16x16x4, "
-                              "72 v_mfma_f64_4x4x4_4b, 62 v_fma_f64, not additive"),
-        "roofline_other_kernel": roof("mlp_fwd" if dom == "mlp_bwd" else "mlp_bwd"),
+        "roofline": dict(roof(dom), whole_iteration_fused=whole_iter_fused, algorithmic_hbm_bytes_per_iteration=ideal_bytes,
+                         note="dominant kernel; frac = ALGORITHMIC flops of SURVEY.md 8(d) (3 C G N for the layer products, C=3, "
+                              "G=1720 per row, + 48 kflop per element of sum-factorised projection) / hipEvent kernel time / "
+                              "78.6 TFLOP/s fp64 peak; the tangent pre-activations the kernel recomputes in its reverse phase "
+                              "(+2/9 of the layer products) are NOT counted; traffic = PMC HBM bytes per launch "
+                              "(profiles/traffic.json) against algorithmic_hbm_bytes_per_iteration = 8 (d N + N_R + 7 P)"),
     }
-    if weak is not None:
-        out["weak_scaling_probe"] = weak
+    for k in kernels:
+        if k != dom:
+            out["roofline_other_kernel"] = roof(k)
+    out.update(extras)
     if world == 1 and not args.no_residual_roofline:
-        # the per-element projection (residual + adjoint) kernel on a batch larger than the 256 MB
-        # Infinity Cache: 2^18 elements of the config-4 element shape, random channels
-        ms, by = model.h.bench_projection(args.residual_elems, 10)
-        gbs = by / (ms * 1e-3) / 1e9
-        out["roofline_residual"] = {"kernel": "project (residual+adjoint)", "bound": "hbm", "achieved": gbs,
-                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                                    "traffic": traffic_tab.get("project_scaled"),
-                                    "bytes_per_launch": by, "avg_ms": ms, "n_elem": args.residual_elems}
+        # the per-element projection kernel on a batch larger than the 256 MB Infinity Cache: 2^18 elements
+        # of the config-4 element shape, random channels.  Residual only = SURVEY's byte count 8 (C_u N + 2 N_R); the
+        # training launch also writes the adjoint channels.
+        res = {}
+        for name, adj in (("residual_only", False), ("residual_plus_adjoint", True)):
+            ms, by = model.h.bench_projection(args.residual_elems, 10, do_adjoint=adj)
+            gbs = by / (ms * 1e-3) / 1e9
+            res[name] = {"achieved": gbs, "frac": gbs / PEAK_HBM_GBS, "bytes_per_launch": by, "avg_ms": ms,
+                         "traffic": traffic_tab.get("project_scaled" if adj else "project_scaled_residual_only")}
+        out["roofline_residual"] = {"kernel": "k_project_tp (stand-alone projection)", "bound": "hbm", "peak": PEAK_HBM_GBS,
+                                    "unit": "GB/s", "n_elem": args.residual_elems,
+                                    "achieved": res["residual_only"]["achieved"], "frac": res["residual_only"]["frac"], **res}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(s, theta, args.cpu_iters)
+        if args.cpu_baseline_full:
+            out["cpu_baseline"] = cpu_baseline_A(s, theta, 20, windows=5)
+            out["cpu_baseline_vectorized"] = cpu_baseline_B(s, theta, 200, windows=5)
+        else:
+            out["cpu_baseline"] = cpu_baseline_A(s, theta, args.cpu_iters)
+            out["cpu_baseline_vectorized"] = cpu_baseline_B(s, theta, 30)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        out["cpu_baseline_vectorized"] = cpu_baseline(s, theta, 10, vectorized=True)
         out["speedup_vs_cpu_baseline_vectorized"] = out["value"] / out["cpu_baseline_vectorized"]["value"]
     print(json.dumps(out))
     if dist is not None:
