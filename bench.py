@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="BASELINE.md section 3 protocol: A 5 x 20, B 5 x 200 iterations, median of the windows (minutes)")
-    ap.add_argument("--l2-iters", type=int, default=20000, help="total Adam iterations before the L2 error is evaluated")
+    ap.add_argument("--l2-iters", type=int, default=30000, help="total Adam iterations before the L2 error is evaluated")
     ap.add_argument("--residual-elems", type=int, default=1 << 18)
     args = ap.parse_args()
 

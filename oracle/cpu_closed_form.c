@@ -18,7 +18,7 @@
  * rows are added in thread order (deterministic for a fixed thread count).  It is checked against the autograd
  * oracle in tests/test_oracle.py (loss <= 1e-12, gradient <= 1e-10 relative) before anything is timed with it.
  *
- * Build (oracle/build_cpu_baseline.sh):  gcc -O3 -march=native -fopenmp -shared -fPIC cpu_closed_form.c -lm
+ * Build (oracle/build_cpu_baseline.sh):  gcc -O3 -march=x86-64-v3 -fopenmp -shared -fPIC cpu_closed_form.c -lm
  */
 #include <math.h>
 #include <stdlib.h>
@@ -215,21 +215,55 @@ typedef struct {
     double lossb_weight;
 } Problem;
 
-/* loss (3) and gradient (P) of the whole problem at theta; nthreads <= 0: OpenMP default */
-static int loss_grad(const Problem* pb, const double* theta, const int* layers, int n_layers, int nthreads,
+/* per-thread scratch, allocated once per call of hpvc_loss_grad / hpvc_train (not per iteration) */
+typedef struct {
+    int nt, P, cap, ok;
+    Work* w;                     /* [nt] */
+    double *x, *gb, *T;          /* [nt][2 cap], [nt][3 cap], [nt][Q ntx + NR + nty Q] */
+    double *grows, *lrows;       /* [nt][P], [nt] */
+    size_t tsz;
+} Scratch;
+
+static int resolve_threads(int nthreads) {
+#ifdef _OPENMP
+    return nthreads > 0 ? nthreads : omp_get_max_threads();
+#else
+    (void)nthreads;
+    return 1;
+#endif
+}
+
+static void scratch_free(Scratch* sc) {
+    if (sc->w) { for (int t = 0; t < sc->nt; ++t) if (sc->w[t].s) work_free(&sc->w[t]); free(sc->w); }
+    free(sc->x); free(sc->gb); free(sc->T); free(sc->grows); free(sc->lrows);
+}
+
+static int scratch_alloc(Scratch* sc, const Problem* pb, const Net* N, int nt) {
+    const int NQ = pb->Q * pb->Q, NR = pb->ntx * pb->nty;
+    memset(sc, 0, sizeof *sc);
+    sc->nt = nt; sc->P = N->P; sc->cap = NQ > pb->nd ? NQ : pb->nd;
+    sc->tsz = (size_t)pb->Q * pb->ntx + NR + (size_t)pb->nty * pb->Q;
+    sc->w = calloc((size_t)nt, sizeof(Work));
+    sc->x = malloc((size_t)nt * 2 * sc->cap * sizeof(double));
+    sc->gb = malloc((size_t)nt * 3 * sc->cap * sizeof(double));
+    sc->T = malloc((size_t)nt * sc->tsz * sizeof(double));
+    sc->grows = malloc((size_t)nt * N->P * sizeof(double));
+    sc->lrows = malloc((size_t)nt * sizeof(double));
+    int bad = !sc->w || !sc->x || !sc->gb || !sc->T || !sc->grows || !sc->lrows;
+    for (int t = 0; t < nt && !bad; ++t) bad = work_alloc(&sc->w[t], sc->cap, N->nh, N->H);
+    if (bad) { scratch_free(sc); return -2; }
+    return 0;
+}
+
+/* loss (3) and gradient (P) of the whole problem at theta */
+static int loss_grad(const Problem* pb, const double* theta, const int* layers, int n_layers, Scratch* sc,
                      double* loss3, double* grad) {
     Net N;
     if (net_init(&N, theta, layers, n_layers)) return -1;
     const int Q = pb->Q, NQ = Q * Q, ntx = pb->ntx, nty = pb->nty, NR = ntx * nty;
-    const int ne = pb->nex * pb->ney, P = N.P;
-    int nt = 1;
-#ifdef _OPENMP
-    nt = nthreads > 0 ? nthreads : omp_get_max_threads();
-#endif
-    double* grows = calloc((size_t)nt * P, sizeof(double));
-    double* lrows = calloc((size_t)nt, sizeof(double));
-    if (!grows || !lrows) return -2;
-    int fail = 0;
+    const int ne = pb->nex * pb->ney, P = N.P, nt = sc->nt;
+    double* grows = sc->grows;
+    double* lrows = sc->lrows;
     double msq = 0.0;
 #pragma omp parallel num_threads(nt)
     {
@@ -237,20 +271,19 @@ static int loss_grad(const Problem* pb, const double* theta, const int* layers, 
 #ifdef _OPENMP
         tid = omp_get_thread_num();
 #endif
-        const int cap = NQ > pb->nd ? NQ : pb->nd;
-        Work w;
-        double* x = malloc((size_t)2 * cap * sizeof(double));
-        double* gb = malloc((size_t)3 * cap * sizeof(double));
-        double* T = malloc(((size_t)Q * ntx + NR + (size_t)nty * Q) * sizeof(double));
-        if (work_alloc(&w, cap, N.nh, N.H) || !x || !gb || !T) {
-#pragma omp atomic write
-            fail = 1;
-        } else {
+        const int cap = sc->cap;
+        Work w = sc->w[tid];
+        double* x = sc->x + (size_t)tid * 2 * cap;
+        double* gb = sc->gb + (size_t)tid * 3 * cap;
+        double* T = sc->T + (size_t)tid * sc->tsz;
+        {
             double* y = x + cap;
             double *gu = gb, *gx = gb + cap, *gy = gb + 2 * cap;
             double* U = T + (size_t)Q * ntx;
             double* S = U + NR;
             double* g = grows + (size_t)tid * P;
+            memset(g, 0, (size_t)P * sizeof(double));
+            lrows[tid] = 0.0;
 #pragma omp for schedule(static)
             for (int e = 0; e < ne; ++e) {
                 const int ex = e / pb->ney, ey = e % pb->ney;
@@ -323,9 +356,7 @@ static int loss_grad(const Problem* pb, const double* theta, const int* layers, 
                     if (grad) backward(&N, &w, x, y, gu, gx, gy, g);
                 }
             }
-            work_free(&w);
         }
-        free(x); free(gb); free(T);
     }
     double lossv = 0.0;
     for (int t = 0; t < nt; ++t) lossv += lrows[t];
@@ -337,8 +368,7 @@ static int loss_grad(const Problem* pb, const double* theta, const int* layers, 
         }
     }
     loss3[0] = pb->lossb_weight * msq + lossv; loss3[1] = msq; loss3[2] = lossv;
-    free(grows); free(lrows);
-    return fail ? -2 : 0;
+    return 0;
 }
 
 static void fill(Problem* pb, const double* xi, const double* wq, int Q, const double* gridx, int nex,
@@ -355,7 +385,13 @@ int hpvc_loss_grad(const double* theta, const int* layers, int n_layers, const d
                    double lossb_weight, int nthreads, double* loss3, double* grad) {
     Problem pb;
     fill(&pb, xi, wq, Q, gridx, nex, gridy, ney, tabx, ntx, taby, nty, F, Xd, ud, nd, lossb_weight);
-    return loss_grad(&pb, theta, layers, n_layers, nthreads, loss3, grad);
+    Net N;
+    if (net_init(&N, theta, layers, n_layers)) return -1;
+    Scratch sc;
+    if (scratch_alloc(&sc, &pb, &N, resolve_threads(nthreads))) return -2;
+    const int rc = loss_grad(&pb, theta, layers, n_layers, &sc, loss3, grad);
+    scratch_free(&sc);
+    return rc;
 }
 
 /* n_iters TF1-Adam iterations in place (theta, m, v, bpow = {beta1^t, beta2^t}); loss_hist[3*it] = the loss triple
@@ -368,13 +404,16 @@ int hpvc_train(double* theta, double* m, double* v, double* bpow, const int* lay
     fill(&pb, xi, wq, Q, gridx, nex, gridy, ney, tabx, ntx, taby, nty, F, Xd, ud, nd, lossb_weight);
     Net N;
     if (net_init(&N, theta, layers, n_layers)) return -1;
+    Scratch sc;
+    if (scratch_alloc(&sc, &pb, &N, resolve_threads(nthreads))) return -2;
     double* g = malloc((size_t)N.P * sizeof(double));
-    if (!g) return -2;
+    if (!g) { scratch_free(&sc); return -2; }
     const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
-    for (int it = 0; it < n_iters; ++it) {
+    int rc = 0;
+    for (int it = 0; it < n_iters && !rc; ++it) {
         double l3[3];
-        int rc = loss_grad(&pb, theta, layers, n_layers, nthreads, l3, g);
-        if (rc) { free(g); return rc; }
+        rc = loss_grad(&pb, theta, layers, n_layers, &sc, l3, g);
+        if (rc) break;
         if (loss_hist) { loss_hist[3 * it] = l3[0]; loss_hist[3 * it + 1] = l3[1]; loss_hist[3 * it + 2] = l3[2]; }
         const double lr_t = lr * sqrt(1.0 - bpow[1]) / (1.0 - bpow[0]);
         for (int i = 0; i < N.P; ++i) {
@@ -385,7 +424,8 @@ int hpvc_train(double* theta, double* m, double* v, double* bpow, const int* lay
         bpow[0] *= b1; bpow[1] *= b2;
     }
     free(g);
-    return 0;
+    scratch_free(&sc);
+    return rc;
 }
 
 int hpvc_max_threads(void) {

@@ -1,0 +1,51 @@
+"""Driver-verifiable convergence: the accuracy half of the metric, against the reference's committed figures
+ -- full-length training runs through the reference's class surface on one MI355X.
+
+  * BASELINE config 4 (16x16 elements, [2,20,20,20,1]): relative L2 error of u on the driver's 201 x 201 test grid
+    <= 1e-2 after 30 000 Adam iterations (seeded Xavier start; 2.1 s of training).
+  * the published 1-D run (3 elements [-1,-0.1,0.1,1], [1,20,20,20,20,1] sin, P1:270-273; Results/loss.pdf, error.pdf):
+    loss <= 1e-4 and max point-wise error <= 1.3e-3 -- evaluated where the reference's own early exit (P1:215) leaves
+    the loop, because the LAST Adam iterate of a 40 000-step run at lr 1e-3 oscillates between 4e-5 and 1e-2.
+  * the 2-D reference defaults ([2,5,5,5,1], 4x4 elements, 10 001 iterations; Results/Poisson2D_VPINNs_PntErr.png, max
+    error ~0.29): a 5-wide network at 10 k iterations is initialisation-dependent -- the published value must lie inside
+    the spread of 8 seeds.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config4_reaches_1e_2_relative_l2():
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    L = [2, 20, 20, 20, 1]
+    s = poisson2d.setup(N_el_x=16, N_el_y=16, N_test_x=10, N_test_y=10, N_quad=20)
+    m = poisson2d.build_model(s, L, init_params=xavier_init(L, 1234))
+    l0 = m.loss()[0]
+    m._step(30000, False)
+    err = m.rel_l2_error(s["X_test"], s["u_test"])
+    assert err <= 1e-2, err
+    assert m.loss()[0] < 1e-2 * l0
+
+
+def test_published_1d_three_element_run():
+    from hp_vpinns_amd.drivers import poisson1d
+    r = poisson1d.run(Opt_Niter=40000 + 1, Opt_tresh=1e-4, N_Element=3, verbose=False)    # reference defaults otherwise
+    rec = np.array(r["total_record"])
+    assert abs(rec[0, 1] - 408.04) < 1.0          # the ~4e2 plateau of Results/loss.pdf = sum_e mean(F_e^2) + 1
+    assert rec[-1, 1] < 1e-4 and rec[-1, 0] < 40000, rec[-1]          # early exit (P1:215) taken
+    err = np.abs(r["setup"]["u_test"] - r["u_pred"]).max()
+    assert err <= 1.3e-3, err
+
+
+def test_2d_reference_defaults_published_error_inside_the_seed_spread():
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    L = [2, 5, 5, 5, 1]
+    errs = []
+    for seed in range(8):
+        r = poisson2d.run(n_iter=10000 + 1, record_every=100, verbose=False, init_params=xavier_init(L, seed))
+        errs.append(float(np.abs(r["setup"]["u_test"] - r["u_pred"]).max()))
+        assert r["loss_his"][-1] < r["loss_his"][0]
+    assert min(errs) < 0.29 < max(errs), errs
