@@ -10,7 +10,7 @@
 #include <hip/hip_runtime.h>
 
 __device__ __forceinline__ double hpv_tanh(double x) {
-    const double ax = fabs(x) < 32.0 ? fabs(x) : (x != x ? x : 32.0);   // NaN propagates (fmin would drop it)
+    const double ax = fmin(fabs(x), 32.0);       // (fmin drops a NaN argument: it is put back on the result below)
     const double y = -2.0 * ax;
     const double k = rint(y * 1.4426950408889634);
     double r = fma(-k, 6.93147180369123816490e-01, y);
@@ -37,5 +37,6 @@ __device__ __forceinline__ double hpv_tanh(double x) {
     double q = -t * rc;
     const double rem = fma(-d, q, -t);           // exact residual of the quotient
     q = fma(rem, rc, q);                         // correction: the quotient is good to ~1 ulp
-    return copysign(q, x);
+    q = copysign(q, x);
+    return x != x ? x : q;                       // NaN in -> NaN out, like ocml / tf.tanh (one compare + select)
 }

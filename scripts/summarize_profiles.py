@@ -36,8 +36,12 @@ def pmc(d):
 
 
 stats("stats")
-stats("stats_proj")
-for tagp, title in (("", "bench (config 4)"), ("_proj", "projection kernel, 2^18-element batch")):
+stats("stats_b")
+stats("stats_proj1")
+stats("stats_proj0")
+TITLES = (("", "bench (config 4), default path: whole-iteration kernel"), ("_b", "bench (config 4), HPV_FUSE=b: forward + projection-fused reverse kernel"),
+          ("_proj1", "projection kernel, residual + adjoint, 2^18-element batch"), ("_proj0", "projection kernel, residual only, 2^18-element batch"))
+for tagp, title in TITLES:
     fe, wr = pmc("pmc_fetch" + tagp), pmc("pmc_write" + tagp)
     if fe or wr:
         print(f"\n### HBM traffic per launch from PMC ({title})\n")
@@ -48,30 +52,40 @@ for tagp, title in (("", "bench (config 4)"), ("_proj", "projection kernel, 2^18
             f_, w_ = fe.get(k, {}).get("FETCH_SIZE", 0.0), wr.get(k, {}).get("WRITE_SIZE", 0.0)
             if f_ + w_ > 1.0:
                 print(f"| `{k}` | {f_:.0f} | {w_:.0f} | {(2 * f_ + w_) * 1024:.3e} |")
-sq = pmc("pmc_sq")
-if sq:
-    print("\n### SQ counters per launch (bench)\n")
-    cols = sorted({c for v in sq.values() for c in v})
-    print("| kernel | " + " | ".join(cols) + " |\n|---|" + "---|" * len(cols))
-    for k, v in sq.items():
-        if v.get("SQ_WAVE_CYCLES", 0) > 1e4:
-            print(f"| `{k}` | " + " | ".join(f"{v.get(c, 0):.3g}" for c in cols) + " |")
+for tagp, title in (("", "default path"), ("2", "default path, second pass"), ("_b", "HPV_FUSE=b")):
+    sq = pmc("pmc_sq" + tagp)
+    if sq:
+        print(f"\n### SQ counters per launch (bench, {title})\n")
+        cols = sorted({c for v in sq.values() for c in v})
+        print("| kernel | " + " | ".join(cols) + " |\n|---|" + "---|" * len(cols))
+        for k, v in sq.items():
+            if max(v.values()) > 1e5 and "rocclr" not in k:
+                print(f"| `{k}` | " + " | ".join(f"{v.get(c, 0):.3g}" for c in cols) + " |")
 
 # machine-readable HBM bytes per launch (corrected) for bench.py's roofline.traffic
 import json
 tj = {}
+
+
+def corrected(fe, wr, k):
+    return (2 * fe.get(k, {}).get("FETCH_SIZE", 0.0) + wr.get(k, {}).get("WRITE_SIZE", 0.0)) * 1024
+
+
 fe, wr = pmc("pmc_fetch"), pmc("pmc_write")
 for k in set(fe) | set(wr):
-    b = (2 * fe.get(k, {}).get("FETCH_SIZE", 0.0) + wr.get(k, {}).get("WRITE_SIZE", 0.0)) * 1024
+    if "k_iter_fused" in k: tj["iter_fused"] = corrected(fe, wr, k)
+    if "k_finalize" in k: tj["finalize"] = corrected(fe, wr, k)
+fe, wr = pmc("pmc_fetch_b"), pmc("pmc_write_b")
+for k in set(fe) | set(wr):
     # (several instantiations may appear -- e.g. the forward kernel without activation store for the loss read-back:
     #  the training iteration's kernel is the one that moves the most bytes)
-    if "k_bwd_mfma" in k: tj["mlp_bwd"] = max(b, tj.get("mlp_bwd", 0.0))
-    if "k_fwd_mfma" in k: tj["mlp_fwd"] = max(b, tj.get("mlp_fwd", 0.0))
-    if "k_project" in k: tj["project"] = b
-fe, wr = pmc("pmc_fetch_proj"), pmc("pmc_write_proj")
-for k in set(fe) | set(wr):
-    if "k_project" in k:
-        tj["project_scaled"] = (2 * fe.get(k, {}).get("FETCH_SIZE", 0.0) + wr.get(k, {}).get("WRITE_SIZE", 0.0)) * 1024
+    if "k_bwd_mfma" in k: tj["mlp_bwd"] = max(corrected(fe, wr, k), tj.get("mlp_bwd", 0.0))
+    if "k_fwd_mfma" in k: tj["mlp_fwd"] = max(corrected(fe, wr, k), tj.get("mlp_fwd", 0.0))
+for tagp, key in (("_proj1", "project_scaled"), ("_proj0", "project_scaled_residual_only")):
+    fe, wr = pmc("pmc_fetch" + tagp), pmc("pmc_write" + tagp)
+    for k in set(fe) | set(wr):
+        if "k_project" in k:
+            tj[key] = corrected(fe, wr, k)
 if tj:
     with open(os.path.join(out, "traffic.json"), "w") as f:
         json.dump(tj, f, indent=1)
