@@ -18,6 +18,7 @@
 //
 // Lane layout, MFMA formulation and the 16 + 4 split of a 20-wide layer are those of kernels_mfma.hip.
 #include <cstdlib>
+#include <type_traits>
 
 #include "hpv_mfma_dev.h"
 
@@ -195,76 +196,17 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     // =============================================================================================
     // phase F: forward
     // =============================================================================================
-    double xn[2];
-    {
-        long p0 = tile_of(0) * 16 + pt;
-        p0 = p0 < g.N ? p0 : g.N - 1;
-        xn[0] = g.X[p0]; xn[1] = g.X[g.N + p0];
-    }
-#pragma unroll 1
-    for (int k = 0; k < n_own; ++k) {
-        const long tile = tile_of(k);
-        const long p = tile * 16 + pt;
-        const bool valid = p < g.N;
-        const double x0 = valid ? xn[0] : 0.0, x1 = valid ? xn[1] : 0.0;
-        if (k + 1 < n_own) {
-            long pn = tile_of(k + 1) * 16 + pt;
-            pn = pn < g.N ? pn : g.N - 1;
-            xn[0] = g.X[pn]; xn[1] = g.X[g.N + pn];
-        }
-        int lofs = lane;
-        asm volatile("" : "+v"(lofs));       // opaque: the LDS fragment reads stay inside the loop
-        double h[FZ_C][MF_KS], sv[NSV];
-        // layer 1 (VALU)
-#pragma unroll
-        for (int s = 0; s < MF_KS; ++s) {
-            const double w0 = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs], w1 = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
-            const double z = lds[M::W1O + (3 * MF_KS + s) * 64 + lofs] + x0 * w0 + x1 * w1;
-            double a, a1, a2;
-            act_fwd<HPV_ACT_TANH>(z, a, a1, a2);
-            sv[s] = a;
-            h[0][s] = a; h[1][s] = a1 * w0; h[2][s] = a1 * w1;
-        }
-#pragma unroll
-        for (int i = 1; i < L; ++i) {
-            double z[FZ_C][MF_KS];
-            fz_layer<true>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, lds + M::BH + (i - 1) * MF_KS * 64, lofs, h[0], z[0]);
-            fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[1], z[1]);
-            fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[2], z[2]);
-#pragma unroll
-            for (int s = 0; s < MF_KS; ++s) {
-                double a, a1, a2;
-                act_fwd<HPV_ACT_TANH>(z[0][s], a, a1, a2);
-                sv[i * MF_KS + s] = a;
-                h[0][s] = a; h[1][s] = a1 * z[1][s]; h[2][s] = a1 * z[2][s];
-            }
-        }
-        // linear head
-        double o[FZ_C];
-#pragma unroll
-        for (int ch = 0; ch < FZ_C; ++ch) {
-            double v = 0.0;
-#pragma unroll
-            for (int s = 0; s < MF_KS; ++s) v += h[ch][s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            o[ch] = v;
-        }
-        o[0] += bo;
-        if (k < n_el) {
-            if (q == 0) {
-                const int lp = (wv + k * FZ_WAVES) * 16 + pt;     // point index inside the element
-                lds[M::CH + lp] = o[1];
-                lds[M::CH + FZ_NQ + lp] = o[2];
-            }
-        } else {
-            // lossb = w mean((u_d - u)^2) (P2:122,127): adjoint of u kept in a register, per-tile partial sum to memory
-            const double dd = valid ? g.ud[p - g.data_off] - o[0] : 0.0;
-            gdat = g.data_scale * dd;
-            double sq = dd * dd;
-            sq = row_sum16(sq);
-            if (lane == 0) g.data_part[tile - g.data_off / 16] = sq;
-        }
+    // Two tiles per trip: their instruction streams are independent, so the scheduler fills the MFMA -> tanh -> MFMA
+    // dependency bubbles of one tile with the other's work (a single wave per SIMD has nothing else to issue); the forward
+    // working set is small enough to hold twice.
+    auto load_x = [&](int k, double (&x)[2], bool& valid, long& p) {
+        const long tile = tile_of(k < n_own ? k : 0);
+        p = tile * 16 + pt;
+        valid = (p < g.N) && (k < n_own);
+        const long pc = p < g.N ? p : g.N - 1;
+        x[0] = g.X[pc]; x[1] = g.X[g.N + pc];
+    };
+    auto stash = [&](int k, const double (&sv)[NSV]) {
         if (k < n_lds) {     // wave-uniform
             double* pk = k == 0 ? PKw : PKw2;
 #pragma unroll
@@ -276,7 +218,96 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
 #undef FZ_STASH
             }
         }
-    }
+    };
+    // one trip over NT (2, or 1 for the odd tile out) tiles starting at the wave's k0-th tile; coordinates were requested a trip ahead
+    double xn[2][2];
+    bool vn[2];
+    long pn[2];
+    auto fwd_trip = [&](int k0, auto NT_) {
+        constexpr int NT = decltype(NT_)::value;
+        double xx[NT][2];
+        bool valid[NT];
+        long pp[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            valid[t] = vn[t]; pp[t] = pn[t];
+            xx[t][0] = valid[t] ? xn[t][0] : 0.0; xx[t][1] = valid[t] ? xn[t][1] : 0.0;
+        }
+        load_x(k0 + NT, xn[0], vn[0], pn[0]);       // the next trip's coordinates travel while this one computes
+        load_x(k0 + NT + 1, xn[1], vn[1], pn[1]);
+        int lofs = lane;
+        asm volatile("" : "+v"(lofs));       // opaque: the LDS fragment reads stay inside the loop
+        double h[NT][FZ_C][MF_KS], sv[NT][NSV];
+        // layer 1 (VALU)
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            const double w0 = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs], w1 = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
+            const double b1v = lds[M::W1O + (3 * MF_KS + s) * 64 + lofs];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const double z = b1v + xx[t][0] * w0 + xx[t][1] * w1;
+                double a, a1, a2;
+                act_fwd<HPV_ACT_TANH>(z, a, a1, a2);
+                sv[t][s] = a;
+                h[t][0][s] = a; h[t][1][s] = a1 * w0; h[t][2][s] = a1 * w1;
+            }
+        }
+#pragma unroll
+        for (int i = 1; i < L; ++i) {
+            double z[NT][FZ_C][MF_KS];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                fz_layer<true>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, lds + M::BH + (i - 1) * MF_KS * 64, lofs, h[t][0], z[t][0]);
+                fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[t][1], z[t][1]);
+                fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[t][2], z[t][2]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+                    double a, a1, a2;
+                    act_fwd<HPV_ACT_TANH>(z[t][0][s], a, a1, a2);
+                    sv[t][i * MF_KS + s] = a;
+                    h[t][0][s] = a; h[t][1][s] = a1 * z[t][1][s]; h[t][2][s] = a1 * z[t][2][s];
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int k = k0 + t;
+            // linear head
+            double o[FZ_C];
+#pragma unroll
+            for (int ch = 0; ch < FZ_C; ++ch) {
+                double v = 0.0;
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) v += h[t][ch][s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                o[ch] = v;
+            }
+            o[0] += bo;
+            if (k < n_el) {
+                if (q == 0) {
+                    const int lp = (wv + k * FZ_WAVES) * 16 + pt;     // point index inside the element
+                    lds[M::CH + lp] = o[1];
+                    lds[M::CH + FZ_NQ + lp] = o[2];
+                }
+            } else {
+                // lossb = w mean((u_d - u)^2) (P2:122,127): adjoint of u kept in a register, per-tile partial sum to memory
+                const double dd = valid[t] ? g.ud[pp[t] - g.data_off] - o[0] : 0.0;
+                gdat = g.data_scale * dd;
+                const double sq = row_sum16(dd * dd);
+                if (lane == 0) g.data_part[pp[t] / 16 - g.data_off / 16] = sq;
+            }
+            stash(k, sv[t]);
+        }
+    };
+    load_x(0, xn[0], vn[0], pn[0]);
+    load_x(1, xn[1], vn[1], pn[1]);
+    int k0 = 0;
+#pragma unroll 1
+    for (; k0 + 1 < n_own; k0 += 2) fwd_trip(k0, std::integral_constant<int, 2>{});
+    if (k0 < n_own) fwd_trip(k0, std::integral_constant<int, 1>{});
     FZ_STAMP(2);
     __syncthreads();
     FZ_STAMP(3);

@@ -756,6 +756,7 @@ int hpv_mfma_max_rows(HpvMfma* m, long n_elem) {
     int r = hpv_mfma_grad_rows(m);
     const long fused_rows = n_elem * fused_split(m, n_elem);
     if (m->bwd_fused && fused_rows > r && fused_rows <= 65536) r = (int)fused_rows;
+    if (n_elem > r && n_elem <= 65536) r = (int)n_elem;      // the whole-iteration kernel writes one row per element
     m->max_rows = r;
     return r;
 }
