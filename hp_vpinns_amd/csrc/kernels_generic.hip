@@ -489,6 +489,14 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
         if (!write_grad) return;
         const int c = threadIdx.x & (FIN_COLS - 1), part = threadIdx.x / FIN_COLS;
         const int idx = blockIdx.x * FIN_COLS + c;
+        // the Adam operands of this block's 16 parameters are requested BEFORE the row sums, so that their memory round trip
+        // overlaps the rows' instead of following it (the kernel is one latency chain)
+        const bool upd = ad.theta && part == 0 && idx < P;
+        double m0 = 0.0, v0 = 0.0, th0 = 0.0, b1p = 0.0, b2p = 0.0;
+        if (upd) {
+            m0 = ad.m[idx]; v0 = ad.v[idx]; th0 = ad.theta[idx];
+            b1p = ad.state[2 * (blockIdx.x + 1)]; b2p = ad.state[2 * (blockIdx.x + 1) + 1];
+        }
         double acc = 0.0;
         if (idx < P) {
             if (GPART_v) for (int r = part; r < rows_v; r += FIN_PARTS) acc += GPART_v[(long)r * P + idx];
@@ -502,7 +510,14 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
 #pragma unroll 8
             for (int k = 0; k < FIN_PARTS; ++k) t += red[k * FIN_COLS + c];
             RB[idx] = t;
-            if (ad.theta) adam_update(ad, idx, t, ad.state[2 * (blockIdx.x + 1)], ad.state[2 * (blockIdx.x + 1) + 1]);
+            if (upd) {   // adam_update with the operands fetched above (same arithmetic, same order)
+                const double lr_t = ad.lr * sqrt(1.0 - b2p) / (1.0 - b1p);
+                const double mi = ad.b1 * m0 + (1.0 - ad.b1) * t;
+                const double vi = ad.b2 * v0 + (1.0 - ad.b2) * t * t;
+                ad.m[idx] = mi;
+                ad.v[idx] = vi;
+                ad.theta[idx] = th0 - lr_t * mi / (sqrt(vi) + ad.eps);
+            }
         }
         if (ad.theta) {   // this block's private copy of the running beta powers (no cross-block race)
             __syncthreads();

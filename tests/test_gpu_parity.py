@@ -13,32 +13,40 @@ TOL = 1e-9
 TRAJ_TOL = 1e-7
 
 
-def _pair_1d(tag, vf, layers=None, backend="auto"):
+def _vec(o, vectorized):
+    # the vectorised oracle variant (proven equal to the reference-structured element loops for every var_form in
+    # tests/test_oracle.py) keeps the many-step comparisons fast on a loaded host; the three *_small tests below use the
+    # element loops themselves
+    o.vectorized = vectorized
+    return o
+
+
+def _pair_1d(tag, vf, layers=None, backend="auto", vectorized=True):
     from hp_vpinns_amd.vpinn import VPINN1D
     from oracle.vpinn_oracle import OracleVPINN1D
     g = gold(tag)
     a = p1_args(g, layers)
     th = theta0(a[8], 11)
     th[1 * a[8][1] + 0: 1 * a[8][1] + a[8][1]] = 0.1 * np.arange(a[8][1])  # non-zero first bias
-    return (OracleVPINN1D(*a, var_form=vf, init_params=th), VPINN1D(*a, var_form=vf, init_params=th, backend=backend))
+    return (_vec(OracleVPINN1D(*a, var_form=vf, init_params=th), vectorized), VPINN1D(*a, var_form=vf, init_params=th, backend=backend))
 
 
-def _pair_2d(tag, vf, layers=None, backend="auto"):
+def _pair_2d(tag, vf, layers=None, backend="auto", vectorized=True):
     from hp_vpinns_amd.vpinn import VPINN2D
     from oracle.vpinn_oracle import OracleVPINN2D
     g = gold(tag)
     a = p2_args(g, layers)
     th = theta0(a[13], 12)
-    return (OracleVPINN2D(*a, var_form=vf, init_params=th), VPINN2D(*a, var_form=vf, init_params=th, backend=backend))
+    return (_vec(OracleVPINN2D(*a, var_form=vf, init_params=th), vectorized), VPINN2D(*a, var_form=vf, init_params=th, backend=backend))
 
 
-def _pair_adv(tag, vf, layers=None, backend="auto"):
+def _pair_adv(tag, vf, layers=None, backend="auto", vectorized=True):
     from hp_vpinns_amd.vpinn import VPINNAdvDiff
     from oracle.vpinn_oracle import OracleVPINNAdvDiff
     g = gold(tag)
     a = p3_args(g, layers)
     th = theta0(a[12], 13, extra=[0.7])
-    return (OracleVPINNAdvDiff(*a, var_form=vf, init_params=th), VPINNAdvDiff(*a, var_form=vf, init_params=th, backend=backend))
+    return (_vec(OracleVPINNAdvDiff(*a, var_form=vf, init_params=th), vectorized), VPINNAdvDiff(*a, var_form=vf, init_params=th, backend=backend))
 
 
 def _check_loss_grad(o, m):
@@ -62,7 +70,7 @@ def _check_traj(o, m, n=12):
 
 @pytest.mark.parametrize("vf", [1, 2, 3])
 def test_poisson1d_small(vf):
-    o, m = _pair_1d("poisson1d_small", vf, backend="generic")
+    o, m = _pair_1d("poisson1d_small", vf, backend="generic", vectorized=False)
     _check_loss_grad(o, m)
     _check_traj(o, m)
     x = np.linspace(-1, 1, 101)[:, None]
@@ -71,7 +79,7 @@ def test_poisson1d_small(vf):
 
 @pytest.mark.parametrize("vf", [0, 1, 2])
 def test_poisson2d_small(vf):
-    o, m = _pair_2d("poisson2d_small", vf, backend="generic")
+    o, m = _pair_2d("poisson2d_small", vf, backend="generic", vectorized=False)
     _check_loss_grad(o, m)
     _check_traj(o, m)
     X = np.random.default_rng(3).uniform(-1, 1, (77, 2))
@@ -80,7 +88,7 @@ def test_poisson2d_small(vf):
 
 @pytest.mark.parametrize("vf", [0, 1])
 def test_advdiff_small(vf):
-    o, m = _pair_adv("advdiff_small", vf, backend="generic")
+    o, m = _pair_adv("advdiff_small", vf, backend="generic", vectorized=False)
     _check_loss_grad(o, m)
     _check_traj(o, m)
     assert abs(float(m.epsilon[0]) - float(o.get_params()[-1])) < 1e-9
