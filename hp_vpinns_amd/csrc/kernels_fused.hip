@@ -143,29 +143,75 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     long long fz_t[8];
 #endif
 
-    // ---- stage every weight fragment and the projection tables (one global round trip) ----
+    // ---- stage every weight fragment and the projection tables ----
+    constexpr int TNX = FZ_NTX, TNY = FZ_NTY, TQX = FZ_QX, TQY = FZ_QY;
+    static_assert(FZ_NTX * FZ_QX == FZ_NTY * FZ_QY, "table staging walks both tables with one index");
     {
-        constexpr int NW = (L - 1) * MF_KS * 64, NRW = (L - 1) * MF_KS * 16, N1 = 4 * MF_KS * 64;
-        for (int f = tid; f < NW; f += FZ_BLOCK) {
-            const int ln = f & 63, s_ = (f >> 6) % MF_KS, i_ = f / (64 * MF_KS) + 1;
-            lds[M::WT + f] = th[g.woff[i_] + (4 * s_ + (ln >> 4)) * MF_H + (ln & 15)];
-            lds[M::BH + f] = th[g.boff[i_] + 4 * s_ + (ln >> 4)];
-            lds[M::WN + f] = th[g.woff[i_] + (ln & 15) * MF_H + 4 * s_ + (ln >> 4)];
+        // layer index as a compile-time constant (kernarg offsets become scalar loads instead of a dependent vector load per
+        // lane), every global read issued before the first LDS store (one memory round trip)
+        constexpr int N1 = 4 * MF_KS * 64, IT1 = (N1 + FZ_BLOCK - 1) / FZ_BLOCK;
+        constexpr int ITW = (MF_KS * 64 + FZ_BLOCK - 1) / FZ_BLOCK;
+        double vwt[L > 1 ? L - 1 : 1][ITW], vbh[L > 1 ? L - 1 : 1][ITW], vwn[L > 1 ? L - 1 : 1][ITW];
+        double vwr[L > 1 ? L - 1 : 1], vwrb[L > 1 ? L - 1 : 1], v1[IT1];
+#pragma unroll
+        for (int i_ = 1; i_ < L; ++i_) {
+            const int wo = g.woff[i_], bo_ = g.boff[i_];
+#pragma unroll
+            for (int it = 0; it < ITW; ++it) {
+                const int f = it * FZ_BLOCK + tid, fc = f < MF_KS * 64 ? f : 0;
+                const int ln = fc & 63, s_ = fc >> 6;
+                vwt[i_ - 1][it] = th[wo + (4 * s_ + (ln >> 4)) * MF_H + (ln & 15)];
+                vbh[i_ - 1][it] = th[bo_ + 4 * s_ + (ln >> 4)];
+                vwn[i_ - 1][it] = th[wo + (ln & 15) * MF_H + 4 * s_ + (ln >> 4)];
+            }
+            const int fr = tid < MF_KS * 16 ? tid : 0;
+            const int a_ = fr & 3, q_ = (fr >> 2) & 3, s_ = fr >> 4;
+            vwr[i_ - 1] = th[wo + (4 * s_ + q_) * MF_H + 16 + a_];
+            vwrb[i_ - 1] = th[wo + (16 + a_) * MF_H + 4 * s_ + q_];
         }
-        for (int f = tid; f < NRW; f += FZ_BLOCK) {
-            const int a_ = f & 3, q_ = (f >> 2) & 3, s_ = (f >> 4) % MF_KS, i_ = f / (16 * MF_KS) + 1;
-            lds[M::WR + f] = th[g.woff[i_] + (4 * s_ + q_) * MF_H + 16 + a_];
-            lds[M::WRB + f] = th[g.woff[i_] + (16 + a_) * MF_H + 4 * s_ + q_];
-        }
-        for (int f = tid; f < N1; f += FZ_BLOCK) {
-            const int ln = f & 63, s_ = (f >> 6) % MF_KS, c_ = f / (64 * MF_KS);
+        const int w0o = g.woff[0], wLo = g.woff[L], b0o = g.boff[0];
+#pragma unroll
+        for (int it = 0; it < IT1; ++it) {
+            const int f = it * FZ_BLOCK + tid, fc = f < N1 ? f : 0;
+            const int ln = fc & 63, s_ = (fc >> 6) % MF_KS, c_ = fc / (64 * MF_KS);
             const int j = 4 * s_ + (ln >> 4);
-            lds[M::W1O + f] = c_ < 2 ? th[g.woff[0] + c_ * MF_H + j] : (c_ == 2 ? th[g.woff[L] + j] : th[g.boff[0] + j]);
+            v1[it] = th[(c_ < 2 ? w0o + c_ * MF_H : (c_ == 2 ? wLo : b0o)) + j];
         }
-        for (int f = tid; f < 2 * FZ_NTX * FZ_QX; f += FZ_BLOCK) {
-            const int t = f / (FZ_NTX * FZ_QX), i = f % (FZ_NTX * FZ_QX);
-            lds[M::AX + f] = pa.wtx[(long)pa.pd.t[t].dx * FZ_NTX * FZ_QX + i];
-            lds[M::BY + f] = pa.wty[(long)pa.pd.t[t].dy * FZ_NTY * FZ_QY + i];
+        constexpr int NTAB = 2 * TNX * TQX, ITT = (NTAB + FZ_BLOCK - 1) / FZ_BLOCK;
+        const int dx0 = pa.pd.t[0].dx, dx1 = pa.pd.t[1].dx, dy0 = pa.pd.t[0].dy, dy1 = pa.pd.t[1].dy;
+        double vax[ITT], vby[ITT];
+#pragma unroll
+        for (int it = 0; it < ITT; ++it) {
+            const int f = it * FZ_BLOCK + tid, fc = f < NTAB ? f : 0;
+            const int tt_ = fc / (TNX * TQX), ti_ = fc % (TNX * TQX);
+            vax[it] = pa.wtx[(long)(tt_ ? dx1 : dx0) * TNX * TQX + ti_];
+            vby[it] = pa.wty[(long)(tt_ ? dy1 : dy0) * TNY * TQY + ti_];
+        }
+#pragma unroll
+        for (int i_ = 1; i_ < L; ++i_) {
+#pragma unroll
+            for (int it = 0; it < ITW; ++it) {
+                const int f = it * FZ_BLOCK + tid;
+                if (f < MF_KS * 64) {
+                    lds[M::WT + (i_ - 1) * MF_KS * 64 + f] = vwt[i_ - 1][it];
+                    lds[M::BH + (i_ - 1) * MF_KS * 64 + f] = vbh[i_ - 1][it];
+                    lds[M::WN + (i_ - 1) * MF_KS * 64 + f] = vwn[i_ - 1][it];
+                }
+            }
+            if (tid < MF_KS * 16) {
+                lds[M::WR + (i_ - 1) * MF_KS * 16 + tid] = vwr[i_ - 1];
+                lds[M::WRB + (i_ - 1) * MF_KS * 16 + tid] = vwrb[i_ - 1];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IT1; ++it) {
+            const int f = it * FZ_BLOCK + tid;
+            if (f < N1) lds[M::W1O + f] = v1[it];
+        }
+#pragma unroll
+        for (int it = 0; it < ITT; ++it) {
+            const int f = it * FZ_BLOCK + tid;
+            if (f < NTAB) { lds[M::AX + f] = vax[it]; lds[M::BY + f] = vby[it]; }
         }
     }
     const double bo = th[g.boff[L]];
@@ -592,6 +638,429 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
 #endif
 }
 
+// ================================================================================================================
+// Small elements: 10x10 quadrature points, 5x5 test functions (BASELINE config 3, the 2-D reference defaults).
+// An element is 7 tiles (the last one partial), so the latency of ONE tile's forward + reverse is what an iteration
+// costs: ONE workgroup of EIGHT wavefronts per element (two per SIMD, 256 registers each), ONE tile per wave -- waves
+// 0..6 the element's tiles, wave 7 one boundary/data tile -- and nothing is recomputed or parked: s and the tangent
+// pre-activations of the wave's single tile simply stay in registers across the projection barrier.  The separate
+// path costs four launches here (forward 7.5 + projection 7.1 + reverse 11.5 + finalize 4.8 us at config 3, each with its own
+// launch + weight-staging prologue for one tile of work per wave); this kernel + finalize are two.
+// ================================================================================================================
+#define SM_WAVES 8
+#define SM_BLOCK (SM_WAVES * 64)
+#define SM_QX 10
+#define SM_QY 10
+#define SM_NTX 5
+#define SM_NTY 5
+#define SM_NQ (SM_QX * SM_QY)
+#define SM_NR (SM_NTX * SM_NTY)
+#define SM_TPE ((SM_NQ + 15) / 16)
+
+template <int L>
+struct SmLds {
+    static constexpr int LH = L > 1 ? L - 1 : 0;
+    static constexpr int WT = 0;                           // weight fragments: as FzLds
+    static constexpr int BH = WT + LH * MF_KS * 64;
+    static constexpr int WR = BH + LH * MF_KS * 64;
+    static constexpr int WN = WR + LH * MF_KS * 16;
+    static constexpr int WRB = WN + LH * MF_KS * 64;
+    static constexpr int W1O = WRB + LH * MF_KS * 16;
+    static constexpr int CH = W1O + 4 * MF_KS * 64;        // [2][NQ] u_x, u_y -> adjoints
+    static constexpr int AX = CH + 2 * SM_NQ;              // [2][NTX][QX]
+    static constexpr int BY = AX + 2 * SM_NTX * SM_QX;     // [2][NTY][QY]
+    static constexpr int T = BY + 2 * SM_NTY * SM_QY;      // [2][QY][NTX]
+    static constexpr int UP = T + 2 * SM_QY * SM_NTX;      // [2][NR]
+    static constexpr int U = UP + 2 * SM_NR;               // [NR]
+    static constexpr int S = U + SM_NR;                    // [2][NTY][QX]
+    static constexpr int RED = S + 2 * SM_NTY * SM_QX;     // [16]
+    static constexpr int TR = RED + 16;                    // per-wave transpose pair (ONE channel at a time) | epilogue rows
+    static constexpr int TR_WAVE = 2 * MF_TRB * MF_LD;
+    static constexpr int total(int P) { return TR + (SM_WAVES * TR_WAVE > SM_WAVES * P ? SM_WAVES * TR_WAVE : SM_WAVES * P); }
+};
+
+template <int L>
+__global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
+    using M = SmLds<L>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, pt = lane & 15;
+    const long e = blockIdx.x;
+    const double* __restrict__ th = g.theta;
+    const ProjArgs& pa = g.pa;
+#ifdef HPV_FZ_TIMING
+    long long fz_t[8];
+    FZ_STAMP(0);
+#endif
+
+    // ---- stage weight fragments and projection tables ----
+    constexpr int TNX = SM_NTX, TNY = SM_NTY, TQX = SM_QX, TQY = SM_QY;
+    static_assert(SM_NTX * SM_QX == SM_NTY * SM_QY, "table staging walks both tables with one index");
+    {
+        // layer index as a compile-time constant (kernarg offsets become scalar loads instead of a dependent vector load per
+        // lane), every global read issued before the first LDS store (one memory round trip)
+        constexpr int N1 = 4 * MF_KS * 64, IT1 = (N1 + SM_BLOCK - 1) / SM_BLOCK;
+        constexpr int ITW = (MF_KS * 64 + SM_BLOCK - 1) / SM_BLOCK;
+        double vwt[L > 1 ? L - 1 : 1][ITW], vbh[L > 1 ? L - 1 : 1][ITW], vwn[L > 1 ? L - 1 : 1][ITW];
+        double vwr[L > 1 ? L - 1 : 1], vwrb[L > 1 ? L - 1 : 1], v1[IT1];
+#pragma unroll
+        for (int i_ = 1; i_ < L; ++i_) {
+            const int wo = g.woff[i_], bo_ = g.boff[i_];
+#pragma unroll
+            for (int it = 0; it < ITW; ++it) {
+                const int f = it * SM_BLOCK + tid, fc = f < MF_KS * 64 ? f : 0;
+                const int ln = fc & 63, s_ = fc >> 6;
+                vwt[i_ - 1][it] = th[wo + (4 * s_ + (ln >> 4)) * MF_H + (ln & 15)];
+                vbh[i_ - 1][it] = th[bo_ + 4 * s_ + (ln >> 4)];
+                vwn[i_ - 1][it] = th[wo + (ln & 15) * MF_H + 4 * s_ + (ln >> 4)];
+            }
+            const int fr = tid < MF_KS * 16 ? tid : 0;
+            const int a_ = fr & 3, q_ = (fr >> 2) & 3, s_ = fr >> 4;
+            vwr[i_ - 1] = th[wo + (4 * s_ + q_) * MF_H + 16 + a_];
+            vwrb[i_ - 1] = th[wo + (16 + a_) * MF_H + 4 * s_ + q_];
+        }
+        const int w0o = g.woff[0], wLo = g.woff[L], b0o = g.boff[0];
+#pragma unroll
+        for (int it = 0; it < IT1; ++it) {
+            const int f = it * SM_BLOCK + tid, fc = f < N1 ? f : 0;
+            const int ln = fc & 63, s_ = (fc >> 6) % MF_KS, c_ = fc / (64 * MF_KS);
+            const int j = 4 * s_ + (ln >> 4);
+            v1[it] = th[(c_ < 2 ? w0o + c_ * MF_H : (c_ == 2 ? wLo : b0o)) + j];
+        }
+        constexpr int NTAB = 2 * TNX * TQX, ITT = (NTAB + SM_BLOCK - 1) / SM_BLOCK;
+        const int dx0 = pa.pd.t[0].dx, dx1 = pa.pd.t[1].dx, dy0 = pa.pd.t[0].dy, dy1 = pa.pd.t[1].dy;
+        double vax[ITT], vby[ITT];
+#pragma unroll
+        for (int it = 0; it < ITT; ++it) {
+            const int f = it * SM_BLOCK + tid, fc = f < NTAB ? f : 0;
+            const int tt_ = fc / (TNX * TQX), ti_ = fc % (TNX * TQX);
+            vax[it] = pa.wtx[(long)(tt_ ? dx1 : dx0) * TNX * TQX + ti_];
+            vby[it] = pa.wty[(long)(tt_ ? dy1 : dy0) * TNY * TQY + ti_];
+        }
+#pragma unroll
+        for (int i_ = 1; i_ < L; ++i_) {
+#pragma unroll
+            for (int it = 0; it < ITW; ++it) {
+                const int f = it * SM_BLOCK + tid;
+                if (f < MF_KS * 64) {
+                    lds[M::WT + (i_ - 1) * MF_KS * 64 + f] = vwt[i_ - 1][it];
+                    lds[M::BH + (i_ - 1) * MF_KS * 64 + f] = vbh[i_ - 1][it];
+                    lds[M::WN + (i_ - 1) * MF_KS * 64 + f] = vwn[i_ - 1][it];
+                }
+            }
+            if (tid < MF_KS * 16) {
+                lds[M::WR + (i_ - 1) * MF_KS * 16 + tid] = vwr[i_ - 1];
+                lds[M::WRB + (i_ - 1) * MF_KS * 16 + tid] = vwrb[i_ - 1];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IT1; ++it) {
+            const int f = it * SM_BLOCK + tid;
+            if (f < N1) lds[M::W1O + f] = v1[it];
+        }
+#pragma unroll
+        for (int it = 0; it < ITT; ++it) {
+            const int f = it * SM_BLOCK + tid;
+            if (f < NTAB) { lds[M::AX + f] = vax[it]; lds[M::BY + f] = vby[it]; }
+        }
+    }
+    const double bo = th[g.boff[L]];
+    const double pc0 = pa.coef[e], pc1 = pa.coef[pa.coef_stride + e];
+    const double pF = (pa.F && tid < SM_NR) ? pa.F[e * SM_NR + tid] : 0.0;
+
+    // ---- this wave's tile: waves 0..6 element tile wv, wave 7 the boundary/data tile blockIdx.x (if there is one) ----
+    const bool is_el = wv < SM_TPE;
+    const long n_dt = g.data_off >= 0 ? g.ntiles - g.data_off / 16 : 0;
+    const bool is_dt = !is_el && (long)blockIdx.x < n_dt;
+    const bool active = is_el || is_dt;                    // wave-uniform
+    const int lp = wv * 16 + pt;                           // point inside the element (element tiles)
+    long p = is_el ? e * SM_NQ + lp : g.data_off + (long)blockIdx.x * 16 + pt;
+    const bool valid = active && (is_el ? lp < SM_NQ : p < g.N);
+    p = valid ? p : 0;
+    const double x0 = valid ? g.X[p] : 0.0, x1 = valid ? g.X[g.N + p] : 0.0;
+    __syncthreads();
+    FZ_STAMP(1);
+
+    // =============================================================================================
+    // phase F: forward of the wave's tile; s and the tangent pre-activations stay in registers
+    // =============================================================================================
+    double sv[L][MF_KS], zc[L][2][MF_KS];
+    double gdat = 0.0;
+    if (active) {
+        double h[FZ_C][MF_KS];
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            const double w0 = lds[M::W1O + (0 * MF_KS + s) * 64 + lane], w1 = lds[M::W1O + (1 * MF_KS + s) * 64 + lane];
+            const double z = lds[M::W1O + (3 * MF_KS + s) * 64 + lane] + x0 * w0 + x1 * w1;
+            double a, a1, a2;
+            act_fwd<HPV_ACT_TANH>(z, a, a1, a2);
+            sv[0][s] = a; zc[0][0][s] = w0; zc[0][1][s] = w1;
+            h[0][s] = a; h[1][s] = a1 * w0; h[2][s] = a1 * w1;
+        }
+#pragma unroll
+        for (int i = 1; i < L; ++i) {
+            double z0[MF_KS];
+            fz_layer<true>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, lds + M::BH + (i - 1) * MF_KS * 64, lane, h[0], z0);
+            fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lane, h[1], zc[i][0]);
+            fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lane, h[2], zc[i][1]);
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                double a, a1, a2;
+                act_fwd<HPV_ACT_TANH>(z0[s], a, a1, a2);
+                sv[i][s] = a;
+                h[0][s] = a; h[1][s] = a1 * zc[i][0][s]; h[2][s] = a1 * zc[i][1][s];
+            }
+        }
+        double o[FZ_C];
+#pragma unroll
+        for (int ch = 0; ch < FZ_C; ++ch) {
+            double v = 0.0;
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) v += h[ch][s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lane];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            o[ch] = v;
+        }
+        o[0] += bo;
+        if (is_el) {
+            if (q == 0 && valid) {
+                lds[M::CH + lp] = o[1];
+                lds[M::CH + SM_NQ + lp] = o[2];
+            }
+        } else {
+            const double dd = valid ? g.ud[p - g.data_off] - o[0] : 0.0;
+            gdat = g.data_scale * dd;
+            const double sq = row_sum16(dd * dd);
+            if (lane == 0) g.data_part[blockIdx.x] = sq;
+        }
+    }
+    FZ_STAMP(2);
+    __syncthreads();
+    FZ_STAMP(3);
+
+    // =============================================================================================
+    // phase P: projection of the element from LDS (two one-hot terms)
+    // =============================================================================================
+    {
+        const double* G = lds + M::CH;
+        for (int o = tid; o < 2 * SM_QY * SM_NTX; o += SM_BLOCK) {
+            const int t = o / (SM_QY * SM_NTX), j = (o / SM_NTX) % SM_QY, r = o % SM_NTX;
+            const double* ax = lds + M::AX + (t * SM_NTX + r) * SM_QX;
+            const double* gr = G + t * SM_NQ + j * SM_QX;
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < SM_QX; ++i) acc = fma(ax[i], gr[i], acc);
+            lds[M::T + o] = acc;
+        }
+        __syncthreads();
+        if (tid < 2 * SM_NR) {
+            const int t = tid / SM_NR, o = tid % SM_NR, kk = o / SM_NTX, r = o % SM_NTX;
+            const double* by = lds + M::BY + (t * SM_NTY + kk) * SM_QY;
+            const double* tt = lds + M::T + t * SM_QY * SM_NTX + r;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < SM_QY; ++j) acc = fma(by[j], tt[j * SM_NTX], acc);
+            lds[M::UP + tid] = (t == 0 ? pc0 : pc1) * acc;
+        }
+        __syncthreads();
+        double sq = 0.0;
+        if (tid < SM_NR) {
+            const double u = (lds[M::UP + tid] + lds[M::UP + SM_NR + tid]) - pF;
+            lds[M::U + tid] = u;
+            pa.R[e * SM_NR + tid] = u;
+            sq = u * u;
+        }
+        if (wv == 0) {
+            sq = pj_wave_sum(sq);
+            if (lane == 0) lds[M::RED] = sq;
+        }
+        __syncthreads();
+        if (tid == 0) pa.loss_e[e] = lds[M::RED] / (double)SM_NR;
+        const double sc = 2.0 / (double)SM_NR;
+        for (int o = tid; o < 2 * SM_NTY * SM_QX; o += SM_BLOCK) {
+            const int t = o / (SM_NTY * SM_QX), kk = (o / SM_QX) % SM_NTY, i = o % SM_QX;
+            const double* ax = lds + M::AX + t * SM_NTX * SM_QX + i;
+            const double* ur = lds + M::U + kk * SM_NTX;
+            double acc = 0.0;
+#pragma unroll
+            for (int r = 0; r < SM_NTX; ++r) acc = fma(ax[r * SM_QX], ur[r], acc);
+            lds[M::S + o] = acc * sc * (t == 0 ? pc0 : pc1);
+        }
+        __syncthreads();
+        for (int o = tid; o < 2 * SM_NQ; o += SM_BLOCK) {
+            const int t = o / SM_NQ, j = (o / SM_QX) % SM_QY, i = o % SM_QX;
+            const double* by = lds + M::BY + t * SM_NTY * SM_QY + j;
+            const double* sr = lds + M::S + t * SM_NTY * SM_QX + i;
+            double acc = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < SM_NTY; ++kk) acc = fma(by[kk * SM_QY], sr[kk * SM_QX], acc);
+            lds[M::CH + o] = acc;
+        }
+        __syncthreads();
+    }
+
+    // =============================================================================================
+    // phase R: reverse pass of the wave's tile; every gradient piece goes to the wave's LDS row as soon as it exists
+    // =============================================================================================
+    // (the rows alias the transpose region: a row is only written after the last transpose read of the tile)
+    FZ_STAMP(4);
+    double* TA = lds + M::TR + wv * M::TR_WAVE;
+    double* TB = TA + MF_TRB * MF_LD;
+    constexpr int LH = L > 1 ? L - 1 : 1;
+    v4d dWacc[LH];
+    double dS10[LH], dS01[LH], accC[LH];
+    double dbv[L][MF_KS], dW1v[2][MF_KS], dWov[MF_KS], dbo = 0.0;
+#pragma unroll
+    for (int i = 0; i < LH; ++i) { dWacc[i] = v4d{0.0, 0.0, 0.0, 0.0}; dS10[i] = 0.0; dS01[i] = 0.0; accC[i] = 0.0; }
+#pragma unroll
+    for (int s = 0; s < MF_KS; ++s) {
+        dWov[s] = 0.0; dW1v[0][s] = 0.0; dW1v[1][s] = 0.0;
+#pragma unroll
+        for (int i = 0; i < L; ++i) dbv[i][s] = 0.0;
+    }
+    if (active) {
+        double gb[FZ_C];
+        if (is_el) { gb[0] = 0.0; gb[1] = valid ? lds[M::CH + lp] : 0.0; gb[2] = valid ? lds[M::CH + SM_NQ + lp] : 0.0; }
+        else { gb[0] = gdat; gb[1] = 0.0; gb[2] = 0.0; }
+        double hbar[FZ_C][MF_KS], zbar[FZ_C][MF_KS];
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            const double a = sv[L - 1][s], a1 = 1.0 - a * a;
+            const double wo = lds[M::W1O + (2 * MF_KS + s) * 64 + lane];
+            dWov[s] = a * gb[0] + a1 * zc[L - 1][0][s] * gb[1] + a1 * zc[L - 1][1][s] * gb[2];
+            hbar[0][s] = gb[0] * wo; hbar[1][s] = gb[1] * wo; hbar[2][s] = gb[2] * wo;
+        }
+        if (q == 0) dbo = gb[0];
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                const double a = sv[i][s];
+                const double a1 = 1.0 - a * a, a2 = -2.0 * a * a1;
+                zbar[1][s] = hbar[1][s] * a1;
+                zbar[2][s] = hbar[2][s] * a1;
+                const double zb = hbar[0][s] * a1 + a2 * (hbar[1][s] * zc[i][0][s] + hbar[2][s] * zc[i][1][s]);
+                zbar[0][s] = zb;
+                dbv[i][s] = zb;
+            }
+            if (i == 0) {
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+                    dW1v[0][s] = x0 * zbar[0][s] + zbar[1][s];
+                    dW1v[1][s] = x1 * zbar[0][s] + zbar[2][s];
+                }
+            } else {
+                // h_{i-1}^T = W_i zbar^T first (needs only registers), then dW_i channel by channel through ONE transpose pair
+                double hnext[FZ_C][MF_KS];
+#pragma unroll
+                for (int ch = 0; ch < FZ_C; ++ch) {
+                    v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
+                    double h4 = 0.0;
+                    const double* wrl = lds + M::WRB + (i - 1) * MF_KS * 16 + q * 4 + (lane & 3);
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s) {
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[M::WN + ((i - 1) * MF_KS + s) * 64 + lane], zbar[ch][s], acc, 0, 0, 0);
+                        h4 = __builtin_amdgcn_mfma_f64_4x4x4f64(wrl[s * 16], zbar[ch][s], h4, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) hnext[ch][s] = acc[s];
+                    hnext[ch][4] = h4;
+                }
+#pragma unroll
+                for (int ch = 0; ch < FZ_C; ++ch) {
+                    pj_wave_sync();
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s) {
+                        const double a = sv[i - 1][s], a1 = 1.0 - a * a;
+                        TA[(4 * s + q) * MF_LD + pt] = ch == 0 ? a : a1 * zc[i - 1][ch - 1][s];
+                        TB[(4 * s + q) * MF_LD + pt] = zbar[ch][s];
+                    }
+                    pj_wave_sync();
+                    double aF[4], bF[4], aS[4], bS[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        aF[kk] = TA[pt * MF_LD + 4 * kk + q];
+                        bF[kk] = TB[pt * MF_LD + 4 * kk + q];
+                        aS[kk] = TA[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                        bS[kk] = TB[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        dWacc[i - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[kk], bF[kk], dWacc[i - 1], 0, 0, 0);
+                        dS10[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(aS[kk], bF[kk], dS10[i - 1], 0, 0, 0);
+                        dS01[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(bS[kk], aF[kk], dS01[i - 1], 0, 0, 0);
+                    }
+                    accC[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(TA[(16 + (lane & 3)) * MF_LD + (pt & 12) + q],
+                                                                   TB[(16 + (lane & 3)) * MF_LD + (pt & 12) + q], accC[i - 1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int ch = 0; ch < FZ_C; ++ch)
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s) hbar[ch][s] = hnext[ch][s];
+            }
+        }
+    }
+
+    // ---- epilogue: each wave's gradient row -> LDS -> one row per workgroup ----
+    FZ_STAMP(5);
+    __syncthreads();
+    FZ_STAMP(6);
+    double* WP = lds + M::TR + (long)wv * g.P;
+#pragma unroll
+    for (int i = 1; i < L; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) WP[g.woff[i] + (4 * r + q) * MF_H + pt] = dWacc[i - 1][r];
+        WP[g.woff[i] + (16 + q) * MF_H + pt] = dS10[i - 1];
+        WP[g.woff[i] + pt * MF_H + 16 + q] = dS01[i - 1];
+    }
+#pragma unroll
+    for (int i = 1; i < L; ++i) {
+        double t = accC[i - 1];
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        if (pt < 4) WP[g.woff[i] + (16 + q) * MF_H + 16 + pt] = t;
+    }
+#pragma unroll
+    for (int s = 0; s < MF_KS; ++s) {
+        const int j = 4 * s + q;
+        double v[L + 3];
+#pragma unroll
+        for (int i = 0; i < L; ++i) v[i] = dbv[i][s];
+        v[L] = dW1v[0][s]; v[L + 1] = dW1v[1][s]; v[L + 2] = dWov[s];
+#pragma unroll
+        for (int kq = 0; kq < L + 3; ++kq) v[kq] = row_sum16(v[kq]);
+        if (pt == 0) {
+#pragma unroll
+            for (int i = 0; i < L; ++i) WP[g.boff[i] + j] = v[i];
+            WP[g.woff[0] + j] = v[L];
+            WP[g.woff[0] + MF_H + j] = v[L + 1];
+            WP[g.woff[L] + j] = v[L + 2];
+        }
+    }
+    {
+        const double t = row_sum16(dbo);
+        if (lane == 0) WP[g.boff[L]] = t;
+    }
+    __syncthreads();
+    const double* W0 = lds + M::TR;
+    double* row = g.GPART + (long)blockIdx.x * g.P;
+    for (int idx = tid; idx < g.P; idx += SM_BLOCK) {
+        double acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < SM_WAVES; ++w) acc += W0[(long)w * g.P + idx];
+        row[idx] = acc;
+    }
+#ifdef HPV_FZ_TIMING
+    if (lane == 0 && g.OUT) {   // [block][wave][8]: staging, forward, wait, projection, reverse, wait, epilogue, total
+        FZ_STAMP(7);
+        double* o = g.OUT + ((long)blockIdx.x * SM_WAVES + wv) * 8;
+        for (int i = 0; i < 7; ++i) o[i] = (double)(fz_t[i + 1] - fz_t[i]);
+        o[7] = (double)(fz_t[7] - fz_t[0]);
+    }
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -606,6 +1075,17 @@ static void launch_iter_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
     hipLaunchKernelGGL((k_iter_fused<L>), dim3(blocks), dim3(FZ_BLOCK), bytes, s, a);
 }
 
+template <int L>
+static void launch_iter_small(const MfmaArgs& a, int blocks, hipStream_t s) {
+    const size_t bytes = (size_t)SmLds<L>::total(a.P) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_iter_small<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_iter_small<L>), dim3(blocks), dim3(SM_BLOCK), bytes, s, a);
+}
+
 // Whole training pass (forward, projection, reverse) of a shard of 20x20 / 10x10 elements in one launch.  Returns false
 // when the shape / variational form / shard is not covered; the caller then runs the separate kernels.
 bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
@@ -614,12 +1094,35 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     const NetDesc& nd = m->nd;
     if (!m->iter_fused_ok) return false;
     if (!(nd.d == 2 && nd.nT1 == 2 && nd.nT2 == 0 && nd.act == HPV_ACT_TANH) || m->L < 2 || m->L > 3) return false;
-    if (!(pd.qx == FZ_QX && pd.qy == FZ_QY && pd.ntx == FZ_NTX && pd.nty == FZ_NTY) || pd.edge || pd.has_eps) return false;
-    if (pd.nterms != 2) return false;
+    const bool small = pd.qx == SM_QX && pd.qy == SM_QY && pd.ntx == SM_NTX && pd.nty == SM_NTY;
+    if (!(pd.qx == FZ_QX && pd.qy == FZ_QY && pd.ntx == FZ_NTX && pd.nty == FZ_NTY) && !small) return false;
+    if (pd.edge || pd.has_eps || pd.nterms != 2) return false;
     for (int t = 0; t < 2; ++t)          // one-hot: term t integrates exactly channel 1 + t with weight 1
         for (int ch = 0; ch < HPV_MAXC; ++ch)
             if (pd.t[t].a0[ch] != (ch == 1 + t ? 1.0 : 0.0) || pd.t[t].a1[ch] != 0.0 || pd.t[t].eps_mult) return false;
     if (n_elem <= 0) return false;
+    if (small) {
+        // batch layout [element points | pad to 16 | data points]; at most one boundary/data tile per workgroup
+        const long npad = (n_elem * SM_NQ + 15) / 16 * 16;
+        const bool has_data = dt && dt->n_data > 0;
+        if (has_data ? dt->data_off != npad : (m->N != npad && m->N != n_elem * SM_NQ)) return false;
+        if (has_data && m->ntiles - npad / 16 > n_elem) return false;
+        if (n_elem > hpv_mfma_grad_rows(m) && n_elem > m->max_rows) return false;
+        MfmaArgs a = m->base;
+        a.theta = theta; a.X = X; a.GPART = GPART;
+        a.OUT = const_cast<double*>(pa.OUT);   // (only written by the -DHPV_FZ_TIMING build)
+        a.data_off = -1;
+        if (has_data) {
+            a.data_off = dt->data_off; a.ud = dt->ud; a.gbar0 = dt->gbar0; a.data_part = dt->data_part;
+            a.data_scale = dt->scale; a.data_write_gbar = dt->write_gbar;
+        }
+        a.proj_n_elem = n_elem;
+        a.proj_split = 1;
+        a.pa = pa;
+        if (m->L == 2) launch_iter_small<2>(a, (int)n_elem, s); else launch_iter_small<3>(a, (int)n_elem, s);
+        if (rows) *rows = (int)n_elem;
+        return true;
+    }
     if (n_elem * 2 <= m->n_cus && !m->iter_fused_force) return false;   // small shards: the split-element reverse kernel fills the chip
     const long rest = m->ntiles - n_elem * FZ_TPE;                  // pad + boundary/data tiles: at most one per workgroup
     if (rest < 0 || rest > n_elem) return false;

@@ -5,14 +5,19 @@ import numpy as np
 from hp_vpinns_amd.drivers import poisson2d
 from hp_vpinns_amd.init import xavier_init
 LAYERS = [2, 20, 20, 20, 1]
-s = poisson2d.setup(N_el_x=16, N_el_y=16, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
+small = len(sys.argv) > 1 and sys.argv[1] == "3"        # config 3 (k_iter_small: 64 workgroups of 8 waves) instead of config 4
+if small:
+    s = poisson2d.setup(N_el_x=8, N_el_y=8, with_test_grid=False)
+else:
+    s = poisson2d.setup(N_el_x=16, N_el_y=16, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
 m = poisson2d.build_model(s, LAYERS, var_form=1, init_params=xavier_init(LAYERS, 1234))
 m.h.step(50, False)
-out = np.empty(256 * 4 * 8)
+NB, NW = (64, 8) if small else (256, 4)
+out = np.empty(NB * NW * 8)
 m.h.lib.hpv_debug_read_out.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t]
 m.h.lib.hpv_debug_read_out(m.h._h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size)
-t = out.reshape(256, 4, 8)
+t = out.reshape(NB, NW, 8)
 names = ["stage-sync", "fwd", "wait-after-fwd", "proj", "rev", "wait-after-rev", "epilogue", "total"]
 print("clock64 ticks (100 MHz?) mean over blocks, per wave:")
-for w in range(4):
+for w in range(NW):
     print("wave", w, {n: round(float(t[:, w, i].mean()), 1) for i, n in enumerate(names)})
