@@ -76,32 +76,32 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) k_fwd_mfma(MfmaArgs g) {
     double* WT = fl;                                   // [(L-1)][MF_KS][64]
     double* BH = fl + (L > 1 ? L - 1 : 0) * MF_KS * 64;       // [(L-1)][MF_KS][64]
     double* WR = BH + (L > 1 ? L - 1 : 0) * MF_KS * 64;       // [(L-1)][MF_KS][4 (q)][4 (a)]
-    {   // all global reads of the staging are issued before the first LDS store (one round trip instead of three)
-        constexpr int NW = (L - 1) * MF_KS * 64, NR_ = (L - 1) * MF_KS * 16;
-        constexpr int ITW = (NW + BLK - 1) / BLK, ITR = (NR_ + BLK - 1) / BLK;
-        double vw[ITW > 0 ? ITW : 1], vb[ITW > 0 ? ITW : 1], vr[ITR > 0 ? ITR : 1];
+    {   // all global reads of the staging are issued before the first LDS store (one round trip instead of three); the layer
+        // index is a compile-time constant, so that the kernarg offsets are scalar loads and not a dependent vector load
+        constexpr int LH_ = L > 1 ? L - 1 : 1, ITW = (MF_KS * 64 + BLK - 1) / BLK;
+        static_assert(MF_KS * 16 <= BLK, "one remainder fragment per thread");
+        double vw[LH_][ITW], vb[LH_][ITW], vr[LH_];
 #pragma unroll
-        for (int it = 0; it < ITW; ++it) {
-            const int f = it * BLK + threadIdx.x, fc = f < NW ? f : 0;
-            const int ln = fc & 63, s_ = (fc >> 6) % MF_KS, i_ = fc / (64 * MF_KS) + 1;
-            vw[it] = th[g.woff[i_] + (4 * s_ + (ln >> 4)) * MF_H + (ln & 15)];
-            vb[it] = th[g.boff[i_] + 4 * s_ + (ln >> 4)];
+        for (int i_ = 1; i_ < L; ++i_) {
+            const int wo_ = g.woff[i_], bo_ = g.boff[i_];
+#pragma unroll
+            for (int it = 0; it < ITW; ++it) {
+                const int f = it * BLK + threadIdx.x, fc = f < MF_KS * 64 ? f : 0;
+                const int ln = fc & 63, s_ = fc >> 6;
+                vw[i_ - 1][it] = th[wo_ + (4 * s_ + (ln >> 4)) * MF_H + (ln & 15)];
+                vb[i_ - 1][it] = th[bo_ + 4 * s_ + (ln >> 4)];
+            }
+            const int fr = threadIdx.x < MF_KS * 16 ? threadIdx.x : 0;
+            vr[i_ - 1] = th[wo_ + (4 * (fr >> 4) + ((fr >> 2) & 3)) * MF_H + 16 + (fr & 3)];
         }
 #pragma unroll
-        for (int it = 0; it < ITR; ++it) {
-            const int f = it * BLK + threadIdx.x, fc = f < NR_ ? f : 0;
-            const int a_ = fc & 3, q_ = (fc >> 2) & 3, s_ = (fc >> 4) % MF_KS, i_ = fc / (16 * MF_KS) + 1;
-            vr[it] = th[g.woff[i_] + (4 * s_ + q_) * MF_H + 16 + a_];
-        }
+        for (int i_ = 1; i_ < L; ++i_) {
 #pragma unroll
-        for (int it = 0; it < ITW; ++it) {
-            const int f = it * BLK + threadIdx.x;
-            if (f < NW) { WT[f] = vw[it]; BH[f] = vb[it]; }
-        }
-#pragma unroll
-        for (int it = 0; it < ITR; ++it) {
-            const int f = it * BLK + threadIdx.x;
-            if (f < NR_) WR[f] = vr[it];
+            for (int it = 0; it < ITW; ++it) {
+                const int f = it * BLK + threadIdx.x;
+                if (f < MF_KS * 64) { WT[(i_ - 1) * MF_KS * 64 + f] = vw[i_ - 1][it]; BH[(i_ - 1) * MF_KS * 64 + f] = vb[i_ - 1][it]; }
+            }
+            if (threadIdx.x < MF_KS * 16) WR[(i_ - 1) * MF_KS * 16 + threadIdx.x] = vr[i_ - 1];
         }
     }
     __syncthreads();
@@ -296,38 +296,46 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES == 8 || (1 + NT1 + NT2) * L
     // per-lane weight fragments
     // first-layer and head weights of this lane's neurons: lane-major in LDS, re-read per tile (not 30 resident VGPRs)
     double* W1O = WRB + (L > 1 ? L - 1 : 0) * MF_KS * 16;    // [(D+1)][MF_KS][64]
-    {   // all global reads of the weight staging are issued before the first LDS store (one round trip instead of three)
+    {   // all global reads of the weight staging are issued before the first LDS store (one round trip instead of three);
+        // compile-time layer index: scalar kernarg offsets instead of a dependent vector load per lane
         constexpr int BT = WAVES * 64;
-        constexpr int N1 = (D + 1) * MF_KS * 64, NW = (L - 1) * MF_KS * 64, NRB = (L - 1) * MF_KS * 16;
-        constexpr int IT1 = (N1 + BT - 1) / BT, ITW = (NW + BT - 1) / BT, ITR = (NRB + BT - 1) / BT;
-        double v1[IT1], vw[ITW > 0 ? ITW : 1], vr[ITR > 0 ? ITR : 1];
+        constexpr int N1 = (D + 1) * MF_KS * 64, IT1 = (N1 + BT - 1) / BT;
+        constexpr int LH_ = L > 1 ? L - 1 : 1, ITW = (MF_KS * 64 + BT - 1) / BT;
+        static_assert(MF_KS * 16 <= BT, "one remainder fragment per thread");
+        double v1[IT1], vw[LH_][ITW], vr[LH_];
+        const int w0o = g.woff[0], wLo = g.woff[L];
 #pragma unroll
         for (int it = 0; it < IT1; ++it) {
             const int f = it * BT + threadIdx.x, fc = f < N1 ? f : 0;
             const int ln = fc & 63, s_ = (fc >> 6) % MF_KS, c_ = fc / (64 * MF_KS);
             const int j = 4 * s_ + (ln >> 4);
-            v1[it] = c_ < D ? th[g.woff[0] + c_ * MF_H + j] : th[g.woff[L] + j];
+            v1[it] = th[(c_ < D ? w0o + c_ * MF_H : wLo) + j];
         }
         // A operand of hbar_in^T = W zbar^T : W[in = 16t+pt][out = 4s+q], kept in LDS (not registers) so that
         // two waves per SIMD fit; every wave of the block reads the same lane-major fragments, conflict-free
 #pragma unroll
-        for (int it = 0; it < ITW; ++it) {
-            const int f = it * BT + threadIdx.x, fc = f < NW ? f : 0;
-            const int ln = fc & 63, s_ = (fc >> 6) % MF_KS, i_ = fc / (64 * MF_KS) + 1;
-            vw[it] = th[g.woff[i_] + (ln & 15) * MF_H + 4 * s_ + (ln >> 4)];
-        }
+        for (int i_ = 1; i_ < L; ++i_) {
+            const int wo_ = g.woff[i_];
 #pragma unroll
-        for (int it = 0; it < ITR; ++it) {
-            const int f = it * BT + threadIdx.x, fc = f < NRB ? f : 0;
-            const int a_ = fc & 3, q_ = (fc >> 2) & 3, s_ = (fc >> 4) % MF_KS, i_ = fc / (16 * MF_KS) + 1;
-            vr[it] = th[g.woff[i_] + (16 + a_) * MF_H + 4 * s_ + q_];
+            for (int it = 0; it < ITW; ++it) {
+                const int f = it * BT + threadIdx.x, fc = f < MF_KS * 64 ? f : 0;
+                const int ln = fc & 63, s_ = fc >> 6;
+                vw[i_ - 1][it] = th[wo_ + (ln & 15) * MF_H + 4 * s_ + (ln >> 4)];
+            }
+            const int fr = threadIdx.x < MF_KS * 16 ? threadIdx.x : 0;
+            vr[i_ - 1] = th[wo_ + (16 + (fr & 3)) * MF_H + 4 * (fr >> 4) + ((fr >> 2) & 3)];
         }
 #pragma unroll
         for (int it = 0; it < IT1; ++it) { const int f = it * BT + threadIdx.x; if (f < N1) W1O[f] = v1[it]; }
 #pragma unroll
-        for (int it = 0; it < ITW; ++it) { const int f = it * BT + threadIdx.x; if (f < NW) WN[f] = vw[it]; }
+        for (int i_ = 1; i_ < L; ++i_) {
 #pragma unroll
-        for (int it = 0; it < ITR; ++it) { const int f = it * BT + threadIdx.x; if (f < NRB) WRB[f] = vr[it]; }
+            for (int it = 0; it < ITW; ++it) {
+                const int f = it * BT + threadIdx.x;
+                if (f < MF_KS * 64) WN[(i_ - 1) * MF_KS * 64 + f] = vw[i_ - 1][it];
+            }
+            if (threadIdx.x < MF_KS * 16) WRB[(i_ - 1) * MF_KS * 16 + threadIdx.x] = vr[i_ - 1];
+        }
     }
     __syncthreads();
     if constexpr (PQX > 0) {
