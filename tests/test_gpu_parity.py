@@ -789,6 +789,38 @@ def test_whole_iteration_kernel_depths_and_forms(nhid):
         del os.environ["HPV_FUSE"]
 
 
+@pytest.mark.parametrize("nhid", [2, 3])
+def test_small_element_iteration_kernel(nhid):
+    """k_iter_small (10x10-point / 5x5-test elements: one workgroup of eight waves per element, one tile per wave, BASELINE
+    config 3's shape) against the oracle and, bit for bit reproducible, against the separate launches (HPV_FUSE=b); a grid
+    with more boundary tiles than elements must fall back to the separate launches with the same results."""
+    import os
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    from oracle.vpinn_oracle import OracleVPINN2D
+    L = [2] + [20] * nhid + [1]
+    th = xavier_init(L, 4)
+    for nex, ney, nb in ((3, 2, 20), (2, 2, 40)):          # 6 elements / 5 boundary tiles; 4 elements / 10 boundary tiles (fallback)
+        s = poisson2d.setup(N_el_x=nex, N_el_y=ney, N_test_x=5, N_test_y=5, N_quad=10, N_bound=nb, with_test_grid=False)
+        m = poisson2d.build_model(s, L, init_params=th)
+        o = OracleVPINN2D(s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"], s["WXY_quad_train"],
+                          None, s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"], None, None, L, init_params=th)
+        o.vectorized = True
+        _check_loss_grad(o, m)
+        assert rel(m.h.residuals(nex * ney * 25), o.last["R"].reshape(-1)) < TOL
+        l3a, ga = m.loss_and_grad()
+        l3b, gb = m.loss_and_grad()
+        assert np.array_equal(ga, gb) and np.array_equal(l3a, l3b)
+        os.environ["HPV_FUSE"] = "b"
+        try:
+            m2 = poisson2d.build_model(s, L, init_params=th)
+            l3s, gs = m2.loss_and_grad()
+        finally:
+            del os.environ["HPV_FUSE"]
+        assert rel(ga, gs) < 1e-12 and rel(l3a, l3s) < 1e-13
+        _check_traj(o, m, n=6)
+
+
 def _p2p_worker(rank, world, port, out_path):
     """One rank of the in-library exchange test: its own process, both ranks on cuda:0 (IPC works within a device)."""
     import os
