@@ -1001,6 +1001,8 @@ int hpv_step(hpv_handle h, int n_iters, double* loss3_after) {
     } else {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
+    if (h->mfma && hpv_mfma_sync_failed(h->mfma))
+        return fail(h, -7, "whole-iteration kernel: the workgroups sharing an element did not meet at their barrier (timeout)");
     return p2p_check(h);
 }
 
@@ -1349,10 +1351,10 @@ int hpv_eval_channels(hpv_handle h, double* out, size_t n) {
     return 0;
 }
 
-// (undeclared debug hook of the -DHPV_FZ_TIMING build: raw read of the channel buffer the fused kernel stamps)
+// (undeclared debug hook of the -DHPV_FZ_TIMING build: raw read of the adjoint channel buffer the fused kernels stamp)
 int hpv_debug_read_out(hpv_handle h, double* out, size_t n) {
-    if (!h || !out || !h->var.OUT) return -1;
-    return hipMemcpy(out, h->var.OUT, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+    if (!h || !out || !h->var.GBAR) return -1;
+    return hipMemcpy(out, h->var.GBAR, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
 int hpv_backend_in_use(hpv_handle h) {
     if (!h) return -1;

@@ -31,4 +31,5 @@ bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, c
 // launch, no activation store.  Returns false when not applicable (shape, variational form, small shard).
 bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
                          const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem);
+bool hpv_mfma_sync_failed(HpvMfma* m);
 int hpv_mfma_max_rows(HpvMfma* m, long n_elem);

@@ -40,6 +40,9 @@ struct MfmaArgs {
     long proj_n_elem;
     int proj_split;       // workgroups per element in the reverse kernel's element-block mode (1, 2, 4 or 8)
     ProjArgs pa;
+    // split whole-iteration kernel: per element the monotonic arrival counter of the partners' barrier, timeout flag
+    unsigned long long* xsync;
+    int* xerr;
 };
 
 struct HpvMfma {
@@ -60,6 +63,12 @@ struct HpvMfma {
     // 'b' = forward + (projection fused into the reverse kernel), 'n' = forward, projection, reverse as separate launches
     // 'i' = the whole-iteration kernel also for shards too small to fill the chip with one workgroup per element (tests)
     bool fuse_bwd = true, iter_fused_ok = true, iter_fused_force = false;
+    // 's' keeps small shards on the forward + split reverse kernels (the whole-iteration kernel's split mode off)
+    bool iter_split_ok = true;
+    unsigned long long* xsync = nullptr;   // [xsync_elems] arrival counters, zero-initialised, monotonic (S per launch and element)
+    int* xerr = nullptr;
+    long xsync_elems = 0;
+    bool split_used = false;               // a split launch happened: hpv_step then reads the timeout flag back
 };
 
 template <int ACT>

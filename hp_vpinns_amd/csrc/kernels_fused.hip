@@ -127,7 +127,39 @@ __device__ __forceinline__ void fz_layer(const double* WTl, const double* WRl, c
     z[4] = z16;
 }
 
-template <int L>
+// Barrier among the S workgroups that share an element (SPLIT mode: small shards of a multi-GPU run) on a per-element arrival
+// counter in device memory, in the fence-free form of cdna_hip_programming.md Guideline 16
+// (R1): the payload (the partners' u_x, u_y) is stored WRITE-THROUGH with agent-scope relaxed atomic stores and read back with
+// agent-scope relaxed atomic loads, every storing wave drains its stores (s_waitcnt vmcnt(0)) before ONE lane bumps the counter,
+// ONE lane polls the generation word relaxed.  (With an agent-scope release fence before the bump and an acquire after the
+// poll -- an L2 write-back and an L1/L2 invalidate -- the barrier cost 18.6 k cycles = 8.5 us; measured, profiles/.)
+// All S workgroups are co-resident (the grid is at most one workgroup per CU); the wait is nevertheless bounded by wall clock
+// -- on expiry *err is set, the launch runs to its end on whatever it sees and hpv_step reports the failure.
+__device__ __forceinline__ void fz_elem_barrier(unsigned long long* cnt, int S, int* err, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        // ONE monotonic arrival counter per element (never reset: launch k takes it from k S to (k + 1) S), so that the arrival
+        // itself tells every workgroup its target and the last arriver needs no second round trip to announce completion
+        const unsigned long long a = __hip_atomic_fetch_add(cnt, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long target = (a / (unsigned long long)S + 1ULL) * (unsigned long long)S;
+        if (a + 1ULL != target) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ULL) { *err = 1; break; }    // 0.2 s at 100 MHz
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// SPLIT: an element is shared by g.proj_split (2, 4 or 8) workgroups -- the shards of a multi-GPU run are too small to fill the
+// chip with one workgroup per element.  Workgroup (e, part) walks the tiles [25 part / S, 25 (part + 1) / S) of element e,
+// publishes their u_x, u_y through the global channel buffer, meets its S - 1 partners at fz_elem_barrier, then EVERY partner
+// projects the whole element for itself (identical values, benign duplicate stores of R and loss_e) and reverses its own tiles.
+template <int L, bool SPLIT = false>
 __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     using M = FzLds<L>;
     constexpr int LH = L > 1 ? L - 1 : 1;
@@ -136,7 +168,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): tile counts and branches on it stay scalar
     const int q = lane >> 4, pt = lane & 15;
-    const long e = blockIdx.x;
+    const int split = SPLIT ? g.proj_split : 1;
+    const long e = SPLIT ? (long)blockIdx.x / split : (long)blockIdx.x;
+    const int part = SPLIT ? (int)(blockIdx.x % split) : 0;
     const double* __restrict__ th = g.theta;
     const ProjArgs& pa = g.pa;
 #ifdef HPV_FZ_TIMING
@@ -223,11 +257,14 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     FZ_STAMP(1);
 
     // ---- tile list of this wave: element tiles wv, wv+4, ..; wave 1 adopts boundary/data tile `dtile` ----
-    const int n_el = (FZ_TPE - wv + FZ_WAVES - 1) / FZ_WAVES;
+    const int tbase = SPLIT ? (part * FZ_TPE) / split : 0;                       // this workgroup's tile range of the element
+    const int tend = SPLIT ? ((part + 1) * FZ_TPE) / split : FZ_TPE;
+    const int n_el = SPLIT ? (tend - tbase - wv + FZ_WAVES - 1 > 0 ? (tend - tbase - wv + FZ_WAVES - 1) / FZ_WAVES : 0)
+                           : (FZ_TPE - wv + FZ_WAVES - 1) / FZ_WAVES;
     const long dtile = g.proj_n_elem * FZ_TPE + blockIdx.x;
     const bool has_d = (wv == 1) && dtile < g.ntiles;
     const int n_own = n_el + (has_d ? 1 : 0);
-    auto tile_of = [&](int k) -> long { return k < n_el ? e * FZ_TPE + wv + (long)k * FZ_WAVES : dtile; };
+    auto tile_of = [&](int k) -> long { return k < n_el ? e * FZ_TPE + tbase + wv + (long)k * FZ_WAVES : dtile; };
 
     // s = tanh(z) of every hidden layer: tile 0's go to LDS (what is left of it), the tiles 1..6 of this wave to the top
     // AGPRs a[ABASE + (k-1) * 2 NSV ..] (see acc_put)
@@ -334,9 +371,14 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             o[0] += bo;
             if (k < n_el) {
                 if (q == 0) {
-                    const int lp = (wv + k * FZ_WAVES) * 16 + pt;     // point index inside the element
-                    lds[M::CH + lp] = o[1];
-                    lds[M::CH + FZ_NQ + lp] = o[2];
+                    const int lp = (tbase + wv + k * FZ_WAVES) * 16 + pt;     // point index inside the element
+                    if constexpr (SPLIT) {   // the partners read them after the barrier
+                        __hip_atomic_store(&g.OUT[1 * g.N + e * FZ_NQ + lp], o[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&g.OUT[2 * g.N + e * FZ_NQ + lp], o[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        lds[M::CH + lp] = o[1];
+                        lds[M::CH + FZ_NQ + lp] = o[2];
+                    }
                 }
             } else {
                 // lossb = w mean((u_d - u)^2) (P2:122,127): adjoint of u kept in a register, per-tile partial sum to memory
@@ -355,6 +397,12 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     for (; k0 + 1 < n_own; k0 += 2) fwd_trip(k0, std::integral_constant<int, 2>{});
     if (k0 < n_own) fwd_trip(k0, std::integral_constant<int, 1>{});
     FZ_STAMP(2);
+    if constexpr (SPLIT) {
+        fz_elem_barrier(g.xsync + e, split, g.xerr, tid);
+        for (int idx = tid; idx < 2 * FZ_NQ; idx += FZ_BLOCK)
+            lds[M::CH + idx] = __hip_atomic_load(&g.OUT[(long)(1 + idx / FZ_NQ) * g.N + e * FZ_NQ + idx % FZ_NQ], __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     FZ_STAMP(3);
 
@@ -464,7 +512,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         }
         double gb[FZ_C];
         if (k < n_el) {
-            const int lp = (wv + k * FZ_WAVES) * 16 + pt;
+            const int lp = (tbase + wv + k * FZ_WAVES) * 16 + pt;
             gb[0] = 0.0; gb[1] = lds[M::CH + lp]; gb[2] = lds[M::CH + FZ_NQ + lp];
         } else {
             gb[0] = gdat; gb[1] = 0.0; gb[2] = 0.0;
@@ -629,9 +677,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         row[idx] = acc;
     }
 #ifdef HPV_FZ_TIMING
-    if (lane == 0 && g.OUT) {   // phase durations in shader cycles: [block][wave][8]
+    if (lane == 0 && pa.GBAR) {   // phase durations in shader cycles: [block][wave][8], into the (otherwise unused) adjoint buffer
         FZ_STAMP(7);
-        double* o = g.OUT + ((long)blockIdx.x * 4 + wv) * 8;
+        double* o = pa.GBAR + ((long)blockIdx.x * 4 + wv) * 8;
         for (int i = 0; i < 7; ++i) o[i] = (double)(fz_t[i + 1] - fz_t[i]);
         o[7] = (double)(fz_t[7] - fz_t[0]);
     }
@@ -1052,9 +1100,9 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
         row[idx] = acc;
     }
 #ifdef HPV_FZ_TIMING
-    if (lane == 0 && g.OUT) {   // [block][wave][8]: staging, forward, wait, projection, reverse, wait, epilogue, total
+    if (lane == 0 && pa.GBAR) {   // [block][wave][8]: staging, forward, wait, projection, reverse, wait, epilogue, total
         FZ_STAMP(7);
-        double* o = g.OUT + ((long)blockIdx.x * SM_WAVES + wv) * 8;
+        double* o = pa.GBAR + ((long)blockIdx.x * SM_WAVES + wv) * 8;
         for (int i = 0; i < 7; ++i) o[i] = (double)(fz_t[i + 1] - fz_t[i]);
         o[7] = (double)(fz_t[7] - fz_t[0]);
     }
@@ -1064,15 +1112,15 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int L>
+template <int L, bool SPLIT>
 static void launch_iter_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
     const size_t bytes = (size_t)FzLds<L>::total(a.P) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_iter_fused<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        (void)hipFuncSetAttribute((const void*)k_iter_fused<L, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_iter_fused<L>), dim3(blocks), dim3(FZ_BLOCK), bytes, s, a);
+    hipLaunchKernelGGL((k_iter_fused<L, SPLIT>), dim3(blocks), dim3(FZ_BLOCK), bytes, s, a);
 }
 
 template <int L>
@@ -1123,13 +1171,21 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
         if (rows) *rows = (int)n_elem;
         return true;
     }
-    if (n_elem * 2 <= m->n_cus && !m->iter_fused_force) return false;   // small shards: the split-element reverse kernel fills the chip
+    // small shards (the multi-GPU runs of config 4): an element is shared by 2 / 4 / 8 workgroups so that every CU works; the
+    // partners meet at a barrier in device memory, which needs all of them resident: at most one workgroup per CU
+    int split = 1;
+    if (n_elem * 2 <= m->n_cus && !m->iter_fused_force) {
+        if (!m->xsync || !m->iter_split_ok) return false;
+        while (split < 8 && n_elem * split * 2 <= m->n_cus) split *= 2;
+        if (n_elem * split > m->n_cus || n_elem > m->xsync_elems) return false;
+    }
+    const long blocks = n_elem * split;
     const long rest = m->ntiles - n_elem * FZ_TPE;                  // pad + boundary/data tiles: at most one per workgroup
-    if (rest < 0 || rest > n_elem) return false;
-    if (n_elem > hpv_mfma_grad_rows(m) && n_elem > m->max_rows) return false;
+    if (rest < 0 || rest > blocks) return false;
+    if (blocks > hpv_mfma_grad_rows(m) && blocks > m->max_rows) return false;
     MfmaArgs a = m->base;
     a.theta = theta; a.X = X; a.GPART = GPART;
-    a.OUT = const_cast<double*>(pa.OUT);   // (only written by the -DHPV_FZ_TIMING build)
+    a.OUT = const_cast<double*>(pa.OUT);   // SPLIT: the partners' channel exchange; otherwise only written by the -DHPV_FZ_TIMING build
     a.data_off = -1;
     if (dt && dt->n_data > 0) {
         a.data_off = dt->data_off; a.ud = dt->ud; a.gbar0 = dt->gbar0; a.data_part = dt->data_part;
@@ -1138,13 +1194,25 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
         return false;    // tiles behind the elements but no data term: not a layout this kernel knows
     }
     a.proj_n_elem = n_elem;
-    a.proj_split = 1;
+    a.proj_split = split;
+    a.xsync = m->xsync;
+    a.xerr = m->xerr;
     a.pa = pa;
-    switch (m->L) {
-        case 2: launch_iter_fused<2>(a, (int)n_elem, s); break;
-        case 3: launch_iter_fused<3>(a, (int)n_elem, s); break;
-        default: return false;
+    if (split > 1) {
+        m->split_used = true;
+        if (m->L == 2) launch_iter_fused<2, true>(a, (int)blocks, s); else launch_iter_fused<3, true>(a, (int)blocks, s);
+    } else {
+        if (m->L == 2) launch_iter_fused<2, false>(a, (int)blocks, s); else launch_iter_fused<3, false>(a, (int)blocks, s);
     }
-    if (rows) *rows = (int)n_elem;
+    if (rows) *rows = (int)blocks;
     return true;
+}
+
+// did an element barrier of the split whole-iteration kernel time out since the last check?  (resets the flag)
+bool hpv_mfma_sync_failed(HpvMfma* m) {
+    if (!m || !m->xerr || !m->split_used) return false;
+    int e = 0;
+    (void)hipMemcpy(&e, m->xerr, sizeof(int), hipMemcpyDeviceToHost);
+    if (e) (void)hipMemset(m->xerr, 0, sizeof(int));
+    return e != 0;
 }

@@ -721,6 +721,19 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
         if (hipMalloc((void**)&m->ACTS, bytes) != hipSuccess) { delete m; return no("hipMalloc of the activation store failed"); }
         (void)hipMemset(m->ACTS, 0, bytes);
     }
+    if (need_store && nd.d == 2 && nd.nT1 == 2 && nd.nT2 == 0 && nd.act == HPV_ACT_TANH) {
+        // barrier words of the split whole-iteration kernel (one pair per element of the largest grid this batch can hold)
+        m->xsync_elems = N / 400 + 1;
+        if (hipMalloc((void**)&m->xsync, (size_t)m->xsync_elems * sizeof(unsigned long long)) == hipSuccess &&
+            hipMalloc((void**)&m->xerr, sizeof(int)) == hipSuccess) {
+            (void)hipMemset(m->xsync, 0, (size_t)m->xsync_elems * sizeof(unsigned long long));
+            (void)hipMemset(m->xerr, 0, sizeof(int));
+        } else {
+            (void)hipGetLastError();
+            if (m->xsync) { (void)hipFree(m->xsync); m->xsync = nullptr; }
+            m->xerr = nullptr;
+        }
+    }
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -736,6 +749,7 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
         m->fuse_bwd = !(e && e[0] == 'n');
         m->iter_fused_ok = !(e && (e[0] == 'n' || e[0] == 'b'));
         m->iter_fused_force = e && e[0] == 'i';
+        m->iter_split_ok = !(e && e[0] == 's');
     }
     MfmaArgs& a = m->base;
     a = MfmaArgs{};
@@ -748,6 +762,8 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
 void hpv_mfma_destroy(HpvMfma* m) {
     if (!m) return;
     if (m->ACTS) (void)hipFree(m->ACTS);
+    if (m->xsync) (void)hipFree(m->xsync);
+    if (m->xerr) (void)hipFree(m->xerr);
     delete m;
 }
 

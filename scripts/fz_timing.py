@@ -5,14 +5,16 @@ import numpy as np
 from hp_vpinns_amd.drivers import poisson2d
 from hp_vpinns_amd.init import xavier_init
 LAYERS = [2, 20, 20, 20, 1]
-small = len(sys.argv) > 1 and sys.argv[1] == "3"        # config 3 (k_iter_small: 64 workgroups of 8 waves) instead of config 4
+mode = sys.argv[1] if len(sys.argv) > 1 else "4"
+small = mode == "3"        # config 3 (k_iter_small: 64 workgroups of 8 waves) instead of config 4
+shard = int(mode[1:]) if mode.startswith("s") else 1     # "s8": the 32-element shard one of 8 GPUs owns (split kernel)
 if small:
     s = poisson2d.setup(N_el_x=8, N_el_y=8, with_test_grid=False)
 else:
-    s = poisson2d.setup(N_el_x=16, N_el_y=16, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
+    s = poisson2d.setup(N_el_x=16, N_el_y=16 // shard, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
 m = poisson2d.build_model(s, LAYERS, var_form=1, init_params=xavier_init(LAYERS, 1234))
 m.h.step(50, False)
-NB, NW = (64, 8) if small else (256, 4)
+NB, NW = (64, 8) if small else (256, 4)      # (a shard of 256 / n elements runs 256 workgroups too: n per element)
 out = np.empty(NB * NW * 8)
 m.h.lib.hpv_debug_read_out.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t]
 m.h.lib.hpv_debug_read_out(m.h._h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size)

@@ -789,6 +789,39 @@ def test_whole_iteration_kernel_depths_and_forms(nhid):
         del os.environ["HPV_FUSE"]
 
 
+@pytest.mark.parametrize("nex,ney", [(16, 8), (16, 4), (16, 2), (5, 3)])
+def test_split_whole_iteration_kernel_on_small_shards(nex, ney):
+    """Shards of <= 128 config-4 elements (what one GPU of a 2 / 4 / 8-GPU run owns): the whole-iteration kernel runs in SPLIT
+    mode -- 2 / 4 / 8 workgroups share an element, exchange u_x, u_y through write-through stores and meet at a barrier in device
+    memory.  Against the forward + split reverse kernels (HPV_FUSE=s): loss / gradient / residuals, bitwise reproducible, an Adam
+    trajectory; then thousands of back-to-back launches (every one crosses the barrier) must neither time out nor drift."""
+    import os
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    s = poisson2d.setup(N_el_x=nex, N_el_y=ney, N_test_x=10, N_test_y=10, N_quad=20, N_bound=13, with_test_grid=False)
+    L = [2, 20, 20, 20, 1]
+    th = xavier_init(L, 6)
+    m = poisson2d.build_model(s, L, init_params=th)
+    l3, g = m.loss_and_grad()
+    r = m.h.residuals(nex * ney * 100)
+    for _ in range(3):
+        l3b, gb = m.loss_and_grad()
+        assert np.array_equal(gb, g) and np.array_equal(l3b, l3)
+    os.environ["HPV_FUSE"] = "s"
+    try:
+        m2 = poisson2d.build_model(s, L, init_params=th)
+        l3s, gs = m2.loss_and_grad()
+        rs = m2.h.residuals(nex * ney * 100)
+        m2._step(40, False)
+    finally:
+        del os.environ["HPV_FUSE"]
+    assert rel(g, gs) < 1e-12 and rel(l3, l3s) < 1e-13 and rel(r, rs) < 1e-12
+    m._step(40, False)
+    assert rel(m.get_params(), m2.get_params()) < 1e-10
+    m._step(4000, False)                 # raises HpvError (-7) if a barrier ever times out
+    assert np.all(np.isfinite(m.get_params())) and np.isfinite(m.loss()[0])
+
+
 @pytest.mark.parametrize("nhid", [2, 3])
 def test_small_element_iteration_kernel(nhid):
     """k_iter_small (10x10-point / 5x5-test elements: one workgroup of eight waves per element, one tile per wave, BASELINE
