@@ -4,6 +4,8 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $HPV_EXTRA_FLAGS"   # e.g. HPV_EXTRA_FLAGS=-DHPV_FZ_TIMING
+# objects are cached by mtime; a change of flags must invalidate them (.flags remembers what the objects were built with)
+if [ "$(cat .flags 2>/dev/null)" != "$FLAGS" ]; then rm -f *.o; echo "$FLAGS" > .flags; fi
 for f in kernels_generic kernels_mfma kernels_fused kernels_project hpv_api; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ hpv_internal.h -nt $f.o ] || [ hpv_mfma.h -nt $f.o ] || [ hpv_mfma_dev.h -nt $f.o ] || [ hpv_project_wg.h -nt $f.o ] || [ hpv_math.h -nt $f.o ] || [ ../../include/hpvpinn.h -nt $f.o ]; then
     if [ $f = kernels_fused ]; then   # the whole-iteration kernel parks live values in AGPRs by hand: verify the compiler stays clear

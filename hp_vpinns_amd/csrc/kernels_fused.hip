@@ -169,12 +169,13 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): tile counts and branches on it stay scalar
     const int q = lane >> 4, pt = lane & 15;
     const int split = SPLIT ? g.proj_split : 1;
-    const long e = SPLIT ? (long)blockIdx.x / split : (long)blockIdx.x;
-    const int part = SPLIT ? (int)(blockIdx.x % split) : 0;
+    const long e = SPLIT ? (long)(blockIdx.x >> __builtin_ctz(split)) : (long)blockIdx.x;     // split is 2, 4 or 8
+    const int part = SPLIT ? (int)(blockIdx.x & (split - 1)) : 0;
     const double* __restrict__ th = g.theta;
     const ProjArgs& pa = g.pa;
 #ifdef HPV_FZ_TIMING
     long long fz_t[8];
+    const long long fz_start = clock64(), fz_wall = wall_clock64();
 #endif
 
     // ---- stage every weight fragment and the projection tables ----
@@ -256,13 +257,30 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     __syncthreads();
     FZ_STAMP(1);
 
-    // ---- tile list of this wave: element tiles wv, wv+4, ..; wave 1 adopts boundary/data tile `dtile` ----
-    const int tbase = SPLIT ? (part * FZ_TPE) / split : 0;                       // this workgroup's tile range of the element
-    const int tend = SPLIT ? ((part + 1) * FZ_TPE) / split : FZ_TPE;
+    // ---- tile list of this wave: element tiles wv, wv+4, .., and possibly one boundary/data tile `dtile` ----
+    const int lg = SPLIT ? __builtin_ctz(split) : 0;                             // split is 2, 4 or 8
+    const int tbase = SPLIT ? (part * FZ_TPE) >> lg : 0;                         // this workgroup's tile range of the element
+    const int tend = SPLIT ? ((part + 1) * FZ_TPE) >> lg : FZ_TPE;
     const int n_el = SPLIT ? (tend - tbase - wv + FZ_WAVES - 1 > 0 ? (tend - tbase - wv + FZ_WAVES - 1) / FZ_WAVES : 0)
                            : (FZ_TPE - wv + FZ_WAVES - 1) / FZ_WAVES;
-    const long dtile = g.proj_n_elem * FZ_TPE + blockIdx.x;
-    const bool has_d = (wv == 1) && dtile < g.ntiles;
+    // The boundary/data tiles behind the elements go one per workgroup to the first wave with the fewest element tiles
+    // (25 tiles over 4 waves: wave 1).  SPLIT: only to workgroups in which that wave has a free slot compared with its
+    // neighbours (tile count not a multiple of 4) -- otherwise the adopted tile is a whole extra forward + reverse that the
+    // element's partners wait for -- as long as there are enough of those.
+    long dtile = g.proj_n_elem * FZ_TPE + blockIdx.x;
+    if constexpr (SPLIT) {
+        int n_free = 0, before = 0;
+        bool mine = false;
+        for (int p = 0; p < split; ++p) {
+            const bool fr = (((((p + 1) * FZ_TPE) >> lg) - ((p * FZ_TPE) >> lg)) % FZ_WAVES) != 0;
+            n_free += fr;
+            before += (fr && p < part);
+            mine = mine || (fr && p == part);
+        }
+        if (g.ntiles - g.proj_n_elem * FZ_TPE <= g.proj_n_elem * n_free)
+            dtile = mine ? g.proj_n_elem * FZ_TPE + e * n_free + before : g.ntiles;
+    }
+    const bool has_d = (wv == (tend - tbase) % FZ_WAVES) && dtile < g.ntiles;
     const int n_own = n_el + (has_d ? 1 : 0);
     auto tile_of = [&](int k) -> long { return k < n_el ? e * FZ_TPE + tbase + wv + (long)k * FZ_WAVES : dtile; };
 
@@ -679,9 +697,13 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
 #ifdef HPV_FZ_TIMING
     if (lane == 0 && pa.GBAR) {   // phase durations in shader cycles: [block][wave][8], into the (otherwise unused) adjoint buffer
         FZ_STAMP(7);
-        double* o = pa.GBAR + ((long)blockIdx.x * 4 + wv) * 8;
-        for (int i = 0; i < 7; ++i) o[i] = (double)(fz_t[i + 1] - fz_t[i]);
-        o[7] = (double)(fz_t[7] - fz_t[0]);
+        double* o = pa.GBAR + ((long)blockIdx.x * 4 + wv) * 10;
+        for (int i = 1; i < 7; ++i) o[i] = (double)(fz_t[i + 1] - fz_t[i]);
+        o[0] = (double)(fz_t[1] - fz_start);                   // staging + first barrier
+        const long long fz_end = wall_clock64();
+        o[7] = (double)(fz_end - fz_wall) * 0.01;              // whole wave, microseconds (100 MHz constant clock)
+        o[8] = (double)(fz_wall & 0xffffffffffll) * 0.01;      // absolute start / end, microseconds: launch skew across workgroups
+        o[9] = (double)(fz_end & 0xffffffffffll) * 0.01;
     }
 #endif
 }
@@ -740,6 +762,7 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
 #ifdef HPV_FZ_TIMING
     long long fz_t[8];
     FZ_STAMP(0);
+    const long long fz_wall = wall_clock64();
 #endif
 
     // ---- stage weight fragments and projection tables ----
@@ -1102,9 +1125,12 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
 #ifdef HPV_FZ_TIMING
     if (lane == 0 && pa.GBAR) {   // [block][wave][8]: staging, forward, wait, projection, reverse, wait, epilogue, total
         FZ_STAMP(7);
-        double* o = pa.GBAR + ((long)blockIdx.x * SM_WAVES + wv) * 8;
+        double* o = pa.GBAR + ((long)blockIdx.x * SM_WAVES + wv) * 10;
         for (int i = 0; i < 7; ++i) o[i] = (double)(fz_t[i + 1] - fz_t[i]);
-        o[7] = (double)(fz_t[7] - fz_t[0]);
+        const long long fz_end = wall_clock64();
+        o[7] = (double)(fz_end - fz_wall) * 0.01;
+        o[8] = (double)(fz_wall & 0xffffffffffll) * 0.01;
+        o[9] = (double)(fz_end & 0xffffffffffll) * 0.01;
     }
 #endif
 }

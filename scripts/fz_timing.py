@@ -15,11 +15,20 @@ else:
 m = poisson2d.build_model(s, LAYERS, var_form=1, init_params=xavier_init(LAYERS, 1234))
 m.h.step(50, False)
 NB, NW = (64, 8) if small else (256, 4)      # (a shard of 256 / n elements runs 256 workgroups too: n per element)
-out = np.empty(NB * NW * 8)
+out = np.empty(NB * NW * 10)
 m.h.lib.hpv_debug_read_out.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t]
 m.h.lib.hpv_debug_read_out(m.h._h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size)
-t = out.reshape(NB, NW, 8)
+t = out.reshape(NB, NW, 10)
 names = ["stage-sync", "fwd", "wait-after-fwd", "proj", "rev", "wait-after-rev", "epilogue", "total"]
-print("clock64 ticks (100 MHz?) mean over blocks, per wave:")
+print("shader cycles, mean over blocks, per wave (k_iter_fused: 'total' = microseconds on the 100 MHz wall clock):")
 for w in range(NW):
     print("wave", w, {n: round(float(t[:, w, i].mean()), 1) for i, n in enumerate(names)})
+t0 = t[:, :, 8].min()
+st, en = t[:, :, 8] - t0, t[:, :, 9] - t0
+print("wall clock, us after the first wave's start: starts  min %.2f  median %.2f  max %.2f | ends  min %.2f  median %.2f  max %.2f"
+      % (st.min(), np.median(st), st.max(), en.min(), np.median(en), en.max()))
+print("start of workgroup b (wave 0), us:", np.round(st[:, 0][:: max(1, NB // 32)], 2).tolist())
+late = np.argsort(-en.max(axis=1))[:6]
+for b in late.tolist() + [int(np.argsort(en.max(axis=1))[NB // 2])]:
+    w = int(np.argmax(en[b]))
+    print("workgroup %3d wave %d ends %.2f us:" % (b, w, en[b, w]), {n: round(float(t[b, w, i]), 1) for i, n in enumerate(names)})
