@@ -40,3 +40,43 @@ __device__ __forceinline__ double hpv_tanh(double x) {
     q = copysign(q, x);
     return x != x ? x : q;                       // NaN in -> NaN out, like ocml / tf.tanh (one compare + select)
 }
+
+// sin and cos together for the 1-D drivers' activation (P1:134; the derivative channels need the cosine).  ocml's sincos is
+// two argument reductions with a Payne-Hanek branch and ~190 instructions; this one is 4 fma of Cody-Waite reduction against
+// pi/2 split into 33 + 33 + 33 + 53 bits (k pi/2 is exact in the first product for |k| < 2^20), the two fdlibm kernel
+// polynomials on [-pi/4, pi/4] and a branch-free quadrant fix-up: ~40 instructions.  Max error 2.2 ulp over |x| <= 1e6
+// (host prototype against mpmath, 4e4 points incl. the doubles nearest to multiples of pi/2; on the device against ocml in
+// tests/test_gpu_parity.py).  |x| > 1e6, NaN and inf take ocml's path (wave-divergent only there).
+__device__ __forceinline__ void hpv_sincos(double x, double* so, double* co) {
+    if (__builtin_expect(!(fabs(x) <= 1.0e6), 0)) {
+        sincos(x, so, co);
+        return;
+    }
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050630396597660e-11, r);
+    r = fma(-k, 2.02226624871116645580e-21, r);
+    r = fma(-k, 8.47842766036889956997e-32, r);
+    const double z = r * r;
+    double p = 1.58969099521155010221e-10;
+    p = fma(p, z, -2.50507602534068634195e-08);
+    p = fma(p, z, 2.75573137070700676789e-06);
+    p = fma(p, z, -1.98412698298579493134e-04);
+    p = fma(p, z, 8.33333333332248946124e-03);
+    p = fma(p, z, -1.66666666666666324348e-01);
+    const double s = fma(z * r, p, r);
+    double q = -1.13596475577881948265e-11;
+    q = fma(q, z, 2.08757232129817482790e-09);
+    q = fma(q, z, -2.75573143513906633035e-07);
+    q = fma(q, z, 2.48015872894767294178e-05);
+    q = fma(q, z, -1.38888888888741095749e-03);
+    q = fma(q, z, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double c = w + (((1.0 - w) - hz) + z * z * q);
+    const int n = (int)k;
+    const double a = (n & 1) ? c : s, b = (n & 1) ? s : c;
+    // quadrant signs: sin flips for n = 2, 3 (mod 4), cos for n = 1, 2
+    const double sv = __longlong_as_double(__double_as_longlong(a) ^ ((long long)(n & 2) << 62));
+    *so = x == 0.0 ? x : sv;                     // sin(-0) = -0 (the reduction's fma turns it into +0)
+    *co = __longlong_as_double(__double_as_longlong(b) ^ ((long long)((n + 1) & 2) << 62));
+}

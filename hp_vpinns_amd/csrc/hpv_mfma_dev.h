@@ -78,7 +78,7 @@ __device__ __forceinline__ void act_fwd(double z, double& a, double& a1, double&
         a1 = 1.0 - a * a;
         a2 = -2.0 * a * a1;
     } else {
-        sincos(z, &a, &a1);
+        hpv_sincos(z, &a, &a1);
         a2 = -a;
     }
 }

@@ -39,7 +39,7 @@ __device__ __forceinline__ void act_eval(int act, double z, double& a, double& a
         a = hpv_tanh(z);
         a1 = 1.0 - a * a;
     } else {
-        sincos(z, &a, &a1);
+        hpv_sincos(z, &a, &a1);
     }
 }
 // s'' and s''' from the saved (s, s').

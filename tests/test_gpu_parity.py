@@ -223,6 +223,28 @@ def test_device_tanh_accuracy():
     assert a[3] == 0.0 and np.signbit(a[3])
 
 
+def test_device_sincos_accuracy():
+    """The hand-written fp64 sincos of the 1-D drivers' activation (P1:134): <= 3 ulp against numpy and ocml for
+    |x| <= 1e6 (incl. the doubles nearest to multiples of pi/2), ocml's own path beyond, NaN / inf -> NaN."""
+    from hp_vpinns_amd import _lib
+    h = _lib.Handle(_lib.PDE_POISSON1D, 1, _lib.ACT_SIN, [1, 20, 1])
+    rng = np.random.default_rng(5)
+    x = np.concatenate([np.linspace(-40, 40, 80001), rng.uniform(-1e6, 1e6, 20000), np.arange(0, 4000) * (np.pi / 2),
+                        np.logspace(-300, 0, 2000), -np.logspace(-300, 0, 2000), [0.0, 1e6, -1e6]])
+    a, a1, ref = h.debug_activation(x)
+    s, c = np.sin(x), np.cos(x)
+    tol = lambda t: 3.0 * np.maximum(np.spacing(np.abs(t)), 1e-30)   # (exact-zero neighbourhoods: absolute 3e-30)
+    assert (np.abs(a - s) <= tol(s)).all() and (np.abs(a1 - c) <= tol(c)).all()
+    assert (np.abs(ref - s) <= tol(s)).all()
+    big = np.array([1.0000001e6, 3e9, -7.5e15, 1e300])
+    a, a1, ref = h.debug_activation(big)
+    assert np.array_equal(a, ref) and (np.abs(a - np.sin(big)) <= tol(np.sin(big))).all()
+    assert (np.abs(a1 - np.cos(big)) <= tol(np.cos(big))).all()
+    a, a1, _ = h.debug_activation(np.array([np.nan, np.inf, -np.inf, -0.0]))
+    assert np.isnan(a[:3]).all() and np.isnan(a1[:3]).all()
+    assert a[3] == 0.0 and np.signbit(a[3]) and a1[3] == 1.0
+
+
 def test_checkpoint_path_without_suffix_and_point_array_validation(tmp_path):
     """np.savez appends '.npz': saving and loading with the same suffix-less path must round-trip; point arrays whose row
     length is not the problem dimension are refused before the C side reads past them."""
