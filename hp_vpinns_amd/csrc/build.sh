@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $HPV_EXTRA_FLAGS"   # e.g. HPV_EXTRA_FLAGS=-DHPV_FZ_TIMING
 # objects are cached by mtime; a change of flags must invalidate them (.flags remembers what the objects were built with)
 if [ "$(cat .flags 2>/dev/null)" != "$FLAGS" ]; then rm -f *.o; echo "$FLAGS" > .flags; fi
-for f in kernels_generic kernels_mfma kernels_fused kernels_project hpv_api; do
+for f in kernels_generic kernels_mfma kernels_fused kernels_tile kernels_project hpv_api; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ hpv_internal.h -nt $f.o ] || [ hpv_mfma.h -nt $f.o ] || [ hpv_mfma_dev.h -nt $f.o ] || [ hpv_project_wg.h -nt $f.o ] || [ hpv_math.h -nt $f.o ] || [ ../../include/hpvpinn.h -nt $f.o ]; then
     if [ $f = kernels_fused ]; then   # the whole-iteration kernel parks live values in AGPRs by hand: verify the compiler stays clear
       $HIPCC $FLAGS -S --cuda-device-only $f.hip -o $f.s 2>/dev/null
@@ -16,5 +16,5 @@ for f in kernels_generic kernels_mfma kernels_fused kernels_project hpv_api; do
     $HIPCC $FLAGS -c $f.hip -o $f.o
   fi
 done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libhpvpinn.so kernels_generic.o kernels_mfma.o kernels_fused.o kernels_project.o hpv_api.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libhpvpinn.so kernels_generic.o kernels_mfma.o kernels_fused.o kernels_tile.o kernels_project.o hpv_api.o
 echo "built $(cd .. && pwd)/libhpvpinn.so"

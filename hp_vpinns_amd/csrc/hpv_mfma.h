@@ -10,6 +10,7 @@ struct HpvMfma;
 HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_store = true);
 void hpv_mfma_destroy(HpvMfma* m);
 int hpv_mfma_grad_rows(HpvMfma* m);
+double* hpv_mfma_activation_store(HpvMfma* m);
 // Boundary/data term evaluated inside the forward kernel for the data tiles of a merged batch.
 struct MfmaDataTerm {
     long data_off;        // first data point (multiple of 16)
@@ -31,5 +32,8 @@ bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, c
 // launch, no activation store.  Returns false when not applicable (shape, variational form, small shard).
 bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
                          const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem);
+// The same for small elements of any channel set (kernels_tile.hip): one tile per wave, the tile's saved state in registers.
+bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
+                        const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem);
 bool hpv_mfma_sync_failed(HpvMfma* m);
 int hpv_mfma_max_rows(HpvMfma* m, long n_elem);

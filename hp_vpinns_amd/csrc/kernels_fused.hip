@@ -94,22 +94,6 @@ __device__ __forceinline__ void acc_get_all(double (&sv)[N]) {
     if constexpr (J < N) { sv[J] = acc_get<BASE + 2 * J>(); acc_get_all<BASE, N, J + 1>(sv); }
 }
 
-// sum over the 16 lanes of a DPP row (= the 16 points of a neuron group), result in every lane: quad butterflies,
-// then row_half_mirror and row_mirror -- VALU only (a __shfl_xor tree is two ds_bpermute per step and double)
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row_sum16(double v) {
-    v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
-    v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
-    v += dpp_move<0x141>(v);   // row_half_mirror
-    v += dpp_move<0x140>(v);   // row_mirror
-    return v;
-}
-
 // hidden -> hidden product of one channel: z^T = W^T h^T (+ bias fragment for the value channel), 16 + 4 split
 template <bool BIAS>
 __device__ __forceinline__ void fz_layer(const double* WTl, const double* WRl, const double* BHl, int lofs,

@@ -768,6 +768,7 @@ void hpv_mfma_destroy(HpvMfma* m) {
 }
 
 int hpv_mfma_grad_rows(HpvMfma* m) { return m->bwd_blocks; }
+double* hpv_mfma_activation_store(HpvMfma* m) { return m ? m->ACTS : nullptr; }   // (the timing builds park their stamps there)
 // Workgroups per element of the fused reverse kernel: one when the shard has an element for every CU, more for the
 // small shards of a multi-GPU run (each workgroup walks 1/split of the element's 25 tiles).
 static int fused_split(HpvMfma* m, long n_elem) {
@@ -781,6 +782,8 @@ int hpv_mfma_max_rows(HpvMfma* m, long n_elem) {
     const long fused_rows = n_elem * fused_split(m, n_elem);
     if (m->bwd_fused && fused_rows > r && fused_rows <= 65536) r = (int)fused_rows;
     if (n_elem > r && n_elem <= 65536) r = (int)n_elem;      // the whole-iteration kernel writes one row per element
+    // kernels_tile.hip: one row per element plus one per 6..8 boundary/data tiles that the elements' free waves do not take
+    if (m->ntiles <= 8192 && n_elem + m->ntiles / 6 + 1 > r) r = (int)(n_elem + m->ntiles / 6 + 1);
     m->max_rows = r;
     return r;
 }

@@ -8,13 +8,30 @@ LAYERS = [2, 20, 20, 20, 1]
 mode = sys.argv[1] if len(sys.argv) > 1 else "4"
 small = mode == "3"        # config 3 (k_iter_small: 64 workgroups of 8 waves) instead of config 4
 shard = int(mode[1:]) if mode.startswith("s") else 1     # "s8": the 32-element shard one of 8 GPUs owns (split kernel)
-if small:
-    s = poisson2d.setup(N_el_x=8, N_el_y=8, with_test_grid=False)
+if mode.startswith("t"):   # k_iter_tile (kernels_tile.hip): t1 / t2 = Poisson-1D with 1 / 16 elements, t5b = AdvDiff 8 elements, 10x10 rule
+    os.environ["HPV_DEBUG_READ_STORE"] = "1"
+    if mode in ("t1", "t2"):
+        from hp_vpinns_amd.drivers import poisson1d
+        from hp_vpinns_amd.vpinn import VPINN1D
+        ne = 1 if mode == "t1" else 16
+        s = poisson1d.setup(N_Element=ne)
+        L1 = [1, 20, 20, 20, 1]
+        m = VPINN1D(s["X_u_train"], s["u_train"], s["X_quad_train"], s["W_quad_train"], s["F_ext_total"], s["grid"],
+                    s["X_test"], s["u_test"], L1, s["X_f_train"], s["f_train"], init_params=xavier_init(L1, 1234))
+        NB, NW = ne, 6
+    else:
+        from hp_vpinns_amd.drivers import advdiff
+        s = advdiff.setup(N_el_x=8, N_quad=10, with_test_grid=False)
+        m = advdiff.build_model(s, LAYERS, init_params=xavier_init(LAYERS, 1234, extra=[1.0]))
+        NB, NW = 8, 8
 else:
-    s = poisson2d.setup(N_el_x=16, N_el_y=16 // shard, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
-m = poisson2d.build_model(s, LAYERS, var_form=1, init_params=xavier_init(LAYERS, 1234))
+    if small:
+        s = poisson2d.setup(N_el_x=8, N_el_y=8, with_test_grid=False)
+    else:
+        s = poisson2d.setup(N_el_x=16, N_el_y=16 // shard, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
+    m = poisson2d.build_model(s, LAYERS, var_form=1, init_params=xavier_init(LAYERS, 1234))
+    NB, NW = (64, 8) if small else (256, 4)      # (a shard of 256 / n elements runs 256 workgroups too: n per element)
 m.h.step(50, False)
-NB, NW = (64, 8) if small else (256, 4)      # (a shard of 256 / n elements runs 256 workgroups too: n per element)
 out = np.empty(NB * NW * 10)
 m.h.lib.hpv_debug_read_out.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t]
 m.h.lib.hpv_debug_read_out(m.h._h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size)
