@@ -25,7 +25,7 @@ EXPORTS = [
     "hpv_set_tables", "hpv_set_elements", "hpv_set_rhs", "hpv_set_data", "hpv_num_params",
     "hpv_set_params", "hpv_get_params", "hpv_loss_and_grad", "hpv_step", "hpv_forward_backward",
     "hpv_reduce_buffer", "hpv_apply_adam", "hpv_eval_loss", "hpv_read_loss", "hpv_sync",
-    "hpv_predict", "hpv_get_residuals", "hpv_backend_in_use", "hpv_enable_timing",
+    "hpv_predict", "hpv_get_residuals", "hpv_backend_in_use", "hpv_pass_structure", "hpv_enable_timing",
     "hpv_kernel_time_ms", "hpv_bench_projection", "hpv_debug_activation", "hpv_get_state", "hpv_set_state",
     "hpv_assemble_rhs", "hpv_set_collocation", "hpv_gll_rule", "hpv_test_tables",
     "hpv_step_record", "hpv_history_reset", "hpv_history_read",
@@ -94,6 +94,7 @@ def load():
     lib.hpv_predict.argtypes = [h, _dp, C.c_int, _dp]
     lib.hpv_get_residuals.argtypes = [h, _dp, C.c_size_t]
     lib.hpv_backend_in_use.argtypes = [h]
+    lib.hpv_pass_structure.argtypes = [h]
     lib.hpv_enable_timing.argtypes = [h, C.c_int]
     lib.hpv_kernel_time_ms.argtypes = [h, C.c_int, _dp, C.POINTER(C.c_long)]
     lib.hpv_bench_projection.argtypes = [h, C.c_long, C.c_int, _dp, _dp]
@@ -349,6 +350,11 @@ class Handle:
         out = np.empty(int(n))
         self._chk(self.lib.hpv_rccl_selftest(self._h, _p(out), out.size))
         return out
+
+    def pass_structure(self):
+        """'separate' | 'fused-reverse' | 'whole-iteration' | 'whole-iteration-split' | 'whole-iteration-tile' (or None)."""
+        return {0: "separate", 1: "fused-reverse", 2: "whole-iteration", 3: "whole-iteration-split",
+                4: "whole-iteration-tile"}.get(int(self.lib.hpv_pass_structure(self._h)))
 
     def rccl_disconnect(self):
         self._chk(self.lib.hpv_rccl_disconnect(self._h))

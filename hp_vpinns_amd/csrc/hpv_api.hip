@@ -94,6 +94,7 @@ struct hpv_ctx {
     // in-library exchange of the packed buffer between the ranks of a node (hpv_p2p_*)
     P2PArgs pp{};
     bool p2p_on = false;
+    int pass_structure = -1;   // see hpv_pass_structure
     double* d_inbox = nullptr;
     unsigned long long* d_flag = nullptr;
     unsigned long long* d_p2p_counter = nullptr;
@@ -388,8 +389,11 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
         if (backward && use_mfma) {
             tstart(h, 2);
             ifused = hpv_mfma_iter_fused(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
-            if (!ifused)   // small elements of the other channel sets (1-D, AdvDiff, var_form 0): kernels_tile.hip
+            if (ifused) h->pass_structure = hpv_mfma_sync_failed_possible(h->mfma) ? 3 : 2;
+            if (!ifused) {   // small elements of the other channel sets (1-D, AdvDiff, var_form 0): kernels_tile.hip
                 ifused = hpv_mfma_iter_tile(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
+                if (ifused) h->pass_structure = 4;
+            }
             if (ifused) tstop(h, 2);   // (otherwise nothing was launched; the start event is re-recorded below)
         }
         if (!ifused) {
@@ -407,6 +411,7 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
                                                  pa, h->n_elem);
                 if (bfused) tstop(h, 2);
             }
+            if (backward) h->pass_structure = bfused ? 1 : 0;
             if (!bfused) {
                 tstart(h, 1);
                 // specialised tensor-product kernel for the hot element shapes unless the generic backend is forced
@@ -1360,6 +1365,7 @@ int hpv_debug_read_out(hpv_handle h, double* out, size_t n) {
     if (getenv("HPV_DEBUG_READ_STORE") && h->mfma && hpv_mfma_activation_store(h->mfma)) src = hpv_mfma_activation_store(h->mfma);
     return hipMemcpy(out, src, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
+int hpv_pass_structure(hpv_handle h) { return h ? h->pass_structure : -1; }
 int hpv_backend_in_use(hpv_handle h) {
     if (!h) return -1;
     if (h->cfg.scheme == HPV_SCHEME_VPINN && h->have_quad && h->have_tables && h->have_elems && h->batch_dirty) {

@@ -47,11 +47,11 @@ __device__ __forceinline__ double hpv_tanh(double x) {
 // polynomials on [-pi/4, pi/4] and a branch-free quadrant fix-up: ~40 instructions.  Max error 2.2 ulp over |x| <= 1e6
 // (host prototype against mpmath, 4e4 points incl. the doubles nearest to multiples of pi/2; on the device against ocml in
 // tests/test_gpu_parity.py).  |x| > 1e6, NaN and inf take ocml's path (wave-divergent only there).
-__device__ __forceinline__ void hpv_sincos(double x, double* so, double* co) {
-    if (__builtin_expect(!(fabs(x) <= 1.0e6), 0)) {
-        sincos(x, so, co);
-        return;
-    }
+// hpv_sincos_fast: the branch-free part, valid for |x| <= HPV_SINCOS_MAX (anything, but finite or NaN, beyond); the MFMA
+// kernels evaluate a whole layer with it and redo the layer through hpv_sincos when any lane of the wave saw a larger
+// argument -- a branch per value would cut the five independent chains of a lane into separate basic blocks.
+#define HPV_SINCOS_MAX 1.0e6
+__device__ __forceinline__ void hpv_sincos_fast(double x, double* so, double* co) {
     const double k = rint(x * 6.36619772367581382433e-01);
     double r = fma(-k, 1.57079632673412561417e+00, x);
     r = fma(-k, 6.07710050630396597660e-11, r);
@@ -79,4 +79,8 @@ __device__ __forceinline__ void hpv_sincos(double x, double* so, double* co) {
     const double sv = __longlong_as_double(__double_as_longlong(a) ^ ((long long)(n & 2) << 62));
     *so = x == 0.0 ? x : sv;                     // sin(-0) = -0 (the reduction's fma turns it into +0)
     *co = __longlong_as_double(__double_as_longlong(b) ^ ((long long)((n + 1) & 2) << 62));
+}
+__device__ __forceinline__ void hpv_sincos(double x, double* so, double* co) {
+    if (__builtin_expect(!(fabs(x) <= HPV_SINCOS_MAX), 0)) sincos(x, so, co);
+    else hpv_sincos_fast(x, so, co);
 }

@@ -36,4 +36,5 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
 bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
                         const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem);
 bool hpv_mfma_sync_failed(HpvMfma* m);
+bool hpv_mfma_sync_failed_possible(HpvMfma* m);   // the last whole-iteration launch ran in SPLIT mode
 int hpv_mfma_max_rows(HpvMfma* m, long n_elem);

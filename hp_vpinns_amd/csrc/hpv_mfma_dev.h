@@ -69,18 +69,29 @@ struct HpvMfma {
     int* xerr = nullptr;
     long xsync_elems = 0;
     bool split_used = false;               // a split launch happened: hpv_step then reads the timeout flag back
+    bool last_split = false;               // the most recent whole-iteration launch was a split one (hpv_pass_structure)
 };
 
-template <int ACT>
+// FAST (sin only): the caller has checked |z| <= HPV_SINCOS_MAX for the whole wave (act_wave_needs_safe below)
+template <int ACT, bool FAST = false>
 __device__ __forceinline__ void act_fwd(double z, double& a, double& a1, double& a2) {
     if constexpr (ACT == HPV_ACT_TANH) {
         a = hpv_tanh(z);
         a1 = 1.0 - a * a;
         a2 = -2.0 * a * a1;
     } else {
-        hpv_sincos(z, &a, &a1);
+        if constexpr (FAST) hpv_sincos_fast(z, &a, &a1); else hpv_sincos(z, &a, &a1);
         a2 = -a;
     }
+}
+// wave-uniform: some lane holds a pre-activation the branch-free sincos does not cover (or a NaN)
+template <int ACT, int NV>
+__device__ __forceinline__ bool act_wave_needs_safe(const double (&z)[NV]) {
+    if constexpr (ACT != HPV_ACT_SIN) return false;
+    bool big = false;
+#pragma unroll
+    for (int s = 0; s < NV; ++s) big = big || !(fabs(z[s]) <= HPV_SINCOS_MAX);
+    return __builtin_amdgcn_ballot_w64(big) != 0ull;
 }
 template <int ACT>
 __device__ __forceinline__ void act_saved(double a, double a1s, double& a1, double& a2, double& a3) {

@@ -48,14 +48,62 @@ constexpr int project_wg_lds_doubles() {
     return QY * (QX + 1) + HPV_MAXT * NTX * QX + HPV_MAXT * NTY * QY + QY * NTX + NTX * NTY + HPV_MAXT * NTY * QX + 64;
 }
 
+// Table staging of project_element_wg<.., PRE = true> split in two, so that a caller can put its own prologue loads between
+// the global reads and the LDS stores: load (registers) ... store (into the scratch `sm`).
+template <int QX, int QY, int NTX, int NTY, int PW_BLOCK>
+struct ProjTableRegs {
+    static constexpr int ITX = (NTX * QX + PW_BLOCK - 1) / PW_BLOCK, ITY = (NTY * QY + PW_BLOCK - 1) / PW_BLOCK;
+    double ax[HPV_MAXT][ITX], by[HPV_MAXT][ITY];
+    __device__ __forceinline__ void load(const ProjArgs& pa) {
+#pragma unroll
+        for (int t = 0; t < HPV_MAXT; ++t) {
+            const bool on = t < pa.pd.nterms;           // (workgroup-uniform: an unused term costs no loads)
+            const int dx = on ? pa.pd.t[t].dx : 0, dy = on ? pa.pd.t[t].dy : 0;
+#pragma unroll
+            for (int it = 0; it < ITX; ++it) {
+                const int i = it * PW_BLOCK + (int)threadIdx.x;
+                ax[t][it] = on ? pa.wtx[(long)dx * NTX * QX + (i < NTX * QX ? i : 0)] : 0.0;
+            }
+#pragma unroll
+            for (int it = 0; it < ITY; ++it) {
+                const int i = it * PW_BLOCK + (int)threadIdx.x;
+                by[t][it] = on ? pa.wty[(long)dy * NTY * QY + (i < NTY * QY ? i : 0)] : 0.0;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(double* sm) const {
+        double* AXl = sm + QY * (QX + 1);
+        double* BYl = AXl + HPV_MAXT * NTX * QX;
+#pragma unroll
+        for (int t = 0; t < HPV_MAXT; ++t) {
+#pragma unroll
+            for (int it = 0; it < ITX; ++it) {
+                const int i = it * PW_BLOCK + (int)threadIdx.x;
+                if (i < NTX * QX) AXl[t * NTX * QX + i] = ax[t][it];
+            }
+#pragma unroll
+            for (int it = 0; it < ITY; ++it) {
+                const int i = it * PW_BLOCK + (int)threadIdx.x;
+                if (i < NTY * QY) BYl[t * NTY * QY + i] = by[t][it];
+            }
+        }
+    }
+};
+
 // Projection (+ adjoint) of ONE element by a whole workgroup of PW_BLOCK threads; `sm` = its LDS scratch of
 // project_wg_lds_doubles<...>() doubles.  Called by k_project_wg (one element per workgroup) and, fused, at
 // the end of the forward kernel's element block (kernels_mfma.hip).
-template <int QX, int QY, int NTX, int NTY, int PW_BLOCK>
-__device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const long e, double* sm) {
+// PRE (the whole-iteration tile kernel): the caller has already staged every term's tables at their places in `sm`
+// (ProjTableRegs, issued with its own prologue loads and followed by a barrier) and keeps the element's channels [C][NQ] and
+// their adjoints in LDS (out_lds / gbar_lds) -- the function then has no table or channel traffic to global memory.
+template <int QX, int QY, int NTX, int NTY, int PW_BLOCK, bool PRE = false>
+__device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const long e, double* sm, const double* out_lds = nullptr,
+                                                   double* gbar_lds = nullptr) {
     const ProjDesc& pd = pa.pd;
-    const double* __restrict__ OUT = pa.OUT;
-    double* __restrict__ GBAR = pa.GBAR;
+    // out_lds / gbar_lds: the element's channels [C][NQ] and their adjoints live in LDS instead of the global rows
+    // (addressed here as OUT[ch * N + e * NQ + q], hence the rebased pointers and N = NQ)
+    const double* __restrict__ OUT = PRE ? out_lds - e * (QX * QY) : pa.OUT;
+    double* __restrict__ GBAR = PRE ? gbar_lds - e * (QX * QY) : pa.GBAR;
     double* __restrict__ R = pa.R;
     const double* __restrict__ F = pa.F;
     const double* __restrict__ coef = pa.coef;
@@ -65,7 +113,7 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
     const double* __restrict__ eps_ptr = pa.eps_ptr;
     double* __restrict__ loss_e = pa.loss_e;
     double* __restrict__ deps_e = pa.deps_e;
-    const long N = pa.N;
+    const long N = PRE ? (long)(QX * QY) : pa.N;
     const int do_adjoint = pa.do_adjoint;
     const double* __restrict__ edge_u = pa.edge_u;
     const double* __restrict__ edge_dphi = pa.edge_dphi;
@@ -91,24 +139,28 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
     //      side, both tables of every term, and every term's integrand at this thread's points ----
     constexpr int ITX = (NTX * QX + PW_BLOCK - 1) / PW_BLOCK, ITY = (NTY * QY + PW_BLOCK - 1) / PW_BLOCK;
     constexpr int ITR = (NR + PW_BLOCK - 1) / PW_BLOCK;
-    double gv[HPV_MAXT][NIT], tax[HPV_MAXT][ITX], tby[HPV_MAXT][ITY], fr[ITR];
+    double gv[HPV_MAXT][NIT], tax[PRE ? 1 : HPV_MAXT][PRE ? 1 : ITX], tby[PRE ? 1 : HPV_MAXT][PRE ? 1 : ITY], fr[ITR], cf[HPV_MAXT];
 #pragma unroll
     for (int it = 0; it < ITR; ++it) {
         const int idx = it * PW_BLOCK + tid;
         fr[it] = (F && idx < NR) ? -F[e * NR + idx] : 0.0;
     }
 #pragma unroll
+    for (int t = 0; t < HPV_MAXT; ++t) cf[t] = coef[(long)(t < nterms ? t : 0) * coef_stride + e];
+#pragma unroll
     for (int t = 0; t < HPV_MAXT; ++t) {
         const int dx = t < nterms ? pd.t[t].dx : 0, dy = t < nterms ? pd.t[t].dy : 0;
+        if constexpr (!PRE) {
 #pragma unroll
-        for (int it = 0; it < ITX; ++it) {
-            const int i = it * PW_BLOCK + tid;
-            tax[t][it] = wtx[(long)dx * NTX * QX + (i < NTX * QX ? i : 0)];
-        }
+            for (int it = 0; it < ITX; ++it) {
+                const int i = it * PW_BLOCK + tid;
+                tax[t][it] = wtx[(long)dx * NTX * QX + (i < NTX * QX ? i : 0)];
+            }
 #pragma unroll
-        for (int it = 0; it < ITY; ++it) {
-            const int i = it * PW_BLOCK + tid;
-            tby[t][it] = wty[(long)dy * NTY * QY + (i < NTY * QY ? i : 0)];
+            for (int it = 0; it < ITY; ++it) {
+                const int i = it * PW_BLOCK + tid;
+                tby[t][it] = wty[(long)dy * NTY * QY + (i < NTY * QY ? i : 0)];
+            }
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) gv[t][it] = 0.0;
@@ -133,17 +185,19 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
         const int idx = it * PW_BLOCK + tid;
         if (idx < NR) U[idx] = fr[it];
     }
+    if constexpr (!PRE) {
 #pragma unroll
-    for (int t = 0; t < HPV_MAXT; ++t) {
+        for (int t = 0; t < HPV_MAXT; ++t) {
 #pragma unroll
-        for (int it = 0; it < ITX; ++it) {
-            const int i = it * PW_BLOCK + tid;
-            if (i < NTX * QX) AXl[t * NTX * QX + i] = tax[t][it];
-        }
+            for (int it = 0; it < ITX; ++it) {
+                const int i = it * PW_BLOCK + tid;
+                if (i < NTX * QX) AXl[t * NTX * QX + i] = tax[t][it];
+            }
 #pragma unroll
-        for (int it = 0; it < ITY; ++it) {
-            const int i = it * PW_BLOCK + tid;
-            if (i < NTY * QY) BYl[t * NTY * QY + i] = tby[t][it];
+            for (int it = 0; it < ITY; ++it) {
+                const int i = it * PW_BLOCK + tid;
+                if (i < NTY * QY) BYl[t * NTY * QY + i] = tby[t][it];
+            }
         }
     }
 #pragma unroll
@@ -174,7 +228,7 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
             }
         }
         __syncthreads();
-        const double c = coef[(long)t * coef_stride + e] * (td.eps_mult ? eps : 1.0);
+        const double c = cf[t] * (td.eps_mult ? eps : 1.0);
         {
             constexpr int SPY = pj_splitk(NR, QY, PW_BLOCK);
             for (int o0 = 0; o0 < NR; o0 += PW_BLOCK / SPY) {
@@ -247,7 +301,7 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
                     double gh = 0.0;
 #pragma unroll 4
                     for (int k = 0; k < NTY; ++k) gh = fma(by[k * QY + j], S[t * NTY * QX + k * QX + i], gh);
-                    gh *= coef[(long)t * coef_stride + e];
+                    gh *= cf[t];
                     const double m = td.eps_mult ? eps : 1.0;
                     double g1 = 0.0, gt = 0.0;
 #pragma unroll

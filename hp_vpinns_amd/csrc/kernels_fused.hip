@@ -1177,6 +1177,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
         a.proj_n_elem = n_elem;
         a.proj_split = 1;
         a.pa = pa;
+        m->last_split = false;
         if (m->L == 2) launch_iter_small<2>(a, (int)n_elem, s); else launch_iter_small<3>(a, (int)n_elem, s);
         if (rows) *rows = (int)n_elem;
         return true;
@@ -1208,6 +1209,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     a.xsync = m->xsync;
     a.xerr = m->xerr;
     a.pa = pa;
+    m->last_split = split > 1;
     if (split > 1) {
         m->split_used = true;
         if (m->L == 2) launch_iter_fused<2, true>(a, (int)blocks, s); else launch_iter_fused<3, true>(a, (int)blocks, s);
@@ -1218,6 +1220,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     return true;
 }
 
+bool hpv_mfma_sync_failed_possible(HpvMfma* m) { return m && m->last_split; }
 // did an element barrier of the split whole-iteration kernel time out since the last check?  (resets the flag)
 bool hpv_mfma_sync_failed(HpvMfma* m) {
     if (!m || !m->xerr || !m->split_used) return false;

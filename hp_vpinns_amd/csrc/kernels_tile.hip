@@ -9,13 +9,14 @@
 // TermDesc projection incl. the trainable epsilon of P3:63), and every wave reverses its tile from the registers.
 // Waves beyond the element's tiles adopt the boundary / data tiles behind the elements (P1:98, P3:184); workgroups
 // beyond the elements take the rest of those, eight per workgroup.  Nothing is stored for the reverse pass and nothing is
-// recomputed; the channel values and their adjoints cross the projection through the (L2-resident) OUT / GBAR rows.
+// recomputed; the channel values and their adjoints cross the projection in LDS, its tables are staged with the weights.
 // k_iter_small (kernels_fused.hip) is the hand-tuned special case of this for Poisson-2D var_form 1.
 //
 // Arithmetic: the forward and reverse tile bodies are those of k_fwd_mfma / k_bwd_mfma (kernels_mfma.hip) with the
 // activation store replaced by registers and one tile per wave (so the gradient "accumulators" are plain values).
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "hpv_mfma_dev.h"
 
@@ -37,7 +38,8 @@ struct TlLds {
     static constexpr int WRB = WN + LH * MF_KS * 64;           // reverse remainder                               [LH][5][16]
     static constexpr int W1O = WRB + LH * MF_KS * 16;          // first-layer rows, head weights, first bias      [D+2][5][64]
     static constexpr int TAB = W1O + (D + 2) * MF_KS * 64;     // per-wave transpose pair, one channel at a time  [WAVES][2][20*17]
-    static constexpr int RA = TAB + WAVES * 2 * MF_TRB * MF_LD;    // projection scratch, then the per-wave gradient rows
+    static constexpr int CHN = TAB + WAVES * 2 * MF_TRB * MF_LD;   // the element's channel values, then their adjoints [2][C][NQ]
+    static constexpr int RA = CHN + 2 * HPV_MAXC * QX * QY;        // projection scratch (tables staged up front), then the per-wave gradient rows
     static constexpr int PROJ = project_wg_lds_doubles<QX, QY, NTX, NTY>();
     static constexpr int total(int P) { return RA + (PROJ > WAVES * P ? PROJ : WAVES * P); }
 };
@@ -82,7 +84,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
     for (int c = 0; c < D; ++c) x[c] = g.X[(long)c * g.N + pc];
     const double udv = (di >= 0 && valid) ? g.ud[pc - g.data_off] : 0.0;
 
-    // ---- stage the weight fragments of both passes: every global read before the first LDS store ----
+    // ---- stage the weight fragments of both passes and the projection's tables: every global read before the first LDS store ----
+    ProjTableRegs<QX, QY, NTX, NTY, BT> ptab;
     {
         constexpr int ITW = (MF_KS * 64 + BT - 1) / BT;
         constexpr int N1 = (D + 2) * MF_KS * 64, IT1 = (N1 + BT - 1) / BT;
@@ -111,6 +114,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
             const int j = 4 * s_ + (ln >> 4);
             v1[it] = th[(c_ < D ? w0o + c_ * MF_H : (c_ == D ? wLo : b0o)) + j];
         }
+        if (elem_wg) ptab.load(pa);      // requested LAST (loads return in order): the weight stores below do not wait for them
 #pragma unroll
         for (int i_ = 1; i_ < L; ++i_) {
 #pragma unroll
@@ -130,6 +134,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
 #pragma unroll
         for (int it = 0; it < IT1; ++it) { const int f = it * BT + tid; if (f < N1) lds[M::W1O + f] = v1[it]; }
     }
+
     const double bo = th[g.boff[L]];
     __syncthreads();
     TL_STAMP(1);
@@ -155,23 +160,35 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
     // =============================================================================================
     if (active) {
         double h[C][MF_KS];
+        // the activation loops exist twice: branch-free sincos (FAST) when the whole wave's pre-activations are in its range --
+        // the five chains of a lane then interleave -- and the guarded one otherwise (tanh: FAST is the only version)
+        {
+            double z1[MF_KS];
 #pragma unroll
-        for (int s = 0; s < MF_KS; ++s) {
-            double z = W1O[((D + 1) * MF_KS + s) * 64 + lane];
+            for (int s = 0; s < MF_KS; ++s) {
+                double z = W1O[((D + 1) * MF_KS + s) * 64 + lane];
 #pragma unroll
-            for (int c = 0; c < D; ++c) z = fma(x[c], W1O[(c * MF_KS + s) * 64 + lane], z);
-            double a, a1, a2;
-            act_fwd<ACT>(z, a, a1, a2);
-            h[0][s] = a;
-            st[0].a[s] = a;
-            st[0].a1s[s] = a1;
-#pragma unroll
-            for (int t = 0; t < NT1; ++t) h[1 + t][s] = a1 * W1O[((t < D ? t : 0) * MF_KS + s) * 64 + lane];
-#pragma unroll
-            for (int b = 0; b < NT2; ++b) {
-                const double zc = W1O[((b < D ? b : 0) * MF_KS + s) * 64 + lane];
-                h[1 + NT1 + b][s] = a2 * zc * zc;
+                for (int c = 0; c < D; ++c) z = fma(x[c], W1O[(c * MF_KS + s) * 64 + lane], z);
+                z1[s] = z;
             }
+            auto act1 = [&](auto fast) {
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+                    double a, a1, a2;
+                    act_fwd<ACT, decltype(fast)::value>(z1[s], a, a1, a2);
+                    h[0][s] = a;
+                    st[0].a[s] = a;
+                    st[0].a1s[s] = a1;
+#pragma unroll
+                    for (int t = 0; t < NT1; ++t) h[1 + t][s] = a1 * W1O[((t < D ? t : 0) * MF_KS + s) * 64 + lane];
+#pragma unroll
+                    for (int b = 0; b < NT2; ++b) {
+                        const double zc = W1O[((b < D ? b : 0) * MF_KS + s) * 64 + lane];
+                        h[1 + NT1 + b][s] = a2 * zc * zc;
+                    }
+                }
+            };
+            if (act_wave_needs_safe<ACT>(z1)) act1(std::false_type{}); else act1(std::true_type{});
         }
 #pragma unroll
         for (int i = 1; i < L; ++i) {
@@ -199,28 +216,34 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
                     z16[ch] = zz;
                 }
             }
+            double zv[MF_KS];
 #pragma unroll
-            for (int s = 0; s < MF_KS; ++s) {
-                double a, a1, a2;
-                act_fwd<ACT>(s < 4 ? acc[0][s & 3] : z16[0], a, a1, a2);
-                h[0][s] = a;
-                st[i].a[s] = a;
-                st[i].a1s[s] = a1;
-                double zc[NT1 > 0 ? NT1 : 1];
+            for (int s = 0; s < MF_KS; ++s) zv[s] = s < 4 ? acc[0][s & 3] : z16[0];
+            auto acti = [&](auto fast) {
 #pragma unroll
-                for (int u = 0; u < NT1; ++u) {
-                    zc[u] = s < 4 ? acc[1 + u][s & 3] : z16[1 + u];
-                    st[i].zc[u][s] = zc[u];
-                    h[1 + u][s] = a1 * zc[u];
+                for (int s = 0; s < MF_KS; ++s) {
+                    double a, a1, a2;
+                    act_fwd<ACT, decltype(fast)::value>(zv[s], a, a1, a2);
+                    h[0][s] = a;
+                    st[i].a[s] = a;
+                    st[i].a1s[s] = a1;
+                    double zc[NT1 > 0 ? NT1 : 1];
+#pragma unroll
+                    for (int u = 0; u < NT1; ++u) {
+                        zc[u] = s < 4 ? acc[1 + u][s & 3] : z16[1 + u];
+                        st[i].zc[u][s] = zc[u];
+                        h[1 + u][s] = a1 * zc[u];
+                    }
+#pragma unroll
+                    for (int b = 0; b < NT2; ++b) {
+                        const double zcc = s < 4 ? acc[1 + NT1 + b][s & 3] : z16[1 + NT1 + b];
+                        const double z1 = zc[b < NT1 ? b : 0];
+                        st[i].zcc[b][s] = zcc;
+                        h[1 + NT1 + b][s] = a2 * z1 * z1 + a1 * zcc;
+                    }
                 }
-#pragma unroll
-                for (int b = 0; b < NT2; ++b) {
-                    const double zcc = s < 4 ? acc[1 + NT1 + b][s & 3] : z16[1 + NT1 + b];
-                    const double z1 = zc[b < NT1 ? b : 0];
-                    st[i].zcc[b][s] = zcc;
-                    h[1 + NT1 + b][s] = a2 * z1 * z1 + a1 * zcc;
-                }
-            }
+            };
+            if (act_wave_needs_safe<ACT>(zv)) acti(std::false_type{}); else acti(std::true_type{});
         }
         // linear head: every lane ends up with the full sum of its point
 #pragma unroll
@@ -232,7 +255,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
             v += __shfl_xor(v, 32, 64);
             if (ch == 0) v += bo;
             if (is_el) {
-                if (q == 0 && valid) g.OUT[(long)ch * g.N + p] = v;
+                if (q == 0 && valid) lds[M::CHN + ch * NQ + 16 * wv + pt] = v;
             } else if (ch == 0) {
                 const double dd = valid ? udv - v : 0.0;
                 gdat = g.data_scale * dd;
@@ -245,13 +268,15 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
     // =============================================================================================
     // projection of the element (residual, element loss, adjoint channels): the general TermDesc device function
     // =============================================================================================
+    // the projection's tables were requested with the weights; they are parked in LDS only now, so that their round trip
+    // (38..77 KB per workgroup) hides behind the forward pass instead of sitting in front of it
+    if (elem_wg) ptab.store(lds + M::RA);
     TL_STAMP(2);
-    __threadfence_block();
     __syncthreads();
     TL_STAMP(3);
     if (elem_wg) {
-        project_element_wg<QX, QY, NTX, NTY, BT>(pa, e, lds + M::RA);
-        __threadfence_block();
+        // (the element's channels and their adjoints stay in LDS)
+        project_element_wg<QX, QY, NTX, NTY, BT, true>(pa, e, lds + M::RA, lds + M::CHN, lds + M::CHN + HPV_MAXC * NQ);
         __syncthreads();
     }
     TL_STAMP(4);
@@ -263,7 +288,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
     if (active) {
         double gb[C];
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) gb[ch] = is_el ? (valid ? pa.GBAR[(long)ch * g.N + p] : 0.0) : (ch == 0 ? gdat : 0.0);
+        for (int ch = 0; ch < C; ++ch)
+            gb[ch] = is_el ? (valid ? lds[M::CHN + (HPV_MAXC + ch) * NQ + 16 * wv + pt] : 0.0) : (ch == 0 ? gdat : 0.0);
         double* TA = lds + M::TAB + wv * (2 * MF_TRB * MF_LD);
         double* TB = TA + MF_TRB * MF_LD;
         auto zc_of = [&](int i, int u, int s) -> double {   // z_c of layer i (compile-time i after unrolling)
@@ -481,7 +507,7 @@ bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double
     const int key = nd.d * 100 + nd.nT1 * 10 + nd.nT2;
     const bool shape1d = pd.qx == 80 && pd.qy == 1 && pd.ntx == 60 && pd.nty == 1 && nd.act == HPV_ACT_SIN && (key == 111 || key == 110);
     const bool shape2d = pd.qx == 10 && pd.qy == 10 && pd.ntx == 5 && pd.nty == 5 && nd.act == HPV_ACT_TANH &&
-                         (key == 220 || key == 221 || key == 222) && m->L <= 3;
+                         (key == 200 || key == 220 || key == 221 || key == 222) && m->L <= 3;
     if (!shape1d && !shape2d) { TL_WHY(2); return false; }
     const int waves = shape1d ? 6 : 8, nq = pd.qx * pd.qy, tpe = (nq + 15) / 16;
     // batch layout [element points | pad to 16 | data points]
@@ -510,6 +536,7 @@ bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double
     } else {
         if (key == 221) ok = launch_iter_tile_L<2, 2, 1, HPV_ACT_TANH, 10, 10, 5, 5, 8, 3>(m->L, a, (int)blocks, s);
         else if (key == 222) ok = launch_iter_tile_L<2, 2, 2, HPV_ACT_TANH, 10, 10, 5, 5, 8, 3>(m->L, a, (int)blocks, s);
+        else if (key == 200) ok = launch_iter_tile_L<2, 0, 0, HPV_ACT_TANH, 10, 10, 5, 5, 8, 3>(m->L, a, (int)blocks, s);
         else ok = launch_iter_tile_L<2, 2, 0, HPV_ACT_TANH, 10, 10, 5, 5, 8, 3>(m->L, a, (int)blocks, s);
     }
     if (ok && rows) *rows = (int)blocks;

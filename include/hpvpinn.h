@@ -177,6 +177,11 @@ int hpv_test_tables(hpv_handle h, int ntest, const double* xi, int q, double* ta
 /* Introspection for tests / benchmarks. */
 int hpv_get_residuals(hpv_handle h, double* R, size_t n);   /* R of the owned elements [ne][nty][ntx] */
 int hpv_backend_in_use(hpv_handle h);                       /* HPV_BACKEND_GENERIC or HPV_BACKEND_MFMA */
+/* Launch structure of the most recent reverse-mode pass over the quadrature batch (tests assert that the kernel they mean to
+ * exercise is the one that ran): 0 separate forward / projection / reverse launches, 1 forward + projection-fused reverse,
+ * 2 element-resident whole-iteration kernel (20x20 / 10x10 Poisson-2D var_form 1), 3 the same in SPLIT mode (small shards),
+ * 4 whole-iteration tile kernel (small elements of the other channel sets); -1 before the first such pass. */
+int hpv_pass_structure(hpv_handle h);
 /* The network value and its input-derivative channels at the owned quadrature points, [C][n_owned*qx*qy]
  * (channel order: u, then d/dx, d/dy (d/dt), then the second derivatives the variational form integrates) --
  * what net_u / net_du / net_dxu / net_dyu / net_dtu return (P1:140-148, P2:171-185, P3:232-245).  One forward launch. */

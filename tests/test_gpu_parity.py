@@ -944,3 +944,74 @@ def test_in_library_exchange_two_ranks_on_one_gpu(tmp_path):
     assert rel(r0["hist"], hist) < 1e-9 and rel(r0["l3b"], l3b) < 1e-9 and rel(r0["theta"], m.get_params()) < 1e-9
     for r in (r0, r1):
         assert r["timeout_raised"] is True and r["state_untouched"] is True, (r["timeout_raised"], r["state_untouched"])
+
+
+def _tile_vs_separate(build, n_res, o=None, n_traj=6):
+    """default build (must run the whole-iteration tile kernel) against HPV_FUSE=n (separate launches) and, if given, the oracle."""
+    import os
+    m = build()
+    l3, g = m.loss_and_grad()
+    assert m.h.pass_structure() == "whole-iteration-tile"
+    r = m.h.residuals(n_res)
+    l3b, gb = m.loss_and_grad()
+    assert np.array_equal(g, gb) and np.array_equal(l3, l3b)          # fixed summation order: bitwise reproducible
+    os.environ["HPV_FUSE"] = "n"
+    try:
+        m2 = build()
+        l3s, gs = m2.loss_and_grad()
+        assert m2.h.pass_structure() == "separate"
+        rs = m2.h.residuals(n_res)
+        m2._step(30, False)
+    finally:
+        del os.environ["HPV_FUSE"]
+    assert rel(g, gs) < 1e-11 and rel(l3, l3s) < 1e-12 and rel(r, rs) < 1e-11
+    m._step(30, False)
+    assert rel(m.get_params(), m2.get_params()) < 1e-9
+    if o is not None:
+        m3 = build()
+        _check_loss_grad(o, m3)
+        _check_traj(o, m3, n=n_traj)
+
+
+@pytest.mark.parametrize("nhid,vf,nel", [(3, 1, 1), (3, 1, 5), (4, 1, 3), (3, 2, 3), (2, 2, 2)])
+def test_tile_iteration_kernel_poisson1d(nhid, vf, nel):
+    """kernels_tile.hip on the 1-D rule (80 points, 60 test functions per element; sin; P1:82-87): one workgroup per element,
+    the boundary tile on a free wave -- var_form 1 (u'') and 2 (u'), 2..4 hidden layers (4 = the reference default, P1:236),
+    against the separate launches and the oracle."""
+    from hp_vpinns_amd.drivers import poisson1d
+    from hp_vpinns_amd.init import xavier_init
+    from hp_vpinns_amd.vpinn import VPINN1D
+    from oracle.vpinn_oracle import OracleVPINN1D
+    s = poisson1d.setup(N_Element=nel)
+    L = [1] + [20] * nhid + [1]
+    th = xavier_init(L, 21)
+    th[L[1]:2 * L[1]] = 0.1          # (a non-zero first bias: the odd sin network otherwise has a round-off-level output-bias gradient)
+    args = (s["X_u_train"], s["u_train"], s["X_quad_train"], s["W_quad_train"], s["F_ext_total"], s["grid"], s["X_test"],
+            s["u_test"], L, s["X_f_train"], s["f_train"])
+    build = lambda: VPINN1D(*args, var_form=vf, init_params=th)
+    o = OracleVPINN1D(*args, var_form=vf, init_params=th)
+    o.vectorized = True
+    _tile_vs_separate(build, nel * 60, o)
+
+
+@pytest.mark.parametrize("case", ["advdiff-vf0", "advdiff-vf1", "poisson2d-vf0", "poisson2d-vf2"])
+def test_tile_iteration_kernel_small_2d_elements(case):
+    """kernels_tile.hip on 10x10-point / 5x5-test elements with the channel sets k_iter_small does not take: AdvDiff with its
+    trainable epsilon (u_t, u_x, u_xx; P3:161-174; hundreds of data points -> extra workgroups of data tiles), Poisson-2D
+    var_form 0 (u_xx, u_yy) and var_form 2 (u against the second derivatives of the test functions)."""
+    from hp_vpinns_amd.drivers import advdiff, poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    L = [2, 20, 20, 20, 1]
+    if case.startswith("advdiff"):
+        vf = int(case[-1])
+        s = advdiff.setup(N_el_x=3, N_quad=10, with_test_grid=False)
+        th = xavier_init(L, 17, extra=[1.0])
+        build = lambda: advdiff.build_model(s, L, var_form=vf, init_params=th)
+        n_res = 3 * 25
+    else:
+        vf = int(case[-1])
+        s = poisson2d.setup(N_el_x=3, N_el_y=2, N_test_x=5, N_test_y=5, N_quad=10, N_bound=30, with_test_grid=False)
+        th = xavier_init(L, 17)
+        build = lambda: poisson2d.build_model(s, L, var_form=vf, init_params=th)
+        n_res = 6 * 25
+    _tile_vs_separate(build, n_res)
