@@ -470,9 +470,11 @@ __device__ __forceinline__ void adam_update(const AdamArgs& ad, int i, double g,
     ad.theta[i] -= lr_t * mi / (sqrt(vi) + ad.eps);
 }
 
-#define FIN_THREADS 1024
 #define FIN_COLS 16                          // parameters per block (one 128-B row segment per partial row)
-#define FIN_PARTS (FIN_THREADS / FIN_COLS)   // row groups summed in parallel
+// FIN_THREADS / FIN_COLS row groups are summed in parallel: 64 for the hundreds of rows of a large batch, 16 (a 256-thread
+// block: 4 waves to launch instead of 16) for the <= 64 rows of a small one -- the kernel is a pure latency chain whose
+// floor (kernarg fetch, one load round trip, the store drain: ~4.7 us behind another kernel) is most of its duration
+template <int FIN_THREADS>
 __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restrict__ GPART_v, int rows_v,
                                                          const double* __restrict__ GPART_b, int rows_b,
                                                          const double* __restrict__ GPART_e, int rows_e,
@@ -481,6 +483,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
                                                          const double* __restrict__ data_part, int n_data_part,
                                                          double lossb_weight, int n_data, int P, int has_eps,
                                                          double* __restrict__ RB, int write_grad, AdamArgs ad) {
+    constexpr int FIN_PARTS = FIN_THREADS / FIN_COLS;
     __shared__ double red[FIN_PARTS * FIN_COLS];
     const int Ptot = P + (has_eps ? 1 : 0);
     if (blockIdx.x < gridDim.x - 1) {
@@ -517,18 +520,25 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
                 ad.m[idx] = mi;
                 ad.v[idx] = vi;
                 ad.theta[idx] = th0 - lr_t * mi / (sqrt(vi) + ad.eps);
-            }
-        }
-        if (ad.theta) {   // this block's private copy of the running beta powers (no cross-block race)
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                ad.state[2 * (blockIdx.x + 1)] *= ad.b1;
-                ad.state[2 * (blockIdx.x + 1) + 1] *= ad.b2;
+                // this block's private copy of the running beta powers (no cross-block race); its only readers are the 16
+                // `upd` lanes of this wave, which consumed them above -- written from the prefetched values, no second round trip
+                if (threadIdx.x == 0) {
+                    ad.state[2 * (blockIdx.x + 1)] = b1p * ad.b1;
+                    ad.state[2 * (blockIdx.x + 1) + 1] = b2p * ad.b2;
+                }
             }
         }
         return;
     }
-    // last block: scalars
+    // last block: scalars.  Everything thread 0 needs at the end is requested up front (one memory round trip, not three
+    // dependent ones behind the reductions)
+    double s0 = 0.0, s1 = 0.0, eps_th = 0.0, eps_m = 0.0, eps_v = 0.0;
+    int hidx = -1;
+    if (threadIdx.x == 0 && ad.theta) {
+        s0 = ad.state[0]; s1 = ad.state[1];
+        if (ad.hist) hidx = *ad.hist_idx;
+        if (has_eps) { eps_th = ad.theta[P]; eps_m = ad.m[P]; eps_v = ad.v[P]; }
+    }
     double lv = 0.0, de = 0.0;
     for (long e = threadIdx.x; e < n_elem; e += blockDim.x) {
         lv += loss_e[e];
@@ -541,15 +551,22 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
     sq = block_sum(sq, red);
     if (threadIdx.x == 0) {
         const double msq = n_data > 0 ? sq / (double)n_data : 0.0;
-        const double eps_now = (has_eps && ad.theta) ? ad.theta[P] : 0.0;   // the coefficient this forward pass used
+        const double eps_now = (has_eps && ad.theta) ? eps_th : 0.0;   // the coefficient this forward pass used
         if (has_eps && write_grad) {
             RB[P] = de;
-            if (ad.theta) adam_update(ad, P, de, ad.state[0], ad.state[1]);   // the trainable epsilon (P3:63)
+            if (ad.theta) {   // the trainable epsilon (P3:63): adam_update with the operands fetched above
+                const double lr_t = ad.lr * sqrt(1.0 - s1) / (1.0 - s0);
+                const double mi = ad.b1 * eps_m + (1.0 - ad.b1) * de;
+                const double vi = ad.b2 * eps_v + (1.0 - ad.b2) * de * de;
+                ad.m[P] = mi;
+                ad.v[P] = vi;
+                ad.theta[P] = eps_th - lr_t * mi / (sqrt(vi) + ad.eps);
+            }
         }
         if (ad.theta) {
-            ad.state[0] *= ad.b1; ad.state[1] *= ad.b2;
+            ad.state[0] = s0 * ad.b1; ad.state[1] = s1 * ad.b2;
             if (ad.hist) {   // single-GPU training iteration: record this forward pass's loss (see AdamArgs)
-                const int i = *ad.hist_idx;
+                const int i = hidx;
                 if (i >= 0 && i < ad.hist_cap) {   // the index saturates at hist_cap (it never wraps)
                     ad.hist[4 * i] = lv; ad.hist[4 * i + 1] = lossb_weight * msq; ad.hist[4 * i + 2] = msq; ad.hist[4 * i + 3] = eps_now;
                     *ad.hist_idx = i + 1;
@@ -570,9 +587,15 @@ void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, i
     int gblocks = (P + FIN_COLS - 1) / FIN_COLS;
     AdamArgs ad{};
     if (fused_adam && write_grad) ad = *fused_adam;
-    hipLaunchKernelGGL(k_finalize, dim3(gblocks + 1), dim3(FIN_THREADS), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e,
-                       rows_e, loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB,
-                       write_grad, ad);
+    const int rows = (GPART_v ? rows_v : 0) + (GPART_b ? rows_b : 0) + (GPART_e ? rows_e : 0);
+    if (rows <= 64 && n_elem <= 4096)
+        hipLaunchKernelGGL(k_finalize<256>, dim3(gblocks + 1), dim3(256), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e,
+                           rows_e, loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB,
+                           write_grad, ad);
+    else
+        hipLaunchKernelGGL(k_finalize<1024>, dim3(gblocks + 1), dim3(1024), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e,
+                           rows_e, loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB,
+                           write_grad, ad);
 }
 int adam_state_doubles(int P) { return 2 * ((P + FIN_COLS - 1) / FIN_COLS + 1); }
 

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -q -x -k "tile_iteration or small_element or split_whole or whole_iteration" 2>&1 | tail -30
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|Error" | tail -5
