@@ -140,6 +140,10 @@ def main():
     #  single-GPU box; throughput is then meaningless)
     one_gpu = os.environ.get("HPV_BENCH_ONE_GPU") == "1"
     if one_gpu:
+        # the SPLIT mode of the whole-iteration kernel needs all workgroups of an element resident at once, i.e. a GPU that
+        # this process does not share with the other ranks' kernels: keep shared-GPU runs on the forward + split reverse kernels
+        os.environ.setdefault("HPV_FUSE", "s")
+    if one_gpu:
         local_rank = 0
         os.environ.setdefault("HPV_EXCHANGE", "p2p")
     torch.cuda.set_device(local_rank)

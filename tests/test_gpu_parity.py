@@ -884,6 +884,7 @@ def _p2p_worker(rank, world, port, out_path):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["HPV_EXCHANGE"] = "p2p"            # (the default, in-library RCCL, needs one GPU per rank)
     os.environ["HPV_P2P_TIMEOUT_MS"] = "1500"
+    os.environ["HPV_FUSE"] = "s"                  # two processes share the GPU: no cross-workgroup barriers (SPLIT mode) here
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from hp_vpinns_amd.drivers import poisson2d
