@@ -25,7 +25,7 @@ EXPORTS = [
     "hpv_set_tables", "hpv_set_elements", "hpv_set_rhs", "hpv_set_data", "hpv_num_params",
     "hpv_set_params", "hpv_get_params", "hpv_loss_and_grad", "hpv_step", "hpv_forward_backward",
     "hpv_reduce_buffer", "hpv_apply_adam", "hpv_eval_loss", "hpv_read_loss", "hpv_sync",
-    "hpv_predict", "hpv_get_residuals", "hpv_backend_in_use", "hpv_pass_structure", "hpv_enable_timing",
+    "hpv_predict", "hpv_get_residuals", "hpv_backend_in_use", "hpv_pass_structure", "hpv_set_active_tests", "hpv_enable_timing",
     "hpv_kernel_time_ms", "hpv_bench_projection", "hpv_debug_activation", "hpv_get_state", "hpv_set_state",
     "hpv_assemble_rhs", "hpv_set_collocation", "hpv_gll_rule", "hpv_test_tables",
     "hpv_step_record", "hpv_history_reset", "hpv_history_read",
@@ -95,6 +95,7 @@ def load():
     lib.hpv_get_residuals.argtypes = [h, _dp, C.c_size_t]
     lib.hpv_backend_in_use.argtypes = [h]
     lib.hpv_pass_structure.argtypes = [h]
+    lib.hpv_set_active_tests.argtypes = [h, C.POINTER(C.c_int), C.c_int]
     lib.hpv_enable_timing.argtypes = [h, C.c_int]
     lib.hpv_kernel_time_ms.argtypes = [h, C.c_int, _dp, C.POINTER(C.c_long)]
     lib.hpv_bench_projection.argtypes = [h, C.c_long, C.c_int, _dp, _dp]
@@ -288,6 +289,14 @@ class Handle:
         out = np.empty((int(n_channels), int(n_points)))
         self._chk(self.lib.hpv_eval_channels(self._h, _p(out), out.size))
         return out
+
+    def set_active_tests(self, n_active):
+        """per-element number of active test functions (1-D p-refinement); None = all."""
+        if n_active is None:
+            self._chk(self.lib.hpv_set_active_tests(self._h, None, 0))
+            return
+        a = np.ascontiguousarray(n_active, dtype=np.int32).reshape(-1)
+        self._chk(self.lib.hpv_set_active_tests(self._h, a.ctypes.data_as(C.POINTER(C.c_int)), a.size))
 
     def residuals(self, n):
         out = np.empty(n)

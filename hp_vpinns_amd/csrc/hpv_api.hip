@@ -63,6 +63,8 @@ struct hpv_ctx {
            *d_deps_e = nullptr;
     std::vector<double> F_all;
     bool have_F = false;
+    std::vector<int> nact_all;     // active test functions per element of the whole grid (empty: all); see hpv_set_active_tests
+    int* d_nact = nullptr;         // ... of the owned elements
     Batch var, data, edge, pred;
     // host copies of the point sets; the device batches are (re)assembled lazily (assemble_batches)
     std::vector<double> Xq_host;   // [dim][Nq] quadrature points of the owned elements
@@ -684,6 +686,7 @@ void hpv_destroy(hpv_handle h) {
                       h->d_deps_e, h->d_udata, h->d_data_part, h->d_theta, h->d_m, h->d_v, h->d_state, h->d_RB, h->d_hist};
     for (double* p : ptrs) if (p) (void)hipFree(p);
     if (h->d_hist_idx) (void)hipFree(h->d_hist_idx);
+    if (h->d_nact) (void)hipFree(h->d_nact);
     for (auto& t : h->timers) for (auto e : t.ev) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -830,7 +833,41 @@ int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* g
         std::vector<double> F = h->F_all;
         if ((rc = hpv_set_rhs(h, F.data(), F.size()))) return rc;
     } else if (h->d_F) { (void)hipFree(h->d_F); h->d_F = nullptr; }
+    if (!h->nact_all.empty()) {   // ... and the active test counts
+        std::vector<int> na = h->nact_all;
+        if ((rc = hpv_set_active_tests(h, na.data(), (int)na.size()))) return rc;
+    }
     if (h->mfma_edge) { hpv_mfma_destroy(h->mfma_edge); h->mfma_edge = nullptr; }
+    return 0;
+}
+
+// p-refinement of the 1-D driver: element e uses only its first n_active[e] test functions (P1:66-67: Ntest_element =
+// len(F_ext_total[e]); P1:268-281 builds F_ext_total from a per-element list N_testfcn_total).  n = elements of the whole grid.
+int hpv_set_active_tests(hpv_handle h, const int* n_active, int n) {
+    if (!h) return -1;
+    drop_graph(h);
+    if (!n_active) {
+        h->nact_all.clear();
+        if (h->d_nact) { (void)hipFree(h->d_nact); h->d_nact = nullptr; }
+        h->pd.nact = nullptr;
+        return 0;
+    }
+    if (h->dim != 1) return fail(h, -1, "per-element test-function counts exist in the 1-D problem only (P2:414 / P3:411 reshape F_ext_total)");
+    if (!h->have_tables) return fail(h, -3, "call hpv_set_tables first");
+    for (int i = 0; i < n; ++i)
+        if (n_active[i] < 1 || n_active[i] > h->ntx) return fail(h, -1, "n_active[%d] = %d is outside 1..%d", i, n_active[i], h->ntx);
+    if (h->have_elems) {
+        if (n != h->nex * h->ney) return fail(h, -1, "n_active has %d entries, expected %d", n, h->nex * h->ney);
+        if (h->d_nact) { (void)hipFree(h->d_nact); h->d_nact = nullptr; }
+        h->pd.nact = nullptr;
+        if (h->n_elem > 0) {
+            HIPCHK(h, hipMalloc((void**)&h->d_nact, (size_t)h->n_elem * sizeof(int)));
+            HIPCHK(h, hipMemcpyAsync(h->d_nact, n_active + h->e_begin, (size_t)h->n_elem * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            h->pd.nact = h->d_nact;
+        }
+    }
+    if (n_active != h->nact_all.data()) h->nact_all.assign(n_active, n_active + n);
     return 0;
 }
 

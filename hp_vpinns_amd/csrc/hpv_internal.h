@@ -42,6 +42,11 @@ struct ProjDesc {
     int C;
     int has_eps;     // theta carries a trailing trainable epsilon
     int edge;        // Poisson-1D var_form 3 boundary term (P1:90)
+    // p-refinement of the 1-D driver (P1:66-67, 268-281: F_ext_total[e] may be shorter in some elements): number of ACTIVE test
+    // functions per owned element (device pointer, nullptr = all ntx); the residual rows beyond it are zero and the element's
+    // mean runs over the active ones.  Only the general projections (k_project, project_element_wg) honour it; the
+    // specialised 2-D kernels are bypassed when it is set.
+    const int* nact;
 };
 
 static inline size_t hpv_proj_lds_bytes(const ProjDesc& pd) {

@@ -250,19 +250,22 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
         for (int o = tid; o < NR; o += PW_BLOCK) U[o] += ce * (uR * edge_dphi[2 * o + 1] - uL * edge_dphi[2 * o]);
         __syncthreads();
     }
+    const int nax = pd.nact ? pd.nact[e] : NTX;          // active test functions of this element (p-refinement, P1:67)
+    const double NRa = (double)(nax * NTY);
     double sq = 0.0;
     for (int o = tid; o < NR; o += PW_BLOCK) {
-        const double u = U[o];
+        const double u = (o % NTX) < nax ? U[o] : 0.0;
+        U[o] = u;                                         // (each entry is read and written by its own thread only)
         R[e * NR + o] = u;
         sq = fma(u, u, sq);
     }
     sq = pj_wave_sum(sq);
     if ((tid & 63) == 0) red[tid >> 6] = sq;
     __syncthreads();
-    if (tid == 0) { double t = 0.0; for (int w = 0; w < NWV; ++w) t += red[w]; loss_e[e] = t / (double)NR; }
+    if (tid == 0) { double t = 0.0; for (int w = 0; w < NWV; ++w) t += red[w]; loss_e[e] = t / NRa; }
     if (!do_adjoint) return;
 
-    const double sc = 2.0 / (double)NR;
+    const double sc = 2.0 / NRa;
     for (int t = 0; t < nterms; ++t) {
         for (int o = tid; o < NTY * QX; o += PW_BLOCK) {
             const int k = o / QX, i = o % QX;

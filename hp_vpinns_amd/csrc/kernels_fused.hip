@@ -1154,7 +1154,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     if (!(nd.d == 2 && nd.nT1 == 2 && nd.nT2 == 0 && nd.act == HPV_ACT_TANH) || m->L < 2 || m->L > 3) return false;
     const bool small = pd.qx == SM_QX && pd.qy == SM_QY && pd.ntx == SM_NTX && pd.nty == SM_NTY;
     if (!(pd.qx == FZ_QX && pd.qy == FZ_QY && pd.ntx == FZ_NTX && pd.nty == FZ_NTY) && !small) return false;
-    if (pd.edge || pd.has_eps || pd.nterms != 2) return false;
+    if (pd.edge || pd.has_eps || pd.nterms != 2 || pd.nact) return false;
     for (int t = 0; t < 2; ++t)          // one-hot: term t integrates exactly channel 1 + t with weight 1
         for (int ch = 0; ch < HPV_MAXC; ++ch)
             if (pd.t[t].a0[ch] != (ch == 1 + t ? 1.0 : 0.0) || pd.t[t].a1[ch] != 0.0 || pd.t[t].eps_mult) return false;

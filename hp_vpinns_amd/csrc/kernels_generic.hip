@@ -350,17 +350,21 @@ __global__ void __launch_bounds__(256) k_project(ProjDesc pd, const double* __re
             U[idx] += ce * (uR * edge_dphi[2 * idx + 1] - uL * edge_dphi[2 * idx]);
         __syncthreads();
     }
+    const int nax = pd.nact ? pd.nact[e] : ntx;          // active test functions of this element (P1:67)
+    const double NRa = (double)(nax * nty);
     double sq = 0.0;
     for (int idx = tid; idx < NR; idx += nthr) {
-        const double u = U[idx];
+        const double u = (idx % ntx) < nax ? U[idx] : 0.0;
+        U[idx] = u;
         R[e * NR + idx] = u;
         sq += u * u;
     }
     sq = block_sum(sq, red);
-    if (tid == 0) loss_e[e] = sq / (double)NR;  // reduce_mean(square(Res)) (P1:95)
+    if (tid == 0) loss_e[e] = sq / NRa;  // reduce_mean(square(Res)) (P1:95)
     if (!do_adjoint) return;
+    __syncthreads();
 
-    const double sc = 2.0 / (double)NR;
+    const double sc = 2.0 / NRa;
     for (int t = 0; t < nterms; ++t) {
         const double* ax = wtx + (long)pd.t[t].dx * ntx * qx;
         for (int idx = tid; idx < nty * qx; idx += nthr) {

@@ -813,7 +813,7 @@ void hpv_mfma_backward(HpvMfma* m, const double* theta, const double* X, const d
 bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, const double* GBAR, double* GPART, int* rows,
                              hipStream_t s, const ProjArgs& pa, long n_elem) {
     const ProjDesc& pd = pa.pd;
-    if (!m->bwd_fused || !m->fuse_bwd || pd.edge || n_elem <= 0) return false;
+    if (!m->bwd_fused || !m->fuse_bwd || pd.edge || pd.nact || n_elem <= 0) return false;
     if (!(pd.qx == 20 && pd.qy == 20 && pd.ntx == 10 && pd.nty == 10)) return false;
     const long tpe = (20 * 20) / 16;
     const long rest = m->ntiles - n_elem * tpe;                 // pad + data tiles: at most one per workgroup

@@ -417,7 +417,7 @@ bool launch_project_wg(const ProjDesc& pd, const double* OUT, double* GBAR, doub
                        double* deps_e, long N, long n_elem, int do_adjoint, const double* edge_u, const double* edge_dphi,
                        const double* edge_coef, double* edge_gbar, hipStream_t s, double* upart) {
     if (n_elem <= 0) return false;
-    if (upart && project_row_split(pd, n_elem, 0) > 1) {   // few tall elements: PJ_SPLIT workgroups per element, two phases
+    if (upart && !pd.nact && project_row_split(pd, n_elem, 0) > 1) {   // few tall elements: PJ_SPLIT workgroups per element, two phases
         ProjArgs pa{pd, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, N, do_adjoint, nullptr, nullptr,
                     nullptr, nullptr};
         launch_rows<80, 80, 5, 5>(pa, n_elem, upart, s);
@@ -437,6 +437,7 @@ bool launch_project_wg(const ProjDesc& pd, const double* OUT, double* GBAR, doub
 bool launch_project_tp(const ProjDesc& pd, const double* OUT, double* GBAR, double* R, const double* F, const double* coef,
                        long coef_stride, const double* wtx, const double* wty, const double* eps_ptr, double* loss_e,
                        double* deps_e, long N, long n_elem, int do_adjoint, hipStream_t s) {
+    if (pd.nact) return false;   // per-element active test counts: the general projections only
     if (pd.edge || n_elem <= 0) return false;
 #define HPV_TP(QX_, QY_, NTX_, NTY_)                                                                              \
     if (pd.qx == QX_ && pd.qy == QY_ && pd.ntx == NTX_ && pd.nty == NTY_)                                          \

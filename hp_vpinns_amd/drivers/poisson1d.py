@@ -25,7 +25,9 @@ def f_ext(x):                                                    # P1:252-254
     return -amp * gtemp
 
 
-def setup(N_Element=1, N_testfcn=60, N_Quad=80, N_F=500, seed=1234):
+def setup(N_Element=1, N_testfcn=60, N_Quad=80, N_F=500, seed=1234, N_testfcn_total=None):
+    """N_testfcn_total: per-element number of test functions (the list the reference builds at P1:268 / 273 and a user
+    edits for p-refinement); F_ext_total / U_ext_total are then lists of columns of different lengths."""
     np.random.seed(seed)                                         # P1:26
     x_quad, w_quad = GaussLobattoJacobiWeights(N_Quad, 0, 0)     # P1:260
     NE = N_Element
@@ -35,14 +37,19 @@ def setup(N_Element=1, N_testfcn=60, N_Quad=80, N_F=500, seed=1234):
     if N_Element == 3:                                           # P1:270-273
         grid = np.array([-1, -0.1, 0.1, 1])
         NE = 3
-    testfcn = Test_fcn(N_testfcn, x_quad)                        # (N_test, Q)
+    ntot = np.array(NE * [N_testfcn]) if N_testfcn_total is None else np.asarray(N_testfcn_total, dtype=int)   # P1:268
+    if ntot.size != NE:
+        raise ValueError("N_testfcn_total needs one entry per element")
+    testfcn = Test_fcn(int(ntot.max()), x_quad)                  # (N_test, Q); element e uses its first ntot[e] rows (P1:280-281)
     U_ext_total, F_ext_total = [], []
     for e in range(NE):                                          # P1:277-291
         x_quad_element = grid[e] + (grid[e + 1] - grid[e]) / 2 * (x_quad + 1)
         jacobian = (grid[e + 1] - grid[e]) / 2
-        U_ext_total.append((jacobian * (testfcn * (w_quad * u_ext(x_quad_element))).sum(axis=1))[:, None])
-        F_ext_total.append((jacobian * (testfcn * (w_quad * f_ext(x_quad_element))).sum(axis=1))[:, None])
-    U_ext_total, F_ext_total = np.asarray(U_ext_total), np.asarray(F_ext_total)
+        te = testfcn[:ntot[e]]
+        U_ext_total.append((jacobian * (te * (w_quad * u_ext(x_quad_element))).sum(axis=1))[:, None])
+        F_ext_total.append((jacobian * (te * (w_quad * f_ext(x_quad_element))).sum(axis=1))[:, None])
+    if len(set(ntot.tolist())) == 1:                             # P1:293-294 (dense when every element has the same count)
+        U_ext_total, F_ext_total = np.asarray(U_ext_total), np.asarray(F_ext_total)
     X_u_train = np.asarray([-1.0, 1.0])[:, None]                 # P1:298-299
     u_train = u_ext(X_u_train)
     X_f_train = (2 * lhs(1, N_F) - 1)                            # P1:303

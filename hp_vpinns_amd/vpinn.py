@@ -423,9 +423,15 @@ class VPINN1D(_VPINNBase):
         self.xf, self.f = X_f_train, f_train
         self.xquad, self.wquad = np.asarray(X_quad, dtype=np.float64), np.asarray(W_quad, dtype=np.float64)
         self.xtest, self.utest = X_test, u_test
-        self.F_ext_total = np.asarray(F_exact_total, dtype=np.float64)
-        self.Nelement = self.F_ext_total.shape[0]          # P1:43
-        self.N_test = self.F_ext_total[0].shape[0]         # P1:44
+        # F_ext_total[e] may be shorter in some elements (p-refinement: the driver's N_testfcn_total list, P1:268-281; the
+        # class reads Ntest_element = len(F_ext_total[e]), P1:66-67): padded here to the longest, with the counts passed on
+        Fe = [np.asarray(f, dtype=np.float64).reshape(-1) for f in F_exact_total]
+        self.Nelement = len(Fe)                            # P1:43
+        self._n_active = np.array([f.size for f in Fe], dtype=np.int32)
+        self.N_test = int(self._n_active.max())            # P1:44 (the reference reads element 0; equal when uniform)
+        self.F_ext_total = np.zeros((self.Nelement, self.N_test, 1))
+        for e, f in enumerate(Fe):
+            self.F_ext_total[e, :f.size, 0] = f
         self.grid = np.asarray(grid, dtype=np.float64)
         self.var_form, self.LR, self.lossb_weight = var_form, LR, lossb_weight
         self.total_record = [] if total_record is None else total_record
@@ -442,6 +448,8 @@ class VPINN1D(_VPINNBase):
         eb, ee = shard_range(self.Nelement, self.rank, self.world)
         self.h.set_elements(self.grid, None, eb, ee)
         self.h.set_rhs(self.F_ext_total.reshape(-1))
+        if np.any(self._n_active != self.N_test):
+            self.h.set_active_tests(self._n_active)
         if self.rank == 0:
             self.h.set_data(self.x, self.u.reshape(-1))
         self._finish()

@@ -81,6 +81,13 @@ int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* g
  * (P1:294, P2:414); pass NULL for a zero right-hand side (P3:180). */
 int hpv_set_rhs(hpv_handle h, const double* F, size_t n);
 
+/* p-refinement of the 1-D driver: element e projects onto its first n_active[e] <= ntest test functions only and its loss
+ * is the mean over those (P1:66-67: Ntest_element = len(F_ext_total[e]); the driver builds F_ext_total from the per-element
+ * list N_testfcn_total, P1:268-281).  n = nex (all elements of the grid); rows of F beyond n_active[e] are ignored and the
+ * residuals returned for them are zero.  NULL restores "all ntest in every element".  1-D only: the 2-D and AdvDiff drivers
+ * reshape F_ext_total into a dense array (P2:414, P3:411), which forbids ragged counts in the reference too. */
+int hpv_set_active_tests(hpv_handle h, const int* n_active, int n);
+
 /* Boundary / data points of lossb (P1:98, P2:122, P3:184): X is [n][dim] row-major, u is [n].
  * The term is weighted by cfg.lossb_weight.  n = 0 disables it (ranks other than 0). */
 int hpv_set_data(hpv_handle h, const double* X, const double* u, int n);

@@ -1016,3 +1016,39 @@ def test_tile_iteration_kernel_small_2d_elements(case):
         build = lambda: poisson2d.build_model(s, L, var_form=vf, init_params=th)
         n_res = 6 * 25
     _tile_vs_separate(build, n_res)
+
+
+@pytest.mark.parametrize("vf,backend", [(1, "auto"), (2, "auto"), (3, "auto"), (1, "generic")])
+def test_poisson1d_per_element_test_function_counts(vf, backend):
+    """p-refinement of the 1-D driver: F_ext_total[e] of different lengths (the reference reads Ntest_element =
+    len(F_ext_total[e]) per element, P1:66-67, and builds the list from N_testfcn_total, P1:268-281).  Loss, gradient,
+    residuals (zero rows beyond an element's count) and an Adam trajectory against the oracle's element loop."""
+    from hp_vpinns_amd.drivers import poisson1d
+    from hp_vpinns_amd.init import xavier_init
+    from hp_vpinns_amd.vpinn import VPINN1D
+    from oracle.vpinn_oracle import OracleVPINN1D
+    counts = [60, 45, 7, 33]
+    s = poisson1d.setup(N_Element=4, N_testfcn_total=counts)
+    assert [f.shape[0] for f in s["F_ext_total"]] == counts
+    L = [1, 20, 20, 20, 1]
+    th = xavier_init(L, 31)
+    th[L[1]:2 * L[1]] = 0.1
+    args = (s["X_u_train"], s["u_train"], s["X_quad_train"], s["W_quad_train"], s["F_ext_total"], s["grid"], s["X_test"],
+            s["u_test"], L, s["X_f_train"], s["f_train"])
+    m = VPINN1D(*args, var_form=vf, init_params=th, backend=backend)
+    o = OracleVPINN1D(*args, var_form=vf, init_params=th)
+    _check_loss_grad(o, m)
+    if backend == "auto" and vf != 3:
+        assert m.h.pass_structure() == "whole-iteration-tile"
+    r = m.h.residuals(4 * 60).reshape(4, 60)
+    for e, n in enumerate(counts):
+        assert np.all(r[e, n:] == 0.0) and np.count_nonzero(r[e, :n]) >= n - 3     # (a high-order row can round to exactly 0)
+    _check_traj(o, m, n=8)
+    # the same counts written as a dense F with trailing zeros and NO counts is a different (and wrong) loss
+    Fd = np.zeros((4, 60, 1))
+    for e, f in enumerate(s["F_ext_total"]):
+        Fd[e, :f.shape[0]] = f
+    a2 = list(args)
+    a2[4] = Fd
+    m2 = VPINN1D(*a2, var_form=vf, init_params=th, backend=backend)
+    assert abs(m2.loss_and_grad()[0][0] - m.loss_and_grad()[0][0]) > 1e-6

@@ -243,3 +243,31 @@ def test_c_closed_form_baseline_equals_the_autograd_oracle(tag, threads):
         l3 = o.adam_step()
         assert abs(l3[0] - hist[k, 0]) < 1e-10 * abs(l3[0])
     assert np.abs(o.get_params() - c.theta).max() < 1e-10
+
+
+def test_oracle_1d_per_element_test_function_counts():
+    """F_ext_total[e] of different lengths (P1:66-67 reads Ntest_element per element): the element loop's variational loss equals
+    sum_e mean(R[e, :n_e]^2) of the dense residuals -- the truncation of the same tables, nothing else."""
+    from hp_vpinns_amd.drivers import poisson1d
+    from hp_vpinns_amd.init import xavier_init
+    from oracle.vpinn_oracle import OracleVPINN1D
+    counts = [12, 60, 5]
+    L = [1, 20, 20, 1]
+    th = xavier_init(L, 3)
+    th[20:40] = 0.1
+    for vf in (1, 2, 3):
+        sr = poisson1d.setup(N_Element=3, N_testfcn_total=counts)
+        sd = poisson1d.setup(N_Element=3)
+        mk = lambda s: OracleVPINN1D(s["X_u_train"], s["u_train"], s["X_quad_train"], s["W_quad_train"], s["F_ext_total"],
+                                     s["grid"], s["X_test"], s["u_test"], L, s["X_f_train"], s["f_train"], var_form=vf,
+                                     init_params=th)
+        orag, oden = mk(sr), mk(sd)
+        assert orag.ragged and not oden.ragged
+        for e, n in enumerate(counts):
+            assert np.array_equal(sr["F_ext_total"][e], sd["F_ext_total"][e][:n])
+        oden.vectorized = True
+        oden.loss_parts()
+        R = oden.last["R"]
+        want = sum(float(np.mean(R[e, :n] ** 2)) for e, n in enumerate(counts))
+        got = float(orag.loss_parts()[2])
+        assert abs(got - want) <= 1e-13 * max(1.0, abs(want))
