@@ -45,7 +45,7 @@ constexpr int pj_splitk(int n_out, int K, int block) {
 
 template <int QX, int QY, int NTX, int NTY>
 constexpr int project_wg_lds_doubles() {
-    return QY * (QX + 1) + HPV_MAXT * NTX * QX + HPV_MAXT * NTY * QY + QY * NTX + NTX * NTY + HPV_MAXT * NTY * QX + 64;
+    return QY * (QX + 1) + HPV_MAXT * NTX * (QX + 1) + HPV_MAXT * NTY * QY + QY * NTX + NTX * NTY + HPV_MAXT * NTY * QX + 64;
 }
 
 // Table staging of project_element_wg<.., PRE = true> split in two, so that a caller can put its own prologue loads between
@@ -53,8 +53,12 @@ constexpr int project_wg_lds_doubles() {
 template <int QX, int QY, int NTX, int NTY, int PW_BLOCK>
 struct ProjTableRegs {
     static constexpr int ITX = (NTX * QX + PW_BLOCK - 1) / PW_BLOCK, ITY = (NTY * QY + PW_BLOCK - 1) / PW_BLOCK;
-    double ax[HPV_MAXT][ITX], by[HPV_MAXT][ITY];
-    __device__ __forceinline__ void load(const ProjArgs& pa) {
+    static constexpr int NR = NTX * NTY, ITR = (NR + PW_BLOCK - 1) / PW_BLOCK;
+    static constexpr int AXLD = QX + 1;          // padded rows: the x-contraction reads 16 different rows per wave
+    double ax[HPV_MAXT][ITX], by[HPV_MAXT][ITY], fr[ITR], sc4;
+    // besides the tables: -F of the element (the initial value of U) and, lane t < 4 of the block, one of the four scalars
+    // {coef[0][e], coef[1][e], epsilon, active test count}
+    __device__ __forceinline__ void load(const ProjArgs& pa, long e) {
 #pragma unroll
         for (int t = 0; t < HPV_MAXT; ++t) {
             const bool on = t < pa.pd.nterms;           // (workgroup-uniform: an unused term costs no loads)
@@ -70,16 +74,28 @@ struct ProjTableRegs {
                 by[t][it] = on ? pa.wty[(long)dy * NTY * QY + (i < NTY * QY ? i : 0)] : 0.0;
             }
         }
+#pragma unroll
+        for (int it = 0; it < ITR; ++it) {
+            const int idx = it * PW_BLOCK + (int)threadIdx.x;
+            fr[it] = (pa.F && idx < NR) ? -pa.F[e * NR + idx] : 0.0;
+        }
+        const int t4 = (int)threadIdx.x;
+        sc4 = 0.0;
+        if (t4 < HPV_MAXT) sc4 = pa.coef[(long)(t4 < pa.pd.nterms ? t4 : 0) * pa.coef_stride + e];
+        else if (t4 == HPV_MAXT) sc4 = pa.eps_ptr ? pa.eps_ptr[0] : 0.0;
+        else if (t4 == HPV_MAXT + 1) sc4 = pa.pd.nact ? (double)pa.pd.nact[e] : (double)NTX;
     }
     __device__ __forceinline__ void store(double* sm) const {
         double* AXl = sm + QY * (QX + 1);
-        double* BYl = AXl + HPV_MAXT * NTX * QX;
+        double* BYl = AXl + HPV_MAXT * NTX * AXLD;
+        double* U = BYl + HPV_MAXT * NTY * QY + QY * NTX;
+        double* red = U + NR + HPV_MAXT * NTY * QX;
 #pragma unroll
         for (int t = 0; t < HPV_MAXT; ++t) {
 #pragma unroll
             for (int it = 0; it < ITX; ++it) {
                 const int i = it * PW_BLOCK + (int)threadIdx.x;
-                if (i < NTX * QX) AXl[t * NTX * QX + i] = ax[t][it];
+                if (i < NTX * QX) AXl[t * NTX * AXLD + (i / QX) * AXLD + (i % QX)] = ax[t][it];
             }
 #pragma unroll
             for (int it = 0; it < ITY; ++it) {
@@ -87,6 +103,12 @@ struct ProjTableRegs {
                 if (i < NTY * QY) BYl[t * NTY * QY + i] = by[t][it];
             }
         }
+#pragma unroll
+        for (int it = 0; it < ITR; ++it) {
+            const int idx = it * PW_BLOCK + (int)threadIdx.x;
+            if (idx < NR) U[idx] = fr[it];
+        }
+        if (threadIdx.x < HPV_MAXT + 2) red[48 + threadIdx.x] = sc4;
     }
 };
 
@@ -123,9 +145,10 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
     static_assert(3 * NWV <= 64, "per-wave reduction scratch");
     constexpr int NQ = QX * QY, NR = NTX * NTY, LDG = QX + 1;
     constexpr int NIT = (NQ + PW_BLOCK - 1) / PW_BLOCK;
+    constexpr int AXLD = PRE ? QX + 1 : QX;      // (the pre-staged tables have padded rows, see ProjTableRegs)
     double* G = sm;                              // [QY][LDG]
-    double* AXl = G + QY * LDG;                  // [HPV_MAXT][NTX][QX]  every term's w_x phi^(dx)
-    double* BYl = AXl + HPV_MAXT * NTX * QX;     // [HPV_MAXT][NTY][QY]  every term's w_y phi^(dy)
+    double* AXl = G + QY * LDG;                  // [HPV_MAXT][NTX][AXLD]  every term's w_x phi^(dx)
+    double* BYl = AXl + HPV_MAXT * NTX * (QX + 1);   // [HPV_MAXT][NTY][QY]  every term's w_y phi^(dy)
     double* T = BYl + HPV_MAXT * NTY * QY;       // [QY][NTX]
     double* U = T + QY * NTX;                    // [NR]
     double* S = U + NR;                          // [HPV_MAXT][NTY][QX]
@@ -133,20 +156,31 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
     const long base = e * NQ;
     const int tid = threadIdx.x;
     const int nterms = pd.nterms, C = pd.C;
-    const double eps = eps_ptr ? eps_ptr[0] : 0.0;
+    static_assert(!PRE || (HPV_MAXT + 2 <= 16 && 3 * NWV <= 48), "pre-staged scalars sit at red[48..]");
+    const double eps = PRE ? red[48 + HPV_MAXT] : (eps_ptr ? eps_ptr[0] : 0.0);
+#ifdef HPV_PJ_TIMING
+    if (PRE && threadIdx.x == 0) pa.GBAR[e * 16 + 0] = (double)clock64();
+#endif
 
     // ---- every global read of the forward half is issued up front (ONE memory round trip): the right-hand
     //      side, both tables of every term, and every term's integrand at this thread's points ----
     constexpr int ITX = (NTX * QX + PW_BLOCK - 1) / PW_BLOCK, ITY = (NTY * QY + PW_BLOCK - 1) / PW_BLOCK;
     constexpr int ITR = (NR + PW_BLOCK - 1) / PW_BLOCK;
     double gv[HPV_MAXT][NIT], tax[PRE ? 1 : HPV_MAXT][PRE ? 1 : ITX], tby[PRE ? 1 : HPV_MAXT][PRE ? 1 : ITY], fr[ITR], cf[HPV_MAXT];
+    if constexpr (PRE) {      // -F is already in U, the coefficients next to the reduction scratch
 #pragma unroll
-    for (int it = 0; it < ITR; ++it) {
-        const int idx = it * PW_BLOCK + tid;
-        fr[it] = (F && idx < NR) ? -F[e * NR + idx] : 0.0;
+        for (int it = 0; it < ITR; ++it) fr[it] = 0.0;
+#pragma unroll
+        for (int t = 0; t < HPV_MAXT; ++t) cf[t] = red[48 + t];
+    } else {
+#pragma unroll
+        for (int it = 0; it < ITR; ++it) {
+            const int idx = it * PW_BLOCK + tid;
+            fr[it] = (F && idx < NR) ? -F[e * NR + idx] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < HPV_MAXT; ++t) cf[t] = coef[(long)(t < nterms ? t : 0) * coef_stride + e];
     }
-#pragma unroll
-    for (int t = 0; t < HPV_MAXT; ++t) cf[t] = coef[(long)(t < nterms ? t : 0) * coef_stride + e];
 #pragma unroll
     for (int t = 0; t < HPV_MAXT; ++t) {
         const int dx = t < nterms ? pd.t[t].dx : 0, dy = t < nterms ? pd.t[t].dy : 0;
@@ -180,10 +214,12 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
             }
         }
     }
+    if constexpr (!PRE) {
 #pragma unroll
-    for (int it = 0; it < ITR; ++it) {
-        const int idx = it * PW_BLOCK + tid;
-        if (idx < NR) U[idx] = fr[it];
+        for (int it = 0; it < ITR; ++it) {
+            const int idx = it * PW_BLOCK + tid;
+            if (idx < NR) U[idx] = fr[it];
+        }
     }
     if constexpr (!PRE) {
 #pragma unroll
@@ -205,12 +241,18 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
         if (t >= nterms) break;
         const TermDesc& td = pd.t[t];
         __syncthreads();                         // tables staged / previous users of G and T are done
+#ifdef HPV_PJ_TIMING
+    if (PRE && threadIdx.x == 0) pa.GBAR[e * 16 + 1] = (double)clock64();
+#endif
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int qd = it * PW_BLOCK + tid;
             if (qd < NQ) G[(qd / QX) * LDG + (qd % QX)] = gv[t][it];
         }
         __syncthreads();
+#ifdef HPV_PJ_TIMING
+    if (PRE && threadIdx.x == 0) pa.GBAR[e * 16 + 2] = (double)clock64();
+#endif
         // split-K: SPX adjacent lanes share one output and a shuffle tree adds their partial sums -- with few
         // outputs (QY*NTX, then NR) and long contractions the phases are latency chains, not throughput
         {
@@ -220,14 +262,30 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
                 const bool ok = o < QY * NTX;
                 const int j = ok ? o / NTX : 0, r = ok ? o % NTX : 0;
                 double acc = 0.0;
+                constexpr int KIT = (QX + SPX - 1) / SPX;        // compile-time trip count: every operand read is issued
+                if constexpr (KIT <= 24) {                       // before the first fma (the phase is one LDS latency, not KIT)
+                    double av[KIT], gq[KIT];
+#pragma unroll
+                    for (int it = 0; it < KIT; ++it) {
+                        const int i = part + it * SPX, ic = i < QX ? i : 0;
+                        av[it] = AXl[t * NTX * AXLD + r * AXLD + ic];
+                        gq[it] = i < QX ? G[j * LDG + ic] : 0.0;
+                    }
+#pragma unroll
+                    for (int it = 0; it < KIT; ++it) acc = fma(av[it], gq[it], acc);
+                } else {
 #pragma unroll 8
-                for (int i = part; i < QX; i += SPX) acc = fma(AXl[t * NTX * QX + r * QX + i], G[j * LDG + i], acc);
+                    for (int i = part; i < QX; i += SPX) acc = fma(AXl[t * NTX * AXLD + r * AXLD + i], G[j * LDG + i], acc);
+                }
 #pragma unroll
                 for (int m = SPX >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
                 if (ok && part == 0) T[o] = acc;
             }
         }
         __syncthreads();
+#ifdef HPV_PJ_TIMING
+    if (PRE && threadIdx.x == 0) pa.GBAR[e * 16 + 3] = (double)clock64();
+#endif
         const double c = cf[t] * (td.eps_mult ? eps : 1.0);
         {
             constexpr int SPY = pj_splitk(NR, QY, PW_BLOCK);
@@ -245,12 +303,15 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
         }
     }
     __syncthreads();
+#ifdef HPV_PJ_TIMING
+    if (PRE && threadIdx.x == 0) pa.GBAR[e * 16 + 4] = (double)clock64();
+#endif
     if (pd.edge) {   // P1:90: + 1/J [u(x_R) phi'_k(1) - u(x_L) phi'_k(-1)]
         const double uL = edge_u[2 * e], uR = edge_u[2 * e + 1], ce = edge_coef[e];
         for (int o = tid; o < NR; o += PW_BLOCK) U[o] += ce * (uR * edge_dphi[2 * o + 1] - uL * edge_dphi[2 * o]);
         __syncthreads();
     }
-    const int nax = pd.nact ? pd.nact[e] : NTX;          // active test functions of this element (p-refinement, P1:67)
+    const int nax = PRE ? (int)red[48 + HPV_MAXT + 1] : (pd.nact ? pd.nact[e] : NTX);   // active test functions (p-refinement, P1:67)
     const double NRa = (double)(nax * NTY);
     double sq = 0.0;
     for (int o = tid; o < NR; o += PW_BLOCK) {
@@ -262,20 +323,46 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
     sq = pj_wave_sum(sq);
     if ((tid & 63) == 0) red[tid >> 6] = sq;
     __syncthreads();
+#ifdef HPV_PJ_TIMING
+    if (PRE && threadIdx.x == 0) pa.GBAR[e * 16 + 5] = (double)clock64();
+#endif
     if (tid == 0) { double t = 0.0; for (int w = 0; w < NWV; ++w) t += red[w]; loss_e[e] = t / NRa; }
     if (!do_adjoint) return;
 
     const double sc = 2.0 / NRa;
-    for (int t = 0; t < nterms; ++t) {
-        for (int o = tid; o < NTY * QX; o += PW_BLOCK) {
-            const int k = o / QX, i = o % QX;
-            double acc = 0.0;
+    {
+        constexpr int SPS = pj_splitk(NTY * QX, NTX, PW_BLOCK);    // lanes per output (80 outputs of 60 terms: 4 x 15)
+        for (int t = 0; t < nterms; ++t) {
+            for (int o0 = 0; o0 < NTY * QX; o0 += PW_BLOCK / SPS) {
+                const int o = o0 + tid / SPS, part = tid % SPS;
+                const bool ok = o < NTY * QX;
+                const int k = ok ? o / QX : 0, i = ok ? o % QX : 0;
+                double acc = 0.0;
+                constexpr int KIT = (NTX + SPS - 1) / SPS;
+                if constexpr (KIT <= 24) {
+                    double av[KIT], uq[KIT];
+#pragma unroll
+                    for (int it = 0; it < KIT; ++it) {
+                        const int r = part + it * SPS, rc = r < NTX ? r : 0;
+                        av[it] = AXl[t * NTX * AXLD + rc * AXLD + i];
+                        uq[it] = r < NTX ? U[k * NTX + rc] : 0.0;
+                    }
+#pragma unroll
+                    for (int it = 0; it < KIT; ++it) acc = fma(av[it], uq[it], acc);
+                } else {
 #pragma unroll 4
-            for (int r = 0; r < NTX; ++r) acc = fma(AXl[t * NTX * QX + r * QX + i], U[k * NTX + r], acc);
-            S[t * NTY * QX + o] = acc * sc;
+                    for (int r = part; r < NTX; r += SPS) acc = fma(AXl[t * NTX * AXLD + r * AXLD + i], U[k * NTX + r], acc);
+                }
+#pragma unroll
+                for (int m = SPS >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+                if (ok && part == 0) S[t * NTY * QX + o] = acc * sc;
+            }
         }
     }
     __syncthreads();
+#ifdef HPV_PJ_TIMING
+    if (PRE && threadIdx.x == 0) pa.GBAR[e * 16 + 6] = (double)clock64();
+#endif
     double deps = 0.0;
     constexpr int CHK = 5;                       // points per thread whose channel re-reads travel together
 #pragma unroll 1

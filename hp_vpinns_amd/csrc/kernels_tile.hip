@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
             const int j = 4 * s_ + (ln >> 4);
             v1[it] = th[(c_ < D ? w0o + c_ * MF_H : (c_ == D ? wLo : b0o)) + j];
         }
-        if (elem_wg) ptab.load(pa);      // requested LAST (loads return in order): the weight stores below do not wait for them
+        if (elem_wg) ptab.load(pa, e);   // requested LAST (loads return in order): the weight stores below do not wait for them
 #pragma unroll
         for (int i_ = 1; i_ < L; ++i_) {
 #pragma unroll
@@ -277,6 +277,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
     if (elem_wg) {
         // (the element's channels and their adjoints stay in LDS)
         project_element_wg<QX, QY, NTX, NTY, BT, true>(pa, e, lds + M::RA, lds + M::CHN, lds + M::CHN + HPV_MAXC * NQ);
+#ifdef HPV_PJ_TIMING
+        if (threadIdx.x == 0) pa.GBAR[e * 16 + 7] = (double)clock64();
+#endif
         __syncthreads();
     }
     TL_STAMP(4);
