@@ -1052,3 +1052,37 @@ def test_poisson1d_per_element_test_function_counts(vf, backend):
     a2[4] = Fd
     m2 = VPINN1D(*a2, var_form=vf, init_params=th, backend=backend)
     assert abs(m2.loss_and_grad()[0][0] - m.loss_and_grad()[0][0]) > 1e-6
+
+
+@pytest.mark.parametrize("backend", ["auto", "generic"])
+def test_poisson1d_shards_with_test_function_counts(backend):
+    """What the ranks of a multi-GPU run own: the element range [e_begin, e_end) with F and the per-element test-function
+    counts sliced inside the library, the boundary term on one shard only (the other runs the tile kernel without data
+    tiles).  Variational losses and gradients of the shards add up to the whole problem's."""
+    from hp_vpinns_amd.drivers import poisson1d
+    from hp_vpinns_amd.init import xavier_init
+    from hp_vpinns_amd.vpinn import VPINN1D
+    counts = [60, 20, 45, 7, 33]
+    s = poisson1d.setup(N_Element=5, N_testfcn_total=counts)
+    L = [1, 20, 20, 20, 1]
+    th = xavier_init(L, 9)
+    th[20:40] = 0.1
+    args = (s["X_u_train"], s["u_train"], s["X_quad_train"], s["W_quad_train"], s["F_ext_total"], s["grid"], s["X_test"],
+            s["u_test"], L, s["X_f_train"], s["f_train"])
+    full = VPINN1D(*args, init_params=th, backend=backend)
+    l3, g = full.h.loss_and_grad()
+    parts = []
+    for eb, ee, with_data in ((0, 2, True), (2, 5, False)):
+        m = VPINN1D(*args, init_params=th, backend=backend)
+        m.h.set_elements(s["grid"], None, eb, ee)
+        if not with_data:
+            m.h.set_data(None, None)
+        parts.append(m.h.loss_and_grad())
+        if backend == "auto":
+            assert m.h.pass_structure() == "whole-iteration-tile"
+        r = m.h.residuals((ee - eb) * 60).reshape(ee - eb, 60)
+        for e in range(eb, ee):
+            assert np.all(r[e - eb, counts[e]:] == 0.0) and np.count_nonzero(r[e - eb, :counts[e]]) >= counts[e] - 3
+    (la, ga), (lb, gb) = parts
+    assert lb[1] == 0.0 and rel(la[1], l3[1]) < 1e-13                      # lossb lives on the shard with the data points
+    assert rel(la[2] + lb[2], l3[2]) < 1e-12 and rel(ga + gb, g) < 1e-11
