@@ -1086,3 +1086,32 @@ def test_poisson1d_shards_with_test_function_counts(backend):
     (la, ga), (lb, gb) = parts
     assert lb[1] == 0.0 and rel(la[1], l3[1]) < 1e-13                      # lossb lives on the shard with the data points
     assert rel(la[2] + lb[2], l3[2]) < 1e-12 and rel(ga + gb, g) < 1e-11
+
+
+def test_active_test_counts_argument_checks_and_reset():
+    """hpv_set_active_tests: counts outside 1..ntest, a wrong number of entries and 2-D problems are refused (the 2-D drivers
+    reshape F_ext_total into a dense array, P2:414); NULL restores the uniform case exactly."""
+    from hp_vpinns_amd import _lib
+    from hp_vpinns_amd.drivers import poisson1d, poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    from hp_vpinns_amd.vpinn import VPINN1D
+    s = poisson1d.setup(N_Element=3)
+    L = [1, 20, 20, 1]
+    th = xavier_init(L, 2)
+    th[20:40] = 0.1
+    m = VPINN1D(s["X_u_train"], s["u_train"], s["X_quad_train"], s["W_quad_train"], s["F_ext_total"], s["grid"], s["X_test"],
+                s["u_test"], L, s["X_f_train"], s["f_train"], init_params=th)
+    l0, g0 = m.h.loss_and_grad()
+    for bad in ([60, 61, 10], [0, 5, 5], [10, 10]):
+        with pytest.raises(_lib.HpvError):
+            m.h.set_active_tests(bad)
+    m.h.set_active_tests([60, 30, 60])
+    l1, _ = m.h.loss_and_grad()
+    assert abs(l1[2] - l0[2]) > 1e-9
+    m.h.set_active_tests(None)
+    l2, g2 = m.h.loss_and_grad()
+    assert np.array_equal(l2, l0) and np.array_equal(g2, g0)
+    s2 = poisson2d.setup(N_el_x=2, N_el_y=2, with_test_grid=False)
+    m2 = poisson2d.build_model(s2, [2, 20, 20, 1], init_params=xavier_init([2, 20, 20, 1], 2))
+    with pytest.raises(_lib.HpvError):
+        m2.h.set_active_tests([5, 5, 5, 5])
