@@ -123,9 +123,9 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
                                                    double* gbar_lds = nullptr) {
     const ProjDesc& pd = pa.pd;
     // out_lds / gbar_lds: the element's channels [C][NQ] and their adjoints live in LDS instead of the global rows
-    // (addressed here as OUT[ch * N + e * NQ + q], hence the rebased pointers and N = NQ)
-    const double* __restrict__ OUT = PRE ? out_lds - e * (QX * QY) : pa.OUT;
-    double* __restrict__ GBAR = PRE ? gbar_lds - e * (QX * QY) : pa.GBAR;
+    // (addressed below as OUT[ch * N + base + q]: N = NQ and base = 0 there)
+    const double* __restrict__ OUT = PRE ? out_lds : pa.OUT;
+    double* __restrict__ GBAR = PRE ? gbar_lds : pa.GBAR;
     double* __restrict__ R = pa.R;
     const double* __restrict__ F = pa.F;
     const double* __restrict__ coef = pa.coef;
@@ -153,7 +153,7 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
     double* U = T + QY * NTX;                    // [NR]
     double* S = U + NR;                          // [HPV_MAXT][NTY][QX]
     double* red = S + HPV_MAXT * NTY * QX;       // [64]: three arrays of one entry per wave (<= 16 waves)
-    const long base = e * NQ;
+    const long base = PRE ? 0 : e * NQ;
     const int tid = threadIdx.x;
     const int nterms = pd.nterms, C = pd.C;
     static_assert(!PRE || (HPV_MAXT + 2 <= 16 && 3 * NWV <= 48), "pre-staged scalars sit at red[48..]");
