@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Cost of the exchange kernel itself: config 4 on one GPU with the in-library exchange connected to a 1-rank
-"world" (its own mailbox): iteration = forward, projection+reverse, finalize, exchange+Adam  vs  the single-GPU
-iteration whose finalize kernel applies Adam."""
+"""Cost of the multi-GPU iteration tail on ONE GPU: the shard one of N GPUs owns (config 4, 256 / N elements) with the
+in-library exchange connected to a 1-rank "world" -- iteration = whole-iteration kernel, finalize, exchange, Adam -- next to the
+single-GPU iteration whose finalize kernel applies Adam.  rccl: ncclAllReduce on a 1-rank communicator + k_adam (what the default
+multi-GPU path launches, minus the xGMI hops); p2p: the one-kernel mailbox exchange + Adam.   exchange_overhead.py"""
 import os
 import sys
 import time
@@ -11,15 +12,23 @@ from hp_vpinns_amd.drivers import poisson2d  # noqa: E402
 from hp_vpinns_amd.init import xavier_init  # noqa: E402
 
 L = [2, 20, 20, 20, 1]
-s = poisson2d.setup(N_el_x=16, N_el_y=16, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
-for p2p in (False, True):
-    m = poisson2d.build_model(s, L, init_params=xavier_init(L, 1234))
-    if p2p:
-        m.h.p2p_connect(m.h.p2p_export(1, 0))
-        out, timed_out = m.h.p2p_selftest(m.h.reduce_buffer()[1])
-        assert not timed_out and abs(out[0] - 1.0) < 1e-15
-    m.h.step(200, False)
-    t0 = time.perf_counter()
-    m.h.step(2000, False)
-    print(("exchange+Adam kernel (1-rank mailbox)" if p2p else "Adam fused into finalize         ") +
-          ": %.1f us/iter" % ((time.perf_counter() - t0) / 2000 * 1e6))
+print("| shard (elements) | Adam fused into finalize | 1-rank RCCL all-reduce + k_adam | 1-rank mailbox exchange + Adam |\n|---|---|---|---|")
+for n in (1, 2, 4, 8):
+    s = poisson2d.setup(N_el_x=16, N_el_y=16 // n, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
+    row = []
+    for mode in ("none", "rccl", "p2p"):
+        m = poisson2d.build_model(s, L, init_params=xavier_init(L, 1234))
+        if mode == "p2p":
+            m.h.p2p_connect(m.h.p2p_export(1, 0))
+            out, timed_out = m.h.p2p_selftest(m.h.reduce_buffer()[1])
+            assert not timed_out and abs(out[0] - 1.0) < 1e-15
+        elif mode == "rccl":
+            m.h.rccl_connect(1, 0, m.h.rccl_unique_id())
+        m.h.step(200, False)
+        m.h.sync()
+        t0 = time.perf_counter()
+        m.h.step(4000, False)
+        m.h.sync()
+        row.append((time.perf_counter() - t0) / 4000 * 1e6)
+        assert m.h.exchange_in_use() == mode
+    print("| 1/%d (%d) | %.1f us | %.1f us | %.1f us |" % (n, 256 // n, row[0], row[1], row[2]))
