@@ -22,6 +22,7 @@
 //
 // First layer (d -> 20) and linear head (20 -> 1) are VALU work (K = 1..2 and M = 1 are no MFMA shapes).
 #include <cstdlib>
+#include <type_traits>
 
 #include "hpv_mfma_dev.h"
 
@@ -125,25 +126,37 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) k_fwd_mfma(MfmaArgs g) {
         asm volatile("" : "+v"(lofs));         // loop instead of being hoisted into ~60 loop-invariant VGPRs
 
         // ---- layer 1 (VALU): z = b + x W, z_c = W[c,:], z_cc = 0 ----
+        // (sin: the activation loops exist in a branch-free and a guarded copy, chosen by ONE wave-uniform test per layer -- a
+        //  fallback branch per value would cut the five independent chains of a lane into separate basic blocks)
+        {
+            double z1[MF_KS];
 #pragma unroll
-        for (int s = 0; s < MF_KS; ++s) {
-            double z = b1[s];
+            for (int s = 0; s < MF_KS; ++s) {
+                double z = b1[s];
 #pragma unroll
-            for (int c = 0; c < D; ++c) z += x[c] * w1[c][s];
-            double a, a1, a2;
-            act_fwd<ACT>(z, a, a1, a2);
-            h[0][s] = a;
-            if constexpr (SAVE) {
-                sv[(0 * MF_KS + s) * 64] = a;
-                if constexpr (ACT == HPV_ACT_SIN) sv[(SA1 * MF_KS + s) * 64] = a1;
+                for (int c = 0; c < D; ++c) z += x[c] * w1[c][s];
+                z1[s] = z;
             }
+            auto act1 = [&](auto fast) {
 #pragma unroll
-            for (int t = 0; t < NT1; ++t) h[1 + t][s] = a1 * w1[t < D ? t : 0][s];   // T1 = coordinates 0..NT1-1
+                for (int s = 0; s < MF_KS; ++s) {
+                    double a, a1, a2;
+                    act_fwd<ACT, decltype(fast)::value>(z1[s], a, a1, a2);
+                    h[0][s] = a;
+                    if constexpr (SAVE) {
+                        sv[(0 * MF_KS + s) * 64] = a;
+                        if constexpr (ACT == HPV_ACT_SIN) sv[(SA1 * MF_KS + s) * 64] = a1;
+                    }
 #pragma unroll
-            for (int b = 0; b < NT2; ++b) {
-                const double zc = w1[b < D ? b : 0][s];   // T2 = coordinates 0..NT2-1
-                h[1 + NT1 + b][s] = a2 * zc * zc;
-            }
+                    for (int t = 0; t < NT1; ++t) h[1 + t][s] = a1 * w1[t < D ? t : 0][s];   // T1 = coordinates 0..NT1-1
+#pragma unroll
+                    for (int b = 0; b < NT2; ++b) {
+                        const double zc = w1[b < D ? b : 0][s];   // T2 = coordinates 0..NT2-1
+                        h[1 + NT1 + b][s] = a2 * zc * zc;
+                    }
+                }
+            };
+            if (act_wave_needs_safe<ACT>(z1)) act1(std::false_type{}); else act1(std::true_type{});
         }
         // ---- hidden -> hidden layers (MFMA) ----
 #pragma unroll
@@ -177,30 +190,36 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) k_fwd_mfma(MfmaArgs g) {
                 }
             }
             double* svl = sv + (long)i * (NS * MF_KS * 64);
+            double zv[MF_KS];
 #pragma unroll
-            for (int s = 0; s < MF_KS; ++s) {
-                double a, a1, a2;
-                act_fwd<ACT>(s < 4 ? acc[0][s & 3] : z16[0], a, a1, a2);
-                h[0][s] = a;
-                if constexpr (SAVE) {
-                    svl[(0 * MF_KS + s) * 64] = a;
-                    if constexpr (ACT == HPV_ACT_SIN) svl[(SA1 * MF_KS + s) * 64] = a1;
-                }
-                double zc[NT1 > 0 ? NT1 : 1];
+            for (int s = 0; s < MF_KS; ++s) zv[s] = s < 4 ? acc[0][s & 3] : z16[0];
+            auto acti = [&](auto fast) {
 #pragma unroll
-                for (int u = 0; u < NT1; ++u) {
-                    zc[u] = s < 4 ? acc[1 + u][s & 3] : z16[1 + u];
-                    if constexpr (SAVE) svl[((SZC + u) * MF_KS + s) * 64] = zc[u];
-                    h[1 + u][s] = a1 * zc[u];
-                }
+                for (int s = 0; s < MF_KS; ++s) {
+                    double a, a1, a2;
+                    act_fwd<ACT, decltype(fast)::value>(zv[s], a, a1, a2);
+                    h[0][s] = a;
+                    if constexpr (SAVE) {
+                        svl[(0 * MF_KS + s) * 64] = a;
+                        if constexpr (ACT == HPV_ACT_SIN) svl[(SA1 * MF_KS + s) * 64] = a1;
+                    }
+                    double zc[NT1 > 0 ? NT1 : 1];
 #pragma unroll
-                for (int b = 0; b < NT2; ++b) {
-                    const double zcc = s < 4 ? acc[1 + NT1 + b][s & 3] : z16[1 + NT1 + b];
-                    const double z1 = zc[b < NT1 ? b : 0];
-                    if constexpr (SAVE) svl[((SZCC + b) * MF_KS + s) * 64] = zcc;
-                    h[1 + NT1 + b][s] = a2 * z1 * z1 + a1 * zcc;
+                    for (int u = 0; u < NT1; ++u) {
+                        zc[u] = s < 4 ? acc[1 + u][s & 3] : z16[1 + u];
+                        if constexpr (SAVE) svl[((SZC + u) * MF_KS + s) * 64] = zc[u];
+                        h[1 + u][s] = a1 * zc[u];
+                    }
+#pragma unroll
+                    for (int b = 0; b < NT2; ++b) {
+                        const double zcc = s < 4 ? acc[1 + NT1 + b][s & 3] : z16[1 + NT1 + b];
+                        const double z1 = zc[b < NT1 ? b : 0];
+                        if constexpr (SAVE) svl[((SZCC + b) * MF_KS + s) * 64] = zcc;
+                        h[1 + NT1 + b][s] = a2 * z1 * z1 + a1 * zcc;
+                    }
                 }
-            }
+            };
+            if (act_wave_needs_safe<ACT>(zv)) acti(std::false_type{}); else acti(std::true_type{});
         }
         // ---- linear head (VALU + 2 cross-lane adds over the 4 neuron groups) ----
 #pragma unroll
