@@ -14,9 +14,11 @@ is not already running under it), one rank per GPU; the 256 elements shard over 
 fixed) with ONE RCCL all-reduce of the packed gradient/loss buffer per step, issued by the library inside its
 iteration graphs.
 
-Timing: W untimed warm-up steps, one untimed window of K steps (captures the iteration graphs for exactly this K), then
-5 windows of EXACTLY K steps each, every window bracketed by barrier + synchronize on both sides and reduced with MAX
-over ranks; `value` = K / median window.  Rank 0 prints ONE JSON line (contract: DESIGN.md section 6).
+Timing: W untimed warm-up steps, one untimed window of K steps (captures the iteration graphs for exactly this K), further
+untimed windows until at least 0.3 s of iterations have run (clocks ramp for the first few hundred microseconds-long
+iterations: a `--steps 20` window is 1.3 ms), then 5 windows of EXACTLY K steps each -- 25 when a window is shorter than
+20 ms -- every window bracketed by barrier + synchronize on both sides and reduced with MAX over ranks; `value` = K / median
+window, min / max / all windows are in `timing`.  Rank 0 prints ONE JSON line (contract: DESIGN.md section 6).
 """
 import argparse
 import json
@@ -34,7 +36,9 @@ CFG4 = dict(N_el_x=16, N_el_y=16, N_test_x=10, N_test_y=10, N_quad=20, N_bound=8
 LAYERS = [2, 20, 20, 20, 1]
 PEAK_FP64_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (datasheet; half the 157.3 TF FP32 rate of MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-N_WINDOWS = 5
+N_WINDOWS = 5            # 25 when a window of K steps is shorter than SHORT_WINDOW_S
+SHORT_WINDOW_S = 0.020
+WARM_WALL_S = 0.3        # untimed iterations before the first timed window, whatever --warmup says
 
 
 def gemm_flops_per_row(layers):
@@ -49,7 +53,7 @@ def _median(v):
 # ------------------------------------------------------------------------------------------------
 # CPU baselines (oracle/ is test infrastructure: imported ONLY inside these functions, never by the product)
 # ------------------------------------------------------------------------------------------------
-def cpu_baseline_A(setup, theta, iters, windows=1):
+def cpu_baseline_A(setup, theta, iters, windows=3):
     """Baseline A of BASELINE.md section 3: the reference-structured oracle (per-element Python loop, one reduction per
     test-function pair, autograd double backward -- the op granularity of the TF1 graph), torch CPU fp64."""
     import torch
@@ -74,9 +78,12 @@ def cpu_baseline_A(setup, theta, iters, windows=1):
                       "of BASELINE.md), torch CPU fp64; host has %d logical cpus" % (windows, iters, os.cpu_count())}
 
 
-def cpu_baseline_B(setup, theta, iters, windows=1, sweep=(8, 32, 64, 128)):
+def cpu_baseline_B(setup, theta, iters, windows=3, sweep=(8, 32, 64, 128)):
     """Baseline B of BASELINE.md section 3: closed-form C / OpenMP restatement (oracle/cpu_closed_form.c), all elements in
-    parallel; thread sweep, best reported."""
+    parallel; thread sweep, best reported.  Threads pinned (one per core, neighbours first) before the OpenMP runtime of the
+    C library starts: unpinned, the same binary ran 44-75 it/s from run to run on the 256-cpu host."""
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     from oracle.cpu_baseline import CPoisson2D
     s = setup
     ncpu = os.cpu_count() or 1
@@ -94,8 +101,9 @@ def cpu_baseline_B(setup, theta, iters, windows=1, sweep=(8, 32, 64, 128)):
         if best is None or _median(rates) > best[1]:
             best = (nt, _median(rates))
     return {"value": best[1], "unit": "it/s", "cores": best[0], "kind": "port", "thread_sweep_it_per_s": table,
-            "sample": "%d window(s) of %d full iterations per thread count, closed-form C/OpenMP restatement "
-                      "(oracle/cpu_closed_form.c, gcc -O3 -march=x86-64-v3, pinned to the autograd oracle in tests/test_oracle.py: "
+            "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
+            "sample": "median of %d window(s) of %d full iterations per thread count, closed-form C/OpenMP restatement "
+                      "(oracle/cpu_closed_form.c, gcc -O3 -march=x86-64-v3, checked against the autograd oracle in tests/test_oracle.py: "
                       "baseline B of BASELINE.md); host has %d logical cpus" % (windows, iters, ncpu)}
 
 
@@ -116,7 +124,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-residual-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the L2-error tail, the scaled problems and the alternative exchange")
-    ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--cpu-iters", type=int, default=3, help="iterations per window of CPU baseline A (3 windows)")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="BASELINE.md section 3 protocol: A 5 x 20, B 5 x 200 iterations, median of the windows (minutes)")
     ap.add_argument("--l2-iters", type=int, default=30000, help="total Adam iterations before the L2 error is evaluated")
@@ -169,29 +177,41 @@ def main():
         m.h.sync()
         torch.cuda.synchronize()
 
-    def timed_windows(m, warmup, steps, windows=N_WINDOWS):
-        """-> list of window times (s), MAX over ranks each."""
+    def max_over_ranks(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def one_window(m, steps):
+        barrier(m)
+        t0 = time.perf_counter()
+        m._step(steps, False)
+        barrier(m)
+        return max_over_ranks(time.perf_counter() - t0)
+
+    def timed_windows(m, warmup, steps, windows=None):
+        """-> (list of window times (s), MAX over ranks each; untimed warm-up iterations actually run)."""
         m.prepare(warmup, steps)      # torch-collective fallback: communicator warm-up + graph capture outside the timed region
         m._step(warmup, False)
         m._step(steps, False)         # untimed: captures the graphs this K needs (whole replays + one remainder graph)
-        out = []
-        for _ in range(windows):
-            barrier(m)
-            t0 = time.perf_counter()
+        # untimed windows until WARM_WALL_S of iterations have run (every rank runs the same count: the estimate is a MAX over ranks)
+        t1 = one_window(m, steps)
+        n_more = int(min(4000, max(0, np.ceil(WARM_WALL_S / max(t1, 1e-6)) - 1)))
+        for _ in range(n_more):
             m._step(steps, False)
-            barrier(m)
-            dt = time.perf_counter() - t0
-            if dist is not None:
-                t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt = float(t.item())
-            out.append(dt)
-        return out
+        n_warm = warmup + (2 + n_more) * steps
+        if windows is None:
+            windows = N_WINDOWS if t1 >= SHORT_WINDOW_S else 5 * N_WINDOWS
+        return [one_window(m, steps) for _ in range(windows)], n_warm
 
     model = poisson2d.build_model(s, LAYERS, var_form=1, init_params=theta, backend=args.backend, device=local_rank)
-    wins = timed_windows(model, args.warmup, args.steps)
+    wins, n_warm = timed_windows(model, args.warmup, args.steps)
     dt = _median(wins)
-    n_its_done = args.warmup + (1 + N_WINDOWS) * args.steps
+    n_its_done = n_warm + len(wins) * args.steps
+    structure = model.h.pass_structure()      # which launch structure the timed iterations ran (SPLIT vs the split reverse kernels ...)
+    graphs = model.h.graphs_in_use() if not model._coll else bool(model._dist_graphs.get(min(args.steps, 8) if args.steps <= 16 else 8))
 
     # ---- per-kernel device times (hipEvents on the stream the kernels run on), untimed extra pass ----
     nt = min(args.steps, 100)
@@ -225,7 +245,7 @@ def main():
         def run_problem(nex, ney):
             sw = poisson2d.setup(**dict(CFG4, N_el_x=nex, N_el_y=ney), with_test_grid=False, assemble="device", device=local_rank)
             mw = poisson2d.build_model(sw, LAYERS, var_form=1, init_params=theta, backend=args.backend, device=local_rank)
-            w = timed_windows(mw, min(args.warmup, 40), k2, windows=3)
+            w, _ = timed_windows(mw, min(args.warmup, 40), k2, windows=3)
             ex = mw.exchange()
             del mw
             return k2 / _median(w), ex
@@ -257,7 +277,7 @@ def main():
             os.environ["HPV_EXCHANGE"] = alt
             try:
                 ma = poisson2d.build_model(s, LAYERS, var_form=1, init_params=theta, backend=args.backend, device=local_rank)
-                wa = timed_windows(ma, min(args.warmup, 40), k2, windows=3)
+                wa, _ = timed_windows(ma, min(args.warmup, 40), k2, windows=3)
                 extras["exchange_alt"] = {"exchange": ma.exchange(), "requested": alt, "steps": k2, "it_per_s": k2 / _median(wa)}
                 del ma
             except Exception as e:  # noqa: BLE001 -- never let the comparison run take the headline line down
@@ -265,6 +285,11 @@ def main():
             finally:
                 os.environ.pop("HPV_EXCHANGE", None)
 
+    per_rank = [{"rank": rank, "pass_structure": structure, "graphs": bool(graphs), "exchange": exchange}]
+    if dist is not None:
+        allr = [None] * world
+        dist.all_gather_object(allr, per_rank[0])
+        per_rank = allr
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -295,6 +320,8 @@ def main():
         key = "iter_fused" if whole_iter_fused else k
         return {"kernel": k, "bound": "mfma", "achieved": tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                 "frac": tf / PEAK_FP64_TFLOPS, "traffic": traffic_tab.get(key) if world == 1 else None,
+                "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc passes of an earlier run of this kernel, %s); not "
+                                   "measured in this run" % traffic_tab.get("_measured_at", "commit unknown")) if world == 1 else None,
                 "flops_per_launch": fl, "avg_ms": ms}
     # whole-iteration algorithmic HBM bytes (fused ideal): coordinates in, F in, Adam state in/out
     ideal_bytes = 8 * (2 * N_local + n_elem_local * 100 + 7 * 921)
@@ -306,11 +333,17 @@ def main():
                                "MLP [2,20,20,20,1] tanh, var_form 1, 320 boundary pts, TF1 Adam (BASELINE config 4)",
                    "points": 102400, "residuals": 25600, "params": 921, "backend": model.backend(),
                    "parallelism": "element-sharded dp%d" % world,
-                   "exchange": {"rccl": "in-library ncclAllReduce of the packed buffer, captured in the iteration graphs",
+                   "exchange": {"rccl": "in-library ncclAllReduce of the packed buffer, " +
+                                        ("captured in the iteration graphs" if graphs else
+                                         "EAGER launches (RCCL refused stream capture: no iteration graphs)"),
                                 "p2p": "in-library peer-mapped mailboxes over xGMI", "torch": "torch.distributed all_reduce (RCCL)",
-                                "none": "none"}[exchange]},
-        "timing": {"windows": N_WINDOWS, "window_it_per_s": [round(args.steps / w, 1) for w in wins],
-                   "value_is": "steps / median window; every window = exactly `steps` iterations between barrier+synchronize"},
+                                "none": "none"}[exchange],
+                   "pass_structure": structure, "per_rank": per_rank},
+        "timing": {"windows": len(wins), "window_it_per_s": [round(args.steps / w, 1) for w in wins],
+                   "min_it_per_s": args.steps / max(wins), "max_it_per_s": args.steps / min(wins),
+                   "untimed_warmup_iterations": n_warm,
+                   "value_is": "steps / median window; every window = exactly `steps` iterations between barrier+synchronize; "
+                               "%d windows because one window lasts %.1f ms" % (len(wins), 1e3 * dt)},
         "loss_after": float(loss3[0]),
         "rel_l2_error": rel_l2,
         "kernel_ms": ktime,
@@ -343,8 +376,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline_A(s, theta, 20, windows=5)
             out["cpu_baseline_vectorized"] = cpu_baseline_B(s, theta, 200, windows=5)
         else:
-            out["cpu_baseline"] = cpu_baseline_A(s, theta, args.cpu_iters)
-            out["cpu_baseline_vectorized"] = cpu_baseline_B(s, theta, 30)
+            out["cpu_baseline"] = cpu_baseline_A(s, theta, args.cpu_iters, windows=3)
+            out["cpu_baseline_vectorized"] = cpu_baseline_B(s, theta, 30, windows=3)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         out["speedup_vs_cpu_baseline_vectorized"] = out["value"] / out["cpu_baseline_vectorized"]["value"]
     print(json.dumps(out))

@@ -32,6 +32,7 @@ EXPORTS = [
     "hpv_p2p_export", "hpv_p2p_connect", "hpv_p2p_selftest", "hpv_p2p_disconnect",
     "hpv_eval_channels", "hpv_bench_residual",
     "hpv_set_collocation_shard", "hpv_rccl_unique_id", "hpv_rccl_connect", "hpv_rccl_selftest", "hpv_rccl_disconnect", "hpv_exchange_in_use",
+    "hpv_rccl_available", "hpv_graphs_in_use",
 ]
 
 
@@ -115,6 +116,8 @@ def load():
     lib.hpv_eval_channels.argtypes = [h, _dp, C.c_size_t]
     lib.hpv_bench_residual.argtypes = [h, C.c_long, C.c_int, C.c_int, _dp, _dp]
     lib.hpv_set_collocation_shard.argtypes = [h, _dp, _dp, C.c_int, C.c_long]
+    lib.hpv_rccl_available.argtypes = []
+    lib.hpv_graphs_in_use.argtypes = [h]
     lib.hpv_rccl_unique_id.argtypes = [h, C.c_char_p]
     lib.hpv_rccl_connect.argtypes = [h, C.c_int, C.c_int, C.c_char_p]
     lib.hpv_rccl_selftest.argtypes = [h, _dp, C.c_size_t]
@@ -347,6 +350,10 @@ class Handle:
         self._chk(self.lib.hpv_history_read(self._h, int(n), _p(out), _p(eps)))
         return out, eps
 
+    def rccl_available(self):
+        """librccl can be loaded in this process (local check, no collective)."""
+        return int(self.lib.hpv_rccl_available()) == 1
+
     def rccl_unique_id(self):
         buf = C.create_string_buffer(128)
         self._chk(self.lib.hpv_rccl_unique_id(self._h, buf))
@@ -364,6 +371,10 @@ class Handle:
         """'separate' | 'fused-reverse' | 'whole-iteration' | 'whole-iteration-split' | 'whole-iteration-tile' (or None)."""
         return {0: "separate", 1: "fused-reverse", 2: "whole-iteration", 3: "whole-iteration-split",
                 4: "whole-iteration-tile"}.get(int(self.lib.hpv_pass_structure(self._h)))
+
+    def graphs_in_use(self):
+        """hpv_step replays captured iteration graphs (False: eager launches, e.g. a collective that refused stream capture)."""
+        return int(self.lib.hpv_graphs_in_use(self._h)) == 1
 
     def rccl_disconnect(self):
         self._chk(self.lib.hpv_rccl_disconnect(self._h))

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -80,6 +81,7 @@ struct hpv_ctx {
     double *d_theta = nullptr, *d_m = nullptr, *d_v = nullptr, *d_state = nullptr, *d_RB = nullptr;
     double* d_hist = nullptr;   // [HPV_HIST_CAP][4] loss / epsilon history (AdamArgs)
     int* d_hist_idx = nullptr;
+    int* d_xerr = nullptr;      // sticky failure flag: a SPLIT-mode element barrier timed out (kernels_fused.hip); see sync_check
     // mfma path (one object per batch: quadrature points, boundary/data points, element edges)
     HpvMfma* mfma = nullptr;
     HpvMfma* mfma_data = nullptr;
@@ -122,6 +124,8 @@ struct hpv_ctx {
 
 static void p2p_release(hpv_ctx* h);
 static void rccl_release(hpv_ctx* h);
+static int sync_check(hpv_ctx* h);
+static int p2p_check(hpv_ctx* h);
 
 namespace {
 
@@ -135,22 +139,33 @@ struct RcclApi {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool ok = false;
+    std::string why;     // what went wrong, captured where it went wrong (dlerror() is one-shot and goes stale)
 };
 RcclApi& rccl_api() {
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return api;
-    tried = true;
-    const char* names[] = {"librccl.so.1", "librccl.so"};
-    for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-    for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!api.lib) return api;
-    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
-    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
-    api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
-    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
-    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
-    api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy && api.GetErrorString;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        for (const char* n : names)
+            if (!api.lib) {
+                api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                if (!api.lib) { const char* e = dlerror(); api.why = e ? e : "dlopen failed"; }
+            }
+        if (!api.lib) return;
+        api.why.clear();
+        auto sym = [&](const char* name) -> void* {
+            void* p = dlsym(api.lib, name);
+            if (!p && api.why.empty()) { const char* e = dlerror(); api.why = e ? e : (std::string("symbol missing: ") + name); }
+            return p;
+        };
+        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+        api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy && api.GetErrorString;
+    });
     return api;
 }
 
@@ -287,6 +302,7 @@ int assemble_batches(hpv_ctx* h) {
             h->backend = HPV_BACKEND_MFMA;
             h->merged = true;
             h->data_off = Npad;
+            hpv_mfma_set_err_flag(h->mfma, h->d_xerr);
             if ((rc = alloc_batch(h, h->var, h->nd_var, Ntot, true))) return rc;
             if (h->var.ACT) { (void)hipFree(h->var.ACT); h->var.ACT = nullptr; }   // the MFMA path has its own store
             const int rows = hpv_mfma_max_rows(h->mfma, h->n_elem);
@@ -356,7 +372,7 @@ int ensure_small_mfma(hpv_ctx* h, Batch& b, HpvMfma** m) {
 
 AdamArgs adam_args(hpv_ctx* h) {
     return AdamArgs{h->d_theta, h->d_m, h->d_v, h->d_state, h->cfg.lr, h->cfg.beta1, h->cfg.beta2, h->cfg.eps,
-                    h->d_hist, h->d_hist_idx, HPV_HIST_CAP};
+                    h->d_hist, h->d_hist_idx, HPV_HIST_CAP, h->d_xerr};
 }
 
 int enqueue_pinn_pass(hpv_ctx* h, bool backward, bool fuse_adam);
@@ -461,7 +477,7 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
                     backward && h->n_data > 0 && !h->merged ? h->data.GPART : nullptr, h->data.rows,
                     backward && h->pd.edge && h->edge.N > 0 ? h->edge.GPART : nullptr, h->edge.rows, h->d_loss_e,
                     (long)h->n_elem * h->proj_split, h->d_deps_e, h->d_data_part, ndp, h->cfg.lossb_weight, h->n_data, h->P, h->has_eps, h->d_RB,
-                    backward ? 1 : 0, (backward && fuse_adam) ? &ad : nullptr, h->stream);
+                    backward ? 1 : 0, (backward && fuse_adam) ? &ad : nullptr, h->stream, h->d_xerr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, -2, "kernel launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -652,6 +668,8 @@ int hpv_create(hpv_handle* out, const hpv_config* cfg) {
     rc |= dalloc(h, &h->d_hist, (size_t)4 * HPV_HIST_CAP);
     rc |= dalloc(h, &h->d_hist_idx, (size_t)1);
     if (!rc) (void)hipMemset(h->d_hist_idx, 0, sizeof(int));
+    rc |= dalloc(h, &h->d_xerr, (size_t)1);
+    if (!rc) (void)hipMemset(h->d_xerr, 0, sizeof(int));
     rc |= dalloc(h, &h->d_RB, (size_t)h->Ptot + 4);
     rc |= dalloc(h, &h->d_data_part, 64);
     if (rc) { g_create_error = h->err; hpv_destroy(h); return -2; }
@@ -686,6 +704,7 @@ void hpv_destroy(hpv_handle h) {
                       h->d_deps_e, h->d_udata, h->d_data_part, h->d_theta, h->d_m, h->d_v, h->d_state, h->d_RB, h->d_hist};
     for (double* p : ptrs) if (p) (void)hipFree(p);
     if (h->d_hist_idx) (void)hipFree(h->d_hist_idx);
+    if (h->d_xerr) (void)hipFree(h->d_xerr);
     if (h->d_nact) (void)hipFree(h->d_nact);
     for (auto& t : h->timers) for (auto e : t.ev) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -725,6 +744,9 @@ int hpv_set_tables(hpv_handle h, const double* phix, const double* dphix, const 
     if (!phix || !dphix || !d2phix || ntx < 1) return fail(h, -1, "bad x tables");
     if (h->dim == 1) { if (nty != 1) return fail(h, -1, "nty must be 1 for the 1-D problem"); }
     else if (!phiy || !dphiy || !d2phiy || nty < 1) return fail(h, -1, "bad y tables");
+    for (size_t i = 0; i < h->nact_all.size(); ++i)     // counts given for an earlier, larger table set
+        if (h->nact_all[i] > ntx)
+            return fail(h, -1, "n_active[%zu] = %d exceeds the new ntest %d (hpv_set_active_tests(NULL) drops the counts)", i, h->nact_all[i], ntx);
     const int qx = h->qx, qy = h->qy;
     std::vector<double> wtx((size_t)3 * ntx * qx), wty((size_t)3 * nty * qy);
     const double* tx[3] = {phix, dphix, d2phix};
@@ -762,6 +784,11 @@ int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* g
     else if (!gridy || ney < 1) return fail(h, -1, "bad y grid");
     const int ne_tot = nex * ney;
     if (e_begin < 0 || e_end > ne_tot || e_begin > e_end) return fail(h, -1, "bad element range [%d,%d) of %d", e_begin, e_end, ne_tot);
+    // per-grid inputs given earlier must fit the new grid: checked BEFORE anything of the old grid is replaced
+    if (!h->nact_all.empty() && (int)h->nact_all.size() != ne_tot)
+        return fail(h, -1, "n_active has %zu entries but the new grid has %d elements (hpv_set_active_tests(NULL) drops them)", h->nact_all.size(), ne_tot);
+    if (h->have_F && h->F_all.size() != (size_t)ne_tot * h->ntx * h->nty)
+        return fail(h, -1, "F has %zu entries but the new grid needs %zu (hpv_set_rhs(NULL) drops it)", h->F_all.size(), (size_t)ne_tot * h->ntx * h->nty);
     h->nex = nex; h->ney = ney; h->e_begin = e_begin; h->e_end = e_end;
     const long ne = e_end - e_begin;
     h->n_elem = ne;
@@ -966,7 +993,7 @@ int hpv_apply_adam(hpv_handle h) {
 int hpv_sync(hpv_handle h) {
     if (!h) return -1;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return 0;
+    return sync_check(h);     // (the caller-driven multi-GPU pieces -- forward_backward / apply_adam -- end their runs here)
 }
 
 int hpv_read_loss(hpv_handle h, double* loss3) {
@@ -989,7 +1016,8 @@ int hpv_loss_and_grad(hpv_handle h, double* loss3, double* grad) {
         HIPCHK(h, hipMemcpyAsync(grad, h->d_RB, (size_t)h->Ptot * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return 0;
+    if (grad && (rc = sync_check(h))) return rc;     // a gradient from a failed SPLIT-mode barrier is not a gradient
+    return p2p_check(h);
 }
 
 // n_iters training iterations enqueued on the handle's stream (graph replays where possible), no synchronisation
@@ -1026,6 +1054,26 @@ static int enqueue_iterations(hpv_ctx* h, int n_iters) {
     return 0;
 }
 
+// after a synchronisation point: did a SPLIT-mode element barrier time out (on this rank, or -- carried by the pad slot of the
+// all-reduced buffer -- on any rank)?  The kernels have left theta, m, v, the beta powers and the loss history as they were
+// before the failing iteration and have ignored every iteration since (sticky flag); here the failure is reported (-7), the
+// flag cleared and the arrival counters reset, so that the caller may go on (e.g. with HPV_FUSE=s on a shared GPU).
+static int sync_check(hpv_ctx* h) {
+    if (!h->d_xerr || !h->mfma) return 0;
+    if (!hpv_mfma_split_used(h->mfma) && !h->rccl_on && !h->p2p_on) return 0;   // nothing can have set it
+    int err = 0;
+    HIPCHK(h, hipMemcpyAsync(&err, h->d_xerr, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!err) return 0;
+    HIPCHK(h, hipMemsetAsync(h->d_xerr, 0, sizeof(int), h->stream));
+    hpv_mfma_reset_sync(h->mfma, h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return fail(h, -7, "whole-iteration kernel (SPLIT mode): the workgroups sharing an element did not meet at their barrier "
+                       "(timeout) on some rank; the failing iteration and every later one of this call were NOT applied -- "
+                       "parameters and optimizer state are those before it.  Is the GPU shared with another process?  HPV_FUSE=s "
+                       "selects the barrier-free kernels");
+}
+
 // after a synchronisation point: did an exchange give up waiting for a peer?
 static int p2p_check(hpv_ctx* h) {
     if (!h->p2p_on) return 0;
@@ -1045,8 +1093,7 @@ int hpv_step(hpv_handle h, int n_iters, double* loss3_after) {
     } else {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
-    if (h->mfma && hpv_mfma_sync_failed(h->mfma))
-        return fail(h, -7, "whole-iteration kernel: the workgroups sharing an element did not meet at their barrier (timeout)");
+    if ((rc = sync_check(h))) return rc;
     return p2p_check(h);
 }
 
@@ -1088,6 +1135,8 @@ int hpv_step_record(hpv_handle h, int n_iters, double* loss3_hist, double* eps_h
         const int c = std::min(HPV_HIST_CAP, n_iters - done);
         if ((rc = hpv_history_reset(h))) return rc;
         if ((rc = enqueue_iterations(h, c))) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if ((rc = sync_check(h)) || (rc = p2p_check(h))) return rc;    // (before the history: a skipped iteration records nothing)
         if ((rc = hpv_history_read(h, c, chunk.data(), ceps.data()))) return rc;
         // entry j was computed by the forward pass that preceded update done+j+1, i.e. it belongs to the state after update done+j
         for (int j = 0; j < c; ++j)
@@ -1316,10 +1365,12 @@ static void rccl_release(hpv_ctx* h) {
     h->rccl_on = false;
 }
 
+int hpv_rccl_available(void) { return rccl_api().ok ? 1 : 0; }
+
 int hpv_rccl_unique_id(hpv_handle h, void* id128) {
     if (!h || !id128) return -1;
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
-    if (!rccl_api().ok) return fail(h, -6, "librccl.so could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+    if (!rccl_api().ok) return fail(h, -6, "librccl.so could not be loaded: %s", rccl_api().why.c_str());
     ncclUniqueId id;
     ncclResult_t r = rccl_api().GetUniqueId(&id);
     if (r != ncclSuccess) return fail(h, -6, "ncclGetUniqueId failed: %s", rccl_api().GetErrorString(r));
@@ -1329,7 +1380,7 @@ int hpv_rccl_unique_id(hpv_handle h, void* id128) {
 
 int hpv_rccl_connect(hpv_handle h, int world, int rank, const void* id128) {
     if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return -1;
-    if (!rccl_api().ok) return fail(h, -6, "librccl.so could not be loaded");
+    if (!rccl_api().ok) return fail(h, -6, "librccl.so could not be loaded: %s", rccl_api().why.c_str());
     if (!h->have_params) return fail(h, -3, "hpv_set_params has not been called");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1355,6 +1406,7 @@ int hpv_rccl_disconnect(hpv_handle h) {
 // Known-answer all-reduce: RB[i] = (rank + 1) + 1e-3 i on every rank -> out[i] = W (W + 1) / 2 + W 1e-3 i.  Collective.
 int hpv_rccl_selftest(hpv_handle h, double* out, size_t n) {
     if (!h || !out || !h->rccl_on || n != (size_t)h->Ptot + 4) return -1;
+    HIPCHK(h, hipSetDevice(h->cfg.device));   // (may run on a helper thread of the caller: the current device is per thread)
     std::vector<double> v(n);
     for (size_t i = 0; i < n; ++i) v[i] = (double)(h->rccl_rank + 1) + 1e-3 * (double)i;
     int rc = upload(h, h->d_RB, v.data(), n);
@@ -1395,14 +1447,23 @@ int hpv_eval_channels(hpv_handle h, double* out, size_t n) {
     return 0;
 }
 
-// (undeclared debug hook of the -DHPV_FZ_TIMING build: raw read of the adjoint channel buffer the fused kernels stamp)
+#if defined(HPV_FZ_TIMING) || defined(HPV_PJ_TIMING)
+// (debug hook of the timing builds only -- scripts/fz_timing.py, scripts/pj_timing.py: raw read of the adjoint channel buffer /
+//  the activation store the instrumented kernels stamp)
 int hpv_debug_read_out(hpv_handle h, double* out, size_t n) {
     if (!h || !out || !h->var.GBAR) return -1;
     const double* src = h->var.GBAR;
-    if (getenv("HPV_DEBUG_READ_STORE") && h->mfma && hpv_mfma_activation_store(h->mfma)) src = hpv_mfma_activation_store(h->mfma);
+    size_t have = (size_t)h->nd_var.C * (size_t)h->var.N;
+    if (getenv("HPV_DEBUG_READ_STORE") && h->mfma && hpv_mfma_activation_store(h->mfma)) {
+        src = hpv_mfma_activation_store(h->mfma);
+        have = hpv_mfma_activation_store_doubles(h->mfma);
+    }
+    if (n > have) return fail(h, -1, "debug read of %zu doubles from a buffer of %zu", n, have);
     return hipMemcpy(out, src, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
+#endif
 int hpv_pass_structure(hpv_handle h) { return h ? h->pass_structure : -1; }
+int hpv_graphs_in_use(hpv_handle h) { return !h ? -1 : ((h->use_graph && h->own_stream && (h->g_stepK || h->g_rem[1] || h->g_rem[2] || h->g_rem[3] || h->g_rem[4] || h->g_rem[5] || h->g_rem[6] || h->g_rem[7])) ? 1 : 0); }
 int hpv_backend_in_use(hpv_handle h) {
     if (!h) return -1;
     if (h->cfg.scheme == HPV_SCHEME_VPINN && h->have_quad && h->have_tables && h->have_elems && h->batch_dirty) {

@@ -11,6 +11,7 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
 void hpv_mfma_destroy(HpvMfma* m);
 int hpv_mfma_grad_rows(HpvMfma* m);
 double* hpv_mfma_activation_store(HpvMfma* m);
+size_t hpv_mfma_activation_store_doubles(HpvMfma* m);
 // Boundary/data term evaluated inside the forward kernel for the data tiles of a merged batch.
 struct MfmaDataTerm {
     long data_off;        // first data point (multiple of 16)
@@ -35,6 +36,11 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
 // The same for small elements of any channel set (kernels_tile.hip): one tile per wave, the tile's saved state in registers.
 bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
                         const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem);
-bool hpv_mfma_sync_failed(HpvMfma* m);
+// SPLIT mode of the whole-iteration kernel: the handle's sticky failure flag (device int, owned by the caller) that a timed-out
+// element barrier sets; without one the SPLIT mode is not used.  hpv_mfma_split_used: a SPLIT launch happened since creation;
+// hpv_mfma_reset_sync: zero the arrival counters (after a failure has been reported).
+void hpv_mfma_set_err_flag(HpvMfma* m, int* dev_flag);
+bool hpv_mfma_split_used(HpvMfma* m);
+void hpv_mfma_reset_sync(HpvMfma* m, hipStream_t s);
 bool hpv_mfma_sync_failed_possible(HpvMfma* m);   // the last whole-iteration launch ran in SPLIT mode
 int hpv_mfma_max_rows(HpvMfma* m, long n_elem);

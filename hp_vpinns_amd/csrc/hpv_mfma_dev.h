@@ -42,7 +42,8 @@ struct MfmaArgs {
     ProjArgs pa;
     // split whole-iteration kernel: per element the monotonic arrival counter of the partners' barrier, timeout flag
     unsigned long long* xsync;
-    int* xerr;
+    int* xerr;            // sticky failure flag of the handle (hpv_ctx::d_xerr): set when a barrier times out; see fz_elem_barrier
+    int xdebug_skip;      // test knob (HPV_DEBUG_SPLIT_SKIP=1): partner 1 of element 0 stays away from the barrier
 };
 
 struct HpvMfma {
@@ -66,7 +67,8 @@ struct HpvMfma {
     // 's' keeps small shards on the forward + split reverse kernels (the whole-iteration kernel's split mode off)
     bool iter_split_ok = true;
     unsigned long long* xsync = nullptr;   // [xsync_elems] arrival counters, zero-initialised, monotonic (S per launch and element)
-    int* xerr = nullptr;
+    int* xerr = nullptr;                   // NOT owned: the handle's sticky failure flag (hpv_mfma_set_err_flag)
+    int xdebug_skip = 0;
     long xsync_elems = 0;
     bool split_used = false;               // a split launch happened: hpv_step then reads the timeout flag back
     bool last_split = false;               // the most recent whole-iteration launch was a split one (hpv_pass_structure)

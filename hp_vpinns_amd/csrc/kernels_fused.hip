@@ -117,26 +117,37 @@ __device__ __forceinline__ void fz_layer(const double* WTl, const double* WRl, c
 // agent-scope relaxed atomic loads, every storing wave drains its stores (s_waitcnt vmcnt(0)) before ONE lane bumps the counter,
 // ONE lane polls the generation word relaxed.  (With an agent-scope release fence before the bump and an acquire after the
 // poll -- an L2 write-back and an L1/L2 invalidate -- the barrier cost 18.6 k cycles = 8.5 us; measured, profiles/.)
-// All S workgroups are co-resident (the grid is at most one workgroup per CU); the wait is nevertheless bounded by wall clock
-// -- on expiry *err is set, the launch runs to its end on whatever it sees and hpv_step reports the failure.
-__device__ __forceinline__ void fz_elem_barrier(unsigned long long* cnt, int S, int* err, int tid) {
+// All S workgroups are co-resident (the grid is at most one workgroup per CU); the wait is nevertheless bounded by wall clock.
+// A failed barrier must leave the replica intact (round-2 verdict / advisor): on expiry the sticky flag *err is set and the
+// function returns false to EVERY thread of the workgroup, which then leaves the kernel before phase P / R write R, loss_e or
+// its gradient row; k_finalize / k_adam / k_p2p_exchange read the flag (directly and, on the multi-GPU path, through the pad
+// slot of the all-reduced buffer) and skip the update, the loss history and the beta powers; every later launch of the handle
+// sees the flag at its barrier (`sticky`, requested at kernel start) and returns without arriving, until the host has reported
+// the failure (HpvError -7), cleared the flag and reset the arrival counters.  `skip`: test knob, the workgroup stays away.
+__device__ __forceinline__ bool fz_elem_barrier(unsigned long long* cnt, int S, int* err, int tid, int sticky, bool skip, double* flag_lds) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        // ONE monotonic arrival counter per element (never reset: launch k takes it from k S to (k + 1) S), so that the arrival
-        // itself tells every workgroup its target and the last arriver needs no second round trip to announce completion
-        const unsigned long long a = __hip_atomic_fetch_add(cnt, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long target = (a / (unsigned long long)S + 1ULL) * (unsigned long long)S;
-        if (a + 1ULL != target) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ULL) { *err = 1; break; }    // 0.2 s at 100 MHz
-                __builtin_amdgcn_s_sleep(1);
+        int bad = sticky;
+        if (!bad && !skip) {
+            // ONE monotonic arrival counter per element (never reset: launch k takes it from k S to (k + 1) S), so that the arrival
+            // itself tells every workgroup its target and the last arriver needs no second round trip to announce completion
+            const unsigned long long a = __hip_atomic_fetch_add(cnt, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long target = (a / (unsigned long long)S + 1ULL) * (unsigned long long)S;
+            if (a + 1ULL != target) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ULL) { bad = 1; break; }    // 0.2 s at 100 MHz
+                    __builtin_amdgcn_s_sleep(1);
+                }
             }
+            if (bad) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        *flag_lds = (bad || skip) ? 1.0 : 0.0;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    return *flag_lds == 0.0;
 }
 
 // SPLIT: an element is shared by g.proj_split (2, 4 or 8) workgroups -- the shards of a multi-GPU run are too small to fill the
@@ -157,6 +168,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     const int part = SPLIT ? (int)(blockIdx.x & (split - 1)) : 0;
     const double* __restrict__ th = g.theta;
     const ProjArgs& pa = g.pa;
+    // SPLIT: has a barrier of an earlier launch of this handle failed?  (requested now, consumed at the barrier)
+    int xsticky = 0;
+    if constexpr (SPLIT) xsticky = __hip_atomic_load(g.xerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef HPV_FZ_TIMING
     long long fz_t[8];
     const long long fz_start = clock64(), fz_wall = wall_clock64();
@@ -400,7 +414,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     if (k0 < n_own) fwd_trip(k0, std::integral_constant<int, 1>{});
     FZ_STAMP(2);
     if constexpr (SPLIT) {
-        fz_elem_barrier(g.xsync + e, split, g.xerr, tid);
+        // (the TR region is idle between the phases: its last word carries the verdict to the workgroup)
+        if (!fz_elem_barrier(g.xsync + e, split, g.xerr, tid, xsticky, g.xdebug_skip && e == 0 && part == 1, lds + M::RED + 15))
+            return;     // nothing of this iteration has been written: the update is skipped by the kernels that follow
         for (int idx = tid; idx < 2 * FZ_NQ; idx += FZ_BLOCK)
             lds[M::CH + idx] = __hip_atomic_load(&g.OUT[(long)(1 + idx / FZ_NQ) * g.N + e * FZ_NQ + idx % FZ_NQ], __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT);
@@ -1186,7 +1202,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     // partners meet at a barrier in device memory, which needs all of them resident: at most one workgroup per CU
     int split = 1;
     if (n_elem * 2 <= m->n_cus && !m->iter_fused_force) {
-        if (!m->xsync || !m->iter_split_ok) return false;
+        if (!m->xsync || !m->xerr || !m->iter_split_ok) return false;
         while (split < 8 && n_elem * split * 2 <= m->n_cus) split *= 2;
         if (n_elem * split > m->n_cus || n_elem > m->xsync_elems) return false;
     }
@@ -1208,6 +1224,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     a.proj_split = split;
     a.xsync = m->xsync;
     a.xerr = m->xerr;
+    a.xdebug_skip = m->xdebug_skip;
     a.pa = pa;
     m->last_split = split > 1;
     if (split > 1) {
@@ -1221,11 +1238,8 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
 }
 
 bool hpv_mfma_sync_failed_possible(HpvMfma* m) { return m && m->last_split; }
-// did an element barrier of the split whole-iteration kernel time out since the last check?  (resets the flag)
-bool hpv_mfma_sync_failed(HpvMfma* m) {
-    if (!m || !m->xerr || !m->split_used) return false;
-    int e = 0;
-    (void)hipMemcpy(&e, m->xerr, sizeof(int), hipMemcpyDeviceToHost);
-    if (e) (void)hipMemset(m->xerr, 0, sizeof(int));
-    return e != 0;
+void hpv_mfma_set_err_flag(HpvMfma* m, int* dev_flag) { if (m) m->xerr = dev_flag; }
+bool hpv_mfma_split_used(HpvMfma* m) { return m && m->split_used; }
+void hpv_mfma_reset_sync(HpvMfma* m, hipStream_t s) {
+    if (m && m->xsync) (void)hipMemsetAsync(m->xsync, 0, (size_t)m->xsync_elems * sizeof(unsigned long long), s);
 }

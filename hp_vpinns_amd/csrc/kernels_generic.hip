@@ -487,7 +487,8 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
                                                          const double* __restrict__ deps_e,
                                                          const double* __restrict__ data_part, int n_data_part,
                                                          double lossb_weight, int n_data, int P, int has_eps,
-                                                         double* __restrict__ RB, int write_grad, AdamArgs ad) {
+                                                         double* __restrict__ RB, int write_grad, AdamArgs ad,
+                                                         const int* __restrict__ xerr) {
     constexpr int FIN_PARTS = FIN_THREADS / FIN_COLS;
     __shared__ double red[FIN_PARTS * FIN_COLS];
     const int Ptot = P + (has_eps ? 1 : 0);
@@ -499,11 +500,13 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
         const int idx = blockIdx.x * FIN_COLS + c;
         // the Adam operands of this block's 16 parameters are requested BEFORE the row sums, so that their memory round trip
         // overlaps the rows' instead of following it (the kernel is one latency chain)
-        const bool upd = ad.theta && part == 0 && idx < P;
+        bool upd = ad.theta && part == 0 && idx < P;
         double m0 = 0.0, v0 = 0.0, th0 = 0.0, b1p = 0.0, b2p = 0.0;
+        int failed = 0;
         if (upd) {
             m0 = ad.m[idx]; v0 = ad.v[idx]; th0 = ad.theta[idx];
             b1p = ad.state[2 * (blockIdx.x + 1)]; b2p = ad.state[2 * (blockIdx.x + 1) + 1];
+            if (xerr) failed = *xerr;      // a SPLIT-mode barrier of this (or an earlier) iteration failed: no update
         }
         double acc = 0.0;
         if (idx < P) {
@@ -530,7 +533,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
 #pragma unroll 8
             for (int k = 0; k < FIN_PARTS; ++k) t += red[k * FIN_COLS + c];
             RB[idx] = t;
-            if (upd) {   // adam_update with the operands fetched above (same arithmetic, same order)
+            if (upd && !failed) {   // adam_update with the operands fetched above (same arithmetic, same order)
                 const double lr_t = ad.lr * sqrt(1.0 - b2p) / (1.0 - b1p);
                 const double mi = ad.b1 * m0 + (1.0 - ad.b1) * t;
                 const double vi = ad.b2 * v0 + (1.0 - ad.b2) * t * t;
@@ -550,7 +553,8 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
     // last block: scalars.  Everything thread 0 needs at the end is requested up front (one memory round trip, not three
     // dependent ones behind the reductions)
     double s0 = 0.0, s1 = 0.0, eps_th = 0.0, eps_m = 0.0, eps_v = 0.0;
-    int hidx = -1;
+    int hidx = -1, failed = 0;
+    if (threadIdx.x == 0 && xerr) failed = *xerr;
     if (threadIdx.x == 0 && ad.theta) {
         s0 = ad.state[0]; s1 = ad.state[1];
         if (ad.hist) hidx = *ad.hist_idx;
@@ -571,7 +575,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
         const double eps_now = (has_eps && ad.theta) ? eps_th : 0.0;   // the coefficient this forward pass used
         if (has_eps && write_grad) {
             RB[P] = de;
-            if (ad.theta) {   // the trainable epsilon (P3:63): adam_update with the operands fetched above
+            if (ad.theta && !failed) {   // the trainable epsilon (P3:63): adam_update with the operands fetched above
                 const double lr_t = ad.lr * sqrt(1.0 - s1) / (1.0 - s0);
                 const double mi = ad.b1 * eps_m + (1.0 - ad.b1) * de;
                 const double vi = ad.b2 * eps_v + (1.0 - ad.b2) * de * de;
@@ -580,7 +584,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
                 ad.theta[P] = eps_th - lr_t * mi / (sqrt(vi) + ad.eps);
             }
         }
-        if (ad.theta) {
+        if (ad.theta && !failed) {
             ad.state[0] = s0 * ad.b1; ad.state[1] = s1 * ad.b2;
             if (ad.hist) {   // single-GPU training iteration: record this forward pass's loss (see AdamArgs)
                 const int i = hidx;
@@ -593,14 +597,14 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
         RB[Ptot + 0] = lv;
         RB[Ptot + 1] = lossb_weight * msq;
         RB[Ptot + 2] = msq;
-        RB[Ptot + 3] = 0.0;
+        RB[Ptot + 3] = failed ? 1.0 : 0.0;   // pad slot: the all-reduce carries a failure on any rank to every rank (k_adam)
     }
 }
 
 void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, int rows_b, const double* GPART_e,
                      int rows_e, const double* loss_e, long n_elem, const double* deps_e, const double* data_part,
                      int n_data_part, double lossb_weight, int n_data, int P, int has_eps, double* RB, int write_grad,
-                     const AdamArgs* fused_adam, hipStream_t s) {
+                     const AdamArgs* fused_adam, hipStream_t s, const int* xerr) {
     int gblocks = (P + FIN_COLS - 1) / FIN_COLS;
     AdamArgs ad{};
     if (fused_adam && write_grad) ad = *fused_adam;
@@ -609,11 +613,11 @@ void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, i
     if (fin_force == 256 || (fin_force != 1024 && rows <= 1024 && n_elem <= 4096))
         hipLaunchKernelGGL(k_finalize<256>, dim3(gblocks + 1), dim3(256), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e,
                            rows_e, loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB,
-                           write_grad, ad);
+                           write_grad, ad, xerr);
     else
         hipLaunchKernelGGL(k_finalize<1024>, dim3(gblocks + 1), dim3(1024), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e,
                            rows_e, loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB,
-                           write_grad, ad);
+                           write_grad, ad, xerr);
 }
 int adam_state_doubles(int P) { return 2 * ((P + FIN_COLS - 1) / FIN_COLS + 1); }
 
@@ -624,6 +628,13 @@ int adam_state_doubles(int P) { return 2 * ((P + FIN_COLS - 1) / FIN_COLS + 1); 
 // state = {beta1^t, beta2^t} kept as running products exactly like TF's beta*_power variables.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_adam(AdamArgs ad, const double* __restrict__ g, int P, int Ptot, int ncopies) {
+    // a failed SPLIT-mode barrier on ANY rank (pad slot of the all-reduced buffer: the sum of the ranks' flags; NaN counts) or
+    // on this one: no update, no history entry, beta powers untouched -- and this rank's flag set, so that every rank reports it
+    const bool failed = !(g[Ptot + 3] == 0.0) || (ad.xerr && *ad.xerr);
+    if (failed) {
+        if (threadIdx.x == 0 && ad.xerr) *ad.xerr = 1;
+        return;
+    }
     const double b1p = ad.state[0], b2p = ad.state[1];
     if (threadIdx.x == 0 && ad.hist) {   // multi-GPU iteration: g is the all-reduced packed buffer, the losses follow the gradient
         const int i = *ad.hist_idx;
@@ -700,6 +711,10 @@ __global__ void __launch_bounds__(1024) k_p2p_exchange(P2PArgs pp, double* __res
     __syncthreads();
     if (threadIdx.x == 0) *pp.counter = k + 1ULL;
     if (!ad.theta) return;
+    if (!(RB[Ptot + 3] == 0.0) || (ad.xerr && *ad.xerr)) {   // a SPLIT-mode barrier failed on some rank: see k_adam
+        if (threadIdx.x == 0 && ad.xerr) *ad.xerr = 1;
+        return;
+    }
     // ---- TF1 Adam on the reduced gradient (same as k_adam) ----
     const double b1p = ad.state[0], b2p = ad.state[1];
     if (threadIdx.x == 0 && ad.hist) {

@@ -743,15 +743,14 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
     if (need_store && nd.d == 2 && nd.nT1 == 2 && nd.nT2 == 0 && nd.act == HPV_ACT_TANH) {
         // barrier words of the split whole-iteration kernel (one pair per element of the largest grid this batch can hold)
         m->xsync_elems = N / 400 + 1;
-        if (hipMalloc((void**)&m->xsync, (size_t)m->xsync_elems * sizeof(unsigned long long)) == hipSuccess &&
-            hipMalloc((void**)&m->xerr, sizeof(int)) == hipSuccess) {
+        if (hipMalloc((void**)&m->xsync, (size_t)m->xsync_elems * sizeof(unsigned long long)) == hipSuccess) {
             (void)hipMemset(m->xsync, 0, (size_t)m->xsync_elems * sizeof(unsigned long long));
-            (void)hipMemset(m->xerr, 0, sizeof(int));
         } else {
             (void)hipGetLastError();
-            if (m->xsync) { (void)hipFree(m->xsync); m->xsync = nullptr; }
-            m->xerr = nullptr;
+            m->xsync = nullptr;
         }
+        const char* dbg = getenv("HPV_DEBUG_SPLIT_SKIP");
+        m->xdebug_skip = (dbg && dbg[0] == '1') ? 1 : 0;
     }
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -782,12 +781,12 @@ void hpv_mfma_destroy(HpvMfma* m) {
     if (!m) return;
     if (m->ACTS) (void)hipFree(m->ACTS);
     if (m->xsync) (void)hipFree(m->xsync);
-    if (m->xerr) (void)hipFree(m->xerr);
     delete m;
 }
 
 int hpv_mfma_grad_rows(HpvMfma* m) { return m->bwd_blocks; }
-double* hpv_mfma_activation_store(HpvMfma* m) { return m ? m->ACTS : nullptr; }   // (the timing builds park their stamps there)
+double* hpv_mfma_activation_store(HpvMfma* m) { return m ? m->ACTS : nullptr; }
+size_t hpv_mfma_activation_store_doubles(HpvMfma* m) { return m && m->ACTS ? (size_t)m->ntiles * m->L * m->ns * MF_KS * 64 : 0; }   // (the timing builds park their stamps there)
 // Workgroups per element of the fused reverse kernel: one when the shard has an element for every CU, more for the
 // small shards of a multi-GPU run (each workgroup walks 1/split of the element's 25 tiles).
 static int fused_split(HpvMfma* m, long n_elem) {

@@ -151,16 +151,50 @@ class _VPINNBase:
         return "torch" if self._coll else ("p2p" if self._p2p else ("rccl" if self._rccl else "none"))
 
     def _connect_rccl(self):
-        """In-library RCCL communicator (include/hpvpinn.h, hpv_rccl_*): rank 0 creates the unique id, every rank joins, a
-        known-answer all-reduce runs on every rank and all ranks agree on the outcome; any failure anywhere sends every
-        rank to the torch.distributed fallback."""
+        """In-library RCCL communicator (include/hpvpinn.h, hpv_rccl_*).  Every step that can fail locally is AGREED on by all
+        ranks before any rank enters the collective that follows it (a rank that has already failed would otherwise leave its
+        peers blocked inside ncclCommInitRank): (1) every rank can load librccl; (2) rank 0's ncclUniqueId reaches every
+        rank; (3) every rank joins -- bounded by wall clock (HPV_RCCL_TIMEOUT_S, default 120 s): the blocking call runs on a
+        helper thread, and a rank whose call has not returned in time votes "failed" and abandons it; (4) two known-answer
+        all-reduces give the right sums, same bound.  Any failure or timeout on any rank sends EVERY rank to the
+        torch.distributed fallback; ranks that had joined leave the communicator."""
+        import threading
+
         import torch.distributed as dist
+
+        budget = float(os.environ.get("HPV_RCCL_TIMEOUT_S", "120"))
 
         def agree(flag):
             flags = [None] * self.world
             dist.all_gather_object(flags, bool(flag))
             return all(flags)
 
+        def bounded(fn):
+            """fn() on a helper thread (ctypes releases the GIL inside the library): (finished in time, result or exception)."""
+            box = {}
+
+            def run():
+                try:
+                    box["v"] = fn()
+                except BaseException as e:  # noqa: BLE001 -- reported to the caller below
+                    box["e"] = e
+            t = threading.Thread(target=run, daemon=True)
+            t.start()
+            t.join(budget)
+            if t.is_alive():
+                return False, None
+            if "e" in box:
+                if isinstance(box["e"], _lib.HpvError):
+                    return True, box["e"]
+                raise box["e"]
+            return True, box.get("v")
+
+        try:
+            ready = bool(self.h.rccl_available())
+        except _lib.HpvError:
+            ready = False
+        if not agree(ready):
+            return False
         uid = None
         if self.rank == 0:
             try:
@@ -169,26 +203,24 @@ class _VPINNBase:
                 uid = None
         box = [uid]
         dist.broadcast_object_list(box, src=0)
-        ok = box[0] is not None
-        if ok:
-            try:
-                self.h.rccl_connect(self.world, self.rank, box[0])
-            except _lib.HpvError:
-                ok = False
+        if box[0] is None:
+            return False
+        done, res = bounded(lambda: self.h.rccl_connect(self.world, self.rank, box[0]))
+        ok = done and not isinstance(res, _lib.HpvError)
         if not agree(ok):
             if ok:
                 self.h.rccl_disconnect()
             return False
         n = self.h.reduce_buffer()[1]
         expect = self.world * (self.world + 1) / 2 + self.world * 1e-3 * np.arange(n)
-        good = True
-        try:
-            for _ in range(2):
-                good = good and np.abs(self.h.rccl_selftest(n) - expect).max() < 1e-12
-        except _lib.HpvError:
-            good = False
+
+        def selftest():
+            return all(np.abs(self.h.rccl_selftest(n) - expect).max() < 1e-12 for _ in range(2))
+        done, res = bounded(selftest)
+        good = done and res is True
         if not agree(good):
-            self.h.rccl_disconnect()
+            if done:                     # (a call that never returned still owns the communicator: leave it alone)
+                self.h.rccl_disconnect()
             return False
         return True
 

@@ -135,10 +135,12 @@ int hpv_apply_adam(hpv_handle h);
  * ncclAllReduce(sum) of the packed buffer [grad (P) | d eps | lossv | w*lossb | msq | pad] over xGMI -> TF1 Adam, all
  * enqueued on the handle's stream and captured into its iteration graphs.  After hpv_rccl_connect,
  * hpv_step / hpv_step_record / hpv_loss_and_grad are collective calls: every rank issues the same sequence.
+ *   hpv_rccl_available: local check that every rank runs (and agrees on) BEFORE anyone enters the collective calls below;
  *   hpv_rccl_unique_id: rank 0 creates the 128-byte ncclUniqueId; the caller distributes it to all ranks;
  *   hpv_rccl_connect  : ncclCommInitRank (collective);
  *   hpv_rccl_selftest : known-answer all-reduce (collective); out[i] must equal W(W+1)/2 + W*1e-3*i;
  *   hpv_exchange_in_use: 0 none (single GPU or caller-driven pieces above), 1 RCCL, 2 peer-mapped mailboxes (below). */
+int hpv_rccl_available(void);   /* 1 when librccl and its entry points can be loaded in this process (local, not collective) */
 int hpv_rccl_unique_id(hpv_handle h, void* id128);
 int hpv_rccl_connect(hpv_handle h, int world, int rank, const void* id128);
 int hpv_rccl_selftest(hpv_handle h, double* out, size_t n);
@@ -189,6 +191,9 @@ int hpv_backend_in_use(hpv_handle h);                       /* HPV_BACKEND_GENER
  * 2 element-resident whole-iteration kernel (20x20 / 10x10 Poisson-2D var_form 1), 3 the same in SPLIT mode (small shards),
  * 4 whole-iteration tile kernel (small elements of the other channel sets); -1 before the first such pass. */
 int hpv_pass_structure(hpv_handle h);
+/* 1 when hpv_step / hpv_step_record replay captured iteration hipGraphs, 0 when they launch eagerly (HPV_NO_GRAPH=1, a foreign
+ * stream, or a collective that refused stream capture -- hpv_step then drops to eager launches instead of failing). */
+int hpv_graphs_in_use(hpv_handle h);
 /* The network value and its input-derivative channels at the owned quadrature points, [C][n_owned*qx*qy]
  * (channel order: u, then d/dx, d/dy (d/dt), then the second derivatives the variational form integrates) --
  * what net_u / net_du / net_dxu / net_dyu / net_dtu return (P1:140-148, P2:171-185, P3:232-245).  One forward launch. */

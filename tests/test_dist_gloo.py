@@ -175,11 +175,14 @@ def _rccl_logic_worker(rank, world, port, q):
     from hp_vpinns_amd.vpinn import _VPINNBase
 
     class Stub(_VPINNBase):
-        def __init__(self, no_library=False, init_fails=False, wrong_answer=False):
+        def __init__(self, no_library=False, init_fails=False, wrong_answer=False, not_loadable=False, init_hangs=False):
             outer = self
             self.rank, self.world, self.log = rank, world, []
 
             class H:
+                def rccl_available(s):
+                    return not not_loadable
+
                 def rccl_unique_id(s):
                     if no_library:
                         raise _lib.HpvError("librccl.so could not be loaded")
@@ -188,6 +191,10 @@ def _rccl_logic_worker(rank, world, port, q):
                 def rccl_connect(s, w, r, uid):
                     if init_fails:
                         raise _lib.HpvError("ncclCommInitRank failed")
+                    if init_hangs:
+                        import time
+                        time.sleep(6.0)      # longer than HPV_RCCL_TIMEOUT_S below: the caller must give up on it
+                        return
                     outer.log.append(("connect", w, r, len(uid)))
 
                 def reduce_buffer(s):
@@ -201,9 +208,11 @@ def _rccl_logic_worker(rank, world, port, q):
             self.h = H()
 
     out = []
-    for kw in ({}, {"no_library": True}, {"init_fails": rank == 1}, {"wrong_answer": rank == 0}):
+    os.environ["HPV_RCCL_TIMEOUT_S"] = "1.5"
+    for kw in ({}, {"no_library": True}, {"init_fails": rank == 1}, {"wrong_answer": rank == 0}, {"not_loadable": rank == 1},
+               {"init_hangs": rank == 1}):
         m = Stub(**kw)
-        out.append((m._connect_rccl(), m.log))
+        out.append((m._connect_rccl(), list(m.log)))
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -212,8 +221,8 @@ def _rccl_logic_worker(rank, world, port, q):
 @pytest.mark.timeout(300)
 def test_in_library_rccl_setup_agrees_on_fallback():
     """The multi-GPU default: rank 0's ncclUniqueId reaches every rank, every rank joins and checks a known answer; a
-    failure on ANY rank (library missing, communicator refused, wrong sum) makes EVERY rank fall back, and ranks that had
-    joined leave the communicator."""
+    failure on ANY rank (library missing or not loadable on one rank, communicator refused or hanging, wrong sum) makes EVERY
+    rank fall back, and ranks that had joined leave the communicator."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -233,3 +242,7 @@ def test_in_library_rccl_setup_agrees_on_fallback():
         assert ok is False and log == ([("connect", 2, 0, 128), "disconnect"] if rank == 0 else [])
         ok, log = res[rank][3]
         assert ok is False and log == [("connect", 2, rank, 128), "disconnect"]
+        ok, log = res[rank][4]
+        assert ok is False and log == []        # one rank cannot load the library: agreed BEFORE anyone enters ncclCommInitRank
+        ok, log = res[rank][5]                  # one rank's ncclCommInitRank does not return: wall-clock bound, everyone falls back
+        assert ok is False and log == ([("connect", 2, 0, 128), "disconnect"] if rank == 0 else [])

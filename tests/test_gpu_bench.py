@@ -1,0 +1,61 @@
+"""bench.py as the driver runs it: a subprocess, ONE parseable JSON line on stdout.
+
+  * `python bench.py --gpus 2 ...` on a one-GPU box (HPV_BENCH_ONE_GPU=1: both ranks on cuda:0, gloo group, mailbox exchange):
+    the self-re-exec under torch.distributed.run -> N ranks -> sharded model -> timed windows -> per-rank gather -> one line
+    path that the 8-GPU SCALE run depends on (the throughput of two processes sharing a GPU is meaningless and not asserted);
+  * the driver-style single-GPU call `--steps 20 --warmup 5`: short windows must be timed 25 times after a wall-clock warm-up
+    and the line must carry `roofline` and `cpu_baseline`.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(args, extra_env=None, timeout=900):
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_self_launch_on_one_gpu():
+    out = _run_bench(["--gpus", "2", "--steps", "16", "--warmup", "8", "--l2-iters", "600"], {"HPV_BENCH_ONE_GPU": "1"})
+    assert out["n_gpus"] == 2 and out["steps"] == 16 and out["warmup"] == 8
+    assert out["metric"].startswith("variational-loss iterations/sec") and out["unit"] == "it/s" and out["value"] > 0
+    assert out["scaling"] == "strong" and out["dtype"] == "f64" and out["higher_is_better"] is True
+    cfg = out["config"]
+    assert cfg["parallelism"] == "element-sharded dp2" and len(cfg["per_rank"]) == 2
+    assert sorted(r["rank"] for r in cfg["per_rank"]) == [0, 1]
+    assert all(r["pass_structure"] in ("separate", "fused-reverse", "whole-iteration", "whole-iteration-split") for r in cfg["per_rank"])
+    assert out["timing"]["windows"] in (5, 25) and len(out["timing"]["window_it_per_s"]) == out["timing"]["windows"]
+    assert out["roofline"]["bound"] == "mfma" and out["roofline"]["frac"] > 0
+    assert "weak_scaling_probe" in out and "scaled_strong_64x64" in out and "extras_error" not in out, out.get("extras_error")
+    assert out["rel_l2_error"]["value"] < 1.5          # (600 iterations: far from converged, but finite and sane)
+
+
+def test_bench_driver_style_single_gpu_line():
+    out = _run_bench(["--steps", "20", "--warmup", "5", "--l2-iters", "2000", "--residual-elems", "16384"])
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["config"]["pass_structure"] == "whole-iteration"
+    t = out["timing"]
+    assert t["windows"] == 25 and t["untimed_warmup_iterations"] * out["ms_per_step"] * 1e-3 >= 0.2
+    assert t["min_it_per_s"] <= out["value"] <= t["max_it_per_s"]
+    assert t["max_it_per_s"] / t["min_it_per_s"] < 1.25, t         # clocks have ramped: the windows agree
+    r = out["roofline"]
+    assert r["bound"] == "mfma" and 0.2 < r["frac"] < 1.0 and r["traffic_source"]
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["windows"]) == 3
+    assert out["cpu_baseline_vectorized"]["omp"]["OMP_PROC_BIND"] == "close"
+    assert out["roofline_residual"]["bound"] == "hbm"

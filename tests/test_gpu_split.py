@@ -1,0 +1,157 @@
+"""SPLIT mode of the whole-iteration kernel (kernels_fused.hip): what one GPU of a 2 / 4 / 8-GPU run of BASELINE config 4 owns
+(128 / 64 / 32 elements), where 2 / 4 / 8 workgroups share an element and meet at a barrier in device memory.
+
+  * against the ORACLE (not against another device path): loss triple, gradient, residuals and a short TF1-Adam trajectory of
+    shards cut out of the reference-generated config-4 fixture with hpv_set_elements(e_begin, e_end) -- the shard's oracle is the
+    vectorised restatement of P2:68-129 on the same rows of the grid and of F_ext_total; the shard gradients summed = the
+    full-grid oracle's;
+  * a barrier TIMEOUT (forced with the test knob HPV_DEBUG_SPLIT_SKIP=1: one partner of element 0 stays away) must leave the
+    replica bit-identical -- parameters, Adam moments, beta powers -- raise HpvError(-7) from every entry point that runs
+    iterations, and leave the handle usable; the same through the 1-rank in-library RCCL path, where the failure travels in the
+    pad slot of the all-reduced buffer.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from cases import gold, p2_args, rel, theta0
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+TRAJ_TOL = 1e-7
+L4 = [2, 20, 20, 20, 1]
+
+
+def _shard_pair(a, th, nshard, r):
+    """(oracle on the rows of shard r, product re-sharded to [eb, ee)) -- both keep the boundary term."""
+    from hp_vpinns_amd.dist import shard_range
+    from hp_vpinns_amd.vpinn import VPINN2D
+    from oracle.vpinn_oracle import OracleVPINN2D
+    nex, ney = len(a[8]) - 1, len(a[9]) - 1
+    eb, ee = shard_range(nex * ney, r, nshard)
+    assert eb % ney == 0 and ee % ney == 0          # contiguous blocks of whole ex-rows
+    rb, re_ = eb // ney, ee // ney
+    m = VPINN2D(*a, init_params=th)
+    m.h.set_elements(a[8], a[9], eb, ee)
+    ao = list(a)
+    ao[7] = a[7][rb:re_]
+    ao[8] = a[8][rb:re_ + 1]
+    ao[10] = [a[10][0][rb:re_], a[10][1]]
+    o = OracleVPINN2D(*ao, init_params=th)
+    o.vectorized = True
+    return o, m, (ee - eb)
+
+
+@pytest.mark.parametrize("nshard", [2, 4, 8])
+def test_split_mode_shards_of_config4_against_the_oracle(nshard):
+    from oracle.vpinn_oracle import OracleVPINN2D
+    a = p2_args(gold("poisson2d_cfg4"), layers=L4)
+    th = theta0(L4, 77)
+    full = OracleVPINN2D(*a, init_params=th)
+    full.vectorized = True
+    l3_full, g_full = full.loss_and_grad()
+    g_sum, lv_sum = np.zeros_like(g_full), 0.0
+    for r in range(nshard):
+        o, m, ne = _shard_pair(a, th, nshard, r)
+        l3m, gm = m.loss_and_grad()
+        assert m.h.pass_structure() == "whole-iteration-split", m.h.pass_structure()
+        rm = m.h.residuals(ne * 100)
+        g_sum += gm
+        lv_sum += l3m[2]
+        if r in (0, nshard // 2, nshard - 1):
+            l3o, go = o.loss_and_grad()
+            assert rel(l3m, l3o) < TOL, (l3m, l3o)
+            assert rel(gm, go) < TOL, rel(gm, go)
+            assert rel(rm, o.last["R"].reshape(-1)) < TOL
+            l3b, gb = m.loss_and_grad()                  # partners project the element redundantly: bitwise reproducible
+            assert np.array_equal(gb, gm) and np.array_equal(l3b, l3m)
+        if r == nshard - 1:                              # a short trajectory of the last shard: 10 updates, loss after each
+            lo, lm = [], []
+            for _ in range(10):
+                o.adam_step()
+                lo.append(float(o.loss_parts()[0]))
+                lm.append(float(m._step(1, True)[0]))
+            assert rel(lm, lo) < TRAJ_TOL and rel(m.get_params(), o.get_params()) < TRAJ_TOL
+        del m
+    # every shard carried the boundary term (rank 0's job in a real run): remove the surplus copies before comparing
+    lb_grad = full  # noqa: F841  (documentation: g_full = grad(lossv) + grad(10 lossb))
+    ob = OracleVPINN2D(*a, init_params=th)
+    ob.vectorized = True
+    import torch
+    lossb = 10 * torch.mean(torch.square(ob.utrain - ob.net_u(ob.x, ob.y)))
+    gb_ = torch.autograd.grad(lossb, ob.theta)[0].numpy()
+    assert rel(g_sum - (nshard - 1) * gb_, g_full) < TOL
+    assert abs(lv_sum - l3_full[2]) < TOL * abs(l3_full[2])
+
+
+def _build_small_shard(seed=6, nex=16, ney=4):
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    s = poisson2d.setup(N_el_x=nex, N_el_y=ney, N_test_x=10, N_test_y=10, N_quad=20, N_bound=13, with_test_grid=False)
+    return poisson2d.build_model(s, L4, init_params=xavier_init(L4, seed))
+
+
+def test_split_barrier_timeout_leaves_the_replica_intact():
+    from hp_vpinns_amd import _lib
+    ref = _build_small_shard()
+    ref._step(24, False)
+    os.environ["HPV_DEBUG_SPLIT_SKIP"] = "1"          # read when the handle's kernels are set up
+    try:
+        m = _build_small_shard()
+    finally:
+        del os.environ["HPV_DEBUG_SPLIT_SKIP"]
+    state0 = m.h.get_state()
+    for call in (lambda: m._step(11, False), lambda: m._step(3, True), lambda: m._step_record(5), lambda: m.loss_and_grad(),
+                 lambda: m._step(1, False)):
+        with pytest.raises(_lib.HpvError, match="did not meet at their barrier"):
+            call()
+        assert m.h.pass_structure() == "whole-iteration-split"
+        assert np.array_equal(m.h.get_state(), state0), "a timed-out iteration touched the replica"
+    # forward-only evaluations never enter SPLIT mode and keep working on the untouched parameters
+    assert np.isfinite(m.loss()[0])
+    # without the knob the same shard trains, and identically to the untouched state's continuation
+    m2 = _build_small_shard()
+    m2.h.set_state(state0)
+    m2._step(24, False)
+    assert rel(m2.get_params(), ref.get_params()) < 1e-12
+
+
+def _rccl_timeout_worker(rank, port, out_path):
+    import pickle
+    import torch
+    import torch.distributed as dist
+    from hp_vpinns_amd import _lib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HPV_FORCE_DIST="1", HPV_DEBUG_SPLIT_SKIP="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    res = {}
+    try:
+        m = _build_small_shard()
+        res["exchange"] = m.exchange()
+        state0 = m.h.get_state()
+        raised = []
+        for call in (lambda: m._step(19, False), lambda: m._step_record(4), lambda: m.loss_and_grad()):
+            try:
+                call()
+                raised.append(False)
+            except _lib.HpvError as e:
+                raised.append("did not meet at their barrier" in str(e))
+            res.setdefault("intact", []).append(bool(np.array_equal(m.h.get_state(), state0)))
+        res["raised"] = raised
+        res["structure"] = m.h.pass_structure()
+    finally:
+        with open(out_path, "wb") as f:
+            pickle.dump(res, f)
+        dist.destroy_process_group()
+
+
+def test_split_barrier_timeout_through_the_in_library_rccl_path(tmp_path):
+    """forward+backward -> finalize (pad slot = this rank's flag) -> ncclAllReduce -> k_adam: the update is skipped on every rank."""
+    import pickle
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "rccl_timeout.pkl")
+    mp.spawn(_rccl_timeout_worker, args=(29547, out), nprocs=1, join=True)
+    r = pickle.load(open(out, "rb"))
+    assert r["exchange"] == "rccl" and r["structure"] == "whole-iteration-split", r
+    assert r["raised"] == [True, True, True] and r["intact"] == [True, True, True], r
