@@ -60,7 +60,8 @@ def test_2d_reference_defaults_published_error_against_eight_seeds():
     for seed in range(8):
         r = poisson2d.run(n_iter=10000 + 1, record_every=100, verbose=False, init_params=xavier_init(L, seed))
         errs.append(float(np.abs(r["setup"]["u_test"] - r["u_pred"]).max()))
-        assert r["loss_his"][-1] < 0.2 * r["loss_his"][0]
+        print("seed", seed, "loss", r["loss_his"][0], "->", r["loss_his"][-1], "max err", errs[-1])
+        assert r["loss_his"][-1] < 0.05 * r["loss_his"][0]      # (round 3, seeds 0..7: 62.5 -> 0.26 .. 1.15)
     errs_sorted = sorted(errs)
     assert errs_sorted[0] < 0.29 < errs_sorted[-1], errs               # the published figure lies inside the spread
     assert errs_sorted[2] < 0.6, errs                                  # three of eight seeds within 2x of the published 0.29
