@@ -368,9 +368,9 @@ class Handle:
         return out
 
     def pass_structure(self):
-        """'separate' | 'fused-reverse' | 'whole-iteration' | 'whole-iteration-split' | 'whole-iteration-tile' (or None)."""
+        """'separate' | 'fused-reverse' | 'whole-iteration' | 'whole-iteration-split' | 'whole-iteration-tile' | 'whole-iteration-tall' (or None)."""
         return {0: "separate", 1: "fused-reverse", 2: "whole-iteration", 3: "whole-iteration-split",
-                4: "whole-iteration-tile"}.get(int(self.lib.hpv_pass_structure(self._h)))
+                4: "whole-iteration-tile", 5: "whole-iteration-tall"}.get(int(self.lib.hpv_pass_structure(self._h)))
 
     def graphs_in_use(self):
         """hpv_step replays captured iteration graphs (False: eager launches, e.g. a collective that refused stream capture)."""

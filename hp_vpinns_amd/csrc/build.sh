@@ -6,15 +6,24 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $HPV_EXTRA_FLAGS"   # e.g. HPV_EXTRA_FLAGS=-DHPV_FZ_TIMING
 # objects are cached by mtime; a change of flags must invalidate them (.flags remembers what the objects were built with)
 if [ "$(cat .flags 2>/dev/null)" != "$FLAGS" ]; then rm -f *.o; echo "$FLAGS" > .flags; fi
-for f in kernels_generic kernels_mfma kernels_fused kernels_tile kernels_project hpv_api; do
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ hpv_internal.h -nt $f.o ] || [ hpv_mfma.h -nt $f.o ] || [ hpv_mfma_dev.h -nt $f.o ] || [ hpv_project_wg.h -nt $f.o ] || [ hpv_math.h -nt $f.o ] || [ ../../include/hpvpinn.h -nt $f.o ]; then
+for f in kernels_generic kernels_mfma kernels_fused kernels_tall kernels_tile kernels_project hpv_api; do
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ hpv_internal.h -nt $f.o ] || [ hpv_mfma.h -nt $f.o ] || [ hpv_mfma_dev.h -nt $f.o ] || [ hpv_project_wg.h -nt $f.o ] || [ hpv_math.h -nt $f.o ] || [ hpv_fused_dev.h -nt $f.o ] || [ ../../include/hpvpinn.h -nt $f.o ]; then
+    XF=""
     if [ $f = kernels_fused ]; then   # the whole-iteration kernel parks live values in AGPRs by hand: verify the compiler stays clear
-      $HIPCC $FLAGS -S --cuda-device-only $f.hip -o $f.s 2>/dev/null
+      XF="$HPV_FUSED_EXTRA"           # (A/B builds: flags for this file only, scripts/build_variant.sh --fused-only)
+      $HIPCC $FLAGS $XF -S --cuda-device-only $f.hip -o $f.s 2>/dev/null
       python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi3 106
       python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi2 156
     fi
-    $HIPCC $FLAGS -c $f.hip -o $f.o
+    if [ $f = kernels_tall ]; then    # same hand-managed AGPR stash (4 tiles x L x 5 doubles at the top of the file)
+      $HIPCC $FLAGS -S --cuda-device-only $f.hip -o $f.s 2>/dev/null
+      python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi1ELi3 136
+      python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi0ELi3 136
+      python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi1ELi2 176
+      python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi0ELi2 176
+    fi
+    $HIPCC $FLAGS $XF -c $f.hip -o $f.o
   fi
 done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libhpvpinn.so kernels_generic.o kernels_mfma.o kernels_fused.o kernels_tile.o kernels_project.o hpv_api.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libhpvpinn.so kernels_generic.o kernels_mfma.o kernels_fused.o kernels_tall.o kernels_tile.o kernels_project.o hpv_api.o
 echo "built $(cd .. && pwd)/libhpvpinn.so"

@@ -110,6 +110,8 @@ struct hpv_ctx {
     int rccl_world = 1, rccl_rank = 0;
     double* d_upart = nullptr; // partial residual sums of the row-split projection (few tall elements)
     int proj_split = 1;        // workgroups per element there; loss_e / deps_e hold n_elem * proj_split entries
+    long n_red_alloc = 0;      // entries loss_e / deps_e were allocated with (>= every launch structure's count)
+    long n_loss_entries = 0;   // entries the most recent pass wrote (what the finalize kernel sums)
     // timing
     bool timing = false;
     TimerClass timers[3];
@@ -395,6 +397,7 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
         (void)hipEventRecord(h->ev_fork, smain);
         (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
     }
+    long n_loss = (long)h->n_elem * h->proj_split;      // loss_e / deps_e entries this pass writes
     // --- variational term on this shard's quadrature batch ---
     if (h->var.N > 0) {
         MfmaDataTerm dt{h->data_off, h->merged ? h->n_data : 0, h->d_udata, h->var.GBAR, h->d_data_part,
@@ -411,6 +414,15 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
             if (!ifused) {   // small elements of the other channel sets (1-D, AdvDiff, var_form 0): kernels_tile.hip
                 ifused = hpv_mfma_iter_tile(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
                 if (ifused) h->pass_structure = 4;
+            }
+            if (!ifused) {   // few tall elements (AdvDiff, 80x80 rule): many workgroups per element, partial sums exchanged (kernels_tall.hip)
+                const int ts = hpv_mfma_tall_split(h->mfma, h->pd, h->n_elem);
+                if (ts > 1 && h->n_elem * ts <= h->n_red_alloc && h->d_upart &&
+                    hpv_mfma_iter_tall(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem, h->d_upart)) {
+                    ifused = true;
+                    h->pass_structure = 5;
+                    n_loss = h->n_elem * ts;
+                }
             }
             if (ifused) tstop(h, 2);   // (otherwise nothing was launched; the start event is re-recorded below)
         }
@@ -476,7 +488,7 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
     launch_finalize(backward && h->var.N > 0 ? h->var.GPART : nullptr, h->var.rows,
                     backward && h->n_data > 0 && !h->merged ? h->data.GPART : nullptr, h->data.rows,
                     backward && h->pd.edge && h->edge.N > 0 ? h->edge.GPART : nullptr, h->edge.rows, h->d_loss_e,
-                    (long)h->n_elem * h->proj_split, h->d_deps_e, h->d_data_part, ndp, h->cfg.lossb_weight, h->n_data, h->P, h->has_eps, h->d_RB,
+                    n_loss, h->d_deps_e, h->d_data_part, ndp, h->cfg.lossb_weight, h->n_data, h->P, h->has_eps, h->d_RB,
                     backward ? 1 : 0, (backward && fuse_adam) ? &ad : nullptr, h->stream, h->d_xerr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, -2, "kernel launch failed: %s", hipGetErrorString(e));
@@ -835,10 +847,13 @@ int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* g
     if (ne > 0 && (rc = upload(h, h->d_jac, jac.data(), jac.size()))) return rc;
     if ((rc = dalloc(h, &h->d_R, (size_t)ne * h->ntx * h->nty))) return rc;
     h->proj_split = project_row_split(h->pd, ne, h->cfg.backend == HPV_BACKEND_GENERIC);
-    const size_t nred = (size_t)ne * h->proj_split;
+    // (the tall-element kernel shares an element among up to 64 workgroups, each with its own loss / d-epsilon / partial-sum slot)
+    const bool tall = h->pd.qx == 80 && h->pd.qy == 80 && h->pd.ntx == 5 && h->pd.nty == 5 && h->cfg.backend != HPV_BACKEND_GENERIC && ne <= 128;
+    const size_t nred = (size_t)ne * std::max(h->proj_split, tall ? 64 : 1);
+    h->n_red_alloc = (long)nred;
     if ((rc = dalloc(h, &h->d_loss_e, nred))) return rc;
     if ((rc = dalloc(h, &h->d_deps_e, nred))) return rc;
-    if ((rc = dalloc(h, &h->d_upart, h->proj_split > 1 ? nred * h->ntx * h->nty : 0))) return rc;
+    if ((rc = dalloc(h, &h->d_upart, (h->proj_split > 1 || tall) ? nred * h->ntx * h->nty : 0))) return rc;
     h->Xq_host = X;
     h->batch_dirty = true;
     if (N > 0) {

@@ -41,6 +41,101 @@ __device__ __forceinline__ double hpv_tanh(double x) {
     return x != x ? x : q;                       // NaN in -> NaN out, like ocml / tf.tanh (one compare + select)
 }
 
+// The same tanh for N independent arguments, written STAGE-MAJOR: every step of the algorithm is applied to all N values before
+// the next step.  hpv_tanh is one dependent chain of ~28 fp64 operations; with one wave per SIMD (k_iter_fused) nothing else
+// issues while a dependent v_fma_f64 waits for its predecessor, and the compiler keeps inlined copies of the scalar routine
+// one after the other.  Interleaved, the N chains cover each other's latency (same arithmetic per value: bit-identical results).
+// Left alone, instruction selection and the machine scheduler re-cluster the chains (they minimise register pressure), and a
+// scheduling fence (sched_barrier) only binds the machine scheduler, which then finds the chains already clustered.  An empty
+// `asm volatile` that takes the N values of a stage as read-write operands pins the stage-major order at every level: volatile
+// asm statements keep their program order, stage k feeds pin k, pin k feeds stage k + 1.  It emits no instruction, and MFMA /
+// LDS / memory instructions that do not touch the pinned values still move freely.
+template <int N>
+__device__ __forceinline__ void hpv_pin(double (&a)[N]) {
+    static_assert(N == 5 || N == 10, "pin lists are written out for 5 and 10 values");
+    if constexpr (N == 10)
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]));
+    else
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]));
+}
+template <int N>
+__device__ __forceinline__ void hpv_tanh_n(const double (&x)[N], double (&out)[N]) {
+    double y[N], k[N], r[N], p[N], s[N], t[N], d[N], rc[N], q[N], e[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = fmin(fabs(x[i]), 32.0);
+    hpv_pin(y);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = -2.0 * y[i];
+    hpv_pin(y);
+#pragma unroll
+    for (int i = 0; i < N; ++i) k[i] = y[i] * 1.4426950408889634;
+    hpv_pin(k);
+#pragma unroll
+    for (int i = 0; i < N; ++i) k[i] = rint(k[i]);
+    hpv_pin(k);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = fma(-k[i], 6.93147180369123816490e-01, y[i]);
+    hpv_pin(r);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = fma(-k[i], 1.90821492927058770002e-10, r[i]);
+    hpv_pin(r);
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = fma(1.6059043836821613e-10, r[i], 2.08767569878681e-09);
+    hpv_pin(p);
+#define HPV_TANH_STEP(C)                  \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) p[i] = fma(p[i], r[i], C); \
+    hpv_pin(p);
+    HPV_TANH_STEP(2.505210838544172e-08)
+    HPV_TANH_STEP(2.755731922398589e-07)
+    HPV_TANH_STEP(2.7557319223985893e-06)
+    HPV_TANH_STEP(2.48015873015873e-05)
+    HPV_TANH_STEP(0.0001984126984126984)
+    HPV_TANH_STEP(0.001388888888888889)
+    HPV_TANH_STEP(0.008333333333333333)
+    HPV_TANH_STEP(0.041666666666666664)
+    HPV_TANH_STEP(0.16666666666666666)
+    HPV_TANH_STEP(0.5)
+#undef HPV_TANH_STEP
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = r[i] * r[i];
+    hpv_pin(e);
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = fma(e[i], p[i], r[i]);
+    hpv_pin(p);
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = __builtin_amdgcn_ldexp(1.0, (int)k[i]);
+    hpv_pin(s);
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = s[i] - 1.0;
+    hpv_pin(e);
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = fma(s[i], p[i], e[i]);
+    hpv_pin(t);
+#pragma unroll
+    for (int i = 0; i < N; ++i) d[i] = 2.0 + t[i];
+    hpv_pin(d);
+#pragma unroll
+    for (int i = 0; i < N; ++i) rc[i] = __builtin_amdgcn_rcp(d[i]);
+    hpv_pin(rc);
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = fma(-d[i], rc[i], 1.0);
+    hpv_pin(e);
+#pragma unroll
+    for (int i = 0; i < N; ++i) rc[i] = fma(rc[i], e[i], rc[i]);
+    hpv_pin(rc);
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = -t[i] * rc[i];
+    hpv_pin(q);
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = fma(-d[i], q[i], -t[i]);
+    hpv_pin(e);
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = fma(e[i], rc[i], q[i]);
+    hpv_pin(q);
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = x[i] != x[i] ? x[i] : copysign(q[i], x[i]);
+}
+
 // sin and cos together for the 1-D drivers' activation (P1:134; the derivative channels need the cosine).  ocml's sincos is
 // two argument reductions with a Payne-Hanek branch and ~190 instructions; this one is 4 fma of Cody-Waite reduction against
 // pi/2 split into 33 + 33 + 33 + 53 bits (k pi/2 is exact in the first product for |k| < 2^20), the two fdlibm kernel

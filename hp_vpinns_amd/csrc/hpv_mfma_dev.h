@@ -44,6 +44,7 @@ struct MfmaArgs {
     unsigned long long* xsync;
     int* xerr;            // sticky failure flag of the handle (hpv_ctx::d_xerr): set when a barrier times out; see fz_elem_barrier
     int xdebug_skip;      // test knob (HPV_DEBUG_SPLIT_SKIP=1): partner 1 of element 0 stays away from the barrier
+    double* upart;        // tall-element kernel (kernels_tall.hip): [n_elem][split][NR] partial residual sums the partners exchange
 };
 
 struct HpvMfma {

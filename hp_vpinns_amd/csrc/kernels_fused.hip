@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "hpv_mfma_dev.h"
+#include "hpv_fused_dev.h"
 
 #define FZ_WAVES 4
 #define FZ_BLOCK (FZ_WAVES * 64)
@@ -67,89 +68,6 @@ struct FzLds {
     static constexpr int total(int P) { return TR + (FZ_WAVES * TR_WAVE > FZ_WAVES * P ? FZ_WAVES * TR_WAVE : FZ_WAVES * P); }
 };
 
-// ---- explicit AGPR stash -------------------------------------------------------------------------------------------
-// At one wave per SIMD a wave owns 512 registers: 256 architectural VGPRs + 256 accumulation registers (AGPRs).  The s
-// values of the wave's tiles 1..6 (6 x L x 5 doubles per lane) are parked in the TOP AGPRs a[FZ_ABASE..255] by hand
-// (v_accvgpr_write/read through inline asm): left to the register allocator, the same values end up behind PHI copies
-// that move hundreds of registers per tile.  The compiler does not know these registers hold live values -- it only sees
-// that a255 is clobbered, which makes the kernel descriptor reserve all 256 AGPRs -- so csrc/build.sh runs
-// scripts/check_agpr.py on the generated assembly: the build FAILS if compiler-generated code touches a[FZ_ABASE..255].
-template <int IDX>
-__device__ __forceinline__ void acc_put(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    asm volatile("v_accvgpr_write_b32 a[%2], %0\n\tv_accvgpr_write_b32 a[%3], %1" ::"v"(lo), "v"(hi), "n"(IDX), "n"(IDX + 1));
-}
-template <int IDX>
-__device__ __forceinline__ double acc_get() {
-    int lo, hi;
-    asm volatile("v_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]" : "=v"(lo), "=v"(hi) : "n"(IDX), "n"(IDX + 1));
-    return __hiloint2double(hi, lo);
-}
-template <int BASE, int N, int J = 0>
-__device__ __forceinline__ void acc_put_all(const double (&sv)[N]) {
-    if constexpr (J < N) { acc_put<BASE + 2 * J>(sv[J]); acc_put_all<BASE, N, J + 1>(sv); }
-}
-template <int BASE, int N, int J = 0>
-__device__ __forceinline__ void acc_get_all(double (&sv)[N]) {
-    if constexpr (J < N) { sv[J] = acc_get<BASE + 2 * J>(); acc_get_all<BASE, N, J + 1>(sv); }
-}
-
-// hidden -> hidden product of one channel: z^T = W^T h^T (+ bias fragment for the value channel), 16 + 4 split
-template <bool BIAS>
-__device__ __forceinline__ void fz_layer(const double* WTl, const double* WRl, const double* BHl, int lofs,
-                                         const double (&h)[MF_KS], double (&z)[MF_KS]) {
-    v4d acc = BIAS ? v4d{BHl[lofs], BHl[64 + lofs], BHl[128 + lofs], BHl[192 + lofs]} : v4d{0.0, 0.0, 0.0, 0.0};
-    double z16 = BIAS ? BHl[256 + lofs] : 0.0;
-    const double* wrl = WRl + (lofs >> 4) * 4 + (lofs & 3);
-#pragma unroll
-    for (int s = 0; s < MF_KS; ++s) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(WTl[s * 64 + lofs], h[s], acc, 0, 0, 0);
-        z16 = __builtin_amdgcn_mfma_f64_4x4x4f64(wrl[s * 16], h[s], z16, 0, 0, 0);
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) z[s] = acc[s];
-    z[4] = z16;
-}
-
-// Barrier among the S workgroups that share an element (SPLIT mode: small shards of a multi-GPU run) on a per-element arrival
-// counter in device memory, in the fence-free form of cdna_hip_programming.md Guideline 16
-// (R1): the payload (the partners' u_x, u_y) is stored WRITE-THROUGH with agent-scope relaxed atomic stores and read back with
-// agent-scope relaxed atomic loads, every storing wave drains its stores (s_waitcnt vmcnt(0)) before ONE lane bumps the counter,
-// ONE lane polls the generation word relaxed.  (With an agent-scope release fence before the bump and an acquire after the
-// poll -- an L2 write-back and an L1/L2 invalidate -- the barrier cost 18.6 k cycles = 8.5 us; measured, profiles/.)
-// All S workgroups are co-resident (the grid is at most one workgroup per CU); the wait is nevertheless bounded by wall clock.
-// A failed barrier must leave the replica intact (round-2 verdict / advisor): on expiry the sticky flag *err is set and the
-// function returns false to EVERY thread of the workgroup, which then leaves the kernel before phase P / R write R, loss_e or
-// its gradient row; k_finalize / k_adam / k_p2p_exchange read the flag (directly and, on the multi-GPU path, through the pad
-// slot of the all-reduced buffer) and skip the update, the loss history and the beta powers; every later launch of the handle
-// sees the flag at its barrier (`sticky`, requested at kernel start) and returns without arriving, until the host has reported
-// the failure (HpvError -7), cleared the flag and reset the arrival counters.  `skip`: test knob, the workgroup stays away.
-__device__ __forceinline__ bool fz_elem_barrier(unsigned long long* cnt, int S, int* err, int tid, int sticky, bool skip, double* flag_lds) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        int bad = sticky;
-        if (!bad && !skip) {
-            // ONE monotonic arrival counter per element (never reset: launch k takes it from k S to (k + 1) S), so that the arrival
-            // itself tells every workgroup its target and the last arriver needs no second round trip to announce completion
-            const unsigned long long a = __hip_atomic_fetch_add(cnt, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long target = (a / (unsigned long long)S + 1ULL) * (unsigned long long)S;
-            if (a + 1ULL != target) {
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ULL) { bad = 1; break; }    // 0.2 s at 100 MHz
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            if (bad) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        *flag_lds = (bad || skip) ? 1.0 : 0.0;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    return *flag_lds == 0.0;
-}
-
 // SPLIT: an element is shared by g.proj_split (2, 4 or 8) workgroups -- the shards of a multi-GPU run are too small to fill the
 // chip with one workgroup per element.  Workgroup (e, part) walks the tiles [25 part / S, 25 (part + 1) / S) of element e,
 // publishes their u_x, u_y through the global channel buffer, meets its S - 1 partners at fz_elem_barrier, then EVERY partner
@@ -168,9 +86,6 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     const int part = SPLIT ? (int)(blockIdx.x & (split - 1)) : 0;
     const double* __restrict__ th = g.theta;
     const ProjArgs& pa = g.pa;
-    // SPLIT: has a barrier of an earlier launch of this handle failed?  (requested now, consumed at the barrier)
-    int xsticky = 0;
-    if constexpr (SPLIT) xsticky = __hip_atomic_load(g.xerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef HPV_FZ_TIMING
     long long fz_t[8];
     const long long fz_start = clock64(), fz_wall = wall_clock64();
@@ -248,6 +163,10 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         }
     }
     const double bo = th[g.boff[L]];
+    // SPLIT: has a barrier of an EARLIER launch of this handle failed?  A plain load (kernel boundaries make those stores
+    // visible) requested behind the staging loads and consumed at the barrier
+    int xsticky = 0;
+    if constexpr (SPLIT) xsticky = *g.xerr;
     // the element's projection constants, requested now so that no global latency sits inside phase P
     const double pc0 = pa.coef[e], pc1 = pa.coef[pa.coef_stride + e];
     const double pF = (pa.F && tid < FZ_NR) ? pa.F[e * FZ_NR + tid] : 0.0;
@@ -337,6 +256,53 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         int lofs = lane;
         asm volatile("" : "+v"(lofs));       // opaque: the LDS fragment reads stay inside the loop
         double h[NT][FZ_C][MF_KS], sv[NT][NSV];
+#ifdef HPV_TANH_VEC
+        // the activations of a layer -- NT x 5 independent values per lane -- go through ONE stage-major tanh (hpv_tanh_n): their
+        // dependent chains interleave instead of running one after the other
+        {   // layer 1 (VALU)
+            double w0[MF_KS], w1[MF_KS], zz[NT * MF_KS], aa[NT * MF_KS];
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                w0[s] = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs]; w1[s] = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
+                const double b1v = lds[M::W1O + (3 * MF_KS + s) * 64 + lofs];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) zz[t * MF_KS + s] = b1v + xx[t][0] * w0[s] + xx[t][1] * w1[s];
+            }
+            hpv_tanh_n<NT * MF_KS>(zz, aa);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+                    const double a = aa[t * MF_KS + s], a1 = 1.0 - a * a;
+                    sv[t][s] = a;
+                    h[t][0][s] = a; h[t][1][s] = a1 * w0[s]; h[t][2][s] = a1 * w1[s];
+                }
+        }
+#pragma unroll
+        for (int i = 1; i < L; ++i) {
+            double z[NT][FZ_C][MF_KS];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                fz_layer<true>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, lds + M::BH + (i - 1) * MF_KS * 64, lofs, h[t][0], z[t][0]);
+                fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[t][1], z[t][1]);
+                fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[t][2], z[t][2]);
+            }
+            double zz[NT * MF_KS], aa[NT * MF_KS];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) zz[t * MF_KS + s] = z[t][0][s];
+            hpv_tanh_n<NT * MF_KS>(zz, aa);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+                    const double a = aa[t * MF_KS + s], a1 = 1.0 - a * a;
+                    sv[t][i * MF_KS + s] = a;
+                    h[t][0][s] = a; h[t][1][s] = a1 * z[t][1][s]; h[t][2][s] = a1 * z[t][2][s];
+                }
+        }
+#else
         // layer 1 (VALU)
 #pragma unroll
         for (int s = 0; s < MF_KS; ++s) {
@@ -370,6 +336,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                     h[t][0][s] = a; h[t][1][s] = a1 * z[t][1][s]; h[t][2][s] = a1 * z[t][2][s];
                 }
         }
+#endif
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int k = k0 + t;

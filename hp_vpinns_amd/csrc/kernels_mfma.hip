@@ -740,8 +740,8 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
         if (hipMalloc((void**)&m->ACTS, bytes) != hipSuccess) { delete m; return no("hipMalloc of the activation store failed"); }
         (void)hipMemset(m->ACTS, 0, bytes);
     }
-    if (need_store && nd.d == 2 && nd.nT1 == 2 && nd.nT2 == 0 && nd.act == HPV_ACT_TANH) {
-        // barrier words of the split whole-iteration kernel (one pair per element of the largest grid this batch can hold)
+    if (need_store && nd.d == 2 && nd.nT1 == 2 && nd.nT2 <= 1 && nd.act == HPV_ACT_TANH) {
+        // barrier words of the split whole-iteration kernels (one per element of the largest grid this batch can hold)
         m->xsync_elems = N / 400 + 1;
         if (hipMalloc((void**)&m->xsync, (size_t)m->xsync_elems * sizeof(unsigned long long)) == hipSuccess) {
             (void)hipMemset(m->xsync, 0, (size_t)m->xsync_elems * sizeof(unsigned long long));
@@ -800,6 +800,7 @@ int hpv_mfma_max_rows(HpvMfma* m, long n_elem) {
     const long fused_rows = n_elem * fused_split(m, n_elem);
     if (m->bwd_fused && fused_rows > r && fused_rows <= 65536) r = (int)fused_rows;
     if (n_elem > r && n_elem <= 65536) r = (int)n_elem;      // the whole-iteration kernel writes one row per element
+    if (n_elem * 64 > r && n_elem * 64 <= m->n_cus) r = (int)(n_elem * 64);   // tall-element kernel: up to 64 workgroups per element
     // kernels_tile.hip: one row per element plus one per 6..8 boundary/data tiles that the elements' free waves do not take
     if (m->ntiles <= 8192 && n_elem + m->ntiles / 6 + 1 > r) r = (int)(n_elem + m->ntiles / 6 + 1);
     m->max_rows = r;

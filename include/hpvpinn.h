@@ -189,7 +189,8 @@ int hpv_backend_in_use(hpv_handle h);                       /* HPV_BACKEND_GENER
 /* Launch structure of the most recent reverse-mode pass over the quadrature batch (tests assert that the kernel they mean to
  * exercise is the one that ran): 0 separate forward / projection / reverse launches, 1 forward + projection-fused reverse,
  * 2 element-resident whole-iteration kernel (20x20 / 10x10 Poisson-2D var_form 1), 3 the same in SPLIT mode (small shards),
- * 4 whole-iteration tile kernel (small elements of the other channel sets); -1 before the first such pass. */
+ * 4 whole-iteration tile kernel (small elements of the other channel sets), 5 whole-iteration kernel for few tall elements
+ * (80x80 points: many workgroups per element exchange partial residual sums); -1 before the first such pass. */
 int hpv_pass_structure(hpv_handle h);
 /* 1 when hpv_step / hpv_step_record replay captured iteration hipGraphs, 0 when they launch eagerly (HPV_NO_GRAPH=1, a foreign
  * stream, or a collective that refused stream capture -- hpv_step then drops to eager launches instead of failing). */

@@ -6,6 +6,27 @@ from hp_vpinns_amd.drivers import poisson2d
 from hp_vpinns_amd.init import xavier_init
 LAYERS = [2, 20, 20, 20, 1]
 mode = sys.argv[1] if len(sys.argv) > 1 else "4"
+if mode == "c5":     # k_iter_tall (kernels_tall.hip): BASELINE config 5, 8 elements x 80x80 points, 32 workgroups per element
+    from hp_vpinns_amd.drivers import advdiff
+    s = advdiff.setup(N_el_x=8, N_quad=80, with_test_grid=False)
+    m = advdiff.build_model(s, LAYERS, init_params=xavier_init(LAYERS, 1234, extra=[1.0]))
+    m.h.step(50, False)
+    out = np.empty(256 * 4 * 12)
+    m.h.lib.hpv_debug_read_out.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t]
+    m.h.lib.hpv_debug_read_out(m.h._h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size)
+    t = out.reshape(256, 4, 12)
+    names = ["staging", "forward", "wait", "partial-proj", "barrier", "residual+adjoint", "reverse", "wait", "epilogue", "total-us", "tiles"]
+    for nt in (3.0, 4.0):
+        sel = t[:, :, 10] == nt
+        print("waves with %d tiles (%d):" % (nt, sel.sum()), {n: round(float(t[:, :, i][sel].mean()), 1) for i, n in enumerate(names)})
+    b4 = t[:, :, 4][t[:, :, 10] == 4.0]
+    print("barrier phase of the 4-tile waves: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f" % (b4.min(), np.percentile(b4, 10), np.median(b4), np.percentile(b4, 90), b4.max()))
+    wg4 = (t[:, :, 10] == 4.0).any(axis=1)
+    fw = t[:, :, 1].max(axis=1)
+    print("forward phase (max over waves) of workgroups with a 4-tile wave: min %.0f median %.0f max %.0f; staging min %.0f median %.0f max %.0f"
+          % (fw[wg4].min(), np.median(fw[wg4]), fw[wg4].max(), t[:, 0, 0].min(), np.median(t[:, 0, 0]), t[:, 0, 0].max()))
+    print("structure", m.h.pass_structure())
+    sys.exit(0)
 small = mode == "3"        # config 3 (k_iter_small: 64 workgroups of 8 waves) instead of config 4
 shard = int(mode[1:]) if mode.startswith("s") else 1     # "s8": the 32-element shard one of 8 GPUs owns (split kernel)
 if mode.startswith("t"):   # k_iter_tile (kernels_tile.hip): t1 / t2 = Poisson-1D with 1 / 16 elements, t5b = AdvDiff 8 elements, 10x10 rule

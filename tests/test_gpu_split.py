@@ -155,3 +155,89 @@ def test_split_barrier_timeout_through_the_in_library_rccl_path(tmp_path):
     r = pickle.load(open(out, "rb"))
     assert r["exchange"] == "rccl" and r["structure"] == "whole-iteration-split", r
     assert r["raised"] == [True, True, True] and r["intact"] == [True, True, True], r
+
+
+# ---- few tall elements (BASELINE config 5: AdvDiff, 8 elements x 80x80 points): kernels_tall.hip ----
+@pytest.mark.parametrize("vf,nhid", [(0, 3), (1, 3), (0, 2), (1, 2)])
+def test_tall_element_kernel_against_the_oracle_and_the_separate_launches(vf, nhid):
+    """80x80-point elements split over 32 workgroups each (partial residual sums exchanged in device memory, one barrier per
+    element): loss triple, gradient incl. d/d epsilon, residuals against the ORACLE; bit-reproducible; trajectory and epsilon
+    against the separate launches (HPV_FUSE=n) and the oracle."""
+    from cases import p3_args
+    from hp_vpinns_amd.vpinn import VPINNAdvDiff
+    from oracle.vpinn_oracle import OracleVPINNAdvDiff
+    L = [2] + [20] * nhid + [1]
+    a = p3_args(gold("advdiff_cfg5"), layers=L)
+    th = theta0(L, 23, extra=[0.6])
+    o = OracleVPINNAdvDiff(*a, var_form=vf, init_params=th)
+    o.vectorized = True
+    m = VPINNAdvDiff(*a, var_form=vf, init_params=th)
+    l3o, go = o.loss_and_grad()
+    l3m, gm = m.loss_and_grad()
+    assert m.h.pass_structure() == "whole-iteration-tall", m.h.pass_structure()
+    assert rel(l3m, l3o) < TOL and rel(gm, go) < TOL, (l3m, l3o, rel(gm, go))
+    assert abs(gm[-1] - go[-1]) < TOL * max(abs(go[-1]), 1e-12)              # d loss / d epsilon
+    assert rel(m.h.residuals(8 * 25), o.last["R"].reshape(-1)) < TOL
+    l3b, gb = m.loss_and_grad()
+    assert np.array_equal(gb, gm) and np.array_equal(l3b, l3m)
+    os.environ["HPV_FUSE"] = "n"
+    try:
+        m2 = VPINNAdvDiff(*a, var_form=vf, init_params=th)
+        l3s, gs = m2.loss_and_grad()
+        assert m2.h.pass_structure() == "separate"
+        m2._step(30, False)
+    finally:
+        del os.environ["HPV_FUSE"]
+    assert rel(gm, gs) < 1e-11 and rel(l3m, l3s) < 1e-12
+    m._step(30, False)
+    assert rel(m.get_params(), m2.get_params()) < 1e-9
+    lo, lm = [], []
+    o2 = OracleVPINNAdvDiff(*a, var_form=vf, init_params=th)
+    o2.vectorized = True
+    m3 = VPINNAdvDiff(*a, var_form=vf, init_params=th)
+    for _ in range(8):
+        o2.adam_step()
+        lo.append(float(o2.loss_parts()[0]))
+        lm.append(float(m3._step(1, True)[0]))
+    assert rel(lm, lo) < TRAJ_TOL and rel(m3.get_params(), o2.get_params()) < TRAJ_TOL
+
+
+def test_tall_element_kernel_on_shards_and_its_barrier_timeout():
+    """Shards of config 5 (4 / 1 of its 8 elements: what a GPU of a 2 / 8-GPU run owns) run the same kernel with 64 workgroups
+    per element; the shard gradients add up to the full-grid model's.  A partner that stays away (HPV_DEBUG_SPLIT_SKIP=1) must
+    leave the replica bit-identical and raise."""
+    from cases import p3_args
+    from hp_vpinns_amd import _lib
+    from hp_vpinns_amd.dist import shard_range
+    from hp_vpinns_amd.vpinn import VPINNAdvDiff
+    L = [2, 20, 20, 20, 1]
+    a = p3_args(gold("advdiff_cfg5"), layers=L)
+    th = theta0(L, 29, extra=[0.9])
+    full = VPINNAdvDiff(*a, init_params=th)
+    l3f, gf = full.loss_and_grad()
+    nodata = VPINNAdvDiff(*a, init_params=th)
+    nodata.h.set_data(None, None)
+    l3n, gn = nodata.loss_and_grad()                     # variational term only
+    gb_ = gf - gn                                        # gradient of the boundary / data term
+    for nshard in (2, 8):
+        g_sum, lv = np.zeros_like(gf), 0.0
+        for r in range(nshard):
+            m = VPINNAdvDiff(*a, init_params=th)
+            eb, ee = shard_range(8, r, nshard)
+            m.h.set_elements(a[7], a[8], eb, ee)
+            l3, g = m.loss_and_grad()
+            assert m.h.pass_structure() == "whole-iteration-tall"
+            g_sum += g
+            lv += l3[2]
+            del m
+        assert rel(g_sum - (nshard - 1) * gb_, gf) < 1e-11 and abs(lv - l3f[2]) < 1e-12 * abs(l3f[2])
+    os.environ["HPV_DEBUG_SPLIT_SKIP"] = "1"
+    try:
+        m = VPINNAdvDiff(*a, init_params=th)
+    finally:
+        del os.environ["HPV_DEBUG_SPLIT_SKIP"]
+    state0 = m.h.get_state()
+    for call in (lambda: m._step(9, False), lambda: m._step_record(3), lambda: m.loss_and_grad()):
+        with pytest.raises(_lib.HpvError, match="did not meet at their barrier"):
+            call()
+        assert np.array_equal(m.h.get_state(), state0)
