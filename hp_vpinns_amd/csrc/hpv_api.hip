@@ -398,6 +398,7 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
         (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
     }
     long n_loss = (long)h->n_elem * h->proj_split;      // loss_e / deps_e entries this pass writes
+    bool fin_done = false;                              // the whole-iteration tile kernel ran the finalize step itself
     // --- variational term on this shard's quadrature batch ---
     if (h->var.N > 0) {
         MfmaDataTerm dt{h->data_off, h->merged ? h->n_data : 0, h->d_udata, h->var.GBAR, h->d_data_part,
@@ -412,7 +413,12 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
             ifused = hpv_mfma_iter_fused(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
             if (ifused) h->pass_structure = hpv_mfma_sync_failed_possible(h->mfma) ? 3 : 2;
             if (!ifused) {   // small elements of the other channel sets (1-D, AdvDiff, var_form 0): kernels_tile.hip
-                ifused = hpv_mfma_iter_tile(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
+                // (a one-workgroup grid finishes the iteration itself: packed buffer, Adam, loss history)
+                MfmaFinalize fin{adam_args(h), h->d_RB, h->cfg.lossb_weight, h->n_data, (h->n_data + 15) / 16, h->has_eps,
+                                 adam_state_doubles(h->P) / 2};
+                if (!fuse_adam) fin.ad.theta = nullptr;
+                ifused = hpv_mfma_iter_tile(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem,
+                                            h->merged ? &fin : nullptr, &fin_done);
                 if (ifused) h->pass_structure = 4;
             }
             if (!ifused) {   // few tall elements (AdvDiff, 80x80 rule): many workgroups per element, partial sums exchanged (kernels_tall.hip)
@@ -485,6 +491,7 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
         (void)hipStreamWaitEvent(smain, h->ev_join, 0);
     }
     const AdamArgs ad = adam_args(h);
+    if (!fin_done)
     launch_finalize(backward && h->var.N > 0 ? h->var.GPART : nullptr, h->var.rows,
                     backward && h->n_data > 0 && !h->merged ? h->data.GPART : nullptr, h->data.rows,
                     backward && h->pd.edge && h->edge.N > 0 ? h->edge.GPART : nullptr, h->edge.rows, h->d_loss_e,

@@ -34,8 +34,17 @@ bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, c
 bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
                          const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem);
 // The same for small elements of any channel set (kernels_tile.hip): one tile per wave, the tile's saved state in registers.
+// fin (optional): everything the finalize step needs; when the grid is ONE workgroup the kernel runs it itself and *fin_done
+// is set (the caller then skips k_finalize).
+struct MfmaFinalize {
+    AdamArgs ad;          // ad.theta == nullptr: packed buffer only
+    double* RB;
+    double lossb_weight;
+    int n_data, n_data_part, has_eps, ncopies;
+};
 bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
-                        const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem);
+                        const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem, const MfmaFinalize* fin = nullptr,
+                        bool* fin_done = nullptr);
 // SPLIT mode of the whole-iteration kernel: the handle's sticky failure flag (device int, owned by the caller) that a timed-out
 // element barrier sets; without one the SPLIT mode is not used.  hpv_mfma_split_used: a SPLIT launch happened since creation;
 // hpv_mfma_reset_sync: zero the arrival counters (after a failure has been reported).

@@ -45,6 +45,13 @@ struct MfmaArgs {
     int* xerr;            // sticky failure flag of the handle (hpv_ctx::d_xerr): set when a barrier times out; see fz_elem_barrier
     int xdebug_skip;      // test knob (HPV_DEBUG_SPLIT_SKIP=1): partner 1 of element 0 stays away from the barrier
     double* upart;        // tall-element kernel (kernels_tall.hip): [n_elem][split][NR] partial residual sums the partners exchange
+    // single-workgroup grids (the reference's own 1-element 1-D default, BASELINE config 1): the whole-iteration tile kernel
+    // finishes the iteration itself -- packed buffer, TF1 Adam, loss history -- instead of a dependent k_finalize launch
+    int fin_mode;         // 0: k_finalize follows; 1: packed buffer only; 2: packed buffer + Adam update
+    AdamArgs fin_ad;
+    double* fin_RB;       // [grad (P) | d eps | lossv | w*lossb | msq | pad]
+    double fin_lossb_weight;
+    int fin_n_data, fin_n_data_part, fin_has_eps, fin_ncopies;
 };
 
 struct HpvMfma {

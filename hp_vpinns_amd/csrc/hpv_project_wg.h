@@ -8,6 +8,13 @@ __device__ __forceinline__ double pj_wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Workgroup barrier for LDS hand-offs that leaves global loads IN FLIGHT: __syncthreads() waits for the whole vector-memory
+// queue (s_waitcnt vmcnt(0)), which puts the round trip of every load requested ahead of it -- the projection tables the
+// whole-iteration kernels request early and park late -- in front of the barrier (cdna_hip_programming.md section 5:
+// "raw s_barrier + lgkmcnt(0) only").  The "memory" clobber keeps the compiler from moving LDS accesses across it.
+__device__ __forceinline__ void pj_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __device__ __forceinline__ void pj_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -56,9 +63,11 @@ struct ProjTableRegs {
     static constexpr int NR = NTX * NTY, ITR = (NR + PW_BLOCK - 1) / PW_BLOCK;
     static constexpr int AXLD = QX + 1;          // padded rows: the x-contraction reads 16 different rows per wave
     double ax[HPV_MAXT][ITX], by[HPV_MAXT][ITY], fr[ITR], sc4;
+    int nterms_loaded = HPV_MAXT;
     // besides the tables: -F of the element (the initial value of U) and, lane t < 4 of the block, one of the four scalars
     // {coef[0][e], coef[1][e], epsilon, active test count}
     __device__ __forceinline__ void load(const ProjArgs& pa, long e) {
+        nterms_loaded = pa.pd.nterms;
 #pragma unroll
         for (int t = 0; t < HPV_MAXT; ++t) {
             const bool on = t < pa.pd.nterms;           // (workgroup-uniform: an unused term costs no loads)
@@ -92,6 +101,7 @@ struct ProjTableRegs {
         double* red = U + NR + HPV_MAXT * NTY * QX;
 #pragma unroll
         for (int t = 0; t < HPV_MAXT; ++t) {
+            if (t >= nterms_loaded) break;      // (workgroup-uniform: the tables of an unused term are never read either)
 #pragma unroll
             for (int it = 0; it < ITX; ++it) {
                 const int i = it * PW_BLOCK + (int)threadIdx.x;

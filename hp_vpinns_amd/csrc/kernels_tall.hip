@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
     for (int t = 0; t < HPV_MAXT; ++t)
         cterm[t] = t < pd.nterms ? pa.coef[(long)t * pa.coef_stride + e] * (pd.t[t].eps_mult ? eps : 1.0) : 0.0;
     const double pF = (pa.F && tid < NR) ? pa.F[e * NR + tid] : 0.0;
-    __syncthreads();
+    pj_lds_barrier();        // the weight fragments are in LDS; tables, sticky flag and the element's scalars stay in flight
     TA_STAMP(1);
 
     // ---- tile list of this wave: element tiles tbase + wv, + 4, ..; possibly one boundary/data tile behind the elements ----

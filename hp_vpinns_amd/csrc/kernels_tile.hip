@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
     }
 
     const double bo = th[g.boff[L]];
-    __syncthreads();
+    pj_lds_barrier();        // the weight fragments are in LDS; the table loads (ptab) and bo stay in flight behind it
     TL_STAMP(1);
 
     const double* WT = lds + M::WT;
@@ -443,11 +443,90 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
     __syncthreads();
     TL_STAMP(6);
     const double* W0 = lds + M::RA;
-    double* row = g.GPART + (long)blockIdx.x * g.P;
-    for (int idx = tid; idx < g.P; idx += BT) {
-        double acc = 0.0;
-        for (int w = 0; w < n_act; ++w) acc += W0[(long)w * g.P + idx];
-        row[idx] = acc;
+    if (g.fin_mode == 0) {
+        double* row = g.GPART + (long)blockIdx.x * g.P;
+        for (int idx = tid; idx < g.P; idx += BT) {
+            double acc = 0.0;
+            for (int w = 0; w < n_act; ++w) acc += W0[(long)w * g.P + idx];
+            row[idx] = acc;
+        }
+    } else {
+        // ONE workgroup is the whole grid: its row IS the gradient -- write the packed buffer, apply the TF1 Adam rule and record
+        // the loss here (k_finalize's arithmetic, kernels_generic.hip), no dependent launch
+        const AdamArgs& ad = g.fin_ad;
+        const bool upd = g.fin_mode == 2;
+        const int P = g.P, Ptot = P + (g.fin_has_eps ? 1 : 0);
+        const double b1p = upd ? ad.state[0] : 0.0, b2p = upd ? ad.state[1] : 0.0;
+        const double lr_t = upd ? ad.lr * sqrt(1.0 - b2p) / (1.0 - b1p) : 0.0;
+        // (every operand of the update is requested before the first sum: one memory round trip, not one per 384 parameters)
+        constexpr int FIT = (1341 + BT - 1) / BT;      // P <= 1341 for the networks this path takes (L <= 4)
+        double m0[FIT], v0[FIT], th0[FIT];
+#pragma unroll
+        for (int it = 0; it < FIT; ++it) {
+            const int idx = it * BT + tid, ic = idx < P ? idx : 0;
+            m0[it] = upd ? ad.m[ic] : 0.0; v0[it] = upd ? ad.v[ic] : 0.0; th0[it] = upd ? ad.theta[ic] : 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < FIT; ++it) {
+            const int idx = it * BT + tid;
+            if (idx < P) {
+                double t = 0.0;
+                for (int w = 0; w < n_act; ++w) t += W0[(long)w * P + idx];
+                g.fin_RB[idx] = t;
+                if (upd) {
+                    const double mi = ad.b1 * m0[it] + (1.0 - ad.b1) * t;
+                    const double vi = ad.b2 * v0[it] + (1.0 - ad.b2) * t * t;
+                    ad.m[idx] = mi;
+                    ad.v[idx] = vi;
+                    ad.theta[idx] = th0[it] - lr_t * mi / (sqrt(vi) + ad.eps);
+                }
+            }
+        }
+        for (int idx = FIT * BT + tid; idx < P; idx += BT) {      // (wider networks than expected: plain loop)
+            double t = 0.0;
+            for (int w = 0; w < n_act; ++w) t += W0[(long)w * P + idx];
+            g.fin_RB[idx] = t;
+            if (upd) {
+                const double mi = ad.b1 * ad.m[idx] + (1.0 - ad.b1) * t;
+                const double vi = ad.b2 * ad.v[idx] + (1.0 - ad.b2) * t * t;
+                ad.m[idx] = mi;
+                ad.v[idx] = vi;
+                ad.theta[idx] = ad.theta[idx] - lr_t * mi / (sqrt(vi) + ad.eps);
+            }
+        }
+        if (tid == 0) {      // the scalars: loss_e / deps_e of the one element were written by this thread (project_element_wg)
+            const double lv = pa.loss_e[0];
+            const double de = (g.fin_has_eps && pa.deps_e) ? pa.deps_e[0] : 0.0;
+            double sq = 0.0;
+            for (int i = 0; i < g.fin_n_data_part; ++i) sq += g.data_part[i];     // (written before the barrier above, this CU)
+            const double msq = g.fin_n_data > 0 ? sq / (double)g.fin_n_data : 0.0;
+            const double eps_now = (g.fin_has_eps && upd) ? ad.theta[P] : 0.0;
+            if (g.fin_has_eps) {
+                g.fin_RB[P] = de;
+                if (upd) {
+                    const double mi = ad.b1 * ad.m[P] + (1.0 - ad.b1) * de;
+                    const double vi = ad.b2 * ad.v[P] + (1.0 - ad.b2) * de * de;
+                    ad.m[P] = mi;
+                    ad.v[P] = vi;
+                    ad.theta[P] = eps_now - lr_t * mi / (sqrt(vi) + ad.eps);
+                }
+            }
+            if (upd && ad.hist) {
+                const int i = *ad.hist_idx;
+                if (i >= 0 && i < ad.hist_cap) {
+                    ad.hist[4 * i] = lv; ad.hist[4 * i + 1] = g.fin_lossb_weight * msq; ad.hist[4 * i + 2] = msq; ad.hist[4 * i + 3] = eps_now;
+                    *ad.hist_idx = i + 1;
+                }
+            }
+            g.fin_RB[Ptot + 0] = lv;
+            g.fin_RB[Ptot + 1] = g.fin_lossb_weight * msq;
+            g.fin_RB[Ptot + 2] = msq;
+            g.fin_RB[Ptot + 3] = 0.0;
+        }
+        if (upd) {           // every replicated copy of the running beta powers advances (k_finalize keeps one per block, k_adam all)
+            __syncthreads();                       // (all reads of state[0..1] above are done)
+            for (int c = tid; c < g.fin_ncopies; c += BT) { ad.state[2 * c] = b1p * ad.b1; ad.state[2 * c + 1] = b2p * ad.b2; }
+        }
     }
 #ifdef HPV_FZ_TIMING
     if (lane == 0 && g.ACTS) {
@@ -503,7 +582,8 @@ static bool launch_iter_tile_L(int L, const MfmaArgs& a, int blocks, hipStream_t
 // element shape / channel set / layout is not covered; the caller then runs the separate kernels.
 #define TL_WHY(K) do { static const bool dbg_ = getenv("HPV_TILE_DEBUG") != nullptr; if (dbg_) fprintf(stderr, "hpv_mfma_iter_tile: not applicable (check %d)\n", K); } while (0)
 bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
-                        const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem) {
+                        const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem, const MfmaFinalize* fin, bool* fin_done) {
+    if (fin_done) *fin_done = false;
     const ProjDesc& pd = pa.pd;
     const NetDesc& nd = m->nd;
     if (!m->iter_fused_ok || pd.edge || n_elem <= 0 || m->L < 2 || m->L > 4) { TL_WHY(1); return false; }
@@ -532,6 +612,14 @@ bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double
     a.proj_n_elem = n_elem;
     a.proj_split = 1;
     a.pa = pa;
+    const bool fin_off = getenv("HPV_NO_INKERNEL_FINALIZE") != nullptr;            // (A/B switch, read per launch / capture)
+    const bool fin_here = fin && blocks == 1 && n_elem == 1 && !fin_off;
+    a.fin_mode = 0;
+    if (fin_here) {
+        a.fin_mode = fin->ad.theta ? 2 : 1;
+        a.fin_ad = fin->ad; a.fin_RB = fin->RB; a.fin_lossb_weight = fin->lossb_weight;
+        a.fin_n_data = fin->n_data; a.fin_n_data_part = fin->n_data_part; a.fin_has_eps = fin->has_eps; a.fin_ncopies = fin->ncopies;
+    }
     bool ok = false;
     if (shape1d) {
         if (key == 111) ok = launch_iter_tile_L<1, 1, 1, HPV_ACT_SIN, 80, 1, 60, 1, 6, 4>(m->L, a, (int)blocks, s);
@@ -543,5 +631,6 @@ bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double
         else ok = launch_iter_tile_L<2, 2, 0, HPV_ACT_TANH, 10, 10, 5, 5, 8, 3>(m->L, a, (int)blocks, s);
     }
     if (ok && rows) *rows = (int)blocks;
+    if (ok && fin_done) *fin_done = fin_here;
     return ok;
 }

@@ -1115,3 +1115,38 @@ def test_active_test_counts_argument_checks_and_reset():
     m2 = poisson2d.build_model(s2, [2, 20, 20, 1], init_params=xavier_init([2, 20, 20, 1], 2))
     with pytest.raises(_lib.HpvError):
         m2.h.set_active_tests([5, 5, 5, 5])
+
+
+def test_single_workgroup_grid_finishes_the_iteration_in_the_kernel():
+    """BASELINE config 1 (one 1-D element = ONE workgroup): the whole-iteration tile kernel writes the packed buffer, applies TF1
+    Adam and records the loss itself; against the same kernel followed by k_finalize (HPV_NO_INKERNEL_FINALIZE=1): loss triple,
+    gradient bit for bit (the same reduction); 25-step trajectory, per-iteration loss history and Adam state to round-off (two
+    compilations of the same update expression may contract their multiply-adds differently); and against the oracle."""
+    import os
+    from hp_vpinns_amd.vpinn import VPINN1D
+    from oracle.vpinn_oracle import OracleVPINN1D
+    a = p1_args(gold("poisson1d_cfg1"), layers=[1, 20, 20, 20, 1])
+    th = theta0(a[8], 41)
+    th[20:40] = 0.03 * np.arange(20)
+    m = VPINN1D(*a, init_params=th)
+    l3, g = m.loss_and_grad()
+    assert m.h.pass_structure() == "whole-iteration-tile"
+    hist = m._step_record(25)[0]
+    st = m.h.get_state()
+    os.environ["HPV_NO_INKERNEL_FINALIZE"] = "1"
+    try:
+        m2 = VPINN1D(*a, init_params=th)
+        l3b, gb = m2.loss_and_grad()
+        hist2 = m2._step_record(25)[0]
+        st2 = m2.h.get_state()
+    finally:
+        del os.environ["HPV_NO_INKERNEL_FINALIZE"]
+    assert np.array_equal(l3, l3b) and np.array_equal(g, gb)
+    assert rel(hist, hist2) < 1e-13 and rel(st, st2) < 1e-12, (rel(hist, hist2), rel(st, st2))
+    o = OracleVPINN1D(*a, init_params=th)
+    o.vectorized = True
+    lo = []
+    for _ in range(25):
+        o.adam_step()
+        lo.append(float(o.loss_parts()[0]))
+    assert rel(hist[:, 0], lo) < TRAJ_TOL and rel(m.get_params(), o.get_params()) < TRAJ_TOL
