@@ -9,18 +9,25 @@ if [ "$(cat .flags 2>/dev/null)" != "$FLAGS" ]; then rm -f *.o; echo "$FLAGS" > 
 for f in kernels_generic kernels_mfma kernels_fused kernels_tall kernels_tile kernels_project hpv_api; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ hpv_internal.h -nt $f.o ] || [ hpv_mfma.h -nt $f.o ] || [ hpv_mfma_dev.h -nt $f.o ] || [ hpv_project_wg.h -nt $f.o ] || [ hpv_math.h -nt $f.o ] || [ hpv_fused_dev.h -nt $f.o ] || [ ../../include/hpvpinn.h -nt $f.o ]; then
     XF=""
-    if [ $f = kernels_fused ]; then   # the whole-iteration kernel parks live values in AGPRs by hand: verify the compiler stays clear
+    # Two sources park live values in hand-chosen AGPRs: compile them to assembly first and verify that the compiler's own
+    # registers stay clear of the hand-managed range.  If a compiler release ever needs more, the library is still built --
+    # WITHOUT those kernels (-DHPV_AGPR_GUARD_TRIPPED: their launch functions decline, the callers fall back to the
+    # forward + projection-fused reverse kernels, i.e. what HPV_FUSE=b selects) -- and the build says so loudly.
+    if [ $f = kernels_fused ]; then
       XF="$HPV_FUSED_EXTRA"           # (A/B builds: flags for this file only, scripts/build_variant.sh --fused-only)
       $HIPCC $FLAGS $XF -S --cuda-device-only $f.hip -o $f.s 2>/dev/null
-      python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi3 106
-      python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi2 156
+      if ! { python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi3 106 && python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi2 156; }; then
+        echo "build.sh: WARNING -- AGPR guard tripped in $f.hip: building without k_iter_fused (fallback = HPV_FUSE=b structure)" >&2
+        XF="$XF -DHPV_AGPR_GUARD_TRIPPED"
+      fi
     fi
     if [ $f = kernels_tall ]; then    # same hand-managed AGPR stash (4 tiles x L x 5 doubles at the top of the file)
       $HIPCC $FLAGS -S --cuda-device-only $f.hip -o $f.s 2>/dev/null
-      python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi1ELi3 136
-      python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi0ELi3 136
-      python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi1ELi2 176
-      python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi0ELi2 176
+      if ! { python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi1ELi3 136 && python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi0ELi3 136 &&
+             python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi1ELi2 176 && python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi0ELi2 176; }; then
+        echo "build.sh: WARNING -- AGPR guard tripped in $f.hip: building without k_iter_tall (fallback = the separate launches)" >&2
+        XF="$XF -DHPV_AGPR_GUARD_TRIPPED"
+      fi
     fi
     $HIPCC $FLAGS $XF -c $f.hip -o $f.o
   fi

@@ -87,3 +87,42 @@ __device__ __forceinline__ bool fz_elem_barrier(unsigned long long* cnt, int S, 
     return *flag_lds == 0.0;
 }
 
+
+// ---- tagged exchange among the workgroups that share an element ------------------------------------------------------------
+// The counter barrier above costs four dependent memory round trips per exchange (payload store acknowledged -> fetch-add ->
+// last poll -> payload loads: 10 k cycles = 4.4 us measured in k_iter_tall).  Here every exchanged double travels as TWO 8-byte
+// granules {32 bits of the value | 32-bit launch tag}, each written by ONE write-through store (cdna_hip_programming.md
+// Guideline 16, form R2: a naturally aligned 8-byte granule needs no ordering): a consumer polls the granules themselves until
+// all carry this launch's tag, so the data's arrival is its own notification -- one one-way trip plus a poll sweep.
+// The tag is *xiter + 1, read at kernel start (xiter is advanced by workgroup 0 at the very end of the launch, i.e. after every
+// workgroup of this launch has long read it; launches of a stream do not overlap).  Waits are bounded by wall clock.
+__device__ __forceinline__ void xg_publish(unsigned long long* slot, double v, unsigned tag) {
+    const unsigned long long t = (unsigned long long)tag << 32;
+    __hip_atomic_store(slot, t | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(slot + 1, t | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Gather `nwords` granules (nwords <= NIT * BLOCK) starting at `src` into the LDS array `dst` (the low halves, consecutively:
+// granules 2i, 2i+1 become the double dst[i]).  Returns false when a granule did not show this launch's tag within ~0.2 s.
+template <int NIT, int BLOCK>
+__device__ __forceinline__ bool xg_gather(const unsigned long long* src, int nwords, unsigned tag, unsigned* dst, int tid) {
+    unsigned long long w[NIT];
+    bool done[NIT];
+    int left = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) { done[it] = it * BLOCK + tid >= nwords; left += done[it] ? 0 : 1; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool failed = false;
+    while (left > 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (!done[it]) w[it] = __hip_atomic_load(src + it * BLOCK + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (!done[it] && (unsigned)(w[it] >> 32) == tag) { dst[it * BLOCK + tid] = (unsigned)w[it]; done[it] = true; --left; }
+        if (left > 0) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ULL) { failed = true; break; }    // 0.2 s at 100 MHz
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    return !failed;
+}

@@ -45,6 +45,10 @@ struct MfmaArgs {
     int* xerr;            // sticky failure flag of the handle (hpv_ctx::d_xerr): set when a barrier times out; see fz_elem_barrier
     int xdebug_skip;      // test knob (HPV_DEBUG_SPLIT_SKIP=1): partner 1 of element 0 stays away from the barrier
     double* upart;        // tall-element kernel (kernels_tall.hip): [n_elem][split][NR] partial residual sums the partners exchange
+    // tagged exchange (hpv_fused_dev.h, xg_*): the payload travels as 8-byte granules {32 bits of data | 32-bit launch tag}, so that
+    // its arrival is its own notification -- no counter, no store-acknowledge / fetch-add / poll chain
+    unsigned long long* xg;      // granule buffer
+    unsigned int* xiter;         // launches so far: the tag of a launch is *xiter + 1; workgroup 0 advances it at its end
     // single-workgroup grids (the reference's own 1-element 1-D default, BASELINE config 1): the whole-iteration tile kernel
     // finishes the iteration itself -- packed buffer, TF1 Adam, loss history -- instead of a dependent k_finalize launch
     int fin_mode;         // 0: k_finalize follows; 1: packed buffer only; 2: packed buffer + Adam update
@@ -77,6 +81,9 @@ struct HpvMfma {
     unsigned long long* xsync = nullptr;   // [xsync_elems] arrival counters, zero-initialised, monotonic (S per launch and element)
     int* xerr = nullptr;                   // NOT owned: the handle's sticky failure flag (hpv_mfma_set_err_flag)
     int xdebug_skip = 0;
+    unsigned long long* xg = nullptr;      // tagged-exchange granules (owned)
+    unsigned int* xiter = nullptr;
+    size_t xg_words = 0;
     long xsync_elems = 0;
     bool split_used = false;               // a split launch happened: hpv_step then reads the timeout flag back
     bool last_split = false;               // the most recent whole-iteration launch was a split one (hpv_pass_structure)

@@ -1142,6 +1142,9 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
         for (int ch = 0; ch < HPV_MAXC; ++ch)
             if (pd.t[t].a0[ch] != (ch == 1 + t ? 1.0 : 0.0) || pd.t[t].a1[ch] != 0.0 || pd.t[t].eps_mult) return false;
     if (n_elem <= 0) return false;
+#ifdef HPV_AGPR_GUARD_TRIPPED     // csrc/build.sh: the compiler's registers reached the hand-managed AGPR range of k_iter_fused
+    if (!small) return false;
+#endif
     if (small) {
         // batch layout [element points | pad to 16 | data points]; at most one boundary/data tile per workgroup
         const long npad = (n_elem * SM_NQ + 15) / 16 * 16;

@@ -512,7 +512,10 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
         if (idx < P) {
             if (GPART_v) {
                 // FIN_U independent loads in flight per thread (the sums stay in row order: same result as the plain loop)
-                constexpr int FIN_U = 8;
+#ifndef HPV_FIN_U
+#define HPV_FIN_U 8
+#endif
+                constexpr int FIN_U = HPV_FIN_U;
                 int r = part;
                 for (; r + (FIN_U - 1) * FIN_PARTS < rows_v; r += FIN_U * FIN_PARTS) {
                     double t[FIN_U];

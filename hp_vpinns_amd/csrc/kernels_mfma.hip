@@ -749,6 +749,17 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
             (void)hipGetLastError();
             m->xsync = nullptr;
         }
+        // tagged-exchange granules: 2 words per exchanged double (tall elements: <= CUs x 25 doubles; SPLIT mode: 800 per element)
+        m->xg_words = (size_t)2 * 800 * (size_t)std::min<long>(m->xsync_elems, 512);
+        if (hipMalloc((void**)&m->xg, m->xg_words * sizeof(unsigned long long)) == hipSuccess &&
+            hipMalloc((void**)&m->xiter, sizeof(unsigned int)) == hipSuccess) {
+            (void)hipMemset(m->xg, 0, m->xg_words * sizeof(unsigned long long));
+            (void)hipMemset(m->xiter, 0, sizeof(unsigned int));
+        } else {
+            (void)hipGetLastError();
+            if (m->xg) { (void)hipFree(m->xg); m->xg = nullptr; }
+            m->xiter = nullptr;
+        }
         const char* dbg = getenv("HPV_DEBUG_SPLIT_SKIP");
         m->xdebug_skip = (dbg && dbg[0] == '1') ? 1 : 0;
     }
@@ -781,6 +792,8 @@ void hpv_mfma_destroy(HpvMfma* m) {
     if (!m) return;
     if (m->ACTS) (void)hipFree(m->ACTS);
     if (m->xsync) (void)hipFree(m->xsync);
+    if (m->xg) (void)hipFree(m->xg);
+    if (m->xiter) (void)hipFree(m->xiter);
     delete m;
 }
 

@@ -154,6 +154,7 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
     // visible), requested behind the staging loads -- an agent-scope load ahead of them held every weight load back behind its
     // own memory round trip (loads return in order) -- and consumed at the barrier
     const int xsticky = *g.xerr;
+    const unsigned xtag = *g.xiter + 1u;          // this launch's exchange tag (hpv_fused_dev.h, xg_*)
     const double eps = pa.eps_ptr ? pa.eps_ptr[0] : 0.0;
     // per-term scalars of the element, requested now: coefficient x (epsilon if the term carries it)
     double cterm[HPV_MAXT];
@@ -310,31 +311,26 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
             double u = 0.0;
 #pragma unroll
             for (int sl = 0; sl < TA_SLICES; ++sl) u += lds[M::UP + sl * NR + tid];
-            // publish write-through (the partners read it with agent-scope loads after the barrier)
-            __hip_atomic_store(&g.upart[wg_slot * NR + tid], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // publish: two tagged granules per value, fire and forget (the partners poll the granules themselves)
+            if (!xsticky && !(g.xdebug_skip && e == 0 && part == 1)) xg_publish(g.xg + (wg_slot * NR + tid) * 2, u, xtag);
         }
         TA_STAMP(4);
-        if (!fz_elem_barrier(g.xsync + e, split, g.xerr, tid, xsticky, g.xdebug_skip && e == 0 && part == 1, lds + M::RED + 15))
-            return;     // nothing of this iteration has been written: the update is skipped by the kernels that follow
-        TA_STAMP(5);
-        // the S x NR partial sums of the element: ONE memory round trip (every thread fetches its share of the contiguous block
-        // into LDS; a loop of dependent agent-scope loads per output cost 32 L2 round trips = 19 us), then a fixed-order sum
         {
-            const double* up = g.upart + (long)e * split * NR;
-            constexpr int NLD = (64 * NR + TA_BLOCK - 1) / TA_BLOCK;
-            double v[NLD];
-#pragma unroll
-            for (int it = 0; it < NLD; ++it) {
-                const int idx = it * TA_BLOCK + tid;
-                v[it] = idx < split * NR ? __hip_atomic_load(up + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-            }
-#pragma unroll
-            for (int it = 0; it < NLD; ++it) {
-                const int idx = it * TA_BLOCK + tid;
-                if (idx < split * NR) lds[M::TR + idx] = v[it];          // (the transpose region is idle between the phases)
+            // the S x NR partial sums of the element, straight into LDS (the transpose region is idle between the phases)
+            constexpr int NITG = (64 * NR * 2 + TA_BLOCK - 1) / TA_BLOCK;
+            const bool stay_away = xsticky || (g.xdebug_skip && e == 0 && part == 1);     // workgroup-uniform
+            bool ok = true;
+            if (!stay_away) ok = xg_gather<NITG, TA_BLOCK>(g.xg + (long)e * split * NR * 2, split * NR * 2, xtag, (unsigned*)(lds + M::TR), tid);
+            const int timed_out = __syncthreads_or(ok ? 0 : 1);       // (also the barrier that makes the gathered sums visible)
+            if (timed_out || stay_away) {
+                // a partner did not show up (or an earlier launch failed: sticky): nothing of this iteration has been written, the
+                // kernels that follow skip the update (kernels_generic.hip), the host reports -7 and resets (hpv_api.hip, sync_check)
+                if (timed_out && tid == 0) __hip_atomic_store(g.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (blockIdx.x == 0 && tid == 0) *g.xiter = xtag;
+                return;
             }
         }
-        __syncthreads();
+        TA_STAMP(5);
         double sq = 0.0;
         if (tid < NR) {
             double u = -pF;
@@ -623,6 +619,7 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
         for (int w = 0; w < TA_WAVES; ++w) acc += W0[(long)w * g.P + idx];
         row[idx] = acc;
     }
+    if (blockIdx.x == 0 && tid == 0) *g.xiter = xtag;      // the next launch's tag is xtag + 1
 #ifdef HPV_FZ_TIMING
     if (lane == 0 && pa.GBAR) {   // [block][wave][12]: staging, forward, wait, partial projection, barrier, residual+adjoint, reverse, wait, epilogue
         TA_STAMP(9);
@@ -652,8 +649,11 @@ static void launch_iter_tall(const MfmaArgs& a, int blocks, hipStream_t s) {
 // Workgroups per element of the tall-element kernel (0: not applicable): the largest power of two with n_elem S <= CUs, at most
 // 64, such that a workgroup's share fits TA_WAVES x TA_MAXT tiles (with room for a boundary/data tile where one is adopted).
 int hpv_mfma_tall_split(HpvMfma* m, const ProjDesc& pd, long n_elem) {
+#ifdef HPV_AGPR_GUARD_TRIPPED     // csrc/build.sh: the compiler's registers reached the hand-managed AGPR range of k_iter_tall
+    return 0;
+#endif
     const NetDesc& nd = m->nd;
-    if (!m->iter_fused_ok || !m->iter_split_ok || !m->xsync || !m->xerr) return 0;
+    if (!m->iter_fused_ok || !m->iter_split_ok || !m->xsync || !m->xerr || !m->xg || !m->xiter) return 0;
     if (!(nd.d == 2 && nd.nT1 == 2 && nd.nT2 <= 1 && nd.act == HPV_ACT_TANH) || m->L < 2 || m->L > 3) return 0;
     if (!(pd.qx == 80 && pd.qy == 80 && pd.ntx == 5 && pd.nty == 5) || pd.edge || pd.nact || pd.nterms < 1) return 0;
     if (n_elem <= 0 || n_elem > m->xsync_elems) return 0;
@@ -690,6 +690,8 @@ bool hpv_mfma_iter_tall(HpvMfma* m, const double* theta, const double* X, double
     a.xerr = m->xerr;
     a.xdebug_skip = m->xdebug_skip;
     a.upart = upart;
+    a.xg = m->xg;
+    a.xiter = m->xiter;
     a.pa = pa;
     m->last_split = true;
     m->split_used = true;

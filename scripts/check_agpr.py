@@ -11,7 +11,7 @@ starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l) and key in l
 assert starts, f"kernel {key} not found in {src}"
 worst = -1
 for st in starts:
-    end = next(i for i in range(st, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    end = next(i for i in range(st, len(lines)) if lines[i].startswith(".Lfunc_end"))   # (a kernel may hold several s_endpgm: early returns)
     for l in lines[st:end]:
         code = l.split(";")[0]
         for m in re.finditer(r"\ba(\d+)\b", code):

@@ -1,0 +1,46 @@
+#!/bin/bash
+# Round-3 GPU-box visit: parity tests, the bench line (default and driver-style), rocprofv3 kernel stats and PMC passes (counters
+# in their own runs, never combined with a trace domain other than --kernel-trace) for config 4 (k_iter_fused) and config 5
+# (k_iter_tall, and its round-2 path HPV_FUSE=n for comparison), per-config timings, shard timings.
+# Usage (from the repo root on the GPU box): bash scripts/gpu_round_r03.sh <tag> [skip-tests]
+TAG=${1:-r03}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+REPO=$PWD
+if [ -z "$2" ]; then python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log; fi
+python bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json; cut -c1-400 $OUT/bench.json
+python bench.py --steps 20 --warmup 5 2> $OUT/bench_driver_style.err | tail -1 > $OUT/bench_driver_style.json; cut -c1-200 $OUT/bench_driver_style.json
+cd /tmp
+BENCH="python $REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-residual-roofline --no-extras"
+C5="python $REPO/scripts/cfg5_quick.py 200"
+SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BENCH > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $BENCH > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $BENCH > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $OUT/pmc_sq -o bench -- $BENCH > $OUT/pmc_sq.log 2>&1
+# config 5: the tall-element kernel, and the round-2 launches (forward -> activation store -> row-split projection -> reverse)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -o c5 -- $C5 > $OUT/stats_c5.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c5 -o c5 -- $C5 > $OUT/pmc_fetch_c5.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c5 -o c5 -- $C5 > $OUT/pmc_write_c5.log 2>&1
+rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $OUT/pmc_sq_c5 -o c5 -- $C5 > $OUT/pmc_sq_c5.log 2>&1
+HPV_FUSE=n rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5n -o c5 -- $C5 > $OUT/stats_c5n.log 2>&1
+HPV_FUSE=n rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c5n -o c5 -- $C5 > $OUT/pmc_fetch_c5n.log 2>&1
+HPV_FUSE=n rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c5n -o c5 -- $C5 > $OUT/pmc_write_c5n.log 2>&1
+# the stand-alone residual kernel on the scaled batch (the HBM-roofline measurement of SURVEY.md 8d)
+for adj in 1 0; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_proj$adj -o proj -- python $REPO/scripts/proj_bench.py 262144 5 $adj > $OUT/stats_proj$adj.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_proj$adj -o proj -- python $REPO/scripts/proj_bench.py 262144 3 $adj > $OUT/pmc_fetch_proj$adj.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_proj$adj -o proj -- python $REPO/scripts/proj_bench.py 262144 3 $adj > $OUT/pmc_write_proj$adj.log 2>&1
+done
+cd $REPO
+python scripts/summarize_profiles.py $OUT > $OUT/summary.md 2>&1
+echo >> $OUT/summary.md; echo "### iterations/sec of the five BASELINE configs (1 GPU)" >> $OUT/summary.md; echo >> $OUT/summary.md
+python scripts/config_bench.py 2>/dev/null | grep "^|" >> $OUT/summary.md
+echo >> $OUT/summary.md; echo "### shards of config 4 one GPU of N owns (SPLIT mode), no communication" >> $OUT/summary.md; echo >> $OUT/summary.md
+python scripts/shard_bench.py 2>/dev/null | sed 's/^/    /' >> $OUT/summary.md
+echo >> $OUT/summary.md; echo "### fp64 issue probe (scripts/f64_issue_probe.hip)" >> $OUT/summary.md; echo >> $OUT/summary.md
+./scripts/f64_issue_probe.bin 2>/dev/null | sed 's/^/    /' >> $OUT/summary.md
+cat $OUT/summary.md
+find $OUT -name "*kernel_trace.csv" -size +2M -delete
+find $OUT -name "*counter_collection.csv" -size +8M -delete

@@ -10,7 +10,7 @@ src, key = sys.argv[1], sys.argv[2]
 minsz = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 lines = open(src).read().split("\n")
 st = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l) and key in l)
-end = next(i for i in range(st, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+end = next(i for i in range(st, len(lines)) if lines[i].startswith(".Lfunc_end"))   # (a kernel may hold several s_endpgm: early returns)
 
 
 def kind(op):

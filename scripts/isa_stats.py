@@ -9,7 +9,7 @@ lines = open(src).read().split("\n")
 starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l) and key in l]
 for st in starts:
     name = lines[st].split(":")[0]
-    end = next(i for i in range(st, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    end = next(i for i in range(st, len(lines)) if lines[i].startswith(".Lfunc_end"))   # (a kernel may hold several s_endpgm: early returns)
     body = [l.strip() for l in lines[st + 1:end + 1] if l.startswith("\t") and not l.strip().startswith((";", "."))]
     c = Counter()
     for l in body:
