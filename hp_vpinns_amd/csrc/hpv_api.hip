@@ -1079,7 +1079,7 @@ static int enqueue_iterations(hpv_ctx* h, int n_iters) {
 // after a synchronisation point: did a SPLIT-mode element barrier time out (on this rank, or -- carried by the pad slot of the
 // all-reduced buffer -- on any rank)?  The kernels have left theta, m, v, the beta powers and the loss history as they were
 // before the failing iteration and have ignored every iteration since (sticky flag); here the failure is reported (-7), the
-// flag cleared and the arrival counters reset, so that the caller may go on (e.g. with HPV_FUSE=s on a shared GPU).
+// flag cleared (the exchange is stateless: tagged granules), so that the caller may go on (e.g. with HPV_FUSE=s on a shared GPU).
 static int sync_check(hpv_ctx* h) {
     if (!h->d_xerr || !h->mfma) return 0;
     if (!hpv_mfma_split_used(h->mfma) && !h->rccl_on && !h->p2p_on) return 0;   // nothing can have set it
@@ -1088,7 +1088,6 @@ static int sync_check(hpv_ctx* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!err) return 0;
     HIPCHK(h, hipMemsetAsync(h->d_xerr, 0, sizeof(int), h->stream));
-    hpv_mfma_reset_sync(h->mfma, h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return fail(h, -7, "whole-iteration kernel (SPLIT mode): the workgroups sharing an element did not meet at their barrier "
                        "(timeout) on some rank; the failing iteration and every later one of this call were NOT applied -- "

@@ -48,54 +48,23 @@ __device__ __forceinline__ void fz_layer(const double* WTl, const double* WRl, c
     z[4] = z16;
 }
 
-// Barrier among the S workgroups that share an element (SPLIT mode: small shards of a multi-GPU run) on a per-element arrival
-// counter in device memory, in the fence-free form of cdna_hip_programming.md Guideline 16
-// (R1): the payload (the partners' u_x, u_y) is stored WRITE-THROUGH with agent-scope relaxed atomic stores and read back with
-// agent-scope relaxed atomic loads, every storing wave drains its stores (s_waitcnt vmcnt(0)) before ONE lane bumps the counter,
-// ONE lane polls the generation word relaxed.  (With an agent-scope release fence before the bump and an acquire after the
-// poll -- an L2 write-back and an L1/L2 invalidate -- the barrier cost 18.6 k cycles = 8.5 us; measured, profiles/.)
-// All S workgroups are co-resident (the grid is at most one workgroup per CU); the wait is nevertheless bounded by wall clock.
-// A failed barrier must leave the replica intact (round-2 verdict / advisor): on expiry the sticky flag *err is set and the
-// function returns false to EVERY thread of the workgroup, which then leaves the kernel before phase P / R write R, loss_e or
-// its gradient row; k_finalize / k_adam / k_p2p_exchange read the flag (directly and, on the multi-GPU path, through the pad
-// slot of the all-reduced buffer) and skip the update, the loss history and the beta powers; every later launch of the handle
-// sees the flag at its barrier (`sticky`, requested at kernel start) and returns without arriving, until the host has reported
-// the failure (HpvError -7), cleared the flag and reset the arrival counters.  `skip`: test knob, the workgroup stays away.
-__device__ __forceinline__ bool fz_elem_barrier(unsigned long long* cnt, int S, int* err, int tid, int sticky, bool skip, double* flag_lds) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        int bad = sticky;
-        if (!bad && !skip) {
-            // ONE monotonic arrival counter per element (never reset: launch k takes it from k S to (k + 1) S), so that the arrival
-            // itself tells every workgroup its target and the last arriver needs no second round trip to announce completion
-            const unsigned long long a = __hip_atomic_fetch_add(cnt, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long target = (a / (unsigned long long)S + 1ULL) * (unsigned long long)S;
-            if (a + 1ULL != target) {
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ULL) { bad = 1; break; }    // 0.2 s at 100 MHz
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            if (bad) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        *flag_lds = (bad || skip) ? 1.0 : 0.0;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    return *flag_lds == 0.0;
-}
-
-
 // ---- tagged exchange among the workgroups that share an element ------------------------------------------------------------
-// The counter barrier above costs four dependent memory round trips per exchange (payload store acknowledged -> fetch-add ->
-// last poll -> payload loads: 10 k cycles = 4.4 us measured in k_iter_tall).  Here every exchanged double travels as TWO 8-byte
+// Workgroups that share an element (SPLIT mode of k_iter_fused: small shards of a multi-GPU run; k_iter_tall: few tall elements)
+// hand each other a few hundred doubles in the middle of the launch.  Rounds 2 / 3a did it with write-through payload stores, a
+// monotonic arrival counter per element and a reload: four dependent memory round trips (payload store acknowledged ->
+// fetch-add -> last poll -> payload loads; 8.7 k cycles in SPLIT mode, 10 k = 4.4 us in k_iter_tall).  Here every exchanged
+// double travels as TWO 8-byte
 // granules {32 bits of the value | 32-bit launch tag}, each written by ONE write-through store (cdna_hip_programming.md
 // Guideline 16, form R2: a naturally aligned 8-byte granule needs no ordering): a consumer polls the granules themselves until
 // all carry this launch's tag, so the data's arrival is its own notification -- one one-way trip plus a poll sweep.
 // The tag is *xiter + 1, read at kernel start (xiter is advanced by workgroup 0 at the very end of the launch, i.e. after every
-// workgroup of this launch has long read it; launches of a stream do not overlap).  Waits are bounded by wall clock.
+// workgroup of this launch has long read it; launches of a stream do not overlap).  All partners are co-resident (the grid is
+// at most one workgroup per CU); the wait is nevertheless bounded by wall clock.  A failed exchange must leave the replica
+// intact (round-2 verdict / advisor): the workgroup that gives up sets the handle's sticky flag *xerr and EVERY thread of it
+// leaves the kernel before it has written R, loss_e or its gradient row; k_finalize / k_adam / k_p2p_exchange read the flag
+// (directly and, on the multi-GPU path, through the pad slot of the all-reduced buffer) and skip the update, the loss history
+// and the beta powers; every later launch of the handle sees the flag at kernel start and stays away from the exchange, until
+// the host has reported the failure (HpvError -7) and cleared it (hpv_api.hip, sync_check).
 __device__ __forceinline__ void xg_publish(unsigned long long* slot, double v, unsigned tag) {
     const unsigned long long t = (unsigned long long)tag << 32;
     __hip_atomic_store(slot, t | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -45,12 +45,11 @@ struct MfmaFinalize {
 bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
                         const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem, const MfmaFinalize* fin = nullptr,
                         bool* fin_done = nullptr);
-// SPLIT mode of the whole-iteration kernel: the handle's sticky failure flag (device int, owned by the caller) that a timed-out
-// element barrier sets; without one the SPLIT mode is not used.  hpv_mfma_split_used: a SPLIT launch happened since creation;
-// hpv_mfma_reset_sync: zero the arrival counters (after a failure has been reported).
+// Split whole-iteration kernels (SPLIT mode of k_iter_fused, k_iter_tall): the handle's sticky failure flag (device int, owned
+// by the caller) that a timed-out exchange sets; without one those modes are not used.  hpv_mfma_split_used: such a launch
+// happened since creation.
 void hpv_mfma_set_err_flag(HpvMfma* m, int* dev_flag);
 bool hpv_mfma_split_used(HpvMfma* m);
-void hpv_mfma_reset_sync(HpvMfma* m, hipStream_t s);
 // Tall elements (80x80 points, 5x5 test functions: BASELINE config 5) split over `split` workgroups each (kernels_tall.hip);
 // hpv_mfma_tall_split: workgroups per element (0 = not applicable), loss_e / deps_e / upart then hold n_elem * split entries.
 struct ProjDesc;

@@ -40,9 +40,8 @@ struct MfmaArgs {
     long proj_n_elem;
     int proj_split;       // workgroups per element in the reverse kernel's element-block mode (1, 2, 4 or 8)
     ProjArgs pa;
-    // split whole-iteration kernel: per element the monotonic arrival counter of the partners' barrier, timeout flag
-    unsigned long long* xsync;
-    int* xerr;            // sticky failure flag of the handle (hpv_ctx::d_xerr): set when a barrier times out; see fz_elem_barrier
+    // split whole-iteration kernels: the handle's sticky failure flag, test knob, exchange buffers
+    int* xerr;            // sticky failure flag of the handle (hpv_ctx::d_xerr): set when an exchange times out; see hpv_fused_dev.h
     int xdebug_skip;      // test knob (HPV_DEBUG_SPLIT_SKIP=1): partner 1 of element 0 stays away from the barrier
     double* upart;        // tall-element kernel (kernels_tall.hip): [n_elem][split][NR] partial residual sums the partners exchange
     // tagged exchange (hpv_fused_dev.h, xg_*): the payload travels as 8-byte granules {32 bits of data | 32-bit launch tag}, so that
@@ -78,7 +77,6 @@ struct HpvMfma {
     bool fuse_bwd = true, iter_fused_ok = true, iter_fused_force = false;
     // 's' keeps small shards on the forward + split reverse kernels (the whole-iteration kernel's split mode off)
     bool iter_split_ok = true;
-    unsigned long long* xsync = nullptr;   // [xsync_elems] arrival counters, zero-initialised, monotonic (S per launch and element)
     int* xerr = nullptr;                   // NOT owned: the handle's sticky failure flag (hpv_mfma_set_err_flag)
     int xdebug_skip = 0;
     unsigned long long* xg = nullptr;      // tagged-exchange granules (owned)

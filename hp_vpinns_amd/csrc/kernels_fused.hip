@@ -70,7 +70,7 @@ struct FzLds {
 
 // SPLIT: an element is shared by g.proj_split (2, 4 or 8) workgroups -- the shards of a multi-GPU run are too small to fill the
 // chip with one workgroup per element.  Workgroup (e, part) walks the tiles [25 part / S, 25 (part + 1) / S) of element e,
-// publishes their u_x, u_y through the global channel buffer, meets its S - 1 partners at fz_elem_barrier, then EVERY partner
+// publishes their u_x, u_y as tagged granules (hpv_fused_dev.h, xg_*), gathers the whole element's from its partners, then EVERY partner
 // projects the whole element for itself (identical values, benign duplicate stores of R and loss_e) and reverses its own tiles.
 template <int L, bool SPLIT = false>
 __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
@@ -166,7 +166,8 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     // SPLIT: has a barrier of an EARLIER launch of this handle failed?  A plain load (kernel boundaries make those stores
     // visible) requested behind the staging loads and consumed at the barrier
     int xsticky = 0;
-    if constexpr (SPLIT) xsticky = *g.xerr;
+    unsigned xtag = 0;             // this launch's exchange tag (hpv_fused_dev.h, xg_*)
+    if constexpr (SPLIT) { xsticky = *g.xerr; xtag = *g.xiter + 1u; }
     // the element's projection constants, requested now so that no global latency sits inside phase P
     const double pc0 = pa.coef[e], pc1 = pa.coef[pa.coef_stride + e];
     const double pF = (pa.F && tid < FZ_NR) ? pa.F[e * FZ_NR + tid] : 0.0;
@@ -211,6 +212,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     double* PKw2 = lds + M::PK + (4 + (wv & 1)) * (NSV * 64) + lane;
     double gdat = 0.0;           // adjoint of u at the data tile's point (boundary term, P2:122)
 
+    // SPLIT: this workgroup takes no part in the exchange (an earlier launch of the handle failed -- sticky flag -- or the test
+    // knob keeps partner 1 of element 0 away): it publishes nothing and leaves at the hand-off point
+    const bool xstay = SPLIT && (xsticky || (g.xdebug_skip && e == 0 && part == 1));
     // =============================================================================================
     // phase F: forward
     // =============================================================================================
@@ -355,9 +359,11 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             if (k < n_el) {
                 if (q == 0) {
                     const int lp = (tbase + wv + k * FZ_WAVES) * 16 + pt;     // point index inside the element
-                    if constexpr (SPLIT) {   // the partners read them after the barrier
-                        __hip_atomic_store(&g.OUT[1 * g.N + e * FZ_NQ + lp], o[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&g.OUT[2 * g.N + e * FZ_NQ + lp], o[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (SPLIT) {   // tagged granules, fire and forget: the partners poll the granules themselves
+                        if (!xstay) {
+                            xg_publish(g.xg + (e * (2 * FZ_NQ) + lp) * 2, o[1], xtag);
+                            xg_publish(g.xg + (e * (2 * FZ_NQ) + FZ_NQ + lp) * 2, o[2], xtag);
+                        }
                     } else {
                         lds[M::CH + lp] = o[1];
                         lds[M::CH + FZ_NQ + lp] = o[2];
@@ -381,12 +387,20 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     if (k0 < n_own) fwd_trip(k0, std::integral_constant<int, 1>{});
     FZ_STAMP(2);
     if constexpr (SPLIT) {
-        // (the TR region is idle between the phases: its last word carries the verdict to the workgroup)
-        if (!fz_elem_barrier(g.xsync + e, split, g.xerr, tid, xsticky, g.xdebug_skip && e == 0 && part == 1, lds + M::RED + 15))
-            return;     // nothing of this iteration has been written: the update is skipped by the kernels that follow
-        for (int idx = tid; idx < 2 * FZ_NQ; idx += FZ_BLOCK)
-            lds[M::CH + idx] = __hip_atomic_load(&g.OUT[(long)(1 + idx / FZ_NQ) * g.N + e * FZ_NQ + idx % FZ_NQ], __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
+        // the element's u_x, u_y from all partners (its own included), straight into the LDS channel array: the granules are
+        // polled until every one carries this launch's tag -- the data's arrival is its own notification (no counter barrier:
+        // that chain of store-acknowledge, fetch-add, poll and reload cost 8.7 k cycles)
+        constexpr int NITG = (2 * FZ_NQ * 2 + FZ_BLOCK - 1) / FZ_BLOCK;
+        bool ok = true;
+        if (!xstay) ok = xg_gather<NITG, FZ_BLOCK>(g.xg + e * (2 * FZ_NQ) * 2, 2 * FZ_NQ * 2, xtag, (unsigned*)(lds + M::CH), tid);
+        const int timed_out = __syncthreads_or(ok ? 0 : 1);
+        if (timed_out || xstay) {
+            // nothing of this iteration has been written: the kernels that follow skip the update (kernels_generic.hip), the host
+            // reports -7, clears the flag and goes on (hpv_api.hip, sync_check)
+            if (timed_out && tid == 0) __hip_atomic_store(g.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0 && tid == 0) *g.xiter = xtag;
+            return;
+        }
     }
     __syncthreads();
     FZ_STAMP(3);
@@ -661,6 +675,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         for (int w = 0; w < FZ_WAVES; ++w) acc += W0[(long)w * g.P + idx];
         row[idx] = acc;
     }
+    if constexpr (SPLIT) { if (blockIdx.x == 0 && tid == 0) *g.xiter = xtag; }      // the next launch's tag is xtag + 1
 #ifdef HPV_FZ_TIMING
     if (lane == 0 && pa.GBAR) {   // phase durations in shader cycles: [block][wave][8], into the (otherwise unused) adjoint buffer
         FZ_STAMP(7);
@@ -1172,9 +1187,9 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     // partners meet at a barrier in device memory, which needs all of them resident: at most one workgroup per CU
     int split = 1;
     if (n_elem * 2 <= m->n_cus && !m->iter_fused_force) {
-        if (!m->xsync || !m->xerr || !m->iter_split_ok) return false;
+        if (!m->xerr || !m->xg || !m->xiter || !m->iter_split_ok) return false;
         while (split < 8 && n_elem * split * 2 <= m->n_cus) split *= 2;
-        if (n_elem * split > m->n_cus || n_elem > m->xsync_elems) return false;
+        if (n_elem * split > m->n_cus || n_elem > m->xsync_elems || (size_t)n_elem * 2 * FZ_NQ * 2 > m->xg_words) return false;
     }
     const long blocks = n_elem * split;
     const long rest = m->ntiles - n_elem * FZ_TPE;                  // pad + boundary/data tiles: at most one per workgroup
@@ -1192,9 +1207,10 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     }
     a.proj_n_elem = n_elem;
     a.proj_split = split;
-    a.xsync = m->xsync;
     a.xerr = m->xerr;
     a.xdebug_skip = m->xdebug_skip;
+    a.xg = m->xg;
+    a.xiter = m->xiter;
     a.pa = pa;
     m->last_split = split > 1;
     if (split > 1) {
@@ -1210,6 +1226,3 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
 bool hpv_mfma_sync_failed_possible(HpvMfma* m) { return m && m->last_split; }
 void hpv_mfma_set_err_flag(HpvMfma* m, int* dev_flag) { if (m) m->xerr = dev_flag; }
 bool hpv_mfma_split_used(HpvMfma* m) { return m && m->split_used; }
-void hpv_mfma_reset_sync(HpvMfma* m, hipStream_t s) {
-    if (m && m->xsync) (void)hipMemsetAsync(m->xsync, 0, (size_t)m->xsync_elems * sizeof(unsigned long long), s);
-}

@@ -741,14 +741,8 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
         (void)hipMemset(m->ACTS, 0, bytes);
     }
     if (need_store && nd.d == 2 && nd.nT1 == 2 && nd.nT2 <= 1 && nd.act == HPV_ACT_TANH) {
-        // barrier words of the split whole-iteration kernels (one per element of the largest grid this batch can hold)
+        // elements the exchange buffers of the split whole-iteration kernels are sized for (the largest grid this batch can hold)
         m->xsync_elems = N / 400 + 1;
-        if (hipMalloc((void**)&m->xsync, (size_t)m->xsync_elems * sizeof(unsigned long long)) == hipSuccess) {
-            (void)hipMemset(m->xsync, 0, (size_t)m->xsync_elems * sizeof(unsigned long long));
-        } else {
-            (void)hipGetLastError();
-            m->xsync = nullptr;
-        }
         // tagged-exchange granules: 2 words per exchanged double (tall elements: <= CUs x 25 doubles; SPLIT mode: 800 per element)
         m->xg_words = (size_t)2 * 800 * (size_t)std::min<long>(m->xsync_elems, 512);
         if (hipMalloc((void**)&m->xg, m->xg_words * sizeof(unsigned long long)) == hipSuccess &&
@@ -791,7 +785,6 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
 void hpv_mfma_destroy(HpvMfma* m) {
     if (!m) return;
     if (m->ACTS) (void)hipFree(m->ACTS);
-    if (m->xsync) (void)hipFree(m->xsync);
     if (m->xg) (void)hipFree(m->xg);
     if (m->xiter) (void)hipFree(m->xiter);
     delete m;

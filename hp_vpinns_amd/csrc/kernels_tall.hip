@@ -8,8 +8,8 @@
 //   phase F  Taylor-mode forward of its tiles (channels u, u_x, u_t[, u_xx]); only s = tanh(z) of every hidden layer is kept,
 //            in the hand-managed top AGPRs (hpv_fused_dev.h); the channel values of its points go to LDS.
 //   phase P  the projection is LINEAR in the channels: the workgroup projects ITS points onto the 25 test-function pairs
-//            (general TermDesc integrands, P3:161-174) and publishes the 25 partial sums write-through; the S partners meet at
-//            the element barrier (fz_elem_barrier, the SPLIT mode's), every partner adds the S x 25 partials in a fixed order
+//            (general TermDesc integrands, P3:161-174) and publishes the 25 partial sums as tagged granules (hpv_fused_dev.h,
+//            xg_*: the data's arrival is its own notification), every partner gathers and adds the S x 25 partials in a fixed order
 //            (bitwise identical everywhere), forms R = U - F and the element loss (P3:176-182), and evaluates the adjoint of
 //            the channels and its share of d loss / d epsilon at its own points.
 //   phase R  reverse pass of its tiles, tangent pre-activations (first AND second order) recomputed from s on the MFMA pipe.
@@ -653,7 +653,7 @@ int hpv_mfma_tall_split(HpvMfma* m, const ProjDesc& pd, long n_elem) {
     return 0;
 #endif
     const NetDesc& nd = m->nd;
-    if (!m->iter_fused_ok || !m->iter_split_ok || !m->xsync || !m->xerr || !m->xg || !m->xiter) return 0;
+    if (!m->iter_fused_ok || !m->iter_split_ok || !m->xerr || !m->xg || !m->xiter) return 0;
     if (!(nd.d == 2 && nd.nT1 == 2 && nd.nT2 <= 1 && nd.act == HPV_ACT_TANH) || m->L < 2 || m->L > 3) return 0;
     if (!(pd.qx == 80 && pd.qy == 80 && pd.ntx == 5 && pd.nty == 5) || pd.edge || pd.nact || pd.nterms < 1) return 0;
     if (n_elem <= 0 || n_elem > m->xsync_elems) return 0;
@@ -686,7 +686,6 @@ bool hpv_mfma_iter_tall(HpvMfma* m, const double* theta, const double* X, double
     }
     a.proj_n_elem = n_elem;
     a.proj_split = split;
-    a.xsync = m->xsync;
     a.xerr = m->xerr;
     a.xdebug_skip = m->xdebug_skip;
     a.upart = upart;
