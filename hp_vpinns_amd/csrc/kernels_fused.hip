@@ -39,8 +39,12 @@
 // projection, reverse, barrier wait, epilogue) per wave into MfmaArgs::OUT; scripts/fz_timing.py prints them.
 #ifdef HPV_FZ_TIMING
 #define FZ_STAMP(I) fz_t[I] = clock64()
+// segments of the reverse tile body, accumulated over the wave's tiles: [0] fetch + tangent recompute, [1] head,
+// [2 + 2 (L-1-i)] layer i: zbar + transposes + hbar chain, [3 + 2 (L-1-i)] layer i: dW products (layer 0: dW1)
+#define FZ_SEG(I) do { const long long t_ = clock64(); fz_seg[I] += t_ - fz_last; fz_last = t_; } while (0)
 #else
 #define FZ_STAMP(I)
+#define FZ_SEG(I)
 #endif
 
 template <int L>
@@ -486,8 +490,15 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         for (int i = 0; i < L; ++i) db[i][s] = 0.0;
     }
 
+#ifdef HPV_FZ_TIMING
+    long long fz_seg[2 + 2 * L], fz_last = clock64();
+    for (int i = 0; i < 2 + 2 * L; ++i) fz_seg[i] = 0;
+#endif
 #pragma unroll 1
     for (int k = 0; k < n_own; ++k) {
+#ifdef HPV_FZ_TIMING
+        fz_last = clock64();
+#endif
         const long tile = tile_of(k);
         const long p = tile * 16 + pt;
         const bool valid = p < g.N;
@@ -536,6 +547,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, hy, zc[i][1]);
         }
 
+        FZ_SEG(0);
         double hbar[FZ_C][MF_KS], zbar[FZ_C][MF_KS];
         // ---- linear head ----
 #pragma unroll
@@ -548,6 +560,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             hbar[0][s] = gb[0] * wo; hbar[1][s] = gb[1] * wo; hbar[2][s] = gb[2] * wo;
         }
         if (q == 0) dbo += gb[0];
+        FZ_SEG(1);
 
         // ---- hidden layers, last to first ----
 #pragma unroll
@@ -599,6 +612,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                     for (int s = 0; s < 4; ++s) hbar[ch][s] = acc[s];
                     hbar[ch][4] = h4;
                 }
+                FZ_SEG(2 + 2 * (L - 1 - i));
                 pj_wave_sync();
 #pragma unroll
                 for (int ch = 0; ch < FZ_C; ++ch) {
@@ -621,8 +635,10 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                     accC[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(TA[(16 + (lane & 3)) * MF_LD + (pt & 12) + q],
                                                                    TB[(16 + (lane & 3)) * MF_LD + (pt & 12) + q], accC[i - 1], 0, 0, 0);
                 }
+                FZ_SEG(3 + 2 * (L - 1 - i));
             }
         }
+        FZ_SEG(1 + 2 * L);
     }
 
 #undef ZC
@@ -686,6 +702,11 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         o[7] = (double)(fz_end - fz_wall) * 0.01;              // whole wave, microseconds (100 MHz constant clock)
         o[8] = (double)(fz_wall & 0xffffffffffll) * 0.01;      // absolute start / end, microseconds: launch skew across workgroups
         o[9] = (double)(fz_end & 0xffffffffffll) * 0.01;
+        if (!SPLIT && g.OUT) {     // reverse-body segments of this wave (sums over its tiles) + its tile count, into the channel buffer
+            double* os = g.OUT + ((long)blockIdx.x * 4 + wv) * 12;
+            for (int i = 0; i < 2 + 2 * L; ++i) os[i] = (double)fz_seg[i];
+            os[2 + 2 * L] = (double)n_own;
+        }
     }
 #endif
 }

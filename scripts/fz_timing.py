@@ -6,6 +6,21 @@ from hp_vpinns_amd.drivers import poisson2d
 from hp_vpinns_amd.init import xavier_init
 LAYERS = [2, 20, 20, 20, 1]
 mode = sys.argv[1] if len(sys.argv) > 1 else "4"
+if mode == "seg":    # k_iter_fused at config 4: segments of the reverse tile body (sums over a wave's tiles / its tile count)
+    os.environ["HPV_DEBUG_READ_CHANNELS"] = "1"
+    s = poisson2d.setup(N_el_x=16, N_el_y=16, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
+    m = poisson2d.build_model(s, LAYERS, var_form=1, init_params=xavier_init(LAYERS, 1234))
+    m.h.step(50, False)
+    out = np.empty(256 * 4 * 12)
+    m.h.lib.hpv_debug_read_out.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t]
+    m.h.lib.hpv_debug_read_out(m.h._h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size)
+    t = out.reshape(256, 4, 12)
+    names = ["fetch+recompute", "head", "L3 zbar+transposes+hbar", "L3 dW", "L2 zbar+transposes+hbar", "L2 dW", "-", "L1 zbar+dW1+loop"]
+    for w in range(4):
+        nt = t[:, w, 8]
+        print("wave", w, "tiles %.2f:" % nt.mean(), {n: round(float((t[:, w, i] / nt).mean()), 1) for i, n in enumerate(names) if n != "-"},
+              "sum/tile %.0f" % float((t[:, w, :8].sum(axis=1) / nt).mean()))
+    sys.exit(0)
 if mode == "c5":     # k_iter_tall (kernels_tall.hip): BASELINE config 5, 8 elements x 80x80 points, 32 workgroups per element
     from hp_vpinns_amd.drivers import advdiff
     s = advdiff.setup(N_el_x=8, N_quad=80, with_test_grid=False)
