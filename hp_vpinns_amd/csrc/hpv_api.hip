@@ -423,8 +423,8 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
             }
             if (!ifused) {   // few tall elements (AdvDiff, 80x80 rule): many workgroups per element, partial sums exchanged (kernels_tall.hip)
                 const int ts = hpv_mfma_tall_split(h->mfma, h->pd, h->n_elem);
-                if (ts > 1 && h->n_elem * ts <= h->n_red_alloc && h->d_upart &&
-                    hpv_mfma_iter_tall(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem, h->d_upart)) {
+                if (ts > 1 && h->n_elem * ts <= h->n_red_alloc &&
+                    hpv_mfma_iter_tall(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem)) {
                     ifused = true;
                     h->pass_structure = 5;
                     n_loss = h->n_elem * ts;
@@ -860,7 +860,7 @@ int hpv_set_elements(hpv_handle h, const double* gridx, int nex, const double* g
     h->n_red_alloc = (long)nred;
     if ((rc = dalloc(h, &h->d_loss_e, nred))) return rc;
     if ((rc = dalloc(h, &h->d_deps_e, nred))) return rc;
-    if ((rc = dalloc(h, &h->d_upart, (h->proj_split > 1 || tall) ? nred * h->ntx * h->nty : 0))) return rc;
+    if ((rc = dalloc(h, &h->d_upart, h->proj_split > 1 ? (size_t)ne * h->proj_split * h->ntx * h->nty : 0))) return rc;
     h->Xq_host = X;
     h->batch_dirty = true;
     if (N > 0) {

@@ -51,10 +51,10 @@ bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double
 void hpv_mfma_set_err_flag(HpvMfma* m, int* dev_flag);
 bool hpv_mfma_split_used(HpvMfma* m);
 // Tall elements (80x80 points, 5x5 test functions: BASELINE config 5) split over `split` workgroups each (kernels_tall.hip);
-// hpv_mfma_tall_split: workgroups per element (0 = not applicable), loss_e / deps_e / upart then hold n_elem * split entries.
+// hpv_mfma_tall_split: workgroups per element (0 = not applicable), loss_e / deps_e then hold n_elem * split entries.
 struct ProjDesc;
 int hpv_mfma_tall_split(HpvMfma* m, const ProjDesc& pd, long n_elem);
 bool hpv_mfma_iter_tall(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
-                        const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem, double* upart);
+                        const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem);
 bool hpv_mfma_sync_failed_possible(HpvMfma* m);   // the last whole-iteration launch ran in SPLIT mode
 int hpv_mfma_max_rows(HpvMfma* m, long n_elem);

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
     const int n_el_grid = (int)g.proj_n_elem;
     const long e = (long)(blockIdx.x % n_el_grid);
     const int part = (int)(blockIdx.x / n_el_grid);
-    const long wg_slot = e * split + part;                  // this workgroup's slot in upart / loss_e / deps_e / data tiles
+    const long wg_slot = e * split + part;                  // this workgroup's slot in the granule buffer / loss_e / deps_e
     const double* __restrict__ th = g.theta;
     const ProjArgs& pa = g.pa;
     const ProjDesc& pd = pa.pd;
@@ -668,9 +668,9 @@ int hpv_mfma_tall_split(HpvMfma* m, const ProjDesc& pd, long n_elem) {
 // Whole training pass (forward, projection, reverse) of a shard of tall elements in one launch.  Returns false when the shape /
 // variational form / shard is not covered; the caller then runs the separate kernels.
 bool hpv_mfma_iter_tall(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
-                        const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem, double* upart) {
+                        const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem) {
     const int split = hpv_mfma_tall_split(m, pa.pd, n_elem);
-    if (split < 2 || !upart) return false;
+    if (split < 2) return false;
     const long blocks = n_elem * split;
     const long rest = m->ntiles - n_elem * (80 * 80 / 16);           // boundary/data tiles: at most one per workgroup
     if (rest < 0 || rest > blocks) return false;
@@ -688,7 +688,6 @@ bool hpv_mfma_iter_tall(HpvMfma* m, const double* theta, const double* X, double
     a.proj_split = split;
     a.xerr = m->xerr;
     a.xdebug_skip = m->xdebug_skip;
-    a.upart = upart;
     a.xg = m->xg;
     a.xiter = m->xiter;
     a.pa = pa;

@@ -14,8 +14,8 @@ What is executed from the reference (nothing is copied -- only its *outputs* are
     BASELINE.json shapes -> grids, F_ext_total, boundary sets, test data.
 
 The TF1 graph itself (loss, tf.gradients, Adam) cannot run here (no tensorflow wheel,
-no network), so the loss/gradient/trajectory fixtures in `make_golden_oracle.py` come from
-the oracle restatement, not from the reference: that part of parity is UNPINNED upstream
+no network), so there are NO loss / gradient / trajectory fixtures: those comparisons run the oracle
+restatement live (tests/test_gpu_*.py), not the reference: that part of parity is UNPINNED upstream
  and anchored only by the known-answer checks in tests/test_oracle.py.
 
 `pyDOE.lhs` is stubbed with `hp_vpinns_amd.sampling.lhs` (published classic-LHS algorithm);

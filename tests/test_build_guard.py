@@ -1,0 +1,45 @@
+"""The build guard of the hand-managed AGPR stash (scripts/check_agpr.py, run by csrc/build.sh on the generated assembly): it must
+see EVERY instruction of a kernel -- also those behind an early `s_endpgm` (round 3: the shared-element kernels return early when
+an exchange times out; scanning up to the first `s_endpgm` had hidden the whole reverse pass) -- and tell compiler-allocated
+registers (`aN`, `a[N:M]`) from the hand-managed ones (printed by the inline asm as `a[0x..]` / `a[N]`)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ASM = """\t.text
+_Z6k_testILi3EEv8MfmaArgs:
+\tv_accvgpr_write_b32 a[200], v1
+\tv_mfma_f64_16x16x4_f64 a[0:7], v[2:3], v[4:5], a[0:7]
+\ts_cbranch_scc1 .LBB0_2
+\ts_endpgm
+.LBB0_2:
+\tv_accvgpr_read_b32 v9, a{hi}
+\tv_mfma_f64_16x16x4_f64 a[16:23], v[2:3], v[4:5], a[16:23]
+\ts_endpgm
+.Lfunc_end0:
+_Z7k_otherv:
+\tv_accvgpr_read_b32 v9, a250
+\ts_endpgm
+.Lfunc_end1:
+"""
+
+
+def _run(tmp_path, hi, base):
+    f = tmp_path / "k.s"
+    f.write_text(ASM.format(hi=hi))
+    return subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_agpr.py"), str(f), "k_testILi3", str(base)],
+                          capture_output=True, text=True)
+
+
+def test_guard_sees_code_behind_an_early_return(tmp_path):
+    ok = _run(tmp_path, 90, 106)
+    assert ok.returncode == 0 and "a90" in ok.stdout, ok.stdout + ok.stderr
+    bad = _run(tmp_path, 120, 106)          # the offending register sits BEHIND the first s_endpgm
+    assert bad.returncode != 0 and "a120" in (bad.stdout + bad.stderr)
+
+
+def test_guard_ignores_other_kernels_and_hand_managed_operands(tmp_path):
+    ok = _run(tmp_path, 23, 24)             # a[16:23] is the highest compiler register; a[200] (hand-managed) and k_other's a250 do not count
+    assert ok.returncode == 0 and "a23" in ok.stdout, ok.stdout + ok.stderr
+    assert _run(tmp_path, 23, 23).returncode != 0
