@@ -32,7 +32,7 @@ EXPORTS = [
     "hpv_p2p_export", "hpv_p2p_connect", "hpv_p2p_selftest", "hpv_p2p_disconnect",
     "hpv_eval_channels", "hpv_bench_residual",
     "hpv_set_collocation_shard", "hpv_rccl_unique_id", "hpv_rccl_connect", "hpv_rccl_selftest", "hpv_rccl_disconnect", "hpv_exchange_in_use",
-    "hpv_rccl_available", "hpv_graphs_in_use",
+    "hpv_rccl_available", "hpv_graphs_in_use", "hpv_updates_applied", "hpv_set_shared_element_kernels", "hpv_shared_element_kernels",
 ]
 
 
@@ -47,7 +47,10 @@ class HpvConfig(C.Structure):
 
 
 class HpvError(RuntimeError):
-    pass
+    """A libhpvpinn entry point returned non-zero; `code` is that value (include/hpvpinn.h lists them)."""
+    code = None
+
+EXCHANGE_TIMEOUT = -7      # an in-kernel exchange between the workgroups of one element timed out (hpv_step and friends)
 
 
 _lib = None
@@ -118,6 +121,9 @@ def load():
     lib.hpv_set_collocation_shard.argtypes = [h, _dp, _dp, C.c_int, C.c_long]
     lib.hpv_rccl_available.argtypes = []
     lib.hpv_graphs_in_use.argtypes = [h]
+    lib.hpv_updates_applied.argtypes = [h, C.POINTER(C.c_longlong)]
+    lib.hpv_set_shared_element_kernels.argtypes = [h, C.c_int]
+    lib.hpv_shared_element_kernels.argtypes = [h]
     lib.hpv_rccl_unique_id.argtypes = [h, C.c_char_p]
     lib.hpv_rccl_connect.argtypes = [h, C.c_int, C.c_int, C.c_char_p]
     lib.hpv_rccl_selftest.argtypes = [h, _dp, C.c_size_t]
@@ -173,7 +179,9 @@ class Handle:
     def _chk(self, rc):
         if rc != 0:
             msg = self.lib.hpv_last_error(self._h)
-            raise HpvError(f"libhpvpinn error {rc}: {msg.decode() if msg else ''}")
+            err = HpvError(f"libhpvpinn error {rc}: {msg.decode() if msg else ''}")
+            err.code = int(rc)
+            raise err
 
     def close(self):
         if getattr(self, "_h", None):
@@ -375,6 +383,20 @@ class Handle:
     def graphs_in_use(self):
         """hpv_step replays captured iteration graphs (False: eager launches, e.g. a collective that refused stream capture)."""
         return int(self.lib.hpv_graphs_in_use(self._h)) == 1
+
+    def updates_applied(self):
+        """Parameter updates applied through this handle so far (synchronises)."""
+        n = C.c_longlong(0)
+        self._chk(self.lib.hpv_updates_applied(self._h, C.byref(n)))
+        return int(n.value)
+
+    def shared_element_kernels(self):
+        """False once the handle stays on launch structures without an in-kernel exchange (set, or after a timeout fallback)."""
+        return int(self.lib.hpv_shared_element_kernels(self._h)) == 1
+
+    def set_shared_element_kernels(self, on):
+        """False: only launch structures without an in-kernel exchange from now on (what HPV_FUSE=s selects at creation)."""
+        self._chk(self.lib.hpv_set_shared_element_kernels(self._h, 1 if on else 0))
 
     def rccl_disconnect(self):
         self._chk(self.lib.hpv_rccl_disconnect(self._h))

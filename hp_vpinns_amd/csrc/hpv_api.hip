@@ -81,6 +81,10 @@ struct hpv_ctx {
     double *d_theta = nullptr, *d_m = nullptr, *d_v = nullptr, *d_state = nullptr, *d_RB = nullptr;
     double* d_hist = nullptr;   // [HPV_HIST_CAP][4] loss / epsilon history (AdamArgs)
     int* d_hist_idx = nullptr;
+    unsigned long long* d_nupd = nullptr;   // updates applied so far (AdamArgs::n_upd)
+    bool shared_elem_ok = true; // hpv_set_shared_element_kernels
+    long long nupd_host = 0;    // updates ENQUEUED so far (equals *d_nupd once the stream is idle unless a run failed)
+    int n_fallbacks = 0;        // runs finished on the barrier-free structures after an exchange timeout (after_exchange_timeout)
     int* d_xerr = nullptr;      // sticky failure flag: a SPLIT-mode element barrier timed out (kernels_fused.hip); see sync_check
     // mfma path (one object per batch: quadrature points, boundary/data points, element edges)
     HpvMfma* mfma = nullptr;
@@ -305,6 +309,7 @@ int assemble_batches(hpv_ctx* h) {
             h->merged = true;
             h->data_off = Npad;
             hpv_mfma_set_err_flag(h->mfma, h->d_xerr);
+            hpv_mfma_set_split_ok(h->mfma, h->shared_elem_ok);
             if ((rc = alloc_batch(h, h->var, h->nd_var, Ntot, true))) return rc;
             if (h->var.ACT) { (void)hipFree(h->var.ACT); h->var.ACT = nullptr; }   // the MFMA path has its own store
             const int rows = hpv_mfma_max_rows(h->mfma, h->n_elem);
@@ -374,7 +379,7 @@ int ensure_small_mfma(hpv_ctx* h, Batch& b, HpvMfma** m) {
 
 AdamArgs adam_args(hpv_ctx* h) {
     return AdamArgs{h->d_theta, h->d_m, h->d_v, h->d_state, h->cfg.lr, h->cfg.beta1, h->cfg.beta2, h->cfg.eps,
-                    h->d_hist, h->d_hist_idx, HPV_HIST_CAP, h->d_xerr};
+                    h->d_hist, h->d_hist_idx, HPV_HIST_CAP, h->d_xerr, h->d_nupd};
 }
 
 int enqueue_pinn_pass(hpv_ctx* h, bool backward, bool fuse_adam);
@@ -689,6 +694,8 @@ int hpv_create(hpv_handle* out, const hpv_config* cfg) {
     if (!rc) (void)hipMemset(h->d_hist_idx, 0, sizeof(int));
     rc |= dalloc(h, &h->d_xerr, (size_t)1);
     if (!rc) (void)hipMemset(h->d_xerr, 0, sizeof(int));
+    rc |= dalloc(h, &h->d_nupd, (size_t)1);
+    if (!rc) (void)hipMemset(h->d_nupd, 0, sizeof(unsigned long long));
     rc |= dalloc(h, &h->d_RB, (size_t)h->Ptot + 4);
     rc |= dalloc(h, &h->d_data_part, 64);
     if (rc) { g_create_error = h->err; hpv_destroy(h); return -2; }
@@ -724,6 +731,7 @@ void hpv_destroy(hpv_handle h) {
     for (double* p : ptrs) if (p) (void)hipFree(p);
     if (h->d_hist_idx) (void)hipFree(h->d_hist_idx);
     if (h->d_xerr) (void)hipFree(h->d_xerr);
+    if (h->d_nupd) (void)hipFree(h->d_nupd);
     if (h->d_nact) (void)hipFree(h->d_nact);
     for (auto& t : h->timers) for (auto e : t.ev) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -1009,6 +1017,7 @@ int hpv_apply_adam(hpv_handle h) {
     launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, -2, "adam launch failed: %s", hipGetErrorString(e));
+    h->nupd_host += 1;
     return 0;
 }
 
@@ -1073,6 +1082,7 @@ static int enqueue_iterations(hpv_ctx* h, int n_iters) {
         for (int it = 0; it < n_iters; ++it)
             if ((rc = enqueue_pass_x(h, true, true))) return rc;
     }
+    h->nupd_host += n_iters;
     return 0;
 }
 
@@ -1095,6 +1105,26 @@ static int sync_check(hpv_ctx* h) {
                        "selects the barrier-free kernels");
 }
 
+// A run of `n` enqueued iterations ended with -7.  The device counter says how many of them were applied; unless the caller
+// opted out (HPV_EXCHANGE_FALLBACK=0) or the handle takes part in an in-library exchange between ranks (every rank would have
+// to take the same decision: left to the launcher), the handle is switched to the launch structures without an in-kernel
+// exchange and the caller finishes the run on those.  Returns the number of iterations that took place, or -1: report the -7.
+static int after_exchange_timeout(hpv_ctx* h, int n) {
+    long long dev = 0;
+    if (hpv_updates_applied(h, &dev)) return -1;
+    const long long done = dev - (h->nupd_host - n);
+    h->nupd_host = dev;
+    const char* e = getenv("HPV_EXCHANGE_FALLBACK");
+    if ((e && e[0] == '0') || !h->shared_elem_ok || h->rccl_on || h->p2p_on || done < 0 || done > n) return -1;
+    if (hpv_set_shared_element_kernels(h, 0)) return -1;
+    if (h->n_fallbacks++ == 0)
+        fprintf(stderr, "libhpvpinn: an in-kernel exchange between the workgroups of one element timed out after %lld of %d "
+                        "iterations (is the GPU shared?); continuing on the launch structures without an exchange "
+                        "(HPV_EXCHANGE_FALLBACK=0: return -7 instead)\n", done, n);
+    h->err.clear();
+    return (int)done;
+}
+
 // after a synchronisation point: did an exchange give up waiting for a peer?
 static int p2p_check(hpv_ctx* h) {
     if (!h->p2p_on) return 0;
@@ -1107,14 +1137,20 @@ static int p2p_check(hpv_ctx* h) {
 int hpv_step(hpv_handle h, int n_iters, double* loss3_after) {
     if (!h) return -1;
     int rc;
-    if ((rc = enqueue_iterations(h, n_iters))) return rc;
-    if (loss3_after) {
-        if ((rc = enqueue_pass_x(h, false, false))) return rc;
-        if ((rc = hpv_read_loss(h, loss3_after))) return rc;
-    } else {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int left = n_iters, round = 0;; ++round) {
+        if ((rc = enqueue_iterations(h, left))) return rc;
+        if (loss3_after) {
+            if ((rc = enqueue_pass_x(h, false, false))) return rc;
+            if ((rc = hpv_read_loss(h, loss3_after))) return rc;
+        } else {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
+        if ((rc = sync_check(h)) != -7 || round) break;
+        const int done = after_exchange_timeout(h, left);      // the rest of the run on the barrier-free structures
+        if (done < 0) break;
+        left -= done;
     }
-    if ((rc = sync_check(h))) return rc;
+    if (rc) return rc;
     return p2p_check(h);
 }
 
@@ -1157,15 +1193,17 @@ int hpv_step_record(hpv_handle h, int n_iters, double* loss3_hist, double* eps_h
         if ((rc = hpv_history_reset(h))) return rc;
         if ((rc = enqueue_iterations(h, c))) return rc;
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if ((rc = sync_check(h)) || (rc = p2p_check(h))) return rc;    // (before the history: a skipped iteration records nothing)
-        if ((rc = hpv_history_read(h, c, chunk.data(), ceps.data()))) return rc;
+        int got = c;       // (a skipped iteration records nothing: after a timeout the history holds the `got` that took place)
+        if ((rc = sync_check(h)) == -7 && (got = after_exchange_timeout(h, c)) >= 0) rc = 0;
+        if (rc || (rc = p2p_check(h))) return rc;
+        if (got && (rc = hpv_history_read(h, got, chunk.data(), ceps.data()))) return rc;
         // entry j was computed by the forward pass that preceded update done+j+1, i.e. it belongs to the state after update done+j
-        for (int j = 0; j < c; ++j)
+        for (int j = 0; j < got; ++j)
             if (done + j >= 1) {
                 std::copy_n(&chunk[(size_t)3 * j], 3, loss3_hist + (size_t)3 * (done + j - 1));
                 if (eps_hist) eps_hist[done + j - 1] = ceps[j];
             }
-        done += c;
+        done += got;
     }
     if (n_iters > 0) {   // the state after the last update: one forward pass
         if ((rc = enqueue_pass_x(h, false, false))) return rc;
@@ -1485,6 +1523,23 @@ int hpv_debug_read_out(hpv_handle h, double* out, size_t n) {
 }
 #endif
 int hpv_pass_structure(hpv_handle h) { return h ? h->pass_structure : -1; }
+int hpv_updates_applied(hpv_handle h, long long* n) {
+    if (!h || !n) return -1;
+    unsigned long long v = 0;
+    HIPCHK(h, hipMemcpyAsync(&v, h->d_nupd, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *n = (long long)v;
+    return 0;
+}
+int hpv_shared_element_kernels(hpv_handle h) { return !h ? -1 : (h->shared_elem_ok ? 1 : 0); }
+int hpv_set_shared_element_kernels(hpv_handle h, int on) {
+    if (!h) return -1;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->shared_elem_ok = on != 0;
+    if (h->mfma) hpv_mfma_set_split_ok(h->mfma, h->shared_elem_ok);
+    drop_graph(h);      // captured iterations hold the launch structure chosen before
+    return 0;
+}
 int hpv_graphs_in_use(hpv_handle h) { return !h ? -1 : ((h->use_graph && h->own_stream && (h->g_stepK || h->g_rem[1] || h->g_rem[2] || h->g_rem[3] || h->g_rem[4] || h->g_rem[5] || h->g_rem[6] || h->g_rem[7])) ? 1 : 0); }
 int hpv_backend_in_use(hpv_handle h) {
     if (!h) return -1;

@@ -66,6 +66,9 @@ struct AdamArgs {
     // sticky failure flag of the handle (a SPLIT-mode element barrier timed out, kernels_fused.hip): while it is set -- or the
     // pad slot of the all-reduced buffer says some rank's is -- no update is applied (theta, m, v, beta powers, history untouched)
     int* xerr;
+    // number of updates applied through this handle since it was created (thread 0 of the kernel that applies one adds 1);
+    // the host reads it after a failed run to learn how many of the requested iterations took place (hpv_updates_applied)
+    unsigned long long* n_upd;
 };
 #define HPV_HIST_CAP 4096
 

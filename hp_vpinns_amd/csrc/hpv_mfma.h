@@ -49,6 +49,9 @@ bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double
 // by the caller) that a timed-out exchange sets; without one those modes are not used.  hpv_mfma_split_used: such a launch
 // happened since creation.
 void hpv_mfma_set_err_flag(HpvMfma* m, int* dev_flag);
+// false: never choose a launch structure in which workgroups of one element exchange partial results (SPLIT mode, k_iter_tall);
+// true: allow them again unless HPV_FUSE=s forbids them
+void hpv_mfma_set_split_ok(HpvMfma* m, bool on);
 bool hpv_mfma_split_used(HpvMfma* m);
 // Tall elements (80x80 points, 5x5 test functions: BASELINE config 5) split over `split` workgroups each (kernels_tall.hip);
 // hpv_mfma_tall_split: workgroups per element (0 = not applicable), loss_e / deps_e then hold n_elem * split entries.

@@ -42,7 +42,7 @@ struct MfmaArgs {
     ProjArgs pa;
     // split whole-iteration kernels: the handle's sticky failure flag, test knob, exchange buffers
     int* xerr;            // sticky failure flag of the handle (hpv_ctx::d_xerr): set when an exchange times out; see hpv_fused_dev.h
-    int xdebug_skip;      // test knob (HPV_DEBUG_SPLIT_SKIP=1): partner 1 of element 0 stays away from the barrier
+    int xdebug_skip;      // test knob (HPV_DEBUG_SPLIT_SKIP=k >= 1): partner 1 of element 0 stays away from the exchange from the k-th launch on
     // tagged exchange (hpv_fused_dev.h, xg_*): the payload travels as 8-byte granules {32 bits of data | 32-bit launch tag}, so that
     // its arrival is its own notification -- no counter, no store-acknowledge / fetch-add / poll chain
     unsigned long long* xg;      // granule buffer

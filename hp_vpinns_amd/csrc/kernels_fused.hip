@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
 
     // SPLIT: this workgroup takes no part in the exchange (an earlier launch of the handle failed -- sticky flag -- or the test
     // knob keeps partner 1 of element 0 away): it publishes nothing and leaves at the hand-off point
-    const bool xstay = SPLIT && (xsticky || (g.xdebug_skip && e == 0 && part == 1));
+    const bool xstay = SPLIT && (xsticky || (g.xdebug_skip && xtag >= (unsigned)g.xdebug_skip && e == 0 && part == 1));
     // =============================================================================================
     // phase F: forward
     // =============================================================================================
@@ -1247,3 +1247,8 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
 bool hpv_mfma_sync_failed_possible(HpvMfma* m) { return m && m->last_split; }
 void hpv_mfma_set_err_flag(HpvMfma* m, int* dev_flag) { if (m) m->xerr = dev_flag; }
 bool hpv_mfma_split_used(HpvMfma* m) { return m && m->split_used; }
+void hpv_mfma_set_split_ok(HpvMfma* m, bool on) {
+    if (!m) return;
+    const char* e = getenv("HPV_FUSE");
+    m->iter_split_ok = on && !(e && e[0] == 's');
+}

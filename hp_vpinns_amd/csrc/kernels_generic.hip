@@ -589,6 +589,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
         }
         if (ad.theta && !failed) {
             ad.state[0] = s0 * ad.b1; ad.state[1] = s1 * ad.b2;
+            if (ad.n_upd) *ad.n_upd += 1;
             if (ad.hist) {   // single-GPU training iteration: record this forward pass's loss (see AdamArgs)
                 const int i = hidx;
                 if (i >= 0 && i < ad.hist_cap) {   // the index saturates at hist_cap (it never wraps)
@@ -639,6 +640,7 @@ __global__ void __launch_bounds__(1024) k_adam(AdamArgs ad, const double* __rest
         return;
     }
     const double b1p = ad.state[0], b2p = ad.state[1];
+    if (threadIdx.x == 0 && ad.n_upd) *ad.n_upd += 1;
     if (threadIdx.x == 0 && ad.hist) {   // multi-GPU iteration: g is the all-reduced packed buffer, the losses follow the gradient
         const int i = *ad.hist_idx;
         if (i >= 0 && i < ad.hist_cap) {   // saturating index
@@ -720,6 +722,7 @@ __global__ void __launch_bounds__(1024) k_p2p_exchange(P2PArgs pp, double* __res
     }
     // ---- TF1 Adam on the reduced gradient (same as k_adam) ----
     const double b1p = ad.state[0], b2p = ad.state[1];
+    if (threadIdx.x == 0 && ad.n_upd) *ad.n_upd += 1;
     if (threadIdx.x == 0 && ad.hist) {
         const int i = *ad.hist_idx;
         if (i >= 0 && i < ad.hist_cap) {   // saturating index

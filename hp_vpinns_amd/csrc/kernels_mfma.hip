@@ -755,7 +755,7 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
             m->xiter = nullptr;
         }
         const char* dbg = getenv("HPV_DEBUG_SPLIT_SKIP");
-        m->xdebug_skip = (dbg && dbg[0] == '1') ? 1 : 0;
+        m->xdebug_skip = dbg ? std::max(0, atoi(dbg)) : 0;
     }
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);

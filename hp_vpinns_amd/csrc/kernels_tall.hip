@@ -312,13 +312,13 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
 #pragma unroll
             for (int sl = 0; sl < TA_SLICES; ++sl) u += lds[M::UP + sl * NR + tid];
             // publish: two tagged granules per value, fire and forget (the partners poll the granules themselves)
-            if (!xsticky && !(g.xdebug_skip && e == 0 && part == 1)) xg_publish(g.xg + (wg_slot * NR + tid) * 2, u, xtag);
+            if (!xsticky && !(g.xdebug_skip && xtag >= (unsigned)g.xdebug_skip && e == 0 && part == 1)) xg_publish(g.xg + (wg_slot * NR + tid) * 2, u, xtag);
         }
         TA_STAMP(4);
         {
             // the S x NR partial sums of the element, straight into LDS (the transpose region is idle between the phases)
             constexpr int NITG = (64 * NR * 2 + TA_BLOCK - 1) / TA_BLOCK;
-            const bool stay_away = xsticky || (g.xdebug_skip && e == 0 && part == 1);     // workgroup-uniform
+            const bool stay_away = xsticky || (g.xdebug_skip && xtag >= (unsigned)g.xdebug_skip && e == 0 && part == 1);     // workgroup-uniform
             bool ok = true;
             if (!stay_away) ok = xg_gather<NITG, TA_BLOCK>(g.xg + (long)e * split * NR * 2, split * NR * 2, xtag, (unsigned*)(lds + M::TR), tid);
             const int timed_out = __syncthreads_or(ok ? 0 : 1);       // (also the barrier that makes the gathered sums visible)

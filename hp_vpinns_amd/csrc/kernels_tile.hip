@@ -511,6 +511,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
                     ad.theta[P] = eps_now - lr_t * mi / (sqrt(vi) + ad.eps);
                 }
             }
+            if (upd && ad.n_upd) *ad.n_upd += 1;
             if (upd && ad.hist) {
                 const int i = *ad.hist_idx;
                 if (i >= 0 && i < ad.hist_cap) {

@@ -195,6 +195,18 @@ int hpv_pass_structure(hpv_handle h);
 /* 1 when hpv_step / hpv_step_record replay captured iteration hipGraphs, 0 when they launch eagerly (HPV_NO_GRAPH=1, a foreign
  * stream, or a collective that refused stream capture -- hpv_step then drops to eager launches instead of failing). */
 int hpv_graphs_in_use(hpv_handle h);
+/* Number of parameter updates applied through this handle since hpv_create (synchronises).  After hpv_step returned -7 (an
+ * in-kernel exchange between the workgroups of one element timed out) the difference to the value before the call says how many
+ * of the requested iterations took place. */
+int hpv_updates_applied(hpv_handle h, long long* n);
+/* on = 0: from now on only launch structures without an in-kernel exchange (no SPLIT mode, no k_iter_tall: what HPV_FUSE=s
+ * selects at creation); on = 1 allows them again.  Drops captured iteration graphs.  hpv_step / hpv_step_record call it
+ * themselves when such an exchange timed out (-7 inside), and finish the requested iterations on the remaining structures:
+ * the run continues instead of ending on a shared GPU.  They return -7 instead when HPV_EXCHANGE_FALLBACK=0 is set or the
+ * handle is connected to other ranks (hpv_rccl_connect / hpv_p2p_connect: the launcher decides for all ranks).
+ * hpv_shared_element_kernels: the current setting (0 after such a fallback). */
+int hpv_shared_element_kernels(hpv_handle h);
+int hpv_set_shared_element_kernels(hpv_handle h, int on);
 /* The network value and its input-derivative channels at the owned quadrature points, [C][n_owned*qx*qy]
  * (channel order: u, then d/dx, d/dy (d/dt), then the second derivatives the variational form integrates) --
  * what net_u / net_du / net_dxu / net_dyu / net_dtu return (P1:140-148, P2:171-185, P3:232-245).  One forward launch. */
