@@ -5,10 +5,12 @@
     shards cut out of the reference-generated config-4 fixture with hpv_set_elements(e_begin, e_end) -- the shard's oracle is the
     vectorised restatement of P2:68-129 on the same rows of the grid and of F_ext_total; the shard gradients summed = the
     full-grid oracle's;
-  * a barrier TIMEOUT (forced with the test knob HPV_DEBUG_SPLIT_SKIP=1: one partner of element 0 stays away) must leave the
-    replica bit-identical -- parameters, Adam moments, beta powers -- raise HpvError(-7) from every entry point that runs
-    iterations, and leave the handle usable; the same through the 1-rank in-library RCCL path, where the failure travels in the
-    pad slot of the all-reduced buffer.
+  * a barrier TIMEOUT (forced with the test knob HPV_DEBUG_SPLIT_SKIP=k: one partner of element 0 stays away from the k-th
+    launch on) must leave the replica bit-identical -- parameters, Adam moments, beta powers -- and, with
+    HPV_EXCHANGE_FALLBACK=0, raise HpvError(-7) from every entry point that runs iterations and leave the handle usable; the
+    same through the 1-rank in-library RCCL path, where the failure travels in the pad slot of the all-reduced buffer;
+  * by default hpv_step / hpv_step_record FINISH such a run on the launch structures without an exchange: the parameters and
+    the recorded loss history equal those of an undisturbed run.
 """
 import os
 
@@ -93,8 +95,9 @@ def _build_small_shard(seed=6, nex=16, ney=4):
     return poisson2d.build_model(s, L4, init_params=xavier_init(L4, seed))
 
 
-def test_split_barrier_timeout_leaves_the_replica_intact():
+def test_split_barrier_timeout_leaves_the_replica_intact(monkeypatch):
     from hp_vpinns_amd import _lib
+    monkeypatch.setenv("HPV_EXCHANGE_FALLBACK", "0")      # report the failure instead of finishing on the barrier-free kernels
     ref = _build_small_shard()
     ref._step(24, False)
     os.environ["HPV_DEBUG_SPLIT_SKIP"] = "1"          # read when the handle's kernels are set up
@@ -105,9 +108,10 @@ def test_split_barrier_timeout_leaves_the_replica_intact():
     state0 = m.h.get_state()
     for call in (lambda: m._step(11, False), lambda: m._step(3, True), lambda: m._step_record(5), lambda: m.loss_and_grad(),
                  lambda: m._step(1, False)):
-        with pytest.raises(_lib.HpvError, match="did not meet at their barrier"):
+        with pytest.raises(_lib.HpvError, match="did not meet at their barrier") as ei:
             call()
-        assert m.h.pass_structure() == "whole-iteration-split"
+        assert ei.value.code == _lib.EXCHANGE_TIMEOUT
+        assert m.h.pass_structure() == "whole-iteration-split" and m.h.shared_element_kernels()
         assert np.array_equal(m.h.get_state(), state0), "a timed-out iteration touched the replica"
     # forward-only evaluations never enter SPLIT mode and keep working on the untouched parameters
     assert np.isfinite(m.loss()[0])
@@ -202,10 +206,11 @@ def test_tall_element_kernel_against_the_oracle_and_the_separate_launches(vf, nh
     assert rel(lm, lo) < TRAJ_TOL and rel(m3.get_params(), o2.get_params()) < TRAJ_TOL
 
 
-def test_tall_element_kernel_on_shards_and_its_barrier_timeout():
+def test_tall_element_kernel_on_shards_and_its_barrier_timeout(monkeypatch):
     """Shards of config 5 (4 / 1 of its 8 elements: what a GPU of a 2 / 8-GPU run owns) run the same kernel with 64 workgroups
     per element; the shard gradients add up to the full-grid model's.  A partner that stays away (HPV_DEBUG_SPLIT_SKIP=1) must
-    leave the replica bit-identical and raise."""
+    leave the replica bit-identical and (HPV_EXCHANGE_FALLBACK=0) raise."""
+    monkeypatch.setenv("HPV_EXCHANGE_FALLBACK", "0")
     from cases import p3_args
     from hp_vpinns_amd import _lib
     from hp_vpinns_amd.dist import shard_range
@@ -241,3 +246,70 @@ def test_tall_element_kernel_on_shards_and_its_barrier_timeout():
         with pytest.raises(_lib.HpvError, match="did not meet at their barrier"):
             call()
         assert np.array_equal(m.h.get_state(), state0)
+
+
+def _with_knob(k, build):
+    os.environ["HPV_DEBUG_SPLIT_SKIP"] = str(k)      # read when the handle's kernels are set up
+    try:
+        return build()
+    finally:
+        del os.environ["HPV_DEBUG_SPLIT_SKIP"]
+
+
+def _fallback_note(capfd):
+    """(iterations that took place before the timeout, iterations requested) from the library's one-line notice on stderr."""
+    import re
+    m = re.search(r"timed out after (\d+) of (\d+) iterations", capfd.readouterr().err)
+    assert m, "no fallback notice"
+    return int(m.group(1)), int(m.group(2))
+
+
+def test_exchange_timeout_mid_run_is_finished_on_the_barrier_free_kernels(capfd):
+    """hpv_step: the partner stays away from the 14th launch on -- the iterations before it were applied, the failing one and
+    the rest of the run are redone without an in-kernel exchange; end state = an undisturbed run's."""
+    ref = _build_small_shard()
+    ref._step(30, False)
+    m = _with_knob(14, _build_small_shard)
+    capfd.readouterr()
+    l3 = m._step(30, True)
+    done, asked = _fallback_note(capfd)
+    assert asked == 30 and 0 < done < 30
+    assert m.h.updates_applied() == 30 and not m.h.shared_element_kernels()
+    assert m.h.pass_structure() in ("whole-iteration", "fused-reverse")      # (small shard: the two-kernel path is the faster one)
+    assert rel(m.get_params(), ref.get_params()) < 1e-10
+    assert rel(l3, ref.loss()) < 1e-9
+    # the handle stays on those kernels: further runs need no second fallback
+    m._step(10, False)
+    ref._step(10, False)
+    assert "timed out" not in capfd.readouterr().err and m.h.updates_applied() == 40
+    assert rel(m.get_params(), ref.get_params()) < 1e-10
+
+
+def test_exchange_timeout_mid_run_keeps_the_recorded_history(capfd):
+    """hpv_step_record: the losses recorded before the timeout are kept, the rest follows from the barrier-free kernels."""
+    ref = _build_small_shard(seed=8)
+    h_ref, _ = ref._step_record(21)
+    m = _with_knob(6, lambda: _build_small_shard(seed=8))
+    capfd.readouterr()
+    h, _ = m._step_record(21)
+    done, asked = _fallback_note(capfd)
+    assert asked == 21 and 0 < done < 21
+    assert rel(h, h_ref) < 1e-9 and rel(m.get_params(), ref.get_params()) < 1e-10
+
+
+def test_tall_element_kernel_timeout_mid_run_is_finished_on_separate_launches(capfd):
+    from cases import p3_args
+    from hp_vpinns_amd.vpinn import VPINNAdvDiff
+    L = [2, 20, 20, 20, 1]
+    a = p3_args(gold("advdiff_cfg5"), layers=L)
+    th = theta0(L, 31, extra=[0.8])
+    ref = VPINNAdvDiff(*a, init_params=th)
+    h_ref, e_ref = ref._step_record(12)
+    assert ref.h.pass_structure() == "whole-iteration-tall"
+    m = _with_knob(5, lambda: VPINNAdvDiff(*a, init_params=th))
+    capfd.readouterr()
+    h, e = m._step_record(12)
+    done, asked = _fallback_note(capfd)
+    assert asked == 12 and 0 < done < 12
+    assert m.h.pass_structure() in ("separate", "fused-reverse") and m.h.updates_applied() == 12
+    assert rel(h, h_ref) < 1e-9 and rel(e, e_ref) < 1e-10 and rel(m.get_params(), ref.get_params()) < 1e-10
