@@ -8,6 +8,34 @@ __device__ __forceinline__ double pj_wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Lane exchanges inside a row of 16 lanes as DPP moves (one VALU instruction per half, no LDS round trip: __shfl_xor compiles
+// to ds_bpermute_b32 pairs, ~100 cycles of latency each in the dependent chains of a reduction)
+template <int CTRL>
+__device__ __forceinline__ double pj_dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// v + (lane ^ 2) + ... in the order of `acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1)`
+__device__ __forceinline__ double pj_quad_sum(double v) {
+    v += pj_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += pj_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
+    return v;
+}
+// the whole wave's sum in every lane: rows of 16 by DPP, the four rows through readlane
+__device__ __forceinline__ double pj_wave_sum_dpp(double v) {
+    v = pj_quad_sum(v);
+    v += pj_dpp<0x141>(v);    // row_half_mirror
+    v += pj_dpp<0x140>(v);    // row_mirror
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), 16 * r);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 16 * r);
+        t += __hiloint2double(hi, lo);
+    }
+    return t;
+}
 // Workgroup barrier for LDS hand-offs that leaves global loads IN FLIGHT: __syncthreads() waits for the whole vector-memory
 // queue (s_waitcnt vmcnt(0)), which puts the round trip of every load requested ahead of it -- the projection tables the
 // whole-iteration kernels request early and park late -- in front of the barrier (cdna_hip_programming.md section 5:
@@ -445,6 +473,196 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
         if ((tid & 63) == 0) red[2 * NWV + (tid >> 6)] = deps;
         __syncthreads();
         if (tid == 0) { double t = 0.0; for (int w = 0; w < NWV; ++w) t += red[2 * NWV + w]; deps_e[e] = t; }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// The same projection for a 1-D element (QY = NTY = 1: P1:82-100) inside the whole-iteration tile kernel (tables pre-staged by
+// ProjTableRegs, channels and adjoints in LDS, no edge term -- the caller's host side excludes var_form 3).  The general
+// function above spends seven workgroup barriers and two LDS hand-offs per term on what is, in 1-D, two matrix-vector
+// products with one NTX x QX table per term; here every term's integrand goes to LDS at once and the element takes two
+// barriers (+ the caller's) (LDS-only ones, pj_lds_barrier: a __syncthreads would also wait for the acknowledgement of the R / loss stores):
+// integrands | residual (one pass over all terms, -F, active-count mask, R, squared sum) | adjoint contraction and the
+// point's adjoint channels by the same lane quad.  Every sum keeps the order of the general function (per-lane chain, then the xor tree, terms in
+// sequence), so the residuals, S and the adjoint channels are bit-identical to it; only the element's squared sum is added up
+// in another lane order.
+// ------------------------------------------------------------------------------------------------
+template <int QX, int NTX, int PW_BLOCK>
+__device__ __forceinline__ void project_element_1d(const ProjArgs& pa, const long e, double* sm, const double* __restrict__ OUT,
+                                                   double* __restrict__ GBAR) {
+    const ProjDesc& pd = pa.pd;
+    constexpr int NWV = PW_BLOCK / 64, AXLD = QX + 1, SP = 4;     // (SP = 4: the lanes of one output are a DPP quad)
+    static_assert(NTX * SP <= PW_BLOCK && QX * SP <= PW_BLOCK, "one pass per contraction");
+    static_assert(3 * NWV <= 48, "pre-staged scalars sit at red[48..]");
+    // the scratch as ProjTableRegs<QX, 1, NTX, 1, PW_BLOCK>::store laid it out
+    double* AXl = sm + (QX + 1);                 // [HPV_MAXT][NTX][AXLD]
+    double* BYl = AXl + HPV_MAXT * NTX * AXLD;   // [HPV_MAXT]  (w_y phi^(dy) of the single y point)
+    double* U = BYl + HPV_MAXT + NTX;            // [NTX]  -F on entry
+    double* S = U + NTX;                         // [HPV_MAXT][QX]  first every term's integrand, then its adjoint contraction
+    double* red = S + HPV_MAXT * QX;             // [64]
+    const int tid = threadIdx.x;
+    const int nterms = pd.nterms, C = pd.C;
+    const double eps = red[48 + HPV_MAXT];
+    const int nax = (int)red[48 + HPV_MAXT + 1];
+    double cf[HPV_MAXT], byv[HPV_MAXT];
+#pragma unroll
+    for (int t = 0; t < HPV_MAXT; ++t) { cf[t] = red[48 + t]; byv[t] = BYl[t]; }
+#ifdef HPV_PJ_TIMING
+    if (threadIdx.x == 0) pa.GBAR[e * 16 + 0] = (double)clock64();
+#endif
+    // every kernarg scalar the phases below need, fetched in one batch (a scalar load in the middle of a latency chain costs its
+    // whole round trip): the destination pointers, and per term the channel coefficients alpha = a0 + eps a1 (kept in registers
+    // for the adjoint channels), the epsilon multiplier
+    double* const Rg = pa.R;
+    double* const loss_g = pa.loss_e;
+    double* const deps_g = pa.deps_e;
+    const int do_adjoint = pa.do_adjoint, has_eps = pd.has_eps;
+    asm volatile("" ::"s"(Rg), "s"(loss_g), "s"(deps_g), "s"(do_adjoint), "s"(has_eps));
+    double al[HPV_MAXT][HPV_MAXC], a1v[HPV_MAXT][HPV_MAXC], mt[HPV_MAXT];
+    bool em[HPV_MAXT];
+#pragma unroll
+    for (int t = 0; t < HPV_MAXT; ++t) {
+        const bool on = t < nterms;
+        em[t] = on && pd.t[t].eps_mult;
+        mt[t] = em[t] ? eps : 1.0;
+#pragma unroll
+        for (int ch = 0; ch < HPV_MAXC; ++ch) {
+            a1v[t][ch] = (on && ch < C) ? pd.t[t].a1[ch] : 0.0;
+            al[t][ch] = (on && ch < C) ? pd.t[t].a0[ch] + eps * a1v[t][ch] : 0.0;
+        }
+    }
+    // ---- integrands of every term at this thread's point ----
+    double ov[HPV_MAXC];
+    {
+        const int q = tid < QX ? tid : QX - 1;
+#pragma unroll
+        for (int ch = 0; ch < HPV_MAXC; ++ch) ov[ch] = OUT[(ch < C ? ch : 0) * QX + q];
+#pragma unroll
+        for (int t = 0; t < HPV_MAXT; ++t) {
+            if (t >= nterms) break;
+            double gsum = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < HPV_MAXC; ++ch) gsum = fma(al[t][ch], ov[ch], gsum);
+            if (tid < QX) S[t * QX + tid] = gsum;
+        }
+    }
+    pj_lds_barrier();
+#ifdef HPV_PJ_TIMING
+    if (threadIdx.x == 0) pa.GBAR[e * 16 + 1] = (double)clock64();
+#endif
+    // ---- residual: SP adjacent lanes share one test function ----
+    {
+        // lanes of a 32-lane LDS group take rows 4 apart: with AXLD = QX + 1 = 17 (mod 32) their ds_read_b64 then cover all
+        // 32 eight-byte bank pairs (rows r0 .. r0 + 7 would collide two by two)
+        const int part = tid % SP, grp = tid >> 5;
+        const int r = (grp & 3) + 4 * ((tid >> 2) & 7) + 32 * (grp >> 2);
+        const bool ok = r < NTX && tid < 256;
+        const int rc = ok ? r : 0;
+        constexpr int KIT = (QX + SP - 1) / SP;
+        static_assert(NTX <= 64 && (QX + 1) % 32 == 17, "lane mapping of the 1-D residual / adjoint contractions");
+        double u = U[rc];
+#pragma unroll
+        for (int t = 0; t < HPV_MAXT; ++t) {
+            if (t >= nterms) break;
+            double av[KIT], gq[KIT];
+#pragma unroll
+            for (int it = 0; it < KIT; ++it) {
+                const int i = part + it * SP, ic = i < QX ? i : 0;
+                av[it] = AXl[t * NTX * AXLD + rc * AXLD + ic];
+                gq[it] = i < QX ? S[t * QX + ic] : 0.0;
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int it = 0; it < KIT; ++it) acc = fma(av[it], gq[it], acc);
+            acc = pj_quad_sum(acc);
+            const double c = cf[t] * mt[t];
+            u = fma(c, fma(byv[t], acc, 0.0), u);
+        }
+        u = rc < nax ? u : 0.0;
+        double sq = 0.0;
+        if (ok && part == 0) {
+            U[r] = u;
+            Rg[e * NTX + r] = u;
+            sq = u * u;
+        }
+        sq = pj_wave_sum_dpp(sq);
+        if ((tid & 63) == 0) red[tid >> 6] = sq;
+    }
+    pj_lds_barrier();
+#ifdef HPV_PJ_TIMING
+    if (threadIdx.x == 0) pa.GBAR[e * 16 + 2] = (double)clock64();
+#endif
+    const double NRa = (double)nax;
+    if (tid == 0) { double t = 0.0; for (int w = 0; w < NWV; ++w) t += red[w]; loss_g[e] = t / NRa; }
+    if (!do_adjoint) return;
+    const double sc = 2.0 / NRa;
+    // ---- adjoint: S_t[i] = sc sum_r AX_t[r][i] U[r] by a lane quad per point, which goes straight on to the point's adjoint
+    //      channels (+ its share of d loss / d epsilon): no hand-off through LDS, no barrier between the two ----
+    double deps = 0.0;
+    {
+        // (columns 4 apart per LDS group: rows part + 4 it are 0, 17, 2, 19 (mod 32) bank pairs apart, see above)
+        const int part = tid % SP, grp = tid >> 5;
+        const int i = (grp & 3) + 4 * ((tid >> 2) & 7) + 32 * (grp >> 2);
+        const bool ok = i < QX;
+        const int ic = ok ? i : 0;
+        constexpr int KIT = (NTX + SP - 1) / SP;
+        static_assert(QX <= 32 * (PW_BLOCK / 128), "every column has its lane quad");
+        double uq[KIT];
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int r = part + it * SP;
+            uq[it] = r < NTX ? U[r] : 0.0;
+        }
+        double oi[HPV_MAXC];                 // the point's channels again (d/d eps only)
+#pragma unroll
+        for (int ch = 0; ch < HPV_MAXC; ++ch) oi[ch] = has_eps ? OUT[(ch < C ? ch : 0) * QX + ic] : 0.0;
+        double gb[HPV_MAXC];
+#pragma unroll
+        for (int ch = 0; ch < HPV_MAXC; ++ch) gb[ch] = 0.0;
+#pragma unroll
+        for (int t = 0; t < HPV_MAXT; ++t) {
+            if (t >= nterms) break;
+            double av[KIT];
+#pragma unroll
+            for (int it = 0; it < KIT; ++it) {
+                const int r = part + it * SP, rc = r < NTX ? r : 0;
+                av[it] = AXl[t * NTX * AXLD + rc * AXLD + ic];
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int it = 0; it < KIT; ++it) acc = fma(av[it], uq[it], acc);
+            acc = pj_quad_sum(acc);
+            double gh = fma(byv[t], acc * sc, 0.0);
+            gh *= cf[t];
+            const double m = mt[t];
+            double g1 = 0.0, gt = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < HPV_MAXC; ++ch) {
+                gb[ch] = fma(al[t][ch], m * gh, gb[ch]);
+                if (has_eps) {
+                    g1 = fma(a1v[t][ch], oi[ch], g1);
+                    gt = fma(al[t][ch], oi[ch], gt);
+                }
+            }
+            if (ok && part == 0) deps = fma(gh, m * g1 + (em[t] ? gt : 0.0), deps);
+        }
+        if (ok && part == 0) {
+#pragma unroll
+            for (int ch = 0; ch < HPV_MAXC; ++ch)
+                if (ch < C) GBAR[ch * QX + i] = gb[ch];
+        }
+    }
+#ifdef HPV_PJ_TIMING
+    if (threadIdx.x == 0) pa.GBAR[e * 16 + 3] = (double)clock64();
+    if (threadIdx.x == 0) pa.GBAR[e * 16 + 4] = (double)clock64();
+#endif
+    if (has_eps) {
+        deps = pj_wave_sum_dpp(deps);
+        pj_lds_barrier();
+        if ((tid & 63) == 0) red[2 * NWV + (tid >> 6)] = deps;
+        pj_lds_barrier();
+        if (tid == 0) { double t = 0.0; for (int w = 0; w < NWV; ++w) t += red[2 * NWV + w]; deps_g[e] = t; }
     }
 }
 

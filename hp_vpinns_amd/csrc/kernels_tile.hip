@@ -58,6 +58,14 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
     const long n_elem = g.proj_n_elem;
     const bool elem_wg = (long)blockIdx.x < n_elem;
     const long e = blockIdx.x;
+    // the projection reads its term descriptors from the kernarg segment half a launch from now, in the middle of latency
+    // chains: touch their cache lines here (scalar loads nobody waits for), so that those reads hit the scalar cache
+#pragma unroll
+    for (int t_ = 0; t_ < HPV_MAXT; ++t_) {
+        asm volatile("" ::"s"(__double2loint(pa.pd.t[t_].a0[0])));
+        asm volatile("" ::"s"(__double2loint(pa.pd.t[t_].a1[HPV_MAXC - 1])));
+    }
+    asm volatile("" ::"s"(pa.R), "s"(pa.loss_e));
 #ifdef HPV_FZ_TIMING
     long long tl_t[8];
     TL_STAMP(0);
@@ -276,11 +284,14 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
     TL_STAMP(3);
     if (elem_wg) {
         // (the element's channels and their adjoints stay in LDS)
-        project_element_wg<QX, QY, NTX, NTY, BT, true>(pa, e, lds + M::RA, lds + M::CHN, lds + M::CHN + HPV_MAXC * NQ);
+        if constexpr (QY == 1 && NTY == 1)
+            project_element_1d<QX, NTX, BT>(pa, e, lds + M::RA, lds + M::CHN, lds + M::CHN + HPV_MAXC * NQ);
+        else
+            project_element_wg<QX, QY, NTX, NTY, BT, true>(pa, e, lds + M::RA, lds + M::CHN, lds + M::CHN + HPV_MAXC * NQ);
 #ifdef HPV_PJ_TIMING
         if (threadIdx.x == 0) pa.GBAR[e * 16 + 7] = (double)clock64();
 #endif
-        __syncthreads();
+        pj_lds_barrier();      // (adjoint channels in LDS; the R / loss stores need not have been acknowledged)
     }
     TL_STAMP(4);
 

@@ -20,4 +20,7 @@ m.h.lib.hpv_debug_read_out.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_si
 m.h.lib.hpv_debug_read_out(m.h._h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size)
 t = out.reshape(NB, 16)[:, :8]
 d = np.diff(t, axis=1).mean(axis=0)
-print(mode, "start->tables-sync, ->G stored, ->contraction 1, ->contraction 2, ->R/loss, ->S, ->end:", np.round(d).tolist(), "total", round(float((t[:, 7] - t[:, 0]).mean())))
+if mode == "t2":   # project_element_1d: five stamps, the kernel's own at [7]
+    print(mode, "integrands+barrier, residual+barrier, adjoint contraction+barrier, adjoint channels, (return):", np.round(d[:4]).tolist(), "total", round(float((t[:, 7] - t[:, 0]).mean())))
+else:
+    print(mode, "start->tables-sync, ->G stored, ->contraction 1, ->contraction 2, ->R/loss, ->S, ->end:", np.round(d).tolist(), "total", round(float((t[:, 7] - t[:, 0]).mean())))
