@@ -1106,16 +1106,19 @@ static int sync_check(hpv_ctx* h) {
 }
 
 // A run of `n` enqueued iterations ended with -7.  The device counter says how many of them were applied; unless the caller
-// opted out (HPV_EXCHANGE_FALLBACK=0) or the handle takes part in an in-library exchange between ranks (every rank would have
-// to take the same decision: left to the launcher), the handle is switched to the launch structures without an in-kernel
-// exchange and the caller finishes the run on those.  Returns the number of iterations that took place, or -1: report the -7.
+// opted out (HPV_EXCHANGE_FALLBACK=0) the handle is switched to the launch structures without an in-kernel exchange and the
+// caller finishes the run on those.  Handles connected to other ranks (in-library RCCL / mailbox exchange) take the same
+// decision without talking to each other: the failure flag travels with the all-reduced buffer of the failing iteration, so
+// every rank's k_adam / exchange kernel skips from the same iteration on, every rank's hpv_step sees -7 in the same call with
+// the same count, and every rank enqueues the same number of remaining iterations (collectives stay matched).
+// Returns the number of iterations that took place, or -1: report the -7.
 static int after_exchange_timeout(hpv_ctx* h, int n) {
     long long dev = 0;
     if (hpv_updates_applied(h, &dev)) return -1;
     const long long done = dev - (h->nupd_host - n);
     h->nupd_host = dev;
     const char* e = getenv("HPV_EXCHANGE_FALLBACK");
-    if ((e && e[0] == '0') || !h->shared_elem_ok || h->rccl_on || h->p2p_on || done < 0 || done > n) return -1;
+    if ((e && e[0] == '0') || !h->shared_elem_ok || done < 0 || done > n) return -1;
     if (hpv_set_shared_element_kernels(h, 0)) return -1;
     if (h->n_fallbacks++ == 0)
         fprintf(stderr, "libhpvpinn: an in-kernel exchange between the workgroups of one element timed out after %lld of %d "

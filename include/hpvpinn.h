@@ -202,8 +202,8 @@ int hpv_updates_applied(hpv_handle h, long long* n);
 /* on = 0: from now on only launch structures without an in-kernel exchange (no SPLIT mode, no k_iter_tall: what HPV_FUSE=s
  * selects at creation); on = 1 allows them again.  Drops captured iteration graphs.  hpv_step / hpv_step_record call it
  * themselves when such an exchange timed out (-7 inside), and finish the requested iterations on the remaining structures:
- * the run continues instead of ending on a shared GPU.  They return -7 instead when HPV_EXCHANGE_FALLBACK=0 is set or the
- * handle is connected to other ranks (hpv_rccl_connect / hpv_p2p_connect: the launcher decides for all ranks).
+ * the run continues instead of ending on a shared GPU (connected ranks all do so in the same call: the failure travels with
+ * the all-reduced buffer).  They return -7 instead when HPV_EXCHANGE_FALLBACK=0 is set.
  * hpv_shared_element_kernels: the current setting (0 after such a fallback). */
 int hpv_shared_element_kernels(hpv_handle h);
 int hpv_set_shared_element_kernels(hpv_handle h, int on);

@@ -127,7 +127,8 @@ def _rccl_timeout_worker(rank, port, out_path):
     import torch
     import torch.distributed as dist
     from hp_vpinns_amd import _lib
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HPV_FORCE_DIST="1", HPV_DEBUG_SPLIT_SKIP="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HPV_FORCE_DIST="1", HPV_DEBUG_SPLIT_SKIP="1",
+                      HPV_EXCHANGE_FALLBACK="0")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     res = {}
     try:
@@ -144,6 +145,17 @@ def _rccl_timeout_worker(rank, port, out_path):
             res.setdefault("intact", []).append(bool(np.array_equal(m.h.get_state(), state0)))
         res["raised"] = raised
         res["structure"] = m.h.pass_structure()
+        # default behaviour: the partner leaves at the 9th launch, the run is finished without the in-kernel exchange -- the
+        # all-reduce inside the iteration stays in place
+        del os.environ["HPV_EXCHANGE_FALLBACK"]
+        os.environ["HPV_DEBUG_SPLIT_SKIP"] = "9"
+        m2 = _build_small_shard()
+        del os.environ["HPV_DEBUG_SPLIT_SKIP"]
+        ref = _build_small_shard()
+        m2._step(20, False)
+        ref._step(20, False)
+        res["fallback"] = (float(rel(m2.get_params(), ref.get_params())), m2.h.updates_applied(), m2.h.shared_element_kernels(),
+                           m2.exchange(), ref.h.pass_structure())
     finally:
         with open(out_path, "wb") as f:
             pickle.dump(res, f)
@@ -159,6 +171,8 @@ def test_split_barrier_timeout_through_the_in_library_rccl_path(tmp_path):
     r = pickle.load(open(out, "rb"))
     assert r["exchange"] == "rccl" and r["structure"] == "whole-iteration-split", r
     assert r["raised"] == [True, True, True] and r["intact"] == [True, True, True], r
+    fr, applied, shared, exch, ref_structure = r["fallback"]
+    assert fr < 1e-10 and applied == 20 and not shared and exch == "rccl" and ref_structure == "whole-iteration-split", r
 
 
 # ---- few tall elements (BASELINE config 5: AdvDiff, 8 elements x 80x80 points): kernels_tall.hip ----
