@@ -134,6 +134,29 @@ __device__ __forceinline__ double dpp_move(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// Sums ACROSS the 16-lane rows (the MFMA operand layouts keep one k-group per row): v[l] + v[l ^ 16] and v[l] + v[l ^ 32] in
+// every lane through gfx950's permlane swaps (v_permlane16_swap exchanges the odd rows of one register with the even rows of
+// another, v_permlane32_swap the upper half of one with the lower half of the other: with both registers = v, the two results
+// are {v_even, v_even} and {v_odd, v_odd} per row pair / half pair, and their sum is the exchange sum) -- two VALU instructions
+// per 64-bit value and step instead of a ds_bpermute pair with its LDS round trip in the middle of a dependency chain.
+// Values identical to `v += __shfl_xor(v, 16, 64)` / `(v, 32, 64)`.
+__device__ __forceinline__ double xrow_sum16(double v) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double xrow_sum32(double v) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+// t[l] + t[l ^ 4] + t[l ^ 8] + t[l ^ 12] for the lanes of the first quad of every row (the others get another association of
+// the same four values): two row rotations instead of two ds_bpermute pairs
+__device__ __forceinline__ double quad4_sum(double t) {
+    t += dpp_move<0x124>(t);   // row_ror:4
+    t += dpp_move<0x128>(t);   // row_ror:8
+    return t;
+}
 __device__ __forceinline__ double row_sum16(double v) {
     v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
     v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]

@@ -355,8 +355,8 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                 double v = 0.0;
 #pragma unroll
                 for (int s = 0; s < MF_KS; ++s) v += h[t][ch][s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
+                v = xrow_sum16(v);
+                v = xrow_sum32(v);
                 o[ch] = v;
             }
             o[0] += bo;
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             sq = u * u;
         }
         if (wv < 2) {
-            sq = pj_wave_sum(sq);
+            sq = pj_wave_sum_dpp(sq);
             if (lane == 0) lds[M::RED + wv] = sq;
         }
         __syncthreads();
@@ -657,8 +657,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
 #pragma unroll
     for (int i = 1; i < L; ++i) {
         double t = accC[i - 1];
-        t += __shfl_xor(t, 4, 64);
-        t += __shfl_xor(t, 8, 64);
+        t = quad4_sum(t);
         if (pt < 4) WP[g.woff[i] + (16 + q) * MF_H + 16 + pt] = t;
     }
 #pragma unroll
@@ -892,8 +891,8 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
             double v = 0.0;
 #pragma unroll
             for (int s = 0; s < MF_KS; ++s) v += h[ch][s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lane];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
+            v = xrow_sum16(v);
+            v = xrow_sum32(v);
             o[ch] = v;
         }
         o[0] += bo;
@@ -946,7 +945,7 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
             sq = u * u;
         }
         if (wv == 0) {
-            sq = pj_wave_sum(sq);
+            sq = pj_wave_sum_dpp(sq);
             if (lane == 0) lds[M::RED] = sq;
         }
         __syncthreads();
@@ -1091,8 +1090,7 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
 #pragma unroll
     for (int i = 1; i < L; ++i) {
         double t = accC[i - 1];
-        t += __shfl_xor(t, 4, 64);
-        t += __shfl_xor(t, 8, 64);
+        t = quad4_sum(t);
         if (pt < 4) WP[g.woff[i] + (16 + q) * MF_H + 16 + pt] = t;
     }
 #pragma unroll

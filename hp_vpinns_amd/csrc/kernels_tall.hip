@@ -237,8 +237,8 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
             double v = 0.0;
 #pragma unroll
             for (int s = 0; s < MF_KS; ++s) v += h[ch][s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
+            v = xrow_sum16(v);
+            v = xrow_sum32(v);
             o[ch] = v;
         }
         o[0] += bo;
@@ -585,8 +585,7 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
 #pragma unroll
     for (int i = 1; i < L; ++i) {
         double t = accC[i - 1];
-        t += __shfl_xor(t, 4, 64);
-        t += __shfl_xor(t, 8, 64);
+        t = quad4_sum(t);
         if (pt < 4) WP[g.woff[i] + (16 + q) * MF_H + 16 + pt] = t;
     }
 #pragma unroll

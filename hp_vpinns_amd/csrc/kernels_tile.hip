@@ -259,8 +259,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
             double v = 0.0;
 #pragma unroll
             for (int s = 0; s < MF_KS; ++s) v = fma(h[ch][s], W1O[(D * MF_KS + s) * 64 + lane], v);
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
+            v = xrow_sum16(v);
+            v = xrow_sum32(v);
             if (ch == 0) v += bo;
             if (is_el) {
                 if (q == 0 && valid) lds[M::CHN + ch * NQ + 16 * wv + pt] = v;
@@ -426,8 +426,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
                 WP[g.woff[i] + pt * MF_H + 16 + q] = dS01;
                 {
                     double t = accC;
-                    t += __shfl_xor(t, 4, 64);
-                    t += __shfl_xor(t, 8, 64);
+                    t = quad4_sum(t);
                     if (pt < 4) WP[g.woff[i] + (16 + q) * MF_H + 16 + pt] = t;
                 }
                 // hbar_in^T = W zbar^T
