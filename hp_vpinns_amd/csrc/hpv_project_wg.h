@@ -3,39 +3,42 @@
 #pragma once
 #include "hpv_internal.h"
 
-__device__ __forceinline__ double pj_wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-// Lane exchanges inside a row of 16 lanes as DPP moves (one VALU instruction per half, no LDS round trip: __shfl_xor compiles
-// to ds_bpermute_b32 pairs, ~100 cycles of latency each in the dependent chains of a reduction)
+// Lane exchanges without an LDS round trip (__shfl_xor compiles to ds_bpermute_b32 pairs, ~100 cycles of latency each in the
+// dependent chain of a reduction): inside a row of 16 lanes DPP moves (one VALU instruction per half), across rows gfx950's
+// permlane swaps (v_permlane16_swap exchanges the odd rows of one register with the even rows of another, v_permlane32_swap
+// the upper half of one with the lower half of the other; with both registers = v the two results add up to v[l] + v[l ^ 16]
+// resp. v[l] + v[l ^ 32] in every lane).
 template <int CTRL>
 __device__ __forceinline__ double pj_dpp(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-// v + (lane ^ 2) + ... in the order of `acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1)`
-__device__ __forceinline__ double pj_quad_sum(double v) {
-    v += pj_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
-    v += pj_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
+__device__ __forceinline__ double pj_xrow16(double v) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double pj_xrow32(double v) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+// sum over every aligned group of SP adjacent lanes (SP a power of two), in every lane of the group; all 64 lanes must be active
+template <int SP>
+__device__ __forceinline__ double pj_group_sum(double v) {
+    static_assert(SP >= 1 && SP <= 64 && (SP & (SP - 1)) == 0, "power of two");
+    if constexpr (SP >= 2) v += pj_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
+    if constexpr (SP >= 4) v += pj_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
+    if constexpr (SP >= 8) v += pj_dpp<0x141>(v);    // row_half_mirror
+    if constexpr (SP >= 16) v += pj_dpp<0x140>(v);   // row_mirror
+    if constexpr (SP >= 32) v = pj_xrow16(v);
+    if constexpr (SP >= 64) v = pj_xrow32(v);
     return v;
 }
-// the whole wave's sum in every lane: rows of 16 by DPP, the four rows through readlane
-__device__ __forceinline__ double pj_wave_sum_dpp(double v) {
-    v = pj_quad_sum(v);
-    v += pj_dpp<0x141>(v);    // row_half_mirror
-    v += pj_dpp<0x140>(v);    // row_mirror
-    double t = 0.0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int lo = __builtin_amdgcn_readlane(__double2loint(v), 16 * r);
-        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 16 * r);
-        t += __hiloint2double(hi, lo);
-    }
-    return t;
-}
+__device__ __forceinline__ double pj_wave_sum(double v) { return pj_group_sum<64>(v); }
+__device__ __forceinline__ double pj_quad_sum(double v) { return pj_group_sum<4>(v); }
+__device__ __forceinline__ double pj_wave_sum_dpp(double v) { return pj_group_sum<64>(v); }
 // Workgroup barrier for LDS hand-offs that leaves global loads IN FLIGHT: __syncthreads() waits for the whole vector-memory
 // queue (s_waitcnt vmcnt(0)), which puts the round trip of every load requested ahead of it -- the projection tables the
 // whole-iteration kernels request early and park late -- in front of the barrier (cdna_hip_programming.md section 5:
@@ -315,8 +318,7 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
 #pragma unroll 8
                     for (int i = part; i < QX; i += SPX) acc = fma(AXl[t * NTX * AXLD + r * AXLD + i], G[j * LDG + i], acc);
                 }
-#pragma unroll
-                for (int m = SPX >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+                acc = pj_group_sum<SPX>(acc);
                 if (ok && part == 0) T[o] = acc;
             }
         }
@@ -334,8 +336,7 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
                 double acc = 0.0;
 #pragma unroll 8
                 for (int j = part; j < QY; j += SPY) acc = fma(BYl[t * NTY * QY + k * QY + j], T[j * NTX + r], acc);
-#pragma unroll
-                for (int m = SPY >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+                acc = pj_group_sum<SPY>(acc);
                 if (ok && part == 0) U[o] = fma(c, acc, U[o]);
             }
         }
@@ -391,8 +392,7 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
 #pragma unroll 4
                     for (int r = part; r < NTX; r += SPS) acc = fma(AXl[t * NTX * AXLD + r * AXLD + i], U[k * NTX + r], acc);
                 }
-#pragma unroll
-                for (int m = SPS >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+                acc = pj_group_sum<SPS>(acc);
                 if (ok && part == 0) S[t * NTY * QX + o] = acc * sc;
             }
         }
@@ -747,8 +747,7 @@ __global__ void __launch_bounds__(PJ_RBLOCK) k_project_rows_fwd(ProjArgs pa, dou
                 double acc = 0.0;
 #pragma unroll 8
                 for (int i = part; i < QX; i += SPX) acc = fma(AXl[t * NTX * QX + r * QX + i], G[j * LDG + i], acc);
-#pragma unroll
-                for (int m = SPX >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+                acc = pj_group_sum<SPX>(acc);
                 if (ok && part == 0) T[o] = acc;
             }
         }
