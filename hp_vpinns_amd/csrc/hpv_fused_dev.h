@@ -48,6 +48,23 @@ __device__ __forceinline__ void fz_layer(const double* WTl, const double* WRl, c
     z[4] = z16;
 }
 
+// the same with the bias fragment scaled per lane (bm = 1 or 0): the packed quarter tile of k_iter_fused<.., QT> carries the value
+// channel in some of its 16 point slots and the tangent channels, which take no bias, in the others
+__device__ __forceinline__ void fz_layer_m(const double* WTl, const double* WRl, const double* BHl, int lofs, double bm,
+                                           const double (&h)[MF_KS], double (&z)[MF_KS]) {
+    v4d acc = v4d{BHl[lofs] * bm, BHl[64 + lofs] * bm, BHl[128 + lofs] * bm, BHl[192 + lofs] * bm};
+    double z16 = BHl[256 + lofs] * bm;
+    const double* wrl = WRl + (lofs >> 4) * 4 + (lofs & 3);
+#pragma unroll
+    for (int s = 0; s < MF_KS; ++s) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(WTl[s * 64 + lofs], h[s], acc, 0, 0, 0);
+        z16 = __builtin_amdgcn_mfma_f64_4x4x4f64(wrl[s * 16], h[s], z16, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) z[s] = acc[s];
+    z[4] = z16;
+}
+
 // ---- tagged exchange among the workgroups that share an element ------------------------------------------------------------
 // Workgroups that share an element (SPLIT mode of k_iter_fused: small shards of a multi-GPU run; k_iter_tall: few tall elements)
 // hand each other a few hundred doubles in the middle of the launch.  Rounds 2 / 3a did it with write-through payload stores, a

@@ -76,8 +76,17 @@ struct FzLds {
 // chip with one workgroup per element.  Workgroup (e, part) walks the tiles [25 part / S, 25 (part + 1) / S) of element e,
 // publishes their u_x, u_y as tagged granules (hpv_fused_dev.h, xg_*), gathers the whole element's from its partners, then EVERY partner
 // projects the whole element for itself (identical values, benign duplicate stores of R and loss_e) and reverses its own tiles.
-template <int L, bool SPLIT = false>
+//
+// QT (one workgroup per element, the full grids): the 25 tiles of an element do not divide by four waves -- 7 + 6 + 6 + 6, and three
+// waves wait a whole tile (12 % of the launch) for the fourth.  With QT every wave takes six tiles and a QUARTER of the 25th:
+// its four points travel as ONE packed operand whose 16 point slots are {value, d/dx, d/dy} x 4 points + 4 points of the
+// workgroup's boundary / data tile (value only) -- the layer products, the hbar chain, the tangent recompute and the dW
+// products then run ONCE for the packed operand instead of once per channel (a third of a full tile's MFMA work, same weight
+// fragments), the channels of a point meet through DPP row shifts in the element-wise steps, and the boundary / data points
+// ride in the slots that would be idle, so no wave owns a seventh tile any more.
+template <int L, bool SPLIT = false, bool QT = false>
 __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
+    static_assert(!(SPLIT && QT), "the quarter-tile scheme is for whole elements");
     using M = FzLds<L>;
     constexpr int LH = L > 1 ? L - 1 : 1;
     constexpr int NSV = L * MF_KS;                 // saved doubles per lane and tile
@@ -183,8 +192,10 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     const int lg = SPLIT ? __builtin_ctz(split) : 0;                             // split is 2, 4 or 8
     const int tbase = SPLIT ? (part * FZ_TPE) >> lg : 0;                         // this workgroup's tile range of the element
     const int tend = SPLIT ? ((part + 1) * FZ_TPE) >> lg : FZ_TPE;
-    const int n_el = SPLIT ? (tend - tbase - wv + FZ_WAVES - 1 > 0 ? (tend - tbase - wv + FZ_WAVES - 1) / FZ_WAVES : 0)
-                           : (FZ_TPE - wv + FZ_WAVES - 1) / FZ_WAVES;
+    const int n_el = QT ? (FZ_TPE - 1) / FZ_WAVES
+                        : SPLIT ? (tend - tbase - wv + FZ_WAVES - 1 > 0 ? (tend - tbase - wv + FZ_WAVES - 1) / FZ_WAVES : 0)
+                                : (FZ_TPE - wv + FZ_WAVES - 1) / FZ_WAVES;
+    static_assert(!QT || (FZ_TPE - 1) % FZ_WAVES == 0, "QT: 24 whole tiles over four waves + one tile in quarters");
     // The boundary/data tiles behind the elements go one per workgroup to the first wave with the fewest element tiles
     // (25 tiles over 4 waves: wave 1).  SPLIT: only to workgroups in which that wave has a free slot compared with its
     // neighbours (tile count not a multiple of 4) -- otherwise the adopted tile is a whole extra forward + reverse that the
@@ -202,7 +213,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         if (g.ntiles - g.proj_n_elem * FZ_TPE <= g.proj_n_elem * n_free)
             dtile = mine ? g.proj_n_elem * FZ_TPE + e * n_free + before : g.ntiles;
     }
-    const bool has_d = (wv == (tend - tbase) % FZ_WAVES) && dtile < g.ntiles;
+    const bool has_d = !QT && (wv == (tend - tbase) % FZ_WAVES) && dtile < g.ntiles;     // (QT: the data points ride in the quarter tile)
     const int n_own = n_el + (has_d ? 1 : 0);
     auto tile_of = [&](int k) -> long { return k < n_el ? e * FZ_TPE + tbase + wv + (long)k * FZ_WAVES : dtile; };
 
@@ -211,7 +222,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     constexpr int NREG = FZ_MAXT - 2;  // tiles whose s live in AGPRs; the first one (waves 0, 1: two) of a wave is parked in LDS
     constexpr int ABASE = 256 - NREG * 2 * NSV;
     asm volatile("" ::: "a255");       // the kernel owns all 256 AGPRs
-    const int n_lds = wv <= 1 ? 2 : 1;
+    const int n_lds = QT ? 1 : (wv <= 1 ? 2 : 1);       // (QT: slots 4, 5 of the parking area hold the quarter tiles' s)
     double* PKw = lds + M::PK + wv * (NSV * 64) + lane;
     double* PKw2 = lds + M::PK + (4 + (wv & 1)) * (NSV * 64) + lane;
     double gdat = 0.0;           // adjoint of u at the data tile's point (boundary term, P2:122)
@@ -383,12 +394,72 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             stash(k, sv[t]);
         }
     };
+    // QT: the packed quarter tile of this wave.  Slot c = pt >> 2 of point j = pt & 3: c = 0 value, c = 1 d/dx, c = 2 d/dy of element
+    // point 384 + 4 wv + j; c = 3 value of point 4 wv + j of the workgroup's boundary / data tile.
+    [[maybe_unused]] const int qcs = pt >> 2, qj = pt & 3;
+    [[maybe_unused]] const bool q_tan = qcs == 1 || qcs == 2;
+    [[maybe_unused]] const long q_pdat = dtile * 16 + 4 * wv + qj;
+    [[maybe_unused]] const bool q_vdat = QT && qcs == 3 && dtile < g.ntiles && q_pdat < g.N;
+    [[maybe_unused]] const long q_p = qcs == 3 ? (q_vdat ? q_pdat : 0) : (e * FZ_TPE + (FZ_TPE - 1)) * 16 + 4 * wv + qj;
+    [[maybe_unused]] const int q_lp = (FZ_TPE - 1) * 16 + 4 * wv + qj;               // the element point inside the element
+    [[maybe_unused]] double* PKQ = lds + M::PK + 4 * (NSV * 64) + wv * (NSV * 32);    // compact: the 32 value / data lanes only
+    [[maybe_unused]] const int q_ci = q * 8 + (qcs == 3 ? 4 : 0) + qj;                // ... at this index (tangent slots: their point's)
+    [[maybe_unused]] double gdat_q = 0.0, qx0 = 0.0, qx1 = 0.0, qud = 0.0;
+    if constexpr (QT) {                     // (requested before the whole tiles: consumed after them)
+        qx0 = g.X[q_p]; qx1 = g.X[g.N + q_p];
+        qud = q_vdat ? g.ud[q_pdat - g.data_off] : 0.0;
+    }
     load_x(0, xn[0], vn[0], pn[0]);
     load_x(1, xn[1], vn[1], pn[1]);
     int k0 = 0;
 #pragma unroll 1
     for (; k0 + 1 < n_own; k0 += 2) fwd_trip(k0, std::integral_constant<int, 2>{});
     if (k0 < n_own) fwd_trip(k0, std::integral_constant<int, 1>{});
+    if constexpr (QT) {
+        int lofs = lane;
+        asm volatile("" : "+v"(lofs));
+        double H[MF_KS], AAq[NSV];
+        // layer 1: every slot evaluates its own point (the tangent slots share the element point of slot 0)
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            const double w0 = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs], w1 = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
+            const double b1v = lds[M::W1O + (3 * MF_KS + s) * 64 + lofs];
+            const double z = b1v + qx0 * w0 + qx1 * w1;
+            double a, a1, a2;
+            act_fwd<HPV_ACT_TANH>(z, a, a1, a2);
+            AAq[s] = a;
+            H[s] = q_tan ? a1 * (qcs == 1 ? w0 : w1) : a;
+        }
+#pragma unroll
+        for (int i = 1; i < L; ++i) {
+            double Z[MF_KS];
+            fz_layer_m(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, lds + M::BH + (i - 1) * MF_KS * 64, lofs,
+                       q_tan ? 0.0 : 1.0, H, Z);
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                double a, a1, a2;
+                act_fwd<HPV_ACT_TANH>(Z[s], a, a1, a2);          // (tangent slots: of a tangent pre-activation, not used)
+                const double a4 = dpp_move<0x114>(a), a8 = dpp_move<0x118>(a);      // row_shr:4 / :8 = the value slot of my point
+                const double ab = qcs == 1 ? a4 : (qcs == 2 ? a8 : a);
+                AAq[i * MF_KS + s] = ab;
+                H[s] = q_tan ? (1.0 - ab * ab) * Z[s] : ab;
+            }
+        }
+        double v = 0.0;
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) v += H[s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
+        v = xrow_sum16(v);
+        v = xrow_sum32(v);
+        if (q == 0 && q_tan) lds[M::CH + (qcs - 1) * FZ_NQ + q_lp] = v;
+        const double dd = q_vdat ? qud - (v + bo) : 0.0;
+        gdat_q = g.data_scale * dd;
+        const double sq = row_sum16(q == 0 ? dd * dd : 0.0);
+        if (lane == 0) lds[M::RED + 8 + wv] = sq;
+        if (!q_tan) {
+#pragma unroll
+            for (int j = 0; j < NSV; ++j) PKQ[j * 32 + q_ci] = AAq[j];
+        }
+    }
     FZ_STAMP(2);
     if constexpr (SPLIT) {
         // the element's u_x, u_y from all partners (its own included), straight into the LDS channel array: the granules are
@@ -408,6 +479,10 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     }
     __syncthreads();
     FZ_STAMP(3);
+    if constexpr (QT) {      // lossb partial of the workgroup's boundary / data tile: the four waves' quarters (P2:122,127)
+        if (tid == 0 && dtile < g.ntiles)
+            g.data_part[dtile - g.data_off / 16] = (lds[M::RED + 8] + lds[M::RED + 9]) + (lds[M::RED + 10] + lds[M::RED + 11]);
+    }
 
     // =============================================================================================
     // phase P: projection of the element from LDS (two one-hot terms: term t integrates channel 1 + t)
@@ -642,6 +717,107 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     }
 
 #undef ZC
+    if constexpr (QT) {
+        // ---- the packed quarter tile, reverse: the whole-tile steps above for ONE packed operand (every slot's adjoint at once) ----
+        int lofs = lane;
+        asm volatile("" : "+v"(lofs));
+        const double X0 = g.X[q_p], X1 = g.X[g.N + q_p];     // (consumed at the very end: first-layer weight gradient)
+        double AAq[NSV];
+#pragma unroll
+        for (int j = 0; j < NSV; ++j) AAq[j] = PKQ[j * 32 + q_ci];
+        // adjoint of the slot's output: d/dx, d/dy slots from the projection, the data slot from the boundary term, value slot none
+        const double GB = q_tan ? lds[M::CH + (qcs - 1) * FZ_NQ + q_lp] : (qcs == 3 ? gdat_q : 0.0);
+        // packed layer inputs H_i and tangent pre-activations (tangent slots; 0 elsewhere), recomputed from s
+        double Hq[L][MF_KS], ZCq[L][MF_KS];
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            const double w0 = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs], w1 = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
+            const double a = AAq[s];
+            ZCq[0][s] = qcs == 1 ? w0 : (qcs == 2 ? w1 : 0.0);
+            Hq[0][s] = q_tan ? (1.0 - a * a) * ZCq[0][s] : a;
+        }
+#pragma unroll
+        for (int i = 1; i < L; ++i) {
+            double Z[MF_KS];
+            fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, Hq[i - 1], Z);
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                const double a = AAq[i * MF_KS + s];
+                ZCq[i][s] = q_tan ? Z[s] : 0.0;
+                Hq[i][s] = q_tan ? (1.0 - a * a) * Z[s] : a;
+            }
+        }
+        double HB[MF_KS], ZB[MF_KS];
+        // linear head
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            const double wo = lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
+            dWo[s] = fma(Hq[L - 1][s], GB, dWo[s]);
+            HB[s] = GB * wo;
+        }
+        if (q == 0 && qcs == 3) dbo += GB;
+        // hidden layers, last to first
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                const double a = AAq[i * MF_KS + s];
+                const double a1 = 1.0 - a * a, a2 = -2.0 * a * a1;
+                const double t = HB[s] * ZCq[i][s];                                     // tangent slots: hbar_c z_c
+                const double t4 = dpp_move<0x104>(t), t8 = dpp_move<0x108>(t);        // row_shl:4 / :8 = my point's d/dx, d/dy slots
+                const double zb = q_tan ? HB[s] * a1 : HB[s] * a1 + a2 * (t4 + t8);
+                ZB[s] = zb;
+                db[i][s] += q_tan ? 0.0 : zb;
+            }
+            if (i == 0) {
+                const double c0 = q_tan ? (qcs == 1 ? 1.0 : 0.0) : X0, c1 = q_tan ? (qcs == 2 ? 1.0 : 0.0) : X1;
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+                    dW1[0][s] = fma(c0, ZB[s], dW1[0][s]);
+                    dW1[1][s] = fma(c1, ZB[s], dW1[1][s]);
+                }
+            } else {
+                pj_wave_sync();
+                double* TA = TAB;
+                double* TB = TA + MF_TRB * MF_LD;
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+                    TA[(4 * s + q) * MF_LD + pt] = Hq[i - 1][s];
+                    TB[(4 * s + q) * MF_LD + pt] = ZB[s];
+                }
+                {
+                    v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
+                    double h4 = 0.0;
+                    const double* wrl = lds + M::WRB + (i - 1) * MF_KS * 16 + q * 4 + (lane & 3);
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s) {
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[M::WN + ((i - 1) * MF_KS + s) * 64 + lofs], ZB[s], acc, 0, 0, 0);
+                        h4 = __builtin_amdgcn_mfma_f64_4x4x4f64(wrl[s * 16], ZB[s], h4, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) HB[s] = acc[s];
+                    HB[4] = h4;
+                }
+                pj_wave_sync();
+                double aF[4], bF[4], aS[4], bS[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    aF[kk] = TA[pt * MF_LD + 4 * kk + q];
+                    bF[kk] = TB[pt * MF_LD + 4 * kk + q];
+                    aS[kk] = TA[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                    bS[kk] = TB[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    dWacc[i - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[kk], bF[kk], dWacc[i - 1], 0, 0, 0);
+                    dS10[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(aS[kk], bF[kk], dS10[i - 1], 0, 0, 0);
+                    dS01[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(bS[kk], aF[kk], dS01[i - 1], 0, 0, 0);
+                }
+                accC[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(TA[(16 + (lane & 3)) * MF_LD + (pt & 12) + q],
+                                                               TB[(16 + (lane & 3)) * MF_LD + (pt & 12) + q], accC[i - 1], 0, 0, 0);
+            }
+        }
+    }
     FZ_STAMP(5);
     // ---- epilogue: per-wave partials -> LDS -> one gradient row per workgroup ----
     __syncthreads();
@@ -1139,15 +1315,15 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int L, bool SPLIT>
+template <int L, bool SPLIT, bool QT = false>
 static void launch_iter_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
     const size_t bytes = (size_t)FzLds<L>::total(a.P) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_iter_fused<L, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        (void)hipFuncSetAttribute((const void*)k_iter_fused<L, SPLIT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_iter_fused<L, SPLIT>), dim3(blocks), dim3(FZ_BLOCK), bytes, s, a);
+    hipLaunchKernelGGL((k_iter_fused<L, SPLIT, QT>), dim3(blocks), dim3(FZ_BLOCK), bytes, s, a);
 }
 
 template <int L>
@@ -1235,8 +1411,10 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     if (split > 1) {
         m->split_used = true;
         if (m->L == 2) launch_iter_fused<2, true>(a, (int)blocks, s); else launch_iter_fused<3, true>(a, (int)blocks, s);
-    } else {
+    } else if (getenv("HPV_NO_QUARTER_TILE")) {      // (A/B switch: seven whole tiles for the first wave, read per launch / capture)
         if (m->L == 2) launch_iter_fused<2, false>(a, (int)blocks, s); else launch_iter_fused<3, false>(a, (int)blocks, s);
+    } else {
+        if (m->L == 2) launch_iter_fused<2, false, true>(a, (int)blocks, s); else launch_iter_fused<3, false, true>(a, (int)blocks, s);
     }
     if (rows) *rows = (int)blocks;
     return true;
