@@ -58,7 +58,8 @@ struct FzLds {
     static constexpr int W1O = WRB + LH * MF_KS * 16;      // [4][5][64]   W1[0][4s+q], W1[1][4s+q], Wo[4s+q], b1[4s+q]
     static constexpr int CH = W1O + 4 * MF_KS * 64;        // [2][400]     u_x, u_y of the element -> their adjoints
     static constexpr int PK = CH + 2 * FZ_NQ;              // [6][L*5][64] parked s: slot w = tile 0 of wave w, slots 4, 5 = tile 1 of waves 0, 1
-    static constexpr int TR = PK + 6 * L * MF_KS * 64;     // phase P: projection scratch | phase R: per-wave transpose tiles | epilogue rows
+    static constexpr int PZ = PK + 6 * L * MF_KS * 64;     // [4][LH*5][32] QT: the quarter tiles' tangent pre-activations of the layers >= 2 (tangent lanes, compact)
+    static constexpr int TR = PZ + FZ_WAVES * LH * MF_KS * 32;   // phase P: projection scratch | phase R: per-wave transpose tiles | epilogue rows
     static constexpr int TR_WAVE = FZ_C * 2 * MF_TRB * MF_LD;
     // projection scratch inside the TR region
     static constexpr int AX = TR;                          // [2][NTX][QX] w_x phi^(dx_t)
@@ -236,6 +237,23 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     // Two tiles per trip: their instruction streams are independent, so the scheduler fills the MFMA -> tanh -> MFMA
     // dependency bubbles of one tile with the other's work (a single wave per SIMD has nothing else to issue); the forward
     // working set is small enough to hold twice.
+    // QT: the packed quarter tile of this wave.  Slot c = pt >> 2 of point j = pt & 3: c = 0 value, c = 1 d/dx, c = 2 d/dy of element
+    // point 384 + 4 wv + j; c = 3 value of point 4 wv + j of the workgroup's boundary / data tile.
+    [[maybe_unused]] const int qcs = pt >> 2, qj = pt & 3;
+    [[maybe_unused]] const bool q_tan = qcs == 1 || qcs == 2;
+    [[maybe_unused]] const long q_pdat = dtile * 16 + 4 * wv + qj;
+    [[maybe_unused]] const bool q_vdat = QT && qcs == 3 && dtile < g.ntiles && q_pdat < g.N;
+    [[maybe_unused]] const long q_p = qcs == 3 ? (q_vdat ? q_pdat : 0) : (e * FZ_TPE + (FZ_TPE - 1)) * 16 + 4 * wv + qj;
+    [[maybe_unused]] const int q_lp = (FZ_TPE - 1) * 16 + 4 * wv + qj;               // the element point inside the element
+    [[maybe_unused]] double* PKQ = lds + M::PK + 4 * (NSV * 64) + wv * (NSV * 32);    // compact: the 32 value / data lanes only
+    [[maybe_unused]] const int q_ci = q * 8 + (qcs == 3 ? 4 : 0) + qj;                // ... at this index (tangent slots: their point's)
+    [[maybe_unused]] double* PKZ = lds + M::PZ + wv * ((L > 1 ? L - 1 : 1) * MF_KS * 32);   // tangent pre-activations, the 32 tangent lanes only
+    [[maybe_unused]] const int q_cz = q * 8 + (qcs == 2 ? 4 : 0) + qj;
+    [[maybe_unused]] double gdat_q = 0.0, qx0 = 0.0, qx1 = 0.0, qud = 0.0;
+    if constexpr (QT) {                     // (requested before the whole tiles: consumed after them)
+        qx0 = g.X[q_p]; qx1 = g.X[g.N + q_p];
+        qud = q_vdat ? g.ud[q_pdat - g.data_off] : 0.0;
+    }
     auto load_x = [&](int k, double (&x)[2], bool& valid, long& p) {
         const long tile = tile_of(k < n_own ? k : 0);
         p = tile * 16 + pt;
@@ -260,8 +278,10 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     double xn[2][2];
     bool vn[2];
     long pn[2];
-    auto fwd_trip = [&](int k0, auto NT_) {
+    // (WQ: the wave's packed quarter tile rides along with this trip -- one more independent instruction stream for the bubbles)
+    auto fwd_trip = [&](int k0, auto NT_, auto WQ_) {
         constexpr int NT = decltype(NT_)::value;
+        constexpr bool WQ = decltype(WQ_)::value;
         double xx[NT][2];
         bool valid[NT];
         long pp[NT];
@@ -275,53 +295,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         int lofs = lane;
         asm volatile("" : "+v"(lofs));       // opaque: the LDS fragment reads stay inside the loop
         double h[NT][FZ_C][MF_KS], sv[NT][NSV];
-#ifdef HPV_TANH_VEC
-        // the activations of a layer -- NT x 5 independent values per lane -- go through ONE stage-major tanh (hpv_tanh_n): their
-        // dependent chains interleave instead of running one after the other
-        {   // layer 1 (VALU)
-            double w0[MF_KS], w1[MF_KS], zz[NT * MF_KS], aa[NT * MF_KS];
-#pragma unroll
-            for (int s = 0; s < MF_KS; ++s) {
-                w0[s] = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs]; w1[s] = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
-                const double b1v = lds[M::W1O + (3 * MF_KS + s) * 64 + lofs];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) zz[t * MF_KS + s] = b1v + xx[t][0] * w0[s] + xx[t][1] * w1[s];
-            }
-            hpv_tanh_n<NT * MF_KS>(zz, aa);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int s = 0; s < MF_KS; ++s) {
-                    const double a = aa[t * MF_KS + s], a1 = 1.0 - a * a;
-                    sv[t][s] = a;
-                    h[t][0][s] = a; h[t][1][s] = a1 * w0[s]; h[t][2][s] = a1 * w1[s];
-                }
-        }
-#pragma unroll
-        for (int i = 1; i < L; ++i) {
-            double z[NT][FZ_C][MF_KS];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                fz_layer<true>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, lds + M::BH + (i - 1) * MF_KS * 64, lofs, h[t][0], z[t][0]);
-                fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[t][1], z[t][1]);
-                fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[t][2], z[t][2]);
-            }
-            double zz[NT * MF_KS], aa[NT * MF_KS];
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int s = 0; s < MF_KS; ++s) zz[t * MF_KS + s] = z[t][0][s];
-            hpv_tanh_n<NT * MF_KS>(zz, aa);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int s = 0; s < MF_KS; ++s) {
-                    const double a = aa[t * MF_KS + s], a1 = 1.0 - a * a;
-                    sv[t][i * MF_KS + s] = a;
-                    h[t][0][s] = a; h[t][1][s] = a1 * z[t][1][s]; h[t][2][s] = a1 * z[t][2][s];
-                }
-        }
-#else
+        [[maybe_unused]] double QH[MF_KS], QA[NSV];      // WQ: the packed quarter tile's layer input and its s
         // layer 1 (VALU)
 #pragma unroll
         for (int s = 0; s < MF_KS; ++s) {
@@ -335,6 +309,13 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                 sv[t][s] = a;
                 h[t][0][s] = a; h[t][1][s] = a1 * w0; h[t][2][s] = a1 * w1;
             }
+            if constexpr (WQ) {      // every slot evaluates its own point (the tangent slots share the element point of slot 0)
+                const double z = b1v + qx0 * w0 + qx1 * w1;
+                double a, a1, a2;
+                act_fwd<HPV_ACT_TANH>(z, a, a1, a2);
+                QA[s] = a;
+                QH[s] = q_tan ? a1 * (qcs == 1 ? w0 : w1) : a;
+            }
         }
 #pragma unroll
         for (int i = 1; i < L; ++i) {
@@ -345,6 +326,10 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                 fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[t][1], z[t][1]);
                 fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[t][2], z[t][2]);
             }
+            [[maybe_unused]] double QZ[MF_KS];
+            if constexpr (WQ)
+                fz_layer_m(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, lds + M::BH + (i - 1) * MF_KS * 64, lofs,
+                           q_tan ? 0.0 : 1.0, QH, QZ);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -354,8 +339,19 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                     sv[t][i * MF_KS + s] = a;
                     h[t][0][s] = a; h[t][1][s] = a1 * z[t][1][s]; h[t][2][s] = a1 * z[t][2][s];
                 }
+            if constexpr (WQ) {
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+                    double a, a1, a2;
+                    act_fwd<HPV_ACT_TANH>(QZ[s], a, a1, a2);         // (tangent slots: of a tangent pre-activation, not used)
+                    const double a4 = dpp_move<0x114>(a), a8 = dpp_move<0x118>(a);      // row_shr:4 / :8 = the value slot of my point
+                    const double ab = qcs == 1 ? a4 : (qcs == 2 ? a8 : a);
+                    QA[i * MF_KS + s] = ab;
+                    QH[s] = q_tan ? (1.0 - ab * ab) * QZ[s] : ab;
+                    if (q_tan) PKZ[((i - 1) * MF_KS + s) * 32 + q_cz] = QZ[s];      // (the reverse pass reads them back instead of recomputing)
+                }
+            }
         }
-#endif
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int k = k0 + t;
@@ -393,72 +389,35 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             }
             stash(k, sv[t]);
         }
+        if constexpr (WQ) {
+            double v = 0.0;
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) v += QH[s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
+            v = xrow_sum16(v);
+            v = xrow_sum32(v);
+            if (q == 0 && q_tan) lds[M::CH + (qcs - 1) * FZ_NQ + q_lp] = v;
+            const double dd = q_vdat ? qud - (v + bo) : 0.0;
+            gdat_q = g.data_scale * dd;
+            const double sq = row_sum16(q == 0 ? dd * dd : 0.0);
+            if (lane == 0) lds[M::RED + 8 + wv] = sq;
+            if (!q_tan) {
+#pragma unroll
+                for (int j = 0; j < NSV; ++j) PKQ[j * 32 + q_ci] = QA[j];
+            }
+        }
     };
-    // QT: the packed quarter tile of this wave.  Slot c = pt >> 2 of point j = pt & 3: c = 0 value, c = 1 d/dx, c = 2 d/dy of element
-    // point 384 + 4 wv + j; c = 3 value of point 4 wv + j of the workgroup's boundary / data tile.
-    [[maybe_unused]] const int qcs = pt >> 2, qj = pt & 3;
-    [[maybe_unused]] const bool q_tan = qcs == 1 || qcs == 2;
-    [[maybe_unused]] const long q_pdat = dtile * 16 + 4 * wv + qj;
-    [[maybe_unused]] const bool q_vdat = QT && qcs == 3 && dtile < g.ntiles && q_pdat < g.N;
-    [[maybe_unused]] const long q_p = qcs == 3 ? (q_vdat ? q_pdat : 0) : (e * FZ_TPE + (FZ_TPE - 1)) * 16 + 4 * wv + qj;
-    [[maybe_unused]] const int q_lp = (FZ_TPE - 1) * 16 + 4 * wv + qj;               // the element point inside the element
-    [[maybe_unused]] double* PKQ = lds + M::PK + 4 * (NSV * 64) + wv * (NSV * 32);    // compact: the 32 value / data lanes only
-    [[maybe_unused]] const int q_ci = q * 8 + (qcs == 3 ? 4 : 0) + qj;                // ... at this index (tangent slots: their point's)
-    [[maybe_unused]] double gdat_q = 0.0, qx0 = 0.0, qx1 = 0.0, qud = 0.0;
-    if constexpr (QT) {                     // (requested before the whole tiles: consumed after them)
-        qx0 = g.X[q_p]; qx1 = g.X[g.N + q_p];
-        qud = q_vdat ? g.ud[q_pdat - g.data_off] : 0.0;
-    }
     load_x(0, xn[0], vn[0], pn[0]);
     load_x(1, xn[1], vn[1], pn[1]);
     int k0 = 0;
+    if constexpr (QT) {      // six whole tiles: two trips of two, then the last two with the quarter tile beside them
+        static_assert((FZ_TPE - 1) / FZ_WAVES == 6, "trip plan of the QT instantiation");
 #pragma unroll 1
-    for (; k0 + 1 < n_own; k0 += 2) fwd_trip(k0, std::integral_constant<int, 2>{});
-    if (k0 < n_own) fwd_trip(k0, std::integral_constant<int, 1>{});
-    if constexpr (QT) {
-        int lofs = lane;
-        asm volatile("" : "+v"(lofs));
-        double H[MF_KS], AAq[NSV];
-        // layer 1: every slot evaluates its own point (the tangent slots share the element point of slot 0)
-#pragma unroll
-        for (int s = 0; s < MF_KS; ++s) {
-            const double w0 = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs], w1 = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
-            const double b1v = lds[M::W1O + (3 * MF_KS + s) * 64 + lofs];
-            const double z = b1v + qx0 * w0 + qx1 * w1;
-            double a, a1, a2;
-            act_fwd<HPV_ACT_TANH>(z, a, a1, a2);
-            AAq[s] = a;
-            H[s] = q_tan ? a1 * (qcs == 1 ? w0 : w1) : a;
-        }
-#pragma unroll
-        for (int i = 1; i < L; ++i) {
-            double Z[MF_KS];
-            fz_layer_m(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, lds + M::BH + (i - 1) * MF_KS * 64, lofs,
-                       q_tan ? 0.0 : 1.0, H, Z);
-#pragma unroll
-            for (int s = 0; s < MF_KS; ++s) {
-                double a, a1, a2;
-                act_fwd<HPV_ACT_TANH>(Z[s], a, a1, a2);          // (tangent slots: of a tangent pre-activation, not used)
-                const double a4 = dpp_move<0x114>(a), a8 = dpp_move<0x118>(a);      // row_shr:4 / :8 = the value slot of my point
-                const double ab = qcs == 1 ? a4 : (qcs == 2 ? a8 : a);
-                AAq[i * MF_KS + s] = ab;
-                H[s] = q_tan ? (1.0 - ab * ab) * Z[s] : ab;
-            }
-        }
-        double v = 0.0;
-#pragma unroll
-        for (int s = 0; s < MF_KS; ++s) v += H[s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
-        v = xrow_sum16(v);
-        v = xrow_sum32(v);
-        if (q == 0 && q_tan) lds[M::CH + (qcs - 1) * FZ_NQ + q_lp] = v;
-        const double dd = q_vdat ? qud - (v + bo) : 0.0;
-        gdat_q = g.data_scale * dd;
-        const double sq = row_sum16(q == 0 ? dd * dd : 0.0);
-        if (lane == 0) lds[M::RED + 8 + wv] = sq;
-        if (!q_tan) {
-#pragma unroll
-            for (int j = 0; j < NSV; ++j) PKQ[j * 32 + q_ci] = AAq[j];
-        }
+        for (; k0 + 3 < n_own; k0 += 2) fwd_trip(k0, std::integral_constant<int, 2>{}, std::false_type{});
+        fwd_trip(k0, std::integral_constant<int, 2>{}, std::true_type{});
+    } else {
+#pragma unroll 1
+        for (; k0 + 1 < n_own; k0 += 2) fwd_trip(k0, std::integral_constant<int, 2>{}, std::false_type{});
+        if (k0 < n_own) fwd_trip(k0, std::integral_constant<int, 1>{}, std::false_type{});
     }
     FZ_STAMP(2);
     if constexpr (SPLIT) {
@@ -727,7 +686,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         for (int j = 0; j < NSV; ++j) AAq[j] = PKQ[j * 32 + q_ci];
         // adjoint of the slot's output: d/dx, d/dy slots from the projection, the data slot from the boundary term, value slot none
         const double GB = q_tan ? lds[M::CH + (qcs - 1) * FZ_NQ + q_lp] : (qcs == 3 ? gdat_q : 0.0);
-        // packed layer inputs H_i and tangent pre-activations (tangent slots; 0 elsewhere), recomputed from s
+        // packed layer inputs H_i from s and the tangent pre-activations (tangent slots; 0 elsewhere) the forward pass left in LDS
         double Hq[L][MF_KS], ZCq[L][MF_KS];
 #pragma unroll
         for (int s = 0; s < MF_KS; ++s) {
@@ -738,13 +697,12 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         }
 #pragma unroll
         for (int i = 1; i < L; ++i) {
-            double Z[MF_KS];
-            fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, Hq[i - 1], Z);
 #pragma unroll
             for (int s = 0; s < MF_KS; ++s) {
                 const double a = AAq[i * MF_KS + s];
-                ZCq[i][s] = q_tan ? Z[s] : 0.0;
-                Hq[i][s] = q_tan ? (1.0 - a * a) * Z[s] : a;
+                const double zc = q_tan ? PKZ[((i - 1) * MF_KS + s) * 32 + q_cz] : 0.0;
+                ZCq[i][s] = zc;
+                Hq[i][s] = q_tan ? (1.0 - a * a) * zc : a;
             }
         }
         double HB[MF_KS], ZB[MF_KS];
