@@ -130,8 +130,10 @@ struct SlotCount {
 // then row_half_mirror and row_mirror -- VALU only (a __shfl_xor tree is two ds_bpermute per step and double)
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    // (bound_ctrl: a lane whose source lies outside its row reads 0 -- the row shifts rely on it -- and no `old` operand has to
+    //  be zeroed first)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // Sums ACROSS the 16-lane rows (the MFMA operand layouts keep one k-group per row): v[l] + v[l ^ 16] and v[l] + v[l ^ 32] in

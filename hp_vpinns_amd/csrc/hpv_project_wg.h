@@ -10,8 +10,10 @@
 // resp. v[l] + v[l ^ 32] in every lane).
 template <int CTRL>
 __device__ __forceinline__ double pj_dpp(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    // (bound_ctrl: a lane whose source lies outside its row reads 0 -- the row shifts rely on it -- and no `old` operand has to
+    //  be zeroed first)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double pj_xrow16(double v) {

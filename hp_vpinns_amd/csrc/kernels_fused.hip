@@ -348,7 +348,10 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                     const double ab = qcs == 1 ? a4 : (qcs == 2 ? a8 : a);
                     QA[i * MF_KS + s] = ab;
                     QH[s] = q_tan ? (1.0 - ab * ab) * QZ[s] : ab;
-                    if (q_tan) PKZ[((i - 1) * MF_KS + s) * 32 + q_cz] = QZ[s];      // (the reverse pass reads them back instead of recomputing)
+                }
+                if (q_tan) {     // (the reverse pass reads the tangent pre-activations back instead of recomputing them)
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s) PKZ[((i - 1) * MF_KS + s) * 32 + q_cz] = QZ[s];
                 }
             }
         }
@@ -684,8 +687,12 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         double AAq[NSV];
 #pragma unroll
         for (int j = 0; j < NSV; ++j) AAq[j] = PKQ[j * 32 + q_ci];
+        // (branch-free on purpose: per-lane selects of loaded values and 0 / 1 masks -- a conditional LDS read or a conditional
+        //  expression with work in it becomes an exec-masked block of its own and cuts the schedule into pieces)
+        const double mval = q_tan ? 0.0 : 1.0;                        // value-like slots (element value, data point)
         // adjoint of the slot's output: d/dx, d/dy slots from the projection, the data slot from the boundary term, value slot none
-        const double GB = q_tan ? lds[M::CH + (qcs - 1) * FZ_NQ + q_lp] : (qcs == 3 ? gdat_q : 0.0);
+        const double gch = lds[M::CH + (q_tan ? (qcs - 1) * FZ_NQ : 0) + q_lp];
+        const double GB = q_tan ? gch : (qcs == 3 ? gdat_q : 0.0);
         // packed layer inputs H_i from s and the tangent pre-activations (tangent slots; 0 elsewhere) the forward pass left in LDS
         double Hq[L][MF_KS], ZCq[L][MF_KS];
 #pragma unroll
@@ -693,16 +700,19 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             const double w0 = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs], w1 = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
             const double a = AAq[s];
             ZCq[0][s] = qcs == 1 ? w0 : (qcs == 2 ? w1 : 0.0);
-            Hq[0][s] = q_tan ? (1.0 - a * a) * ZCq[0][s] : a;
+            const double ht = (1.0 - a * a) * ZCq[0][s];
+            Hq[0][s] = q_tan ? ht : a;
         }
 #pragma unroll
         for (int i = 1; i < L; ++i) {
 #pragma unroll
             for (int s = 0; s < MF_KS; ++s) {
                 const double a = AAq[i * MF_KS + s];
-                const double zc = q_tan ? PKZ[((i - 1) * MF_KS + s) * 32 + q_cz] : 0.0;
+                const double zr = PKZ[((i - 1) * MF_KS + s) * 32 + q_cz];      // (value-like lanes read a neighbour's, unused)
+                const double zc = q_tan ? zr : 0.0;
+                const double ht = (1.0 - a * a) * zc;
                 ZCq[i][s] = zc;
-                Hq[i][s] = q_tan ? (1.0 - a * a) * zc : a;
+                Hq[i][s] = q_tan ? ht : a;
             }
         }
         double HB[MF_KS], ZB[MF_KS];
@@ -713,7 +723,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             dWo[s] = fma(Hq[L - 1][s], GB, dWo[s]);
             HB[s] = GB * wo;
         }
-        if (q == 0 && qcs == 3) dbo += GB;
+        dbo += (q == 0 && qcs == 3) ? GB : 0.0;
         // hidden layers, last to first
 #pragma unroll
         for (int i = L - 1; i >= 0; --i) {
@@ -723,9 +733,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                 const double a1 = 1.0 - a * a, a2 = -2.0 * a * a1;
                 const double t = HB[s] * ZCq[i][s];                                     // tangent slots: hbar_c z_c
                 const double t4 = dpp_move<0x104>(t), t8 = dpp_move<0x108>(t);        // row_shl:4 / :8 = my point's d/dx, d/dy slots
-                const double zb = q_tan ? HB[s] * a1 : HB[s] * a1 + a2 * (t4 + t8);
+                const double zb = fma(a2 * mval, t4 + t8, HB[s] * a1);
                 ZB[s] = zb;
-                db[i][s] += q_tan ? 0.0 : zb;
+                db[i][s] = fma(mval, zb, db[i][s]);
             }
             if (i == 0) {
                 const double c0 = q_tan ? (qcs == 1 ? 1.0 : 0.0) : X0, c1 = q_tan ? (qcs == 2 ? 1.0 : 0.0) : X1;
