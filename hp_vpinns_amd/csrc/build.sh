@@ -16,9 +16,14 @@ for f in kernels_generic kernels_mfma kernels_fused kernels_tall kernels_tile ke
     if [ $f = kernels_fused ]; then
       XF="$HPV_FUSED_EXTRA"           # (A/B builds: flags for this file only, scripts/build_variant.sh --fused-only)
       $HIPCC $FLAGS $XF -S --cuda-device-only $f.hip -o $f.s 2>/dev/null
-      if ! { python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi3 106 && python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi2 156; }; then
+      # (instantiations: <L, SPLIT, QT>; the quarter-tile one sits closest to the hand-managed range and has its own fallback)
+      if ! { python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi3ELb0ELb0 106 && python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi3ELb1ELb0 106 &&
+             python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi2ELb0ELb0 156 && python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi2ELb1ELb0 156; }; then
         echo "build.sh: WARNING -- AGPR guard tripped in $f.hip: building without k_iter_fused (fallback = HPV_FUSE=b structure)" >&2
         XF="$XF -DHPV_AGPR_GUARD_TRIPPED"
+      elif ! { python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi3ELb0ELb1 106 && python3 ../../scripts/check_agpr.py $f.s k_iter_fusedILi2ELb0ELb1 156; }; then
+        echo "build.sh: WARNING -- AGPR guard tripped in the quarter-tile instantiation of k_iter_fused: building with 7 / 6 / 6 / 6 whole tiles per wave" >&2
+        XF="$XF -DHPV_AGPR_GUARD_TRIPPED_QT"
       fi
     fi
     if [ $f = kernels_tall ]; then    # same hand-managed AGPR stash (4 tiles x L x 5 doubles at the top of the file)

@@ -1379,7 +1379,11 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     if (split > 1) {
         m->split_used = true;
         if (m->L == 2) launch_iter_fused<2, true>(a, (int)blocks, s); else launch_iter_fused<3, true>(a, (int)blocks, s);
+#ifdef HPV_AGPR_GUARD_TRIPPED_QT                    // csrc/build.sh: the compiler's registers reached the stash of the QT instantiation
+    } else if (true) {
+#else
     } else if (getenv("HPV_NO_QUARTER_TILE")) {      // (A/B switch: seven whole tiles for the first wave, read per launch / capture)
+#endif
         if (m->L == 2) launch_iter_fused<2, false>(a, (int)blocks, s); else launch_iter_fused<3, false>(a, (int)blocks, s);
     } else {
         if (m->L == 2) launch_iter_fused<2, false, true>(a, (int)blocks, s); else launch_iter_fused<3, false, true>(a, (int)blocks, s);
