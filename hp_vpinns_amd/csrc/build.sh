@@ -28,10 +28,16 @@ for f in kernels_generic kernels_mfma kernels_fused kernels_tall kernels_tile ke
     fi
     if [ $f = kernels_tall ]; then    # same hand-managed AGPR stash (4 tiles x L x 5 doubles at the top of the file)
       $HIPCC $FLAGS -S --cuda-device-only $f.hip -o $f.s 2>/dev/null
-      if ! { python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi1ELi3 136 && python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi0ELi3 136 &&
-             python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi1ELi2 176 && python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi0ELi2 176; }; then
+      # (template tail: <.., 80, 80, 5, 5, QT>; the QT instantiations keep one stash slot less: their range starts 30 registers higher)
+      T=ELi80ELi80ELi5ELi5
+      if ! { python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi1ELi3${T}ELb0 136 && python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi0ELi3${T}ELb0 136 &&
+             python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi1ELi2${T}ELb0 176 && python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi0ELi2${T}ELb0 176; }; then
         echo "build.sh: WARNING -- AGPR guard tripped in $f.hip: building without k_iter_tall (fallback = the separate launches)" >&2
         XF="$XF -DHPV_AGPR_GUARD_TRIPPED"
+      elif ! { python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi1ELi3${T}ELb1 166 && python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi0ELi3${T}ELb1 166 &&
+               python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi1ELi2${T}ELb1 196 && python3 ../../scripts/check_agpr.py $f.s k_iter_tallILi2ELi0ELi2${T}ELb1 196; }; then
+        echo "build.sh: WARNING -- AGPR guard tripped in the quarter-tile instantiations of k_iter_tall: building with whole tiles only" >&2
+        XF="$XF -DHPV_AGPR_GUARD_TRIPPED_QT"
       fi
     fi
     $HIPCC $FLAGS $XF -c $f.hip -o $f.o

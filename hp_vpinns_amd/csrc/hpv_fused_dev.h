@@ -48,6 +48,11 @@ __device__ __forceinline__ void fz_layer(const double* WTl, const double* WRl, c
     z[4] = z16;
 }
 
+// An opaque use of a computed value: keeps the compiler from sinking its computation into one arm of a later per-lane select --
+// which would turn the select into an exec-masked block of its own and cut the straight-line schedule into pieces (the packed
+// quarter tiles choose per lane between the value-slot and the tangent-slot formulas all the time).
+__device__ __forceinline__ void fz_keep(double& x) { asm volatile("" : "+v"(x)); }
+
 // the same with the bias fragment scaled per lane (bm = 1 or 0): the packed quarter tile of k_iter_fused<.., QT> carries the value
 // channel in some of its 16 point slots and the tangent channels, which take no bias, in the others
 __device__ __forceinline__ void fz_layer_m(const double* WTl, const double* WRl, const double* BHl, int lofs, double bm,

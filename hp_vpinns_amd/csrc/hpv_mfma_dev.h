@@ -49,6 +49,7 @@ struct MfmaArgs {
     unsigned int* xiter;         // launches so far: the tag of a launch is *xiter + 1; workgroup 0 advances it at its end
     // single-workgroup grids (the reference's own 1-element 1-D default, BASELINE config 1): the whole-iteration tile kernel
     // finishes the iteration itself -- packed buffer, TF1 Adam, loss history -- instead of a dependent k_finalize launch
+    int tall_qt;          // k_iter_tall: the quarter-tile plan (every workgroup's tile count is 0 or 1 mod 4, see kernels_tall.hip)
     int fin_mode;         // 0: k_finalize follows; 1: packed buffer only; 2: packed buffer + Adam update
     AdamArgs fin_ad;
     double* fin_RB;       // [grad (P) | d eps | lossv | w*lossb | msq | pad]

@@ -54,10 +54,13 @@ struct TaLds {
     static constexpr int RED = U + NR;                         // [16]         scalars (last word: the barrier's verdict)
     static constexpr int TR = RED + 16;                        // per-wave transpose tiles of ALL channels | epilogue rows
     static constexpr int TR_WAVE = C * 2 * MF_TRB * MF_LD;
-    static constexpr int total(int P) { return TR + (TA_WAVES * TR_WAVE > TA_WAVES * P ? TA_WAVES * TR_WAVE : TA_WAVES * P); }
+    // QT: the quarters' s behind everything else ([TA_WAVES][L*5][16]: value-slot lanes, compact) -- at the end, so that the offsets
+    // of the regions above (and with them the whole-tile code's addressing) are those of the instantiation without quarters
+    static constexpr int pq(int P) { return TR + (TA_WAVES * TR_WAVE > TA_WAVES * P ? TA_WAVES * TR_WAVE : TA_WAVES * P); }
+    static constexpr int total(int P) { return pq(P) + TA_WAVES * L * MF_KS * 16; }
 };
 
-template <int NT1, int NT2, int L, int QX, int QY, int NTX, int NTY>
+template <int NT1, int NT2, int L, int QX, int QY, int NTX, int NTY, bool QT>
 __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
     constexpr int C = 1 + NT1 + NT2, NQ = QX * QY, TPE = NQ / 16, NR = NTX * NTY, LH = L - 1, NSV = L * MF_KS;
     static_assert(NQ % 16 == 0 && L >= 2 && NT2 <= NT1, "whole tiles per element; second tangents ride on first ones");
@@ -168,15 +171,37 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
     // ---- tile list of this wave: element tiles tbase + wv, + 4, ..; possibly one boundary/data tile behind the elements ----
     const int tbase = (part * TPE) >> lg, tend = ((part + 1) * TPE) >> lg;
     const int n_mine = tend - tbase;                                    // element tiles of this workgroup (<= 16)
-    const int n_el = (n_mine - wv + TA_WAVES - 1 > 0) ? (n_mine - wv + TA_WAVES - 1) / TA_WAVES : 0;
-    const long dtile = g.proj_n_elem * TPE + blockIdx.x;                // one data tile per workgroup, as far as they go
+    // Quarter-tile plan (g.tall_qt, decided by the host for the whole grid: every workgroup's tile count is 0 or 1 mod 4).
+    // 400 tiles over 32 workgroups are 12 or 13 tiles per workgroup, i.e. 3 + 3 + 3 + 3 or 4 + 3 + 3 + 3 per wave -- and the
+    // boundary / data tiles made a 4-tile wave in the others: every launch lasted four tile-times for 3.2 of work.  Here every
+    // wave owns n_mine / 4 whole tiles, and the workgroup's one extra tile -- its 13th element tile, or (12-tile workgroups)
+    // a boundary / data tile -- is cut in four: a wave takes four of its points as ONE packed operand whose 16 point slots are
+    // the C channels x 4 points (kernels_fused.hip, QT: layer products, hbar chain, tangent recompute and dW products once per
+    // packed operand, the channels of a point coupled through DPP row shifts in the element-wise steps).
+    constexpr bool qt = QT;                 // (the host launches the QT instantiation when its plan holds for the whole grid)
+    const int nwq = n_mine / TA_WAVES;
+    // one data tile per workgroup, as far as they go -- QT: per workgroup WITHOUT a 13th element tile
+    auto dtile_of = [&]() -> long {
+        if constexpr (QT) {
+            int c0 = 0;
+            for (int p_ = 0; p_ < part; ++p_) c0 += ((((p_ + 1) * TPE) >> lg) - ((p_ * TPE) >> lg)) % TA_WAVES == 0 ? 1 : 0;
+            return n_mine % TA_WAVES == 0 ? g.proj_n_elem * TPE + (long)c0 * n_el_grid + e : g.ntiles;
+        } else {
+            return g.proj_n_elem * TPE + blockIdx.x;
+        }
+    };
+    const long dtile = dtile_of();
+    const int q_kind = !qt ? 0 : (n_mine % TA_WAVES == 1 ? 1 : (dtile < g.ntiles ? 2 : 0));     // 1 element quarter, 2 data quarter
+    const int n_el = qt ? nwq : ((n_mine - wv + TA_WAVES - 1 > 0) ? (n_mine - wv + TA_WAVES - 1) / TA_WAVES : 0);
     (void)wg_slot;
-    const bool has_d = (wv == n_mine % TA_WAVES) && dtile < g.ntiles && n_el < TA_MAXT;
+    const bool has_d = !qt && (wv == n_mine % TA_WAVES) && dtile < g.ntiles && n_el < TA_MAXT;
     const int n_own = n_el + (has_d ? 1 : 0);
     auto tile_of = [&](int k) -> long { return k < n_el ? e * TPE + tbase + wv + (long)k * TA_WAVES : dtile; };
     auto lp_of = [&](int k) -> int { return (wv + k * TA_WAVES) * 16 + pt; };      // point index inside this workgroup's range
 
-    constexpr int ABASE = 256 - TA_MAXT * 2 * NSV;
+    // (QT: at most TA_MAXT - 1 whole tiles per wave, the quarter's s lives in LDS: one stash slot less for the compiler's benefit)
+    constexpr int NSLOT = QT ? TA_MAXT - 1 : TA_MAXT;
+    constexpr int ABASE = 256 - NSLOT * 2 * NSV;
     asm volatile("" ::: "a255");       // the kernel owns all 256 AGPRs; a[ABASE..255] are hand-managed (scripts/check_agpr.py)
     double gdat = 0.0;
 
@@ -256,9 +281,74 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
             if (lane == 0) g.data_part[p / 16 - g.data_off / 16] = sq;
         }
         switch (k) {     // wave-uniform; the stash slot must be a compile-time register index
-#define TA_STASH(K) case K: acc_put_all<ABASE + K * 2 * NSV, NSV>(sv); break;
+#define TA_STASH(K) case K: if constexpr (K < NSLOT) acc_put_all<ABASE + K * 2 * NSV, NSV>(sv); break;
             TA_STASH(0) TA_STASH(1) TA_STASH(2) TA_STASH(3)
 #undef TA_STASH
+        }
+    }
+    // ---- QT: this wave's packed quarter of the workgroup's extra tile (slot c = pt >> 2 = channel, j = pt & 3 = point) ----
+    const int qcs = pt >> 2, qj = pt & 3;
+    const bool q_val = qcs == 0, q_first = qcs >= 1 && qcs <= NT1, q_second = qcs > NT1 && qcs < C;
+    const int q_lp = (TA_WAVES * nwq) * 16 + 4 * wv + qj;                     // element quarter: the point inside this workgroup's range
+    const long q_p = q_kind == 1 ? (e * TPE + tbase + TA_WAVES * nwq) * 16 + 4 * wv + qj : (q_kind == 2 ? dtile * 16 + 4 * wv + qj : 0);
+    const bool q_valid = q_kind != 0 && q_p < g.N;
+    double gdat_q = 0.0;
+    if (QT && q_kind != 0) {               // (wave- and workgroup-uniform)
+        const long pc = q_valid ? q_p : 0;
+        const double x0 = g.X[pc], x1 = g.X[g.N + pc];
+        const double udq = (q_kind == 2 && q_valid) ? g.ud[pc - g.data_off] : 0.0;
+        int lofs = lane;
+        asm volatile("" : "+v"(lofs));
+        // per-lane 0 / 1 masks of the slot kinds and slot indices: the element-wise steps BLEND the candidates arithmetically (exactly
+        // one mask is 1, so the blend is exact) -- chains of per-lane selects on the slot index become branches otherwise
+        const double mv = q_val ? 1.0 : 0.0, mf = q_first ? 1.0 : 0.0, ms = q_second ? 1.0 : 0.0;
+        const double m1 = qcs == 1 ? 1.0 : 0.0, m2 = qcs == 2 ? 1.0 : 0.0, m3 = qcs == 3 ? 1.0 : 0.0;
+        double H[MF_KS], AAq[NSV];
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            const double w0 = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs], w1 = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
+            const double z = lds[M::W1O + (3 * MF_KS + s) * 64 + lofs] + x0 * w0 + x1 * w1;
+            double a, a1, a2;
+            act_fwd<HPV_ACT_TANH>(z, a, a1, a2);
+            AAq[s] = a;
+            const double wf = qcs == 1 ? w0 : w1;                              // first tangent u = qcs - 1
+            const double wb = (qcs - 1 - NT1) == 0 ? w0 : w1;                  // second tangent b = qcs - 1 - NT1
+            H[s] = mv * a + (mf * a1) * wf + (ms * a2) * (wb * wb);
+        }
+#pragma unroll
+        for (int i = 1; i < L; ++i) {
+            double Z[MF_KS];
+            fz_layer_m(WTl + (i - 1) * MF_KS * 64, WRl + (i - 1) * MF_KS * 16, BHl + (i - 1) * MF_KS * 64, lofs, q_val ? 1.0 : 0.0, H, Z);
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                double a, a1, a2;
+                act_fwd<HPV_ACT_TANH>(Z[s], a, a1, a2);                    // (tangent slots: of a tangent pre-activation, not used)
+                const double a4 = dpp_move<0x114>(a), a8 = dpp_move<0x118>(a), a12 = dpp_move<0x11C>(a);   // row_shr: the value slot of my point
+                const double ab = (mv * a + m1 * a4) + (m2 * a8 + m3 * a12);
+                const double zx = dpp_move<0x110 + 4 * NT1>(Z[s]);        // second-tangent slots: z_c of their first tangent
+                const double b1 = 1.0 - ab * ab, b2 = -2.0 * ab * b1;
+                AAq[i * MF_KS + s] = ab;
+                H[s] = mv * ab + ((mf + ms) * b1) * Z[s] + (ms * b2) * (zx * zx);
+            }
+        }
+        double v = 0.0;
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) v += H[s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
+        v = xrow_sum16(v);
+        v = xrow_sum32(v);
+        if (q_val) v += bo;
+        if (q_kind == 1) {
+            if (q == 0 && qcs < C) lds[M::CH + qcs * MAXP + q_lp] = v;
+        } else {
+            // lossb partial of the boundary / data tile (P3:184): the four waves' quarters meet in LDS
+            const double dd = (q_valid && q_val) ? udq - v : 0.0;
+            gdat_q = g.data_scale * dd;
+            const double sq = row_sum16(q == 0 ? dd * dd : 0.0);
+            if (lane == 0) lds[M::RED + 8 + wv] = sq;
+        }
+        if (q_val) {       // the quarter's s: value-slot lanes only (the tangent slots read their point's back)
+#pragma unroll
+            for (int j = 0; j < NSV; ++j) lds[M::pq(g.P) + (wv * NSV + j) * 16 + q * 4 + qj] = AAq[j];
         }
     }
 #pragma unroll
@@ -268,6 +358,8 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
     TA_STAMP(2);
     __syncthreads();
     TA_STAMP(3);
+    if (q_kind == 2 && tid == 0)
+        g.data_part[dtile - g.data_off / 16] = (lds[M::RED + 8] + lds[M::RED + 9]) + (lds[M::RED + 10] + lds[M::RED + 11]);
 
     // =============================================================================================
     // phase P: partial projection of this workgroup's points, exchange, residual, adjoint at its points
@@ -417,7 +509,7 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
         asm volatile("" : "+v"(lofs));
         double sv[NSV];
         switch (k) {
-#define TA_FETCH(K) case K: acc_get_all<ABASE + K * 2 * NSV, NSV>(sv); break;
+#define TA_FETCH(K) case K: if constexpr (K < NSLOT) acc_get_all<ABASE + K * 2 * NSV, NSV>(sv); break;
             TA_FETCH(0) TA_FETCH(1) TA_FETCH(2) TA_FETCH(3)
 #undef TA_FETCH
             default:
@@ -570,6 +662,126 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
         }
     }
 
+    if (QT && q_kind != 0) {
+        // ---- the packed quarter, reverse (branch-free: per-lane selects and unconditional loads, see kernels_fused.hip) ----
+        int lofs = lane;
+        asm volatile("" : "+v"(lofs));
+        const long pc = q_valid ? q_p : 0;
+        const double x0 = g.X[pc], x1 = g.X[g.N + pc];
+        double AAq[NSV];
+#pragma unroll
+        for (int j = 0; j < NSV; ++j) AAq[j] = lds[M::pq(g.P) + (wv * NSV + j) * 16 + q * 4 + qj];
+        const double gch = lds[M::GB + (qcs < C ? qcs : 0) * MAXP + (q_kind == 1 ? q_lp : 0)];
+        const double GB = q_kind == 1 ? (qcs < C ? gch : 0.0) : (q_val ? gdat_q : 0.0);
+        const bool q_tan = q_first || q_second;
+        // packed layer inputs, own-slot pre-activations z_c / z_cc (0 in the value slot) and, for the second-tangent slots, z_c
+        // of their first tangent -- recomputed from s with ONE product per layer
+        double Hq[L][MF_KS], ZCq[L][MF_KS], ZXq[L][MF_KS];
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            const double w0 = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs], w1 = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
+            const double a = AAq[s], a1 = 1.0 - a * a, a2 = -2.0 * a * a1;
+            const double wf = qcs == 1 ? w0 : w1, wb = (qcs - 1 - NT1) == 0 ? w0 : w1;
+            ZCq[0][s] = q_first ? wf : 0.0;
+            ZXq[0][s] = q_second ? wb : 0.0;
+            double hf = a1 * wf, hs = a2 * wb * wb;
+            fz_keep(hf); fz_keep(hs);
+            Hq[0][s] = q_val ? a : (q_first ? hf : (q_second ? hs : 0.0));
+        }
+#pragma unroll
+        for (int i = 1; i < L; ++i) {
+            double Z[MF_KS];
+            fz_layer<false>(WTl + (i - 1) * MF_KS * 64, WRl + (i - 1) * MF_KS * 16, nullptr, lofs, Hq[i - 1], Z);
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                const double a = AAq[i * MF_KS + s], a1 = 1.0 - a * a, a2 = -2.0 * a * a1;
+                const double zx = dpp_move<0x110 + 4 * NT1>(Z[s]);
+                ZCq[i][s] = q_tan ? Z[s] : 0.0;
+                ZXq[i][s] = q_second ? zx : 0.0;
+                double hf = a1 * Z[s], hs = a2 * zx * zx + a1 * Z[s];
+                fz_keep(hf); fz_keep(hs);
+                Hq[i][s] = q_val ? a : (q_first ? hf : (q_second ? hs : 0.0));
+            }
+        }
+        double HB[MF_KS], ZB[MF_KS];
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            const double wo = lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
+            dWo[s] = fma(Hq[L - 1][s], GB, dWo[s]);
+            HB[s] = GB * wo;
+        }
+        dbo += (q == 0 && q_val) ? GB : 0.0;
+        const double mval = q_val ? 1.0 : 0.0;
+        const double mfx = (q_first && qcs - 1 < NT2) ? 1.0 : 0.0;       // first tangents that carry a second one
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                const double a = AAq[i * MF_KS + s];
+                const double a1 = 1.0 - a * a, a2 = -2.0 * a * a1, a3 = -2.0 * a1 * (1.0 - 3.0 * a * a);
+                const double zc = ZCq[i][s], zxx = ZXq[i][s];
+                // what the value slot collects from the tangent slots of its point
+                double tf = HB[s] * a2 * zc, ts = HB[s] * (a3 * zxx * zxx + a2 * zc);
+                fz_keep(tf); fz_keep(ts);
+                const double T = q_first ? tf : (q_second ? ts : 0.0);
+                const double t4 = dpp_move<0x104>(T), t8 = dpp_move<0x108>(T), t12 = dpp_move<0x10C>(T);
+                const double hb2 = dpp_move<0x100 + 4 * NT1>(HB[s]);      // first-tangent slots: hbar of their second tangent
+                double zb = HB[s] * a1;
+                zb = fma(mval, (t4 + t8) + t12, zb);
+                zb = fma(mfx * 2.0 * hb2 * a2, zc, zb);
+                ZB[s] = zb;
+                db[i][s] = fma(mval, zb, db[i][s]);
+            }
+            if (i == 0) {
+                const double c0 = q_val ? x0 : (qcs == 1 ? 1.0 : 0.0), c1 = q_val ? x1 : ((NT1 > 1 && qcs == 2) ? 1.0 : 0.0);
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+                    dW1[0][s] = fma(c0, ZB[s], dW1[0][s]);
+                    dW1[1][s] = fma(c1, ZB[s], dW1[1][s]);
+                }
+            } else {
+                pj_wave_sync();
+                double* TA = TAB;
+                double* TB = TA + MF_TRB * MF_LD;
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+                    TA[(4 * s + q) * MF_LD + pt] = Hq[i - 1][s];
+                    TB[(4 * s + q) * MF_LD + pt] = ZB[s];
+                }
+                {
+                    v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
+                    double h4 = 0.0;
+                    const double* wrl = lds + M::WRB + (i - 1) * MF_KS * 16 + q * 4 + (lane & 3);
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s) {
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[M::WN + ((i - 1) * MF_KS + s) * 64 + lofs], ZB[s], acc, 0, 0, 0);
+                        h4 = __builtin_amdgcn_mfma_f64_4x4x4f64(wrl[s * 16], ZB[s], h4, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) HB[s] = acc[s];
+                    HB[4] = h4;
+                }
+                pj_wave_sync();
+                double aF[4], bF[4], aS[4], bS[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    aF[kk] = TA[pt * MF_LD + 4 * kk + q];
+                    bF[kk] = TB[pt * MF_LD + 4 * kk + q];
+                    aS[kk] = TA[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                    bS[kk] = TB[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    dWacc[i - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[kk], bF[kk], dWacc[i - 1], 0, 0, 0);
+                    dS10[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(aS[kk], bF[kk], dS10[i - 1], 0, 0, 0);
+                    dS01[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(bS[kk], aF[kk], dS01[i - 1], 0, 0, 0);
+                }
+                accC[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(TA[(16 + (lane & 3)) * MF_LD + (pt & 12) + q],
+                                                               TB[(16 + (lane & 3)) * MF_LD + (pt & 12) + q], accC[i - 1], 0, 0, 0);
+            }
+        }
+    }
+
     // ---- epilogue: per-wave partials -> LDS -> one gradient row per workgroup ----
     TA_STAMP(7);
     __syncthreads();
@@ -633,16 +845,24 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int NT1, int NT2, int L, int QX, int QY, int NTX, int NTY>
-static void launch_iter_tall(const MfmaArgs& a, int blocks, hipStream_t s) {
+template <int NT1, int NT2, int L, int QX, int QY, int NTX, int NTY, bool QT>
+static void launch_iter_tall_q(const MfmaArgs& a, int blocks, hipStream_t s) {
     constexpr int C = 1 + NT1 + NT2;
     const size_t bytes = (size_t)TaLds<L, C, QX, QY, NTX, NTY, 16 * TA_WAVES * TA_MAXT>::total(a.P) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_iter_tall<NT1, NT2, L, QX, QY, NTX, NTY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        (void)hipFuncSetAttribute((const void*)k_iter_tall<NT1, NT2, L, QX, QY, NTX, NTY, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_iter_tall<NT1, NT2, L, QX, QY, NTX, NTY>), dim3(blocks), dim3(TA_BLOCK), bytes, s, a);
+    hipLaunchKernelGGL((k_iter_tall<NT1, NT2, L, QX, QY, NTX, NTY, QT>), dim3(blocks), dim3(TA_BLOCK), bytes, s, a);
+}
+
+template <int NT1, int NT2, int L, int QX, int QY, int NTX, int NTY>
+static void launch_iter_tall(const MfmaArgs& a, int blocks, hipStream_t s) {
+#ifndef HPV_AGPR_GUARD_TRIPPED_QT     // csrc/build.sh: only the quarter-tile instantiations reached their hand-managed AGPR range
+    if (a.tall_qt) { launch_iter_tall_q<NT1, NT2, L, QX, QY, NTX, NTY, true>(a, blocks, s); return; }
+#endif
+    launch_iter_tall_q<NT1, NT2, L, QX, QY, NTX, NTY, false>(a, blocks, s);
 }
 
 // Workgroups per element of the tall-element kernel (0: not applicable): the largest power of two with n_elem S <= CUs, at most
@@ -685,6 +905,20 @@ bool hpv_mfma_iter_tall(HpvMfma* m, const double* theta, const double* X, double
     }
     a.proj_n_elem = n_elem;
     a.proj_split = split;
+    {
+        // quarter-tile plan: every workgroup's tile count must be 0 or 1 mod 4 (its one extra tile is cut in four), its whole tiles
+        // must leave a stash slot for the quarter, and the workgroups without a 13th element tile must suffice for the data tiles
+        const int tpe = 80 * 80 / 16, lg = __builtin_ctz(split);
+        bool qt = getenv("HPV_NO_QUARTER_TILE") == nullptr;
+        long n0 = 0;
+        for (int p_ = 0; p_ < split; ++p_) {
+            const int n = (((p_ + 1) * tpe) >> lg) - ((p_ * tpe) >> lg);
+            if (n % TA_WAVES > 1 || n / TA_WAVES + 1 > TA_MAXT) qt = false;
+            if (n % TA_WAVES == 0) ++n0;
+        }
+        if (rest > n0 * n_elem) qt = false;
+        a.tall_qt = qt ? 1 : 0;
+    }
     a.xerr = m->xerr;
     a.xdebug_skip = m->xdebug_skip;
     a.xg = m->xg;
