@@ -140,3 +140,42 @@ def test_config5_full_trajectory(tag, q):
     ne = (len(a[7]) - 1) * (len(a[8]) - 1)
     _check_point(o, m, 4, ne * q * q, ne * 25)
     _check_trajectory(OracleVPINNAdvDiff(*a, init_params=th), m, _grid2(-1, 1, 0, 1), adv=True)
+
+
+@pytest.mark.parametrize("cfg", ["poisson2d_cfg4", "advdiff_cfg5"])
+def test_quarter_tile_plan_against_whole_tiles(cfg):
+    """The whole-iteration kernels of configs 4 and 5 balance their waves with packed QUARTER tiles (k_iter_fused<.., QT>,
+    k_iter_tall<.., QT>: channels x 4 points in the 16 point slots of one operand, the boundary points in otherwise idle slots).
+    Against the same kernels on whole tiles only (HPV_NO_QUARTER_TILE=1): loss triple, gradient, residuals to round-off
+    (different summation orders of the same terms) and a 50-step TF1-Adam trajectory incl. epsilon."""
+    import os
+    if cfg == "poisson2d_cfg4":
+        from hp_vpinns_amd.vpinn import VPINN2D as Model
+        L = [2, 20, 20, 20, 1]
+        a = p2_args(gold(cfg), layers=L)
+        th = theta0(L, 51)
+        n_res = 256 * 100
+    else:
+        from hp_vpinns_amd.vpinn import VPINNAdvDiff as Model
+        L = [2, 20, 20, 20, 1]
+        a = p3_args(gold(cfg), layers=L)
+        th = theta0(L, 52, extra=[0.85])
+        n_res = 8 * 25
+
+    def run():
+        m = Model(*a, init_params=th)
+        l3, g = m.loss_and_grad()
+        r = m.h.residuals(n_res)
+        hist, eps = m._step_record(50)
+        return l3, g, r, hist, eps, m.get_params(), m.h.pass_structure()
+
+    q = run()
+    os.environ["HPV_NO_QUARTER_TILE"] = "1"
+    try:
+        w = run()
+    finally:
+        del os.environ["HPV_NO_QUARTER_TILE"]
+    assert q[6] == w[6] and q[6] in ("whole-iteration", "whole-iteration-tall")
+    assert rel(q[0], w[0]) < 1e-13 and rel(q[1], w[1]) < 1e-12 and rel(q[2], w[2]) < 1e-12
+    assert rel(q[3], w[3]) < 1e-9 and rel(q[5], w[5]) < 1e-9 and rel(q[4] + 1.0, w[4] + 1.0) < 1e-10
+    assert not np.array_equal(q[1], w[1])          # (the two plans really are different code paths)
