@@ -382,6 +382,45 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
             }
         }
         __syncthreads();
+        if constexpr (QT) {
+            // sum-factorised over the rows of the quadrature grid this workgroup's points touch (at most NRW: its <= 15 tiles are a
+            // contiguous run of points of a QX-wide grid): T_t[jj][r] = sum_i AX_t[r][i] G_t[(j0 + jj, i)] by a lane quad per output
+            // (the points outside the workgroup's range masked), then U[k][r] = sum_t sum_jj BY_t[k][j0 + jj] T_t[jj][r] -- a tenth of
+            // the LDS reads of the point-by-point version below, and no slice partials
+            constexpr int NRW = (MAXP + QX - 2) / QX + 1;
+            static_assert(HPV_MAXT * NRW * NTX * 4 <= TA_BLOCK && HPV_MAXT * NRW * NTX <= TA_SLICES * NR && QX % 4 == 0, "row partials fit the block and the slice scratch");
+            const int j0 = (int)qe0 / QX;
+            {
+                const int o = tid >> 2, part4 = tid & 3;
+                const bool ok = o < HPV_MAXT * NRW * NTX;
+                const int oc = ok ? o : 0;
+                const int t = oc / (NRW * NTX), jj = (oc / NTX) % NRW, r = oc % NTX;
+                const int lp0 = (j0 + jj) * QX - (int)qe0;          // lp of the row's first point (may lie outside the range)
+                double acc = 0.0;
+#pragma unroll
+                for (int it = 0; it < QX / 4; ++it) {
+                    const int i = part4 + 4 * it, lp = lp0 + i;
+                    const bool in = lp >= 0 && lp < np;
+                    const double av = lds[M::AX + (t * NTX + r) * QX + i] * (in ? 1.0 : 0.0);
+                    acc = fma(av, lds[M::GB + t * MAXP + (in ? lp : 0)], acc);
+                }
+                acc = pj_group_sum<4>(acc);
+                if (ok && part4 == 0) lds[M::UP + oc] = acc;
+            }
+            __syncthreads();
+            if (tid < NR) {
+                const int kk = tid / NTX, r = tid % NTX;
+                double u = 0.0;
+#pragma unroll
+                for (int t = 0; t < HPV_MAXT; ++t)
+#pragma unroll
+                    for (int jj = 0; jj < NRW; ++jj) {
+                        const int j = j0 + jj < QY ? j0 + jj : QY - 1;        // (rows past the grid: their T is zero)
+                        u = fma(lds[M::BY + (t * NTY + kk) * QY + j], lds[M::UP + (t * NRW + jj) * NTX + r], u);
+                    }
+                if (!xsticky && !(g.xdebug_skip && xtag >= (unsigned)g.xdebug_skip && e == 0 && part == 1)) xg_publish(g.xg + (wg_slot * NR + tid) * 2, u, xtag);
+            }
+        } else {
         if (tid < NR * TA_SLICES) {
             const int o = tid % NR, sl = tid / NR, kk = o / NTX, r = o % NTX;
             double acc = 0.0;
@@ -405,6 +444,7 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
             for (int sl = 0; sl < TA_SLICES; ++sl) u += lds[M::UP + sl * NR + tid];
             // publish: two tagged granules per value, fire and forget (the partners poll the granules themselves)
             if (!xsticky && !(g.xdebug_skip && xtag >= (unsigned)g.xdebug_skip && e == 0 && part == 1)) xg_publish(g.xg + (wg_slot * NR + tid) * 2, u, xtag);
+        }
         }
         TA_STAMP(4);
         {
