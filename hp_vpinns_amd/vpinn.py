@@ -9,10 +9,20 @@ signatures, array layouts and `train` / `predict` semantics:
 
 Host work here is set-up only (tables, packing, sharding); every iteration -- MLP forward with
 its input derivatives, test-function projection, residual, gradients, Adam -- runs in the HIP
-library.  Module-level globals the reference classes read (`var_form`, `LR`, `lossb_weight`,
-`scheme`, `V`, `total_record`, `loss_his`) are keyword arguments with the reference defaults.
+library.
+
+Module-level globals.  The reference classes read names of the module they are defined in: the
+hyper-parameters `var_form`, `LR`, `lossb_weight`, `scheme`, `V` while the graph is built in
+`__init__` (P1:82-102, P2:93-128, P3:161-191) and the history lists `total_record` / `loss_his`
+while `train` runs (P1:214, P2:244) -- the drivers create those lists AFTER the constructor
+(P1:333 then :335, P2:430 then :433).  The classes here keep that timing: every such name is a
+keyword argument; one that is not given is looked up in the CALLER's module globals (or the
+dict passed as `module_globals=`) -- the hyper-parameters when the constructor runs, the lists
+when `train` runs -- and only then falls back to the reference's default / a private list.  So
+`from hp_vpinns_amd.vpinn import VPINN2D as VPINN` is the whole binding.
 """
 import os
+import sys
 import time
 
 import numpy as np
@@ -52,6 +62,27 @@ def _tensor_rule(X_quad, W_quad):
     if not ok:
         raise ValueError("quadrature arrays are not the x-fastest tensor product the reference builds (P2:355-360)")
     return xi, wx, yi, wy
+
+
+def _caller_globals(depth=2):
+    """Module globals of whoever called the public method `depth - 1` frames above this function."""
+    try:
+        return sys._getframe(depth).f_globals
+    except ValueError:      # pragma: no cover - no such frame
+        return {}
+
+
+def _resolve(value, name, ns, default, kinds):
+    """keyword argument > the caller's module global of that name (what the reference class reads) > reference default."""
+    if value is not None:
+        return value
+    v = ns.get(name) if ns is not None else None
+    if isinstance(v, kinds) and not isinstance(v, bool):
+        return v
+    return default
+
+
+_NUM = (int, float, np.integer, np.floating)
 
 
 def _uniform(lst, what):
@@ -111,6 +142,18 @@ class _VPINNBase:
         if self._dist:
             import torch
             torch.cuda.set_device(device)
+
+    def _history(self, name, handed_in, caller_ns):
+        """The list `train` appends to: the one handed to the constructor, else the module-level list of that name the
+        caller holds NOW (the reference appends to its module global at train time: P1:214, P2:244 -- the drivers create
+        it after the constructor), else the private one this object has kept since construction."""
+        if handed_in is not None:
+            return handed_in
+        for ns in (self._module_globals, caller_ns):
+            lst = ns.get(name) if ns is not None else None
+            if isinstance(lst, list):
+                return lst
+        return getattr(self, name)
 
     def _to_dev(self, theta):
         """user parameter layout -> the layout the library holds (zero-padded for narrow networks)."""
@@ -449,8 +492,13 @@ class VPINN1D(_VPINNBase):
     _pde, _act = _lib.PDE_POISSON1D, _lib.ACT_SIN   # tf.sin, P1:134
 
     def __init__(self, X_u_train, u_train, X_quad, W_quad, F_exact_total, grid, X_test, u_test, layers,
-                 X_f_train=None, f_train=None, *, var_form=1, lossb_weight=1, LR=0.001, init_params=None,
-                 seed=1234, backend="auto", device=None, total_record=None):
+                 X_f_train=None, f_train=None, *, var_form=None, lossb_weight=None, LR=None, init_params=None,
+                 seed=1234, backend="auto", device=None, total_record=None, module_globals=None):
+        ns = module_globals if module_globals is not None else _caller_globals()
+        self._module_globals = module_globals
+        var_form = _resolve(var_form, "var_form", ns, 1, (int, np.integer))              # P1:234 (read at P1:82-91)
+        lossb_weight = _resolve(lossb_weight, "lossb_weight", ns, 1, _NUM)               # P1:240 (read at P1:100)
+        LR = _resolve(LR, "LR", ns, 0.001, _NUM)                                         # P1:231 (read at P1:102)
         self.x, self.u = np.asarray(X_u_train, dtype=np.float64), np.asarray(u_train, dtype=np.float64)
         self.xf, self.f = X_f_train, f_train
         self.xquad, self.wquad = np.asarray(X_quad, dtype=np.float64), np.asarray(W_quad, dtype=np.float64)
@@ -466,6 +514,7 @@ class VPINN1D(_VPINNBase):
             self.F_ext_total[e, :f.size, 0] = f
         self.grid = np.asarray(grid, dtype=np.float64)
         self.var_form, self.LR, self.lossb_weight = var_form, LR, lossb_weight
+        self._total_record_arg = total_record
         self.total_record = [] if total_record is None else total_record
         if self.grid.size != self.Nelement + 1:
             raise ValueError("grid must have Nelement+1 entries")
@@ -491,7 +540,9 @@ class VPINN1D(_VPINNBase):
 
     def train(self, nIter, tresh):
         """P1:201-224.  The loss is read back every 10 iterations, AFTER that iteration's update,
-        appended to `total_record` as [it, loss]; early exit when loss < tresh."""
+        appended to `total_record` as [it, loss]; early exit when loss < tresh.  `total_record` is the list handed to the
+        constructor, else the caller's module-level `total_record` as it exists now (P1:335 creates it after P1:333)."""
+        self.total_record = self._history("total_record", self._total_record_arg, _caller_globals())
         start_time = time.time()
         it = 0
         while it < nIter:
@@ -519,8 +570,13 @@ class VPINN2D(_VPINNBase):
     _pde, _act = _lib.PDE_POISSON2D, _lib.ACT_TANH   # tf.tanh, P2:165
 
     def __init__(self, X_u_train, u_train, X_f_train, f_train, X_quad, W_quad, U_exact_total, F_exact_total,
-                 gridx, gridy, N_testfcn, X_test, u_test, layers, *, var_form=1, scheme="VPINNs", LR=0.001,
-                 lossb_weight=10, init_params=None, seed=1234, backend="auto", device=None, loss_his=None):
+                 gridx, gridy, N_testfcn, X_test, u_test, layers, *, var_form=None, scheme=None, LR=0.001,
+                 lossb_weight=10, init_params=None, seed=1234, backend="auto", device=None, loss_his=None,
+                 module_globals=None):
+        ns = module_globals if module_globals is not None else _caller_globals()
+        self._module_globals = module_globals
+        var_form = _resolve(var_form, "var_form", ns, 1, (int, np.integer))              # P2:281 (read at P2:93-115)
+        scheme = _resolve(scheme, "scheme", ns, "VPINNs", str)                           # P2:279 (read at P2:125-128)
         if scheme not in ("VPINNs", "PINNs"):
             raise ValueError("scheme is either 'PINNs' or 'VPINNs' (P2:269)")
         self.scheme = scheme
@@ -535,6 +591,7 @@ class VPINN2D(_VPINNBase):
         self.gridx, self.gridy = np.asarray(gridx, dtype=np.float64), np.asarray(gridy, dtype=np.float64)
         self.X_test, self.utest = X_test, u_test
         self.var_form = var_form
+        self._loss_his_arg = loss_his
         self.loss_his = [] if loss_his is None else loss_his
         if self.F_ext_total.shape != (self.Nelementx, self.Nelementy, self.Ntesty, self.Ntestx):
             raise ValueError(f"F_exact_total has shape {self.F_ext_total.shape}, expected "
@@ -567,7 +624,9 @@ class VPINN2D(_VPINNBase):
     def train(self, nIter, record_every=1):
         """P2:233-253: the loss is read back EVERY iteration (after the update) into `loss_his`.
         `record_every=k` reads it every k-th iteration instead (the device then runs k iterations
-        back to back); the default 1 is the reference behaviour."""
+        back to back); the default 1 is the reference behaviour.  `loss_his` is the list handed to the constructor, else the
+        caller's module-level `loss_his` as it exists now (P2:433 creates it after P2:430)."""
+        self.loss_his = self._history("loss_his", self._loss_his_arg, _caller_globals())
         start_time = time.time()
         it = 0
         while it < nIter:
@@ -596,8 +655,13 @@ class VPINNAdvDiff(_VPINNBase):
     _n_extra = 1                                   # epsilon, init 1.0 (P3:63)
 
     def __init__(self, XT_u_train, u_train, XT_f_train, XT_quad, W_quad, T_quad, WT_quad, grid_x, grid_t,
-                 N_testfcn, XT_test, u_test, layers, lb=None, ub=None, *, var_form=0, LR=0.001, V=1.0,
-                 lossb_weight=10, init_params=None, seed=1234, backend="auto", device=None):
+                 N_testfcn, XT_test, u_test, layers, lb=None, ub=None, *, var_form=None, LR=None, V=None,
+                 lossb_weight=10, init_params=None, seed=1234, backend="auto", device=None, module_globals=None):
+        ns = module_globals if module_globals is not None else _caller_globals()
+        self._module_globals = module_globals
+        var_form = _resolve(var_form, "var_form", ns, 0, (int, np.integer))              # P3:38 (read at P3:161-174)
+        LR = _resolve(LR, "LR", ns, 0.001, _NUM)                                         # P3:35 (read at P3:191)
+        V = _resolve(V, "V", ns, 1.0, _NUM)                                              # P3:43 (read at P3:163,171)
         self.lb, self.ub = lb, ub
         self.XT_u_train = np.asarray(XT_u_train, dtype=np.float64)
         self.u = np.asarray(u_train, dtype=np.float64)
