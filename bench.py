@@ -211,6 +211,7 @@ def main():
     dt = _median(wins)
     n_its_done = n_warm + len(wins) * args.steps
     structure = model.h.pass_structure()      # which launch structure the timed iterations ran (SPLIT vs the split reverse kernels ...)
+    variant = model.h.kernel_variant()        # ... and which kernel instantiation (quarter-tile plan or whole tiles, split factor)
     graphs = model.h.graphs_in_use() if not model._coll else bool(model._dist_graphs.get(min(args.steps, 8) if args.steps <= 16 else 8))
 
     # ---- per-kernel device times (hipEvents on the stream the kernels run on), untimed extra pass ----
@@ -303,7 +304,7 @@ def main():
             finally:
                 os.environ.pop("HPV_EXCHANGE", None)
 
-    per_rank = [{"rank": rank, "pass_structure": structure, "graphs": bool(graphs), "exchange": exchange}]
+    per_rank = [{"rank": rank, "pass_structure": structure, "kernel_variant": variant, "graphs": bool(graphs), "exchange": exchange}]
     if dist is not None:
         allr = [None] * world
         dist.all_gather_object(allr, per_rank[0])
@@ -356,7 +357,7 @@ def main():
                                          "EAGER launches (RCCL refused stream capture: no iteration graphs)"),
                                 "p2p": "in-library peer-mapped mailboxes over xGMI", "torch": "torch.distributed all_reduce (RCCL)",
                                 "none": "none"}[exchange],
-                   "pass_structure": structure, "per_rank": per_rank},
+                   "pass_structure": structure, "kernel_variant": variant, "build": model.h.build_info(), "per_rank": per_rank},
         "timing": {"windows": len(wins), "window_it_per_s": [round(args.steps / w, 1) for w in wins],
                    "min_it_per_s": args.steps / max(wins), "max_it_per_s": args.steps / min(wins),
                    "untimed_warmup_iterations": n_warm,

@@ -33,6 +33,7 @@ EXPORTS = [
     "hpv_eval_channels", "hpv_bench_residual",
     "hpv_set_collocation_shard", "hpv_rccl_unique_id", "hpv_rccl_connect", "hpv_rccl_selftest", "hpv_rccl_disconnect", "hpv_exchange_in_use",
     "hpv_rccl_available", "hpv_graphs_in_use", "hpv_updates_applied", "hpv_set_shared_element_kernels", "hpv_shared_element_kernels",
+    "hpv_kernel_variant", "hpv_build_info", "hpv_rccl_abandon",
 ]
 
 
@@ -53,23 +54,45 @@ class HpvError(RuntimeError):
 EXCHANGE_TIMEOUT = -7      # an in-kernel exchange between the workgroups of one element timed out (hpv_step and friends)
 
 
+TEST_HOOKS_LIB_PATH = os.path.join(_HERE, "libhpvpinn_testhooks.so")   # the -DHPV_TEST_HOOKS build (fault-injection knobs; tests only)
+
 _lib = None
+_libs = {}                # path -> loaded library (the product library and, in the test suite, the test-hooks build beside it)
+_current = [None]         # path new Handles bind to (None: LIB_PATH); see `library`
 _dp = C.POINTER(C.c_double)
+
+
+class library:
+    """Context manager: Handles created inside bind to another build of the library (e.g. TEST_HOOKS_LIB_PATH).  Both builds
+    are linked -Bsymbolic, so two of them may live in one process; a Handle keeps the library it was created with."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        self.prev = _current[0]
+        _current[0] = self.path
+        return load()
+
+    def __exit__(self, *exc):
+        _current[0] = self.prev
+        return False
 
 
 def load():
     """Load libhpvpinn.so (after torch, so that both share one HIP runtime)."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise HpvError(f"{LIB_PATH} is missing: build it with hp_vpinns_amd/csrc/build.sh "
+    path = _current[0] or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise HpvError(f"{path} is missing: build it with hp_vpinns_amd/csrc/build.sh "
                        "(or __graft_entry__.build()); there is no CPU fallback")
     try:  # torch first: its bundled libamdhip64 (same soname) then serves both
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is optional for the single-GPU path
         pass
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL if path == LIB_PATH else C.RTLD_LOCAL)
     h = C.c_void_p
     lib.hpv_create.argtypes = [C.POINTER(h), C.POINTER(HpvConfig)]
     lib.hpv_destroy.argtypes = [h]
@@ -129,8 +152,20 @@ def load():
     lib.hpv_rccl_selftest.argtypes = [h, _dp, C.c_size_t]
     lib.hpv_rccl_disconnect.argtypes = [h]
     lib.hpv_exchange_in_use.argtypes = [h]
-    _lib = lib
+    lib.hpv_rccl_abandon.argtypes = [h]
+    lib.hpv_kernel_variant.argtypes = [h, C.c_char_p, C.c_size_t]
+    lib.hpv_build_info.argtypes = []
+    lib.hpv_build_info.restype = C.c_char_p
+    _libs[path] = lib
+    if path == LIB_PATH:
+        _lib = lib
     return lib
+
+
+def build_info(lib=None):
+    """{'k_iter_fused': 'ok' | 'no-quarter-tile' | 'absent', 'k_iter_tall': ..., 'test_hooks': '0' | '1'} of a loaded build."""
+    raw = (lib or load()).hpv_build_info().decode()
+    return dict(kv.split("=", 1) for kv in raw.split(";"))
 
 
 def _p(a):
@@ -147,6 +182,9 @@ def _points(X, dim, what):
     if X.ndim != 2 or X.shape[1] != dim:
         raise ValueError(f"{what} must have shape (n, {dim}), got {X.shape}")
     return X
+
+
+_LEAKED = []       # handles abandoned with a call still inside the library (Handle.leak)
 
 
 class Handle:
@@ -374,6 +412,24 @@ class Handle:
         out = np.empty(int(n))
         self._chk(self.lib.hpv_rccl_selftest(self._h, _p(out), out.size))
         return out
+
+    def kernel_variant(self):
+        """Name(s) of the kernel instantiation(s) the most recent reverse-mode pass launched (hpv_kernel_variant)."""
+        buf = C.create_string_buffer(320)
+        self._chk(self.lib.hpv_kernel_variant(self._h, buf, 320))
+        return buf.value.decode()
+
+    def build_info(self):
+        return build_info(self.lib)
+
+    def rccl_abandon(self):
+        """Thread-safe: stop waiting for a blocking rccl_connect / rccl_selftest that runs on a helper thread."""
+        self.lib.hpv_rccl_abandon(self._h)
+
+    def leak(self):
+        """Never destroy this handle (a helper thread may still be inside the library with it)."""
+        _LEAKED.append(self._h)
+        self._h = None
 
     def pass_structure(self):
         """'separate' | 'fused-reverse' | 'whole-iteration' | 'whole-iteration-split' | 'whole-iteration-tile' | 'whole-iteration-tall' (or None)."""

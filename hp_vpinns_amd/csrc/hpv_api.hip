@@ -1,9 +1,11 @@
 // C-ABI of libhpvpinn.so (include/hpvpinn.h): host orchestration of one hp-VPINN training
 // handle = one GPU's shard of elements + a replica of the network parameters.
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>   // types and prototypes only: the library is dlopen'ed on first multi-GPU use (no link-time dependency)
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -103,6 +105,7 @@ struct hpv_ctx {
     P2PArgs pp{};
     bool p2p_on = false;
     int pass_structure = -1;   // see hpv_pass_structure
+    char variant[320] = "";    // see hpv_kernel_variant
     double* d_inbox = nullptr;
     unsigned long long* d_flag = nullptr;
     unsigned long long* d_p2p_counter = nullptr;
@@ -112,6 +115,10 @@ struct hpv_ctx {
     ncclComm_t rccl_comm = nullptr;
     bool rccl_on = false;
     int rccl_world = 1, rccl_rank = 0;
+    // hpv_rccl_abandon (the ONE entry point that may be called from another thread while a call is inside the library): the
+    // caller has given up waiting for a blocking hpv_rccl_connect / hpv_rccl_selftest that runs on a helper thread.  The
+    // abandoned call then never touches the handle again: a communicator that comes up late is destroyed, rccl_on stays false
+    std::atomic<int> rccl_abandoned{0};
     double* d_upart = nullptr; // partial residual sums of the row-split projection (few tall elements)
     int proj_split = 1;        // workgroups per element there; loss_e / deps_e hold n_elem * proj_split entries
     long n_red_alloc = 0;      // entries loss_e / deps_e were allocated with (>= every launch structure's count)
@@ -173,6 +180,22 @@ RcclApi& rccl_api() {
         api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy && api.GetErrorString;
     });
     return api;
+}
+
+// ncclAllReduce as the library issues it.  -DHPV_TEST_HOOKS builds (libhpvpinn_testhooks.so) can make it fail on demand --
+// HPV_TEST_RCCL_FAIL="capture": every call on a capturing stream fails (a collective that refuses stream capture);
+// HPV_TEST_RCCL_FAIL="eager:k": the k-th call outside a capture fails (k >= 1) -- the product library has no such switch.
+ncclResult_t rccl_allreduce(hpv_ctx* h, void* buf, size_t n, hipStream_t s) {
+#ifdef HPV_TEST_HOOKS
+    if (const char* e = getenv("HPV_TEST_RCCL_FAIL")) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &st);
+        static long eager_calls = 0;
+        if (!strncmp(e, "capture", 7)) { if (st == hipStreamCaptureStatusActive) return ncclInvalidUsage; }
+        else if (!strncmp(e, "eager:", 6) && st != hipStreamCaptureStatusActive) { if (++eager_calls == atol(e + 6)) return ncclSystemError; }
+    }
+#endif
+    return rccl_api().AllReduce(buf, buf, n, ncclDouble, ncclSum, h->rccl_comm, s);
 }
 
 int fail(hpv_ctx* h, int code, const char* fmt, ...) {
@@ -329,6 +352,12 @@ int assemble_batches(hpv_ctx* h) {
             HIPCHK(h, hipMemsetAsync(h->d_data_part, 0, nparts * sizeof(double), h->stream));
         } else if (h->cfg.backend == HPV_BACKEND_MFMA) {
             return fail(h, -4, "MFMA backend requested but not available for this shape: %s", why.c_str());
+        } else {
+            // no silent cliff: the generic kernels are one to two orders of magnitude slower than the MFMA path
+            static std::atomic<int> warned{0};
+            if (!warned.exchange(1))
+                fprintf(stderr, "libhpvpinn: WARNING -- this network / channel set is not covered by the MFMA kernels (%s); running the "
+                                "generic kernels, which are far slower (hpv_backend_in_use reports HPV_BACKEND_GENERIC)\n", why.c_str());
         }
     }
     if (!h->merged) {
@@ -404,6 +433,7 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
     }
     long n_loss = (long)h->n_elem * h->proj_split;      // loss_e / deps_e entries this pass writes
     bool fin_done = false;                              // the whole-iteration tile kernel ran the finalize step itself
+    bool xch_used = false;                              // a shared-element kernel (SPLIT mode, k_iter_tall) ran in this pass
     // --- variational term on this shard's quadrature batch ---
     if (h->var.N > 0) {
         MfmaDataTerm dt{h->data_off, h->merged ? h->n_data : 0, h->d_udata, h->var.GBAR, h->d_data_part,
@@ -435,7 +465,11 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
                     n_loss = h->n_elem * ts;
                 }
             }
-            if (ifused) tstop(h, 2);   // (otherwise nothing was launched; the start event is re-recorded below)
+            if (ifused) {
+                tstop(h, 2);   // (otherwise nothing was launched; the start event is re-recorded below)
+                snprintf(h->variant, sizeof h->variant, "%s", hpv_mfma_variant(h->mfma, 0));
+                xch_used = hpv_mfma_sync_failed_possible(h->mfma);      // this launch used the tagged exchange: k_finalize advances its counter
+            }
         }
         if (!ifused) {
             tstart(h, 0);
@@ -453,20 +487,30 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
                 if (bfused) tstop(h, 2);
             }
             if (backward) h->pass_structure = bfused ? 1 : 0;
+            if (bfused && backward)
+                snprintf(h->variant, sizeof h->variant, "%s + %s", hpv_mfma_variant(h->mfma, 1), hpv_mfma_variant(h->mfma, 3));
             if (!bfused) {
                 tstart(h, 1);
                 // specialised tensor-product kernel for the hot element shapes unless the generic backend is forced
                 // (needs GBAR's unused channels pre-zeroed: true for every batch, see alloc_batch)
-                if (h->cfg.backend == HPV_BACKEND_GENERIC ||
-                    (!launch_project_tp(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
-                                        eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->stream) &&
-                     !launch_project_wg(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
-                                        eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT,
-                                        h->d_edge_dphi, h->d_edge_coef, h->edge.GBAR, h->stream, h->d_upart)))
+                const char* pname = "k_project";
+                if (h->cfg.backend != HPV_BACKEND_GENERIC &&
+                    launch_project_tp(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
+                                      eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->stream))
+                    pname = "k_project_tp";
+                else if (h->cfg.backend != HPV_BACKEND_GENERIC &&
+                         launch_project_wg(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
+                                           eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT,
+                                           h->d_edge_dphi, h->d_edge_coef, h->edge.GBAR, h->stream, h->d_upart))
+                    pname = h->proj_split > 1 ? "k_project_rows" : "k_project_wg";
+                else
                     launch_project(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
                                    h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi,
                                    h->d_edge_coef, h->edge.GBAR, h->stream);
                 tstop(h, 1);
+                if (backward)
+                    snprintf(h->variant, sizeof h->variant, "%s + %s<%dx%d/%dx%d> + %s", use_mfma ? hpv_mfma_variant(h->mfma, 1) : "k_mlp_fwd_generic",
+                             pname, h->pd.qx, h->pd.qy, h->pd.ntx, h->pd.nty, use_mfma ? hpv_mfma_variant(h->mfma, 2) : "k_mlp_bwd_generic");
                 if (backward) {
                     tstart(h, 2);
                     if (use_mfma) hpv_mfma_backward(h->mfma, h->d_theta, h->var.X, h->var.GBAR, h->var.GPART, &h->var.rows, h->stream);
@@ -501,7 +545,8 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
                     backward && h->n_data > 0 && !h->merged ? h->data.GPART : nullptr, h->data.rows,
                     backward && h->pd.edge && h->edge.N > 0 ? h->edge.GPART : nullptr, h->edge.rows, h->d_loss_e,
                     n_loss, h->d_deps_e, h->d_data_part, ndp, h->cfg.lossb_weight, h->n_data, h->P, h->has_eps, h->d_RB,
-                    backward ? 1 : 0, (backward && fuse_adam) ? &ad : nullptr, h->stream, h->d_xerr);
+                    backward ? 1 : 0, (backward && fuse_adam) ? &ad : nullptr, h->stream, h->d_xerr,
+                    xch_used ? hpv_mfma_xiter(h->mfma) : nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, -2, "kernel launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -564,7 +609,7 @@ int enqueue_pass_x(hpv_ctx* h, bool backward, bool fuse_adam) {
         // update on every rank
         int rc = enqueue_pass(h, backward, false);
         if (rc) return rc;
-        ncclResult_t r = rccl_api().AllReduce(h->d_RB, h->d_RB, (size_t)h->Ptot + 4, ncclDouble, ncclSum, h->rccl_comm, h->stream);
+        ncclResult_t r = rccl_allreduce(h, h->d_RB, (size_t)h->Ptot + 4, h->stream);
         if (r != ncclSuccess) return fail(h, -6, "ncclAllReduce failed: %s", rccl_api().GetErrorString(r));
         if (backward && fuse_adam) launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream);
         hipError_t e = hipGetLastError();
@@ -1071,16 +1116,20 @@ static int enqueue_iterations(hpv_ctx* h, int n_iters) {
         const int rem = n_iters - it;
         if (rem > 0) {
             if (!h->g_rem[rem] && (rc = build_step_graph(h, rem, &h->g_rem[rem]))) {
-                if (!h->rccl_on) return rc;
+                if (!h->rccl_on) { h->nupd_host += it; return rc; }
                 h->use_graph = false;
                 h->err.clear();
+                h->nupd_host += it;           // (the iterations already launched through g_stepK: advisor, round 3)
                 return enqueue_iterations(h, rem);
             }
             HIPCHK(h, hipGraphLaunch(h->g_rem[rem], h->stream));
         }
     } else {
-        for (int it = 0; it < n_iters; ++it)
+        for (int it = 0; it < n_iters; ++it) {
             if ((rc = enqueue_pass_x(h, true, true))) return rc;
+            h->nupd_host += 1;            // (counted per enqueued iteration: an error exit leaves the count right)
+        }
+        return 0;
     }
     h->nupd_host += n_iters;
     return 0;
@@ -1442,6 +1491,7 @@ int hpv_rccl_unique_id(hpv_handle h, void* id128) {
 
 int hpv_rccl_connect(hpv_handle h, int world, int rank, const void* id128) {
     if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return -1;
+    if (h->rccl_abandoned.load()) return fail(h, -6, "this handle abandoned an RCCL call earlier (hpv_rccl_abandon)");
     if (!rccl_api().ok) return fail(h, -6, "librccl.so could not be loaded: %s", rccl_api().why.c_str());
     if (!h->have_params) return fail(h, -3, "hpv_set_params has not been called");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1450,10 +1500,32 @@ int hpv_rccl_connect(hpv_handle h, int world, int rank, const void* id128) {
     rccl_release(h);
     ncclUniqueId id;
     memcpy(&id, id128, 128);
-    ncclResult_t r = rccl_api().CommInitRank(&h->rccl_comm, world, id, rank);
-    if (r != ncclSuccess) { h->rccl_comm = nullptr; return fail(h, -6, "ncclCommInitRank failed: %s", rccl_api().GetErrorString(r)); }
+    // The blocking part.  The caller may run this on a helper thread and stop waiting (hpv_rccl_abandon): from here on nothing of
+    // the handle is touched unless the token is still clear -- a communicator that comes up late is destroyed again and the
+    // handle stays unconnected (advisor, round 3: a late success used to set rccl_on in the middle of the fallback's training).
+    ncclComm_t comm = nullptr;
+#ifdef HPV_TEST_HOOKS
+    if (const char* e = getenv("HPV_TEST_RCCL_CONNECT_DELAY_MS")) usleep((useconds_t)(atof(e) * 1000.0));
+#endif
+    ncclResult_t r = rccl_api().CommInitRank(&comm, world, id, rank);
+    if (h->rccl_abandoned.load()) {
+        if (r == ncclSuccess && comm) (void)rccl_api().CommDestroy(comm);
+        return -6;
+    }
+    if (r != ncclSuccess) return fail(h, -6, "ncclCommInitRank failed: %s", rccl_api().GetErrorString(r));
+    h->rccl_comm = comm;
     h->rccl_world = world; h->rccl_rank = rank;
     h->rccl_on = true;
+    return 0;
+}
+
+// The caller gave up waiting for a hpv_rccl_connect / hpv_rccl_selftest that blocks on another thread.  Thread-safe (the only
+// entry point that is); the abandoned call returns -6 without touching the handle again.  A connect that was abandoned leaves
+// the handle usable (unconnected); after an abandoned self-test the stream may be blocked behind a collective that never
+// completes -- the caller must not use this handle any more (the Python classes build a fresh one).
+int hpv_rccl_abandon(hpv_handle h) {
+    if (!h) return -1;
+    h->rccl_abandoned.store(1);
     return 0;
 }
 
@@ -1473,10 +1545,13 @@ int hpv_rccl_selftest(hpv_handle h, double* out, size_t n) {
     for (size_t i = 0; i < n; ++i) v[i] = (double)(h->rccl_rank + 1) + 1e-3 * (double)i;
     int rc = upload(h, h->d_RB, v.data(), n);
     if (rc) return rc;
-    ncclResult_t r = rccl_api().AllReduce(h->d_RB, h->d_RB, n, ncclDouble, ncclSum, h->rccl_comm, h->stream);
+    ncclResult_t r = rccl_allreduce(h, h->d_RB, n, h->stream);
+    if (h->rccl_abandoned.load()) return -6;      // the caller stopped waiting: the handle is no longer ours to touch
     if (r != ncclSuccess) return fail(h, -6, "ncclAllReduce failed: %s", rccl_api().GetErrorString(r));
-    HIPCHK(h, hipMemcpyAsync(out, h->d_RB, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipError_t e1 = hipMemcpyAsync(out, h->d_RB, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    hipError_t e2 = e1 == hipSuccess ? hipStreamSynchronize(h->stream) : e1;
+    if (h->rccl_abandoned.load()) return -6;
+    if (e2 != hipSuccess) return fail(h, -2, "rccl self-test copy failed: %s", hipGetErrorString(e2));
     return 0;
 }
 
@@ -1526,6 +1601,24 @@ int hpv_debug_read_out(hpv_handle h, double* out, size_t n) {
 }
 #endif
 int hpv_pass_structure(hpv_handle h) { return h ? h->pass_structure : -1; }
+int hpv_kernel_variant(hpv_handle h, char* buf, size_t n) {
+    if (!h || !buf || n == 0) return -1;
+    snprintf(buf, n, "%s", h->variant);
+    return 0;
+}
+const char* hpv_build_info(void) {
+    static std::string info;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        info = std::string("k_iter_fused=") + hpv_fused_build_state() + ";k_iter_tall=" + hpv_tall_build_state() + ";test_hooks=";
+#ifdef HPV_TEST_HOOKS
+        info += "1";
+#else
+        info += "0";
+#endif
+    });
+    return info.c_str();
+}
 int hpv_updates_applied(hpv_handle h, long long* n) {
     if (!h || !n) return -1;
     unsigned long long v = 0;

@@ -10,7 +10,9 @@
 // (v_accvgpr_write/read through inline asm): left to the register allocator, the same values end up behind PHI copies
 // that move hundreds of registers per tile.  The compiler does not know these registers hold live values -- it only sees
 // that a255 is clobbered, which makes the kernel descriptor reserve all 256 AGPRs -- so csrc/build.sh runs
-// scripts/check_agpr.py on the generated assembly: the build FAILS if compiler-generated code touches a[FZ_ABASE..255].
+// scripts/check_agpr.py on the generated assembly: if compiler-generated code touches a[FZ_ABASE..255] the library is built WITHOUT
+// that kernel / instantiation (-DHPV_AGPR_GUARD_TRIPPED[_QT], reported by hpv_build_info); the build FAILS when the check itself
+// cannot run (symbol renamed, no assembly).
 template <int IDX>
 __device__ __forceinline__ void acc_put(double v) {
     const int lo = __double2loint(v), hi = __double2hiint(v);
@@ -79,8 +81,10 @@ __device__ __forceinline__ void fz_layer_m(const double* WTl, const double* WRl,
 // granules {32 bits of the value | 32-bit launch tag}, each written by ONE write-through store (cdna_hip_programming.md
 // Guideline 16, form R2: a naturally aligned 8-byte granule needs no ordering): a consumer polls the granules themselves until
 // all carry this launch's tag, so the data's arrival is its own notification -- one one-way trip plus a poll sweep.
-// The tag is *xiter + 1, read at kernel start (xiter is advanced by workgroup 0 at the very end of the launch, i.e. after every
-// workgroup of this launch has long read it; launches of a stream do not overlap).  All partners are co-resident (the grid is
+// The tag is *xiter + 1, read at kernel start.  xiter is advanced by the kernel that FOLLOWS the launch on the stream (k_finalize,
+// thread 0 of its last block: `xiter_bump`), i.e. strictly after EVERY workgroup of this launch has ended -- also one that was
+// dispatched late on a shared GPU, the case the time-out exists for.  (Round 3 let workgroup 0 advance it at its own end; a
+// workgroup of another element dispatched after that could then publish with the next launch's tag: advisor, round 3.)  All partners are co-resident (the grid is
 // at most one workgroup per CU); the wait is nevertheless bounded by wall clock.  A failed exchange must leave the replica
 // intact (round-2 verdict / advisor): the workgroup that gives up sets the handle's sticky flag *xerr and EVERY thread of it
 // leaves the kernel before it has written R, loss_e or its gradient row; k_finalize / k_adam / k_p2p_exchange read the flag

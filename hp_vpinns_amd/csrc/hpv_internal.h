@@ -101,7 +101,7 @@ void launch_data_loss(const double* U, const double* Ud, double* GBAR, double sc
 void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, int rows_b, const double* GPART_e,
                      int rows_e, const double* loss_e, long n_elem, const double* deps_e, const double* data_part,
                      int n_data_part, double lossb_weight, int n_data, int P, int has_eps, double* RB, int write_grad,
-                     const AdamArgs* fused_adam, hipStream_t s, const int* xerr = nullptr);
+                     const AdamArgs* fused_adam, hipStream_t s, const int* xerr = nullptr, unsigned int* xiter_bump = nullptr);
 void launch_adam(const AdamArgs& ad, const double* RB, int P, int Ptot, hipStream_t s);
 void launch_p2p_exchange(const P2PArgs& pp, double* RB, const AdamArgs* adam_or_null, int P, int Ptot, hipStream_t s);
 int adam_state_doubles(int P);

@@ -59,5 +59,12 @@ struct ProjDesc;
 int hpv_mfma_tall_split(HpvMfma* m, const ProjDesc& pd, long n_elem);
 bool hpv_mfma_iter_tall(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
                         const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem);
+// Names of the kernel instantiations (hpv_kernel_variant): which = 0 the whole-iteration kernel most recently launched, 1 the
+// separate forward kernel, 2 the separate reverse kernel, 3 the reverse kernel with the projection fused in
+const char* hpv_mfma_variant(HpvMfma* m, int which);
+unsigned int* hpv_mfma_xiter(HpvMfma* m);         // launch counter of the tagged exchange (advanced by k_finalize behind a shared-element launch)
+// "ok" | "no-quarter-tile" (AGPR guard tripped in the QT instantiation) | "absent" (guard tripped: kernel compiled out)
+const char* hpv_fused_build_state();
+const char* hpv_tall_build_state();
 bool hpv_mfma_sync_failed_possible(HpvMfma* m);   // the last whole-iteration launch ran in SPLIT mode
 int hpv_mfma_max_rows(HpvMfma* m, long n_elem);

@@ -42,7 +42,8 @@ struct MfmaArgs {
     ProjArgs pa;
     // split whole-iteration kernels: the handle's sticky failure flag, test knob, exchange buffers
     int* xerr;            // sticky failure flag of the handle (hpv_ctx::d_xerr): set when an exchange times out; see hpv_fused_dev.h
-    int xdebug_skip;      // test knob (HPV_DEBUG_SPLIT_SKIP=k >= 1): partner 1 of element 0 stays away from the exchange from the k-th launch on
+    int xdebug_skip;      // -DHPV_TEST_HOOKS builds only (libhpvpinn_testhooks.so; always 0 in the product): HPV_DEBUG_SPLIT_SKIP=k >= 1 --
+                          // partner 1 of element 0 stays away from the exchange from the k-th launch on
     // tagged exchange (hpv_fused_dev.h, xg_*): the payload travels as 8-byte granules {32 bits of data | 32-bit launch tag}, so that
     // its arrival is its own notification -- no counter, no store-acknowledge / fetch-add / poll chain
     unsigned long long* xg;      // granule buffer
@@ -56,6 +57,14 @@ struct MfmaArgs {
     double fin_lossb_weight;
     int fin_n_data, fin_n_data_part, fin_has_eps, fin_ncopies;
 };
+
+// Fault injection for the exchange-timeout tests: compiled into libhpvpinn_testhooks.so only (csrc/build.sh); in the product
+// library the condition is the constant false and the kernels carry no such branch.
+#ifdef HPV_TEST_HOOKS
+#define HPV_XDEBUG_SKIP(g, xtag, e, part) ((g).xdebug_skip && (xtag) >= (unsigned)(g).xdebug_skip && (e) == 0 && (part) == 1)
+#else
+#define HPV_XDEBUG_SKIP(g, xtag, e, part) false
+#endif
 
 struct HpvMfma {
     NetDesc nd;
@@ -85,6 +94,8 @@ struct HpvMfma {
     long xsync_elems = 0;
     bool split_used = false;               // a split launch happened: hpv_step then reads the timeout flag back
     bool last_split = false;               // the most recent whole-iteration launch was a split one (hpv_pass_structure)
+    char variant[160] = "";                // whole-iteration kernel instantiation most recently launched through this object (hpv_kernel_variant)
+    char vfwd[96] = "", vbwd[96] = "", vbwd_fused[128] = "";   // the separate forward / reverse kernels of this object
 };
 
 // FAST (sin only): the caller has checked |z| <= HPV_SINCOS_MAX for the whole wave (act_wave_needs_safe below)

@@ -17,6 +17,7 @@
 //   workgroup.
 //
 // Lane layout, MFMA formulation and the 16 + 4 split of a 20-wide layer are those of kernels_mfma.hip.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -230,7 +231,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
 
     // SPLIT: this workgroup takes no part in the exchange (an earlier launch of the handle failed -- sticky flag -- or the test
     // knob keeps partner 1 of element 0 away): it publishes nothing and leaves at the hand-off point
-    const bool xstay = SPLIT && (xsticky || (g.xdebug_skip && xtag >= (unsigned)g.xdebug_skip && e == 0 && part == 1));
+    const bool xstay = SPLIT && (xsticky || HPV_XDEBUG_SKIP(g, xtag, e, part));
     // =============================================================================================
     // phase F: forward
     // =============================================================================================
@@ -435,8 +436,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             // nothing of this iteration has been written: the kernels that follow skip the update (kernels_generic.hip), the host
             // reports -7, clears the flag and goes on (hpv_api.hip, sync_check)
             if (timed_out && tid == 0) __hip_atomic_store(g.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (blockIdx.x == 0 && tid == 0) *g.xiter = xtag;
-            return;
+            return;      // (the launch counter is advanced by the kernel that FOLLOWS this launch: k_finalize, hpv_fused_dev.h)
         }
     }
     __syncthreads();
@@ -834,7 +834,6 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         for (int w = 0; w < FZ_WAVES; ++w) acc += W0[(long)w * g.P + idx];
         row[idx] = acc;
     }
-    if constexpr (SPLIT) { if (blockIdx.x == 0 && tid == 0) *g.xiter = xtag; }      // the next launch's tag is xtag + 1
 #ifdef HPV_FZ_TIMING
     if (lane == 0 && pa.GBAR) {   // phase durations in shader cycles: [block][wave][8], into the (otherwise unused) adjoint buffer
         FZ_STAMP(7);
@@ -1342,6 +1341,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
         a.proj_split = 1;
         a.pa = pa;
         m->last_split = false;
+        snprintf(m->variant, sizeof m->variant, "k_iter_small<L=%d>", m->L);
         if (m->L == 2) launch_iter_small<2>(a, (int)n_elem, s); else launch_iter_small<3>(a, (int)n_elem, s);
         if (rows) *rows = (int)n_elem;
         return true;
@@ -1378,20 +1378,32 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     m->last_split = split > 1;
     if (split > 1) {
         m->split_used = true;
+        snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=true,QT=false> split=%d", m->L, split);
         if (m->L == 2) launch_iter_fused<2, true>(a, (int)blocks, s); else launch_iter_fused<3, true>(a, (int)blocks, s);
 #ifdef HPV_AGPR_GUARD_TRIPPED_QT                    // csrc/build.sh: the compiler's registers reached the stash of the QT instantiation
     } else if (true) {
 #else
     } else if (getenv("HPV_NO_QUARTER_TILE")) {      // (A/B switch: seven whole tiles for the first wave, read per launch / capture)
 #endif
+        snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=false,QT=false>", m->L);
         if (m->L == 2) launch_iter_fused<2, false>(a, (int)blocks, s); else launch_iter_fused<3, false>(a, (int)blocks, s);
     } else {
+        snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=false,QT=true>", m->L);
         if (m->L == 2) launch_iter_fused<2, false, true>(a, (int)blocks, s); else launch_iter_fused<3, false, true>(a, (int)blocks, s);
     }
     if (rows) *rows = (int)blocks;
     return true;
 }
 
+const char* hpv_fused_build_state() {
+#if defined(HPV_AGPR_GUARD_TRIPPED)
+    return "absent";
+#elif defined(HPV_AGPR_GUARD_TRIPPED_QT)
+    return "no-quarter-tile";
+#else
+    return "ok";
+#endif
+}
 bool hpv_mfma_sync_failed_possible(HpvMfma* m) { return m && m->last_split; }
 void hpv_mfma_set_err_flag(HpvMfma* m, int* dev_flag) { if (m) m->xerr = dev_flag; }
 bool hpv_mfma_split_used(HpvMfma* m) { return m && m->split_used; }

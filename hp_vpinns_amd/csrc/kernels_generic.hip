@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
                                                          const double* __restrict__ data_part, int n_data_part,
                                                          double lossb_weight, int n_data, int P, int has_eps,
                                                          double* __restrict__ RB, int write_grad, AdamArgs ad,
-                                                         const int* __restrict__ xerr) {
+                                                         const int* __restrict__ xerr, unsigned int* __restrict__ xiter_bump) {
     constexpr int FIN_PARTS = FIN_THREADS / FIN_COLS;
     __shared__ double red[FIN_PARTS * FIN_COLS];
     const int Ptot = P + (has_eps ? 1 : 0);
@@ -602,13 +602,16 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
         RB[Ptot + 1] = lossb_weight * msq;
         RB[Ptot + 2] = msq;
         RB[Ptot + 3] = failed ? 1.0 : 0.0;   // pad slot: the all-reduce carries a failure on any rank to every rank (k_adam)
+        // launch counter of the shared-element kernels' tagged exchange (hpv_fused_dev.h): advanced HERE, behind the launch that used
+        // the tag -- every workgroup of that launch has ended, so none of them can read the advanced value
+        if (xiter_bump) *xiter_bump += 1u;
     }
 }
 
 void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, int rows_b, const double* GPART_e,
                      int rows_e, const double* loss_e, long n_elem, const double* deps_e, const double* data_part,
                      int n_data_part, double lossb_weight, int n_data, int P, int has_eps, double* RB, int write_grad,
-                     const AdamArgs* fused_adam, hipStream_t s, const int* xerr) {
+                     const AdamArgs* fused_adam, hipStream_t s, const int* xerr, unsigned int* xiter_bump) {
     int gblocks = (P + FIN_COLS - 1) / FIN_COLS;
     AdamArgs ad{};
     if (fused_adam && write_grad) ad = *fused_adam;
@@ -617,11 +620,11 @@ void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, i
     if (fin_force == 256 || (fin_force != 1024 && rows <= 1024 && n_elem <= 4096))
         hipLaunchKernelGGL(k_finalize<256>, dim3(gblocks + 1), dim3(256), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e,
                            rows_e, loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB,
-                           write_grad, ad, xerr);
+                           write_grad, ad, xerr, xiter_bump);
     else
         hipLaunchKernelGGL(k_finalize<1024>, dim3(gblocks + 1), dim3(1024), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e,
                            rows_e, loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB,
-                           write_grad, ad, xerr);
+                           write_grad, ad, xerr, xiter_bump);
 }
 int adam_state_doubles(int P) { return 2 * ((P + FIN_COLS - 1) / FIN_COLS + 1); }
 

@@ -21,6 +21,7 @@
 //   4x16 and 16x4 strips and the 4x4 corner on 4x4x4_4b.
 //
 // First layer (d -> 20) and linear head (20 -> 1) are VALU work (K = 1..2 and M = 1 are no MFMA shapes).
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -688,6 +689,10 @@ static bool pick(HpvMfma* m) {
     m->bwd = run_bwd<D, NT1, NT2, ACT, L>;
     if constexpr (D == 2 && NT1 == 2 && NT2 == 0 && ACT == HPV_ACT_TANH)   // BASELINE config 4 (Poisson-2D var_form 1)
         m->bwd_fused = run_bwd_fused<D, NT1, NT2, ACT, L, 20, 20, 10, 10>;
+    const char* an = ACT == HPV_ACT_SIN ? "sin" : "tanh";
+    snprintf(m->vfwd, sizeof m->vfwd, "k_fwd_mfma<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=20>", D, NT1, NT2, an, L);
+    snprintf(m->vbwd, sizeof m->vbwd, "k_bwd_mfma<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=20>", D, NT1, NT2, an, L);
+    if (m->bwd_fused) snprintf(m->vbwd_fused, sizeof m->vbwd_fused, "k_bwd_mfma<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=20,proj=20x20/10x10,waves=%d>", D, NT1, NT2, an, L, L <= 3 ? 8 : 4);
     size_t lds = bwd_lds_bytes(m->nd.P, L, 1 + NT1 + NT2);
     int of = 1, ob = 1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, k_fwd_mfma<D, NT1, NT2, ACT, L>, MF_BLOCK, fwd_lds_bytes(L));
@@ -754,8 +759,10 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
             if (m->xg) { (void)hipFree(m->xg); m->xg = nullptr; }
             m->xiter = nullptr;
         }
+#ifdef HPV_TEST_HOOKS   // libhpvpinn_testhooks.so only: the product library does not read the variable
         const char* dbg = getenv("HPV_DEBUG_SPLIT_SKIP");
         m->xdebug_skip = dbg ? std::max(0, atoi(dbg)) : 0;
+#endif
     }
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -791,6 +798,11 @@ void hpv_mfma_destroy(HpvMfma* m) {
 }
 
 int hpv_mfma_grad_rows(HpvMfma* m) { return m->bwd_blocks; }
+const char* hpv_mfma_variant(HpvMfma* m, int which) {
+    if (!m) return "";
+    return which == 0 ? m->variant : (which == 1 ? m->vfwd : (which == 2 ? m->vbwd : m->vbwd_fused));
+}
+unsigned int* hpv_mfma_xiter(HpvMfma* m) { return m ? m->xiter : nullptr; }
 double* hpv_mfma_activation_store(HpvMfma* m) { return m ? m->ACTS : nullptr; }
 size_t hpv_mfma_activation_store_doubles(HpvMfma* m) { return m && m->ACTS ? (size_t)m->ntiles * m->L * m->ns * MF_KS * 64 : 0; }   // (the timing builds park their stamps there)
 // Workgroups per element of the fused reverse kernel: one when the shard has an element for every CU, more for the

@@ -18,6 +18,7 @@
 //
 // Lane layout, MFMA formulation and the 16 + 4 split of a 20-wide layer are those of kernels_mfma.hip; the reverse-pass algebra
 // for second tangents is that of k_bwd_mfma / k_iter_tile (hand-derived third-order reverse pass).
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -418,7 +419,7 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
                         const int j = j0 + jj < QY ? j0 + jj : QY - 1;        // (rows past the grid: their T is zero)
                         u = fma(lds[M::BY + (t * NTY + kk) * QY + j], lds[M::UP + (t * NRW + jj) * NTX + r], u);
                     }
-                if (!xsticky && !(g.xdebug_skip && xtag >= (unsigned)g.xdebug_skip && e == 0 && part == 1)) xg_publish(g.xg + (wg_slot * NR + tid) * 2, u, xtag);
+                if (!xsticky && !HPV_XDEBUG_SKIP(g, xtag, e, part)) xg_publish(g.xg + (wg_slot * NR + tid) * 2, u, xtag);
             }
         } else {
         if (tid < NR * TA_SLICES) {
@@ -443,14 +444,14 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
 #pragma unroll
             for (int sl = 0; sl < TA_SLICES; ++sl) u += lds[M::UP + sl * NR + tid];
             // publish: two tagged granules per value, fire and forget (the partners poll the granules themselves)
-            if (!xsticky && !(g.xdebug_skip && xtag >= (unsigned)g.xdebug_skip && e == 0 && part == 1)) xg_publish(g.xg + (wg_slot * NR + tid) * 2, u, xtag);
+            if (!xsticky && !HPV_XDEBUG_SKIP(g, xtag, e, part)) xg_publish(g.xg + (wg_slot * NR + tid) * 2, u, xtag);
         }
         }
         TA_STAMP(4);
         {
             // the S x NR partial sums of the element, straight into LDS (the transpose region is idle between the phases)
             constexpr int NITG = (64 * NR * 2 + TA_BLOCK - 1) / TA_BLOCK;
-            const bool stay_away = xsticky || (g.xdebug_skip && xtag >= (unsigned)g.xdebug_skip && e == 0 && part == 1);     // workgroup-uniform
+            const bool stay_away = xsticky || HPV_XDEBUG_SKIP(g, xtag, e, part);     // workgroup-uniform
             bool ok = true;
             if (!stay_away) ok = xg_gather<NITG, TA_BLOCK>(g.xg + (long)e * split * NR * 2, split * NR * 2, xtag, (unsigned*)(lds + M::TR), tid);
             const int timed_out = __syncthreads_or(ok ? 0 : 1);       // (also the barrier that makes the gathered sums visible)
@@ -458,8 +459,7 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
                 // a partner did not show up (or an earlier launch failed: sticky): nothing of this iteration has been written, the
                 // kernels that follow skip the update (kernels_generic.hip), the host reports -7 and resets (hpv_api.hip, sync_check)
                 if (timed_out && tid == 0) __hip_atomic_store(g.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (blockIdx.x == 0 && tid == 0) *g.xiter = xtag;
-                return;
+                return;      // (the launch counter is advanced by the kernel that FOLLOWS this launch: k_finalize, hpv_fused_dev.h)
             }
         }
         TA_STAMP(5);
@@ -870,7 +870,6 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
         for (int w = 0; w < TA_WAVES; ++w) acc += W0[(long)w * g.P + idx];
         row[idx] = acc;
     }
-    if (blockIdx.x == 0 && tid == 0) *g.xiter = xtag;      // the next launch's tag is xtag + 1
 #ifdef HPV_FZ_TIMING
     if (lane == 0 && pa.GBAR) {   // [block][wave][12]: staging, forward, wait, partial projection, barrier, residual+adjoint, reverse, wait, epilogue
         TA_STAMP(9);
@@ -905,6 +904,15 @@ static void launch_iter_tall(const MfmaArgs& a, int blocks, hipStream_t s) {
     launch_iter_tall_q<NT1, NT2, L, QX, QY, NTX, NTY, false>(a, blocks, s);
 }
 
+const char* hpv_tall_build_state() {
+#if defined(HPV_AGPR_GUARD_TRIPPED)
+    return "absent";
+#elif defined(HPV_AGPR_GUARD_TRIPPED_QT)
+    return "no-quarter-tile";
+#else
+    return "ok";
+#endif
+}
 // Workgroups per element of the tall-element kernel (0: not applicable): the largest power of two with n_elem S <= CUs, at most
 // 64, such that a workgroup's share fits TA_WAVES x TA_MAXT tiles (with room for a boundary/data tile where one is adopted).
 int hpv_mfma_tall_split(HpvMfma* m, const ProjDesc& pd, long n_elem) {
@@ -966,6 +974,15 @@ bool hpv_mfma_iter_tall(HpvMfma* m, const double* theta, const double* X, double
     a.pa = pa;
     m->last_split = true;
     m->split_used = true;
+    {
+#ifdef HPV_AGPR_GUARD_TRIPPED_QT
+        const bool qt_run = false;
+#else
+        const bool qt_run = a.tall_qt != 0;
+#endif
+        snprintf(m->variant, sizeof m->variant, "k_iter_tall<NT1=2,NT2=%d,L=%d,80,80,5,5,QT=%s> split=%d", m->nd.nT2, m->L,
+                 qt_run ? "true" : "false", split);
+    }
     const int key = m->nd.nT2 * 10 + m->L;
     switch (key) {
         case 12: launch_iter_tall<2, 1, 2, 80, 80, 5, 5>(a, (int)blocks, s); break;

@@ -631,6 +631,9 @@ bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double
         a.fin_ad = fin->ad; a.fin_RB = fin->RB; a.fin_lossb_weight = fin->lossb_weight;
         a.fin_n_data = fin->n_data; a.fin_n_data_part = fin->n_data_part; a.fin_has_eps = fin->has_eps; a.fin_ncopies = fin->ncopies;
     }
+    m->last_split = false;
+    snprintf(m->variant, sizeof m->variant, "k_iter_tile<D=%d,NT1=%d,NT2=%d,%s,L=%d,%dx%d/%dx%d,waves=%d>%s", nd.d, nd.nT1, nd.nT2,
+             nd.act == HPV_ACT_SIN ? "sin" : "tanh", m->L, pd.qx, pd.qy, pd.ntx, pd.nty, waves, fin_here ? " +finalize" : "");
     bool ok = false;
     if (shape1d) {
         if (key == 111) ok = launch_iter_tile_L<1, 1, 1, HPV_ACT_SIN, 80, 1, 60, 1, 6, 4>(m->L, a, (int)blocks, s);

@@ -126,8 +126,10 @@ class _VPINNBase:
         # and this class maps parameters / gradients between the two layouts.
         plan = None if backend == "generic" else pad_plan(self.layers, self._n_extra)
         self._dev_layers, self._pad_idx = (plan if plan is not None else (self.layers, None))
-        self.h = _lib.Handle(self._pde, var_form, self._act, self._dev_layers, lr=LR, lossb_weight=lossb_weight,
-                             V=V, device=device, backend=bk, scheme=scheme)
+        self._handle_args = ((self._pde, var_form, self._act, self._dev_layers),
+                             dict(lr=LR, lossb_weight=lossb_weight, V=V, device=device, backend=bk, scheme=scheme))
+        self._populate = None      # set by the subclass: hands the problem (rule, tables, elements, F, data) to self.h
+        self.h = _lib.Handle(*self._handle_args[0], **self._handle_args[1])
         if init_params is None:
             init_params = xavier_init(self.layers, seed, extra=[1.0] * self._n_extra)
         self._init_params = np.asarray(init_params, dtype=np.float64).reshape(-1).copy()
@@ -167,9 +169,35 @@ class _VPINNBase:
     def _from_dev(self, v):
         return v if self._pad_idx is None else np.ascontiguousarray(np.asarray(v)[self._pad_idx])
 
+    def _replace_handle(self):
+        """A bounded library call on a helper thread did not return in time (`_connect_rccl`): that thread may still be inside
+        the library with this handle, and after a hung collective the handle's stream may never drain.  The handle is told
+        (hpv_rccl_abandon: the late call then touches nothing), is never destroyed (`leak`), and a FRESH handle takes its
+        place -- two threads never share a handle (advisor, round 3)."""
+        old = self.h
+        old.rccl_abandon()
+        old.leak()
+        self.h = self._new_handle()
+
+    def _new_handle(self):
+        """A fresh library handle holding this model's problem and initial parameters (what the constructor built)."""
+        prev = self.h
+        try:
+            self.h = _lib.Handle(*self._handle_args[0], **self._handle_args[1])
+            self._populate()
+            self.h.set_params(self._to_dev(self._init_params))
+            self.h.backend_in_use()
+            return self.h
+        finally:
+            self.h = prev
+
     def _finish(self):
         self.h.set_params(self._to_dev(self._init_params))
         self.h.backend_in_use()   # assembles the device batches; raises if a requested backend is unavailable
+        if self.backend() == "generic" and self._handle_args[1]["backend"] == _lib.BACKEND_AUTO and self.rank == 0:
+            import warnings
+            warnings.warn(f"hp_vpinns_amd: layers {self.layers} are not covered by the MFMA kernels; this model runs on the "
+                          "generic kernels, which are one to two orders of magnitude slower (see README.md, 'network shapes')")
         if self._dist:
             # Exchange of the packed buffer, in order of preference (every rank takes the same decision):
             #   "rccl"  (default) ncclAllReduce issued by the library on its own stream, inside its iteration graphs;
@@ -200,7 +228,9 @@ class _VPINNBase:
         rank; (3) every rank joins -- bounded by wall clock (HPV_RCCL_TIMEOUT_S, default 120 s): the blocking call runs on a
         helper thread, and a rank whose call has not returned in time votes "failed" and abandons it; (4) two known-answer
         all-reduces give the right sums, same bound.  Any failure or timeout on any rank sends EVERY rank to the
-        torch.distributed fallback; ranks that had joined leave the communicator."""
+        torch.distributed fallback; ranks that had joined leave the communicator.  A rank that abandoned a call never
+        uses that handle again (`_replace_handle`): the helper thread may return late -- a late ncclCommInitRank success
+        would otherwise connect the handle in the middle of the fallback's training."""
         import threading
 
         import torch.distributed as dist
@@ -248,8 +278,11 @@ class _VPINNBase:
         dist.broadcast_object_list(box, src=0)
         if box[0] is None:
             return False
-        done, res = bounded(lambda: self.h.rccl_connect(self.world, self.rank, box[0]))
+        hh = self.h
+        done, res = bounded(lambda: hh.rccl_connect(self.world, self.rank, box[0]))
         ok = done and not isinstance(res, _lib.HpvError)
+        if not done:
+            self._replace_handle()       # the helper thread is still inside ncclCommInitRank with the old handle
         if not agree(ok):
             if ok:
                 self.h.rccl_disconnect()
@@ -258,11 +291,15 @@ class _VPINNBase:
         expect = self.world * (self.world + 1) / 2 + self.world * 1e-3 * np.arange(n)
 
         def selftest():
-            return all(np.abs(self.h.rccl_selftest(n) - expect).max() < 1e-12 for _ in range(2))
+            return all(np.abs(hh.rccl_selftest(n) - expect).max() < 1e-12 for _ in range(2))
         done, res = bounded(selftest)
         good = done and res is True
+        if not done:
+            # the call that never returned still owns the communicator AND the handle's stream (a collective that never
+            # completes blocks everything enqueued behind it): the fallback trains on a fresh handle
+            self._replace_handle()
         if not agree(good):
-            if done:                     # (a call that never returned still owns the communicator: leave it alone)
+            if done:
                 self.h.rccl_disconnect()
             return False
         return True
@@ -519,20 +556,24 @@ class VPINN1D(_VPINNBase):
         if self.grid.size != self.Nelement + 1:
             raise ValueError("grid must have Nelement+1 entries")
         self._create(layers, var_form, LR, lossb_weight, 1.0, init_params, seed, backend, device)
-        xi = self.xquad.reshape(-1)
-        self.h.set_quadrature(xi, self.wquad.reshape(-1))
-        edge = None
-        if var_form == 3:
-            d1b = dTest_fcn(self.N_test, np.array([-1.0, 1.0]))[0]     # (N_test, 2): phi'(-1), phi'(1)  (P1:79)
-            edge = np.ascontiguousarray(d1b)
-        self.h.set_tables(tables_1d(self.N_test, xi), None, edge)
-        eb, ee = shard_range(self.Nelement, self.rank, self.world)
-        self.h.set_elements(self.grid, None, eb, ee)
-        self.h.set_rhs(self.F_ext_total.reshape(-1))
-        if np.any(self._n_active != self.N_test):
-            self.h.set_active_tests(self._n_active)
-        if self.rank == 0:
-            self.h.set_data(self.x, self.u.reshape(-1))
+
+        def populate():
+            xi = self.xquad.reshape(-1)
+            self.h.set_quadrature(xi, self.wquad.reshape(-1))
+            edge = None
+            if var_form == 3:
+                d1b = dTest_fcn(self.N_test, np.array([-1.0, 1.0]))[0]     # (N_test, 2): phi'(-1), phi'(1)  (P1:79)
+                edge = np.ascontiguousarray(d1b)
+            self.h.set_tables(tables_1d(self.N_test, xi), None, edge)
+            eb, ee = shard_range(self.Nelement, self.rank, self.world)
+            self.h.set_elements(self.grid, None, eb, ee)
+            self.h.set_rhs(self.F_ext_total.reshape(-1))
+            if np.any(self._n_active != self.N_test):
+                self.h.set_active_tests(self._n_active)
+            if self.rank == 0:
+                self.h.set_data(self.x, self.u.reshape(-1))
+        self._populate = populate
+        populate()
         self._finish()
 
     def predict(self, x):                                   # P1:197-199
@@ -598,24 +639,28 @@ class VPINN2D(_VPINNBase):
                              f"{(self.Nelementx, self.Nelementy, self.Ntesty, self.Ntestx)} (P2:414)")
         self._create(layers, var_form, LR, lossb_weight, 1.0, init_params, seed, backend, device,
                      scheme=_lib.SCHEME_PINN if scheme == "PINNs" else _lib.SCHEME_VPINN)
-        if scheme == "PINNs":
-            # strong-form branch (P2:128-129): loss = 10 lossb + mean((u_xx+u_yy-f)^2) at X_f_train
-            # multi-GPU: the collocation points shard over the ranks in contiguous blocks (lossp is a mean of independent
-            # point-wise terms), the boundary term stays on rank 0, one all-reduce of the packed buffer per iteration
-            Xf, ff = np.asarray(X_f_train, dtype=np.float64), np.asarray(f_train, dtype=np.float64).reshape(-1)
-            if Xf.shape[0] < self.world:
-                raise ValueError("fewer collocation points than ranks")
-            cb, ce = shard_range(Xf.shape[0], self.rank, self.world)
-            self.h.set_collocation(Xf[cb:ce], ff[cb:ce], n_total=Xf.shape[0])
-        else:
-            xi, wx, yi, wy = _tensor_rule(X_quad, W_quad)
-            self.h.set_quadrature(xi, wx, yi, wy)
-            self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntesty, yi))
-            eb, ee = shard_range(self.Nelementx * self.Nelementy, self.rank, self.world)
-            self.h.set_elements(self.gridx, self.gridy, eb, ee)
-            self.h.set_rhs(self.F_ext_total.reshape(-1))
-        if self.rank == 0:
-            self.h.set_data(self.X_u_train, self.utrain.reshape(-1))
+
+        def populate():
+            if scheme == "PINNs":
+                # strong-form branch (P2:128-129): loss = 10 lossb + mean((u_xx+u_yy-f)^2) at X_f_train
+                # multi-GPU: the collocation points shard over the ranks in contiguous blocks (lossp is a mean of independent
+                # point-wise terms), the boundary term stays on rank 0, one all-reduce of the packed buffer per iteration
+                Xf, ff = np.asarray(X_f_train, dtype=np.float64), np.asarray(f_train, dtype=np.float64).reshape(-1)
+                if Xf.shape[0] < self.world:
+                    raise ValueError("fewer collocation points than ranks")
+                cb, ce = shard_range(Xf.shape[0], self.rank, self.world)
+                self.h.set_collocation(Xf[cb:ce], ff[cb:ce], n_total=Xf.shape[0])
+            else:
+                xi, wx, yi, wy = _tensor_rule(X_quad, W_quad)
+                self.h.set_quadrature(xi, wx, yi, wy)
+                self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntesty, yi))
+                eb, ee = shard_range(self.Nelementx * self.Nelementy, self.rank, self.world)
+                self.h.set_elements(self.gridx, self.gridy, eb, ee)
+                self.h.set_rhs(self.F_ext_total.reshape(-1))
+            if self.rank == 0:
+                self.h.set_data(self.X_u_train, self.utrain.reshape(-1))
+        self._populate = populate
+        populate()
         self._finish()
 
     def predict(self, X=None):                              # P2:255-257 (stored test grid)
@@ -673,14 +718,18 @@ class VPINNAdvDiff(_VPINNBase):
         self.XT_test, self.utest = XT_test, u_test
         self.var_form, self.V = var_form, V
         self._create(layers, var_form, LR, lossb_weight, V, init_params, seed, backend, device)
-        xi, wx, ti, wt = _tensor_rule(XT_quad, W_quad)
-        self.h.set_quadrature(xi, wx, ti, wt)
-        self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntestt, ti))
-        eb, ee = shard_range(self.Nelementx * self.Nelementt, self.rank, self.world)
-        self.h.set_elements(self.grid_x, self.grid_t, eb, ee)
-        self.h.set_rhs(None)                               # zero right-hand side (P3:180)
-        if self.rank == 0:
-            self.h.set_data(self.XT_u_train, self.u.reshape(-1))
+
+        def populate():
+            xi, wx, ti, wt = _tensor_rule(XT_quad, W_quad)
+            self.h.set_quadrature(xi, wx, ti, wt)
+            self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntestt, ti))
+            eb, ee = shard_range(self.Nelementx * self.Nelementt, self.rank, self.world)
+            self.h.set_elements(self.grid_x, self.grid_t, eb, ee)
+            self.h.set_rhs(None)                               # zero right-hand side (P3:180)
+            if self.rank == 0:
+                self.h.set_data(self.XT_u_train, self.u.reshape(-1))
+        self._populate = populate
+        populate()
         self._finish()
 
     @property

@@ -145,6 +145,12 @@ int hpv_rccl_unique_id(hpv_handle h, void* id128);
 int hpv_rccl_connect(hpv_handle h, int world, int rank, const void* id128);
 int hpv_rccl_selftest(hpv_handle h, double* out, size_t n);
 int hpv_rccl_disconnect(hpv_handle h);
+/* The caller stopped waiting for a hpv_rccl_connect / hpv_rccl_selftest that blocks on a helper thread (wall-clock bound of the
+ * communicator set-up).  The ONLY entry point that may be called while another thread is inside the library on the same
+ * handle: the abandoned call returns -6 and never touches the handle again (a communicator that comes up late is destroyed).
+ * After an abandoned connect the handle stays usable, unconnected; after an abandoned self-test its stream may sit behind a
+ * collective that never completes -- do not use that handle again (and do not destroy it while the call is still inside). */
+int hpv_rccl_abandon(hpv_handle h);
 int hpv_exchange_in_use(hpv_handle h);
 /* Opt-in alternative (HPV_EXCHANGE=p2p in the Python classes): in-library exchange over peer-mapped mailboxes instead of
  * a collective-library call every iteration: each rank owns a mailbox that every peer maps through hipIpc; one kernel per
@@ -192,6 +198,15 @@ int hpv_backend_in_use(hpv_handle h);                       /* HPV_BACKEND_GENER
  * 4 whole-iteration tile kernel (small elements of the other channel sets), 5 whole-iteration kernel for few tall elements
  * (80x80 points: many workgroups per element exchange partial residual sums); -1 before the first such pass. */
 int hpv_pass_structure(hpv_handle h);
+/* The kernel INSTANTIATION(s) of that pass by name, e.g. "k_iter_fused<L=3,SPLIT=false,QT=true>" (quarter-tile plan) vs
+ * "k_iter_fused<L=3,SPLIT=false,QT=false>" (7/6/6/6 whole tiles: HPV_NO_QUARTER_TILE=1, or the build's AGPR guard tripped),
+ * "k_iter_tall<..,QT=true> split=32", "k_iter_tile<..>", "k_fwd_mfma<..> + k_project_tp<20x20/10x10> + k_bwd_mfma<..>",
+ * "k_mlp_fwd_generic + k_project<..> + k_mlp_bwd_generic" -- so that a green test run says which code it exercised. */
+int hpv_kernel_variant(hpv_handle h, char* buf, size_t n);
+/* How this library was built: "k_iter_fused=ok|no-quarter-tile|absent;k_iter_tall=ok|no-quarter-tile|absent;test_hooks=0|1"
+ * (csrc/build.sh compiles a whole-iteration kernel out when the compiler's registers reach its hand-managed AGPR range;
+ * test_hooks=1 only in libhpvpinn_testhooks.so, the build that carries the fault-injection knobs of the tests). */
+const char* hpv_build_info(void);
 /* 1 when hpv_step / hpv_step_record replay captured iteration hipGraphs, 0 when they launch eagerly (HPV_NO_GRAPH=1, a foreign
  * stream, or a collective that refused stream capture -- hpv_step then drops to eager launches instead of failing). */
 int hpv_graphs_in_use(hpv_handle h);

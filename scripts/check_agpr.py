@@ -1,17 +1,30 @@
 #!/usr/bin/env python3
 """Build guard for kernels_fused.hip: the kernel parks live values in the AGPRs a[base..255] by hand (inline asm, printed
 as `a[0x..]`); compiler-generated code (printed as `aN` / `a[N:M]`) must stay below `base`.
-usage: check_agpr.py file.s kernel-substring base"""
+usage: check_agpr.py file.s kernel-substring base
+exit codes: 0 = clear, 1 = register overlap (the guard TRIPPED: build.sh then builds without that kernel / instantiation),
+            2 = the check itself could not run (no assembly file, kernel symbol not found after a rename / mangling change,
+                no function end marker): build.sh FAILS on it -- a silently compiled-out kernel would be a large, quiet
+                performance regression"""
 import re
 import sys
 
 src, key, base = sys.argv[1], sys.argv[2], int(sys.argv[3])
-lines = open(src).read().split("\n")
+try:
+    lines = open(src).read().split("\n")
+except OSError as e:
+    print(f"check_agpr: ERROR -- cannot read {src}: {e}", file=sys.stderr)
+    sys.exit(2)
 starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l) and key in l]
-assert starts, f"kernel {key} not found in {src}"
+if not starts:
+    print(f"check_agpr: ERROR -- kernel {key} not found in {src} (renamed? template arguments changed?)", file=sys.stderr)
+    sys.exit(2)
 worst = -1
 for st in starts:
-    end = next(i for i in range(st, len(lines)) if lines[i].startswith(".Lfunc_end"))   # (a kernel may hold several s_endpgm: early returns)
+    end = next((i for i in range(st, len(lines)) if lines[i].startswith(".Lfunc_end")), None)   # (a kernel may hold several s_endpgm: early returns)
+    if end is None:
+        print(f"check_agpr: ERROR -- no function end marker behind {key} in {src}", file=sys.stderr)
+        sys.exit(2)
     for l in lines[st:end]:
         code = l.split(";")[0]
         for m in re.finditer(r"\ba(\d+)\b", code):
@@ -20,4 +33,5 @@ for st in starts:
             worst = max(worst, int(m.group(2)))
 print(f"check_agpr: {key}: highest compiler-allocated AGPR a{worst}, hand-managed range starts at a{base}")
 if worst >= base:
-    sys.exit(f"check_agpr: FAILED -- the compiler uses a{worst}, which overlaps the hand-managed AGPR stash of {key}")
+    print(f"check_agpr: FAILED -- the compiler uses a{worst}, which overlaps the hand-managed AGPR stash of {key}", file=sys.stderr)
+    sys.exit(1)

@@ -43,3 +43,15 @@ def test_guard_ignores_other_kernels_and_hand_managed_operands(tmp_path):
     ok = _run(tmp_path, 23, 24)             # a[16:23] is the highest compiler register; a[200] (hand-managed) and k_other's a250 do not count
     assert ok.returncode == 0 and "a23" in ok.stdout, ok.stdout + ok.stderr
     assert _run(tmp_path, 23, 23).returncode != 0
+
+
+def test_guard_tells_a_trip_from_a_check_that_could_not_run(tmp_path):
+    """exit 1 = overlap (build.sh builds without the kernel), exit 2 = symbol / file missing (build.sh must FAIL: advisor, round 3)."""
+    assert _run(tmp_path, 120, 106).returncode == 1
+    f = tmp_path / "k.s"
+    f.write_text(ASM.format(hi=90))
+    script = os.path.join(ROOT, "scripts", "check_agpr.py")
+    renamed = subprocess.run([sys.executable, script, str(f), "k_renamedILi3", "106"], capture_output=True, text=True)
+    assert renamed.returncode == 2 and "not found" in renamed.stderr
+    nofile = subprocess.run([sys.executable, script, str(tmp_path / "missing.s"), "k_testILi3", "106"], capture_output=True, text=True)
+    assert nofile.returncode == 2 and "cannot read" in nofile.stderr

@@ -175,7 +175,8 @@ def _rccl_logic_worker(rank, world, port, q):
     from hp_vpinns_amd.vpinn import _VPINNBase
 
     class Stub(_VPINNBase):
-        def __init__(self, no_library=False, init_fails=False, wrong_answer=False, not_loadable=False, init_hangs=False):
+        def __init__(self, no_library=False, init_fails=False, wrong_answer=False, not_loadable=False, init_hangs=False,
+                     selftest_hangs=False, slow_s=4.0):
             outer = self
             self.rank, self.world, self.log = rank, world, []
 
@@ -188,12 +189,15 @@ def _rccl_logic_worker(rank, world, port, q):
                         raise _lib.HpvError("librccl.so could not be loaded")
                     return b"\x07" * 128
 
+                abandoned = leaked = False
+
                 def rccl_connect(s, w, r, uid):
                     if init_fails:
                         raise _lib.HpvError("ncclCommInitRank failed")
                     if init_hangs:
                         import time
-                        time.sleep(6.0)      # longer than HPV_RCCL_TIMEOUT_S below: the caller must give up on it
+                        time.sleep(slow_s)   # longer than HPV_RCCL_TIMEOUT_S below: the caller must give up on it
+                        outer.late.append(s.abandoned and s.leaked and outer.h is not s)   # the late return finds itself disowned
                         return
                     outer.log.append(("connect", w, r, len(uid)))
 
@@ -201,18 +205,40 @@ def _rccl_logic_worker(rank, world, port, q):
                     return 0, 10
 
                 def rccl_selftest(s, n):
+                    if selftest_hangs:
+                        import time
+                        time.sleep(slow_s)
+                        outer.late.append(s.abandoned and s.leaked and outer.h is not s)
                     return world * (world + 1) / 2 + world * 1e-3 * np.arange(n) + (1.0 if wrong_answer else 0.0)
 
                 def rccl_disconnect(s):
                     outer.log.append("disconnect")
+
+                def rccl_abandon(s):
+                    s.abandoned = True
+
+                def leak(s):
+                    s.leaked = True
+            self.late = []
+            self._H = H
             self.h = H()
+
+        def _new_handle(self):               # (the real one builds a fresh _lib.Handle and hands it the problem again)
+            self.log.append("fresh-handle")
+            return self._H()
 
     out = []
     os.environ["HPV_RCCL_TIMEOUT_S"] = "1.5"
-    for kw in ({}, {"no_library": True}, {"init_fails": rank == 1}, {"wrong_answer": rank == 0}, {"not_loadable": rank == 1},
-               {"init_hangs": rank == 1}):
+    slow = world - 1                         # the last rank is the slow / failing one
+    keep = []
+    for kw in ({}, {"no_library": True}, {"init_fails": rank == slow}, {"wrong_answer": rank == 0}, {"not_loadable": rank == slow},
+               {"init_hangs": rank == slow}, {"selftest_hangs": rank == slow}):
         m = Stub(**kw)
         out.append((m._connect_rccl(), list(m.log)))
+        keep.append(m)
+    import time
+    time.sleep(4.5)                          # let the abandoned helper threads come back: they must find themselves disowned
+    out.append([list(m.late) for m in keep])
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -245,4 +271,38 @@ def test_in_library_rccl_setup_agrees_on_fallback():
         ok, log = res[rank][4]
         assert ok is False and log == []        # one rank cannot load the library: agreed BEFORE anyone enters ncclCommInitRank
         ok, log = res[rank][5]                  # one rank's ncclCommInitRank does not return: wall-clock bound, everyone falls back
-        assert ok is False and log == ([("connect", 2, 0, 128), "disconnect"] if rank == 0 else [])
+        assert ok is False and log == ([("connect", 2, 0, 128), "disconnect"] if rank == 0 else ["fresh-handle"])
+        ok, log = res[rank][6]                  # one rank's self-test all-reduce never completes: that rank trains on a FRESH handle
+        assert ok is False and log == ([("connect", 2, 0, 128), "disconnect"] if rank == 0 else [("connect", 2, 1, 128), "fresh-handle"])
+        late = res[rank][7]
+        assert late[5] == ([True] if rank == 1 else []) and late[6] == ([True] if rank == 1 else [])
+
+
+@pytest.mark.timeout(600)
+def test_world8_rccl_setup_agrees_with_one_slow_rank():
+    """The world size the SCALE run uses: eight ranks agree on every step of the communicator set-up, the element shards
+    partition the grid, and ONE slow rank (its ncclCommInitRank / self-test outlasts the wall-clock bound) sends all eight
+    to the fallback -- the seven that had joined leave the communicator, the slow one moves to a fresh handle."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_logic_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=500) for _ in range(8))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from hp_vpinns_amd.dist import shard_range
+    r = [shard_range(256, k, 8) for k in range(8)]
+    assert r == [(32 * k, 32 * k + 32) for k in range(8)]
+    for rank in range(8):
+        ok, log = res[rank][0]
+        assert ok is True and log == [("connect", 8, rank, 128)]
+        assert res[rank][1] == (False, []) and res[rank][4] == (False, [])
+        ok, log = res[rank][2]
+        assert ok is False and log == ([("connect", 8, rank, 128), "disconnect"] if rank != 7 else [])
+        ok, log = res[rank][5]
+        assert ok is False and log == ([("connect", 8, rank, 128), "disconnect"] if rank != 7 else ["fresh-handle"])
+        ok, log = res[rank][6]
+        assert ok is False and log == ([("connect", 8, rank, 128), "disconnect"] if rank != 7 else [("connect", 8, 7, 128), "fresh-handle"])

@@ -21,8 +21,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run_bench(args, extra_env=None, timeout=900):
     env = dict(os.environ)
     env.update(extra_env or {})
-    env.pop("RANK", None)
-    env.pop("WORLD_SIZE", None)
+    if "RANK" not in (extra_env or {}):
+        env.pop("RANK", None)
+        env.pop("WORLD_SIZE", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=timeout)
     assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
@@ -49,6 +50,9 @@ def test_bench_two_ranks_self_launch_on_one_gpu():
 def test_bench_driver_style_single_gpu_line():
     out = _run_bench(["--steps", "20", "--warmup", "5", "--l2-iters", "2000", "--residual-elems", "16384"])
     assert out["n_gpus"] == 1 and out["steps"] == 20 and out["config"]["pass_structure"] == "whole-iteration"
+    bi = out["config"]["build"]
+    assert bi["test_hooks"] == "0" and bi["k_iter_fused"] in ("ok", "no-quarter-tile")
+    assert out["config"]["kernel_variant"] == "k_iter_fused<L=3,SPLIT=false,QT=%s>" % ("true" if bi["k_iter_fused"] == "ok" else "false")
     t = out["timing"]
     assert t["windows"] == 25 and t["untimed_warmup_iterations"] * out["ms_per_step"] * 1e-3 >= 0.2
     assert t["min_it_per_s"] <= out["value"] <= t["max_it_per_s"]
@@ -59,3 +63,21 @@ def test_bench_driver_style_single_gpu_line():
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["windows"]) == 3
     assert out["cpu_baseline_vectorized"]["omp"]["OMP_PROC_BIND"] == "close"
     assert out["roofline_residual"]["bound"] == "hbm"
+
+
+def test_bench_default_rccl_exchange_with_a_one_rank_group():
+    """What N ranks run by DEFAULT -- the library's own ncclAllReduce inside its iteration graphs (HPV_EXCHANGE unset = rccl) --
+    driven through bench.py on one rank (HPV_FORCE_DIST=1: a 1-rank nccl group; the 2-rank test above runs gloo + mailboxes)."""
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    out = _run_bench(["--steps", "16", "--warmup", "8", "--l2-iters", "600", "--no-cpu-baseline", "--no-residual-roofline"],
+                     {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "HPV_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1",
+                      "MASTER_PORT": str(port)})
+    cfg = out["config"]
+    assert out["n_gpus"] == 1 and cfg["per_rank"][0]["exchange"] == "rccl" and cfg["exchange"].startswith("in-library ncclAllReduce")
+    assert cfg["per_rank"][0]["graphs"] is True, cfg          # the collective was captured into the iteration graphs
+    assert cfg["pass_structure"] == "whole-iteration" and out["value"] > 0
+    assert out["rel_l2_error"]["value"] < 1.5

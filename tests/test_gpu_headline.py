@@ -93,7 +93,17 @@ def test_config4_full_size_against_the_oracle():
     o, m = OracleVPINN2D(*a, init_params=th), VPINN2D(*a, init_params=th)
     assert m.backend() == "mfma"
     _check_point(o, m, 3, 102400, 25600)
+    # WHICH code this green result vouches for: the element-resident kernel, and the quarter-tile instantiation unless the
+    # build's AGPR guard compiled it out (hpv_build_info says so; csrc/build.sh)
+    bi = m.h.build_info()
+    assert m.h.pass_structure() == ("whole-iteration" if bi["k_iter_fused"] != "absent" else "fused-reverse")
+    want = {"ok": "k_iter_fused<L=3,SPLIT=false,QT=true>", "no-quarter-tile": "k_iter_fused<L=3,SPLIT=false,QT=false>"}.get(bi["k_iter_fused"])
+    if want is not None:
+        assert m.h.kernel_variant() == want, (m.h.kernel_variant(), bi)
+    assert bi["test_hooks"] == "0"
     _check_trajectory(OracleVPINN2D(*a, init_params=th), m, _grid2(-1, 1, -1, 1))
+    if want is not None:
+        assert m.h.kernel_variant() == want
 
 
 @pytest.mark.parametrize("vf", [0, 2])
@@ -167,7 +177,7 @@ def test_quarter_tile_plan_against_whole_tiles(cfg):
         l3, g = m.loss_and_grad()
         r = m.h.residuals(n_res)
         hist, eps = m._step_record(50)
-        return l3, g, r, hist, eps, m.get_params(), m.h.pass_structure()
+        return l3, g, r, hist, eps, m.get_params(), m.h.pass_structure(), m.h.kernel_variant(), m.h.build_info()
 
     q = run()
     os.environ["HPV_NO_QUARTER_TILE"] = "1"
@@ -176,5 +186,13 @@ def test_quarter_tile_plan_against_whole_tiles(cfg):
     finally:
         del os.environ["HPV_NO_QUARTER_TILE"]
     assert q[6] == w[6] and q[6] in ("whole-iteration", "whole-iteration-tall")
+    # the two runs must have been two different instantiations -- unless this build's AGPR guard compiled the quarter-tile one
+    # out, in which case both are the whole-tile plan and the build says so
+    state = q[8]["k_iter_fused" if cfg == "poisson2d_cfg4" else "k_iter_tall"]
+    assert "QT=false" in w[7], w[7]
+    if state == "ok":
+        assert "QT=true" in q[7] and q[7] != w[7], (q[7], w[7])
+    else:
+        assert state == "no-quarter-tile" and q[7] == w[7]
     assert rel(q[0], w[0]) < 1e-13 and rel(q[1], w[1]) < 1e-12 and rel(q[2], w[2]) < 1e-12
     assert rel(q[3], w[3]) < 1e-9 and rel(q[5], w[5]) < 1e-9 and rel(q[4] + 1.0, w[4] + 1.0) < 1e-10

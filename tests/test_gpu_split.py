@@ -100,11 +100,7 @@ def test_split_barrier_timeout_leaves_the_replica_intact(monkeypatch):
     monkeypatch.setenv("HPV_EXCHANGE_FALLBACK", "0")      # report the failure instead of finishing on the barrier-free kernels
     ref = _build_small_shard()
     ref._step(24, False)
-    os.environ["HPV_DEBUG_SPLIT_SKIP"] = "1"          # read when the handle's kernels are set up
-    try:
-        m = _build_small_shard()
-    finally:
-        del os.environ["HPV_DEBUG_SPLIT_SKIP"]
+    m = _with_knob(1, _build_small_shard)
     state0 = m.h.get_state()
     for call in (lambda: m._step(11, False), lambda: m._step(3, True), lambda: m._step_record(5), lambda: m.loss_and_grad(),
                  lambda: m._step(1, False)):
@@ -127,12 +123,11 @@ def _rccl_timeout_worker(rank, port, out_path):
     import torch
     import torch.distributed as dist
     from hp_vpinns_amd import _lib
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HPV_FORCE_DIST="1", HPV_DEBUG_SPLIT_SKIP="1",
-                      HPV_EXCHANGE_FALLBACK="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HPV_FORCE_DIST="1", HPV_EXCHANGE_FALLBACK="0")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     res = {}
     try:
-        m = _build_small_shard()
+        m = _with_knob(1, _build_small_shard)
         res["exchange"] = m.exchange()
         state0 = m.h.get_state()
         raised = []
@@ -148,9 +143,7 @@ def _rccl_timeout_worker(rank, port, out_path):
         # default behaviour: the partner leaves at the 9th launch, the run is finished without the in-kernel exchange -- the
         # all-reduce inside the iteration stays in place
         del os.environ["HPV_EXCHANGE_FALLBACK"]
-        os.environ["HPV_DEBUG_SPLIT_SKIP"] = "9"
-        m2 = _build_small_shard()
-        del os.environ["HPV_DEBUG_SPLIT_SKIP"]
+        m2 = _with_knob(9, _build_small_shard)
         ref = _build_small_shard()
         m2._step(20, False)
         ref._step(20, False)
@@ -250,11 +243,7 @@ def test_tall_element_kernel_on_shards_and_its_barrier_timeout(monkeypatch):
             lv += l3[2]
             del m
         assert rel(g_sum - (nshard - 1) * gb_, gf) < 1e-11 and abs(lv - l3f[2]) < 1e-12 * abs(l3f[2])
-    os.environ["HPV_DEBUG_SPLIT_SKIP"] = "1"
-    try:
-        m = VPINNAdvDiff(*a, init_params=th)
-    finally:
-        del os.environ["HPV_DEBUG_SPLIT_SKIP"]
+    m = _with_knob(1, lambda: VPINNAdvDiff(*a, init_params=th))
     state0 = m.h.get_state()
     for call in (lambda: m._step(9, False), lambda: m._step_record(3), lambda: m.loss_and_grad()):
         with pytest.raises(_lib.HpvError, match="did not meet at their barrier"):
@@ -263,9 +252,15 @@ def test_tall_element_kernel_on_shards_and_its_barrier_timeout(monkeypatch):
 
 
 def _with_knob(k, build):
+    """The model built on libhpvpinn_testhooks.so (the -DHPV_TEST_HOOKS build: the product library neither reads the knob nor
+    carries the branch) with partner 1 of element 0 staying away from the in-kernel exchange from the k-th launch on."""
+    from hp_vpinns_amd import _lib
     os.environ["HPV_DEBUG_SPLIT_SKIP"] = str(k)      # read when the handle's kernels are set up
     try:
-        return build()
+        with _lib.library(_lib.TEST_HOOKS_LIB_PATH):
+            m = build()
+        assert m.h.build_info()["test_hooks"] == "1"
+        return m
     finally:
         del os.environ["HPV_DEBUG_SPLIT_SKIP"]
 
