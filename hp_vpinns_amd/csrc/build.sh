@@ -8,7 +8,8 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $HPV_EXTRA_FLAGS"   # e.g. HPV_EXTRA_FLAGS=-DHPV_FZ_TIMING
-SRCS="kernels_generic kernels_mfma kernels_fused kernels_tall kernels_tile kernels_project kernels_wide hpv_api"
+SRCS="kernels_generic kernels_mfma kernels_fused kernels_tall kernels_tile kernels_project hpv_api"
+WIDE_WIDTHS="24 32 40 48 64"                            # kernels_wide.hip: one object per hidden width (= HPV_WIDE_WIDTHS of hpv_mfma.h)
 HOOKED="kernels_mfma kernels_fused kernels_tall hpv_api"        # the sources that contain test hooks (built twice)
 CHK="python3 ../../scripts/check_agpr.py"
 # objects are cached by mtime; a change of flags must invalidate them (.flags remembers what the objects were built with)
@@ -88,6 +89,11 @@ done
 for f in $HOOKED; do
   if stale $f.th.o $f.hip; then compile_one $f $f.th.o "-DHPV_TEST_HOOKS" & pids+=($!); names+=($f.th.o); fi
 done
+for w in $WIDE_WIDTHS; do
+  if stale kernels_wide_$w.o kernels_wide.hip; then
+    $HIPCC $FLAGS -DHPV_WIDE_H=$w -c kernels_wide.hip -o kernels_wide_$w.o & pids+=($!); names+=(kernels_wide_$w.o)
+  fi
+done
 fail=0
 for i in "${!pids[@]}"; do
   if ! wait ${pids[$i]}; then echo "build.sh: ERROR -- ${names[$i]} failed" >&2; rm -f ${names[$i]}; fail=1; fi
@@ -100,6 +106,7 @@ for f in $SRCS; do
   OBJS="$OBJS $f.o"
   case " $HOOKED " in *" $f "*) TOBJS="$TOBJS $f.th.o";; *) TOBJS="$TOBJS $f.o";; esac
 done
+for w in $WIDE_WIDTHS; do OBJS="$OBJS kernels_wide_$w.o"; TOBJS="$TOBJS kernels_wide_$w.o"; done
 # -Bsymbolic: the two libraries may live in one process (the tests load both); each must bind its internal calls to itself
 $HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o ../libhpvpinn.so $OBJS
 $HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o ../libhpvpinn_testhooks.so $TOBJS

@@ -5,6 +5,12 @@
 #include "hpv_internal.h"
 
 struct HpvMfma;
+// kernels_wide.hip: forward / reverse kernels for the hidden widths kernels_mfma.hip (H = 20) does not take; false = not instantiated
+bool hpv_wide_pick(HpvMfma* m, int H, int key, int act, int L);
+#define HPV_WIDE_WIDTHS(X) X(24) X(32) X(40) X(48) X(64)      // = WIDE_WIDTHS of csrc/build.sh, = WIDE_WIDTHS of hp_vpinns_amd/init.py
+#define HPV_WIDE_DECL(Hw) bool hpv_wide_pick_##Hw(HpvMfma* m, int key, int act, int L);
+HPV_WIDE_WIDTHS(HPV_WIDE_DECL)
+#undef HPV_WIDE_DECL
 
 // Returns nullptr (and a reason) when the network shape is not covered by the fast path.
 HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_store = true);

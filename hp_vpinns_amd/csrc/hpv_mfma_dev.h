@@ -70,6 +70,8 @@ struct HpvMfma {
     NetDesc nd;
     long N, ntiles;
     int L;
+    int H = MF_H;      // uniform hidden width (20: kernels_mfma.hip and the whole-iteration kernels; other widths: kernels_wide.hip)
+    int ks = MF_KS;    // values per lane, channel and layer = H / 4 (the activation store is [tile][layer][slot][ks][64])
     int ns;            // saved slots per layer
     double* ACTS = nullptr;
     int fwd_blocks, bwd_blocks;

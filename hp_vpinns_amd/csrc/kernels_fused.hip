@@ -1311,6 +1311,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     const ProjDesc& pd = pa.pd;
     const NetDesc& nd = m->nd;
     if (!m->iter_fused_ok) return false;
+    if (m->H != MF_H) return false;      // written for 20-wide layers (other widths: kernels_wide.hip)
     if (!(nd.d == 2 && nd.nT1 == 2 && nd.nT2 == 0 && nd.act == HPV_ACT_TANH) || m->L < 2 || m->L > 3) return false;
     const bool small = pd.qx == SM_QX && pd.qy == SM_QY && pd.ntx == SM_NTX && pd.nty == SM_NTY;
     if (!(pd.qx == FZ_QX && pd.qy == FZ_QY && pd.ntx == FZ_NTX && pd.nty == FZ_NTY) && !small) return false;

@@ -712,12 +712,22 @@ static bool pick_L(HpvMfma* m, int L) {
     }
 }
 
+bool hpv_wide_pick(HpvMfma* m, int H, int key, int act, int L) {
+    switch (H) {
+#define HPV_WIDE_CASE(Hw) case Hw: return hpv_wide_pick_##Hw(m, key, act, L);
+        HPV_WIDE_WIDTHS(HPV_WIDE_CASE)
+#undef HPV_WIDE_CASE
+        default: return false;
+    }
+}
+
 HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_store) {
     auto no = [&](const char* msg) -> HpvMfma* { if (why) *why = msg; return nullptr; };
     const int L = nd.nl - 1;
     if (L < 1 || L > 4) return no("1..4 hidden layers are covered");
+    const int H = nd.width[1];
     for (int l = 1; l <= L; ++l)
-        if (nd.width[l] != MF_H) return no("all hidden layers must be 20 wide");
+        if (nd.width[l] != H) return no("all hidden layers must have the same width (the Python classes zero-pad to one)");
     for (int u = 0; u < nd.nT1; ++u) if (nd.t1dim[u] != u) return no("tangent channels must be coordinates 0..nT1-1");
     for (int b = 0; b < nd.nT2; ++b) if (nd.t2idx[b] != b) return no("second tangents must be coordinates 0..nT2-1");
     HpvMfma* m = new HpvMfma();
@@ -725,7 +735,13 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
     m->ntiles = (N + 15) / 16;
     bool ok = false;
     const int key = nd.d * 100 + nd.nT1 * 10 + nd.nT2;
-    if (nd.act == HPV_ACT_SIN) {
+    m->H = H; m->ks = H / 4;
+    if (H != MF_H) {
+        // any other width: the width-generic kernels (kernels_wide.hip), forward + activation store -> projection -> reverse
+        ok = H % 4 == 0 && hpv_wide_pick(m, H, key, nd.act, L);
+        m->ns = (nd.act == HPV_ACT_SIN ? 2 : 1) + nd.nT1 + nd.nT2;
+        if (!ok) { delete m; return no("hidden width not instantiated (kernels_wide.hip: 24, 32, 40, 48, 64; 20: kernels_mfma.hip) or too deep for its LDS"); }
+    } else if (nd.act == HPV_ACT_SIN) {
         // Poisson-1D channel sets (P1:82-91)
         if (key == 111) ok = pick_L<1, 1, 1, HPV_ACT_SIN>(m, L);
         else if (key == 110) ok = pick_L<1, 1, 0, HPV_ACT_SIN>(m, L);
@@ -741,11 +757,11 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
     }
     if (!ok) { delete m; return no("channel set / activation combination not instantiated"); }
     if (need_store) {   // forward-only users (predict) run with save_act = 0 and need no activation store
-        size_t bytes = (size_t)m->ntiles * L * m->ns * MF_KS * 64 * sizeof(double);
+        size_t bytes = (size_t)m->ntiles * L * m->ns * m->ks * 64 * sizeof(double);
         if (hipMalloc((void**)&m->ACTS, bytes) != hipSuccess) { delete m; return no("hipMalloc of the activation store failed"); }
         (void)hipMemset(m->ACTS, 0, bytes);
     }
-    if (need_store && nd.d == 2 && nd.nT1 == 2 && nd.nT2 <= 1 && nd.act == HPV_ACT_TANH) {
+    if (need_store && H == MF_H && nd.d == 2 && nd.nT1 == 2 && nd.nT2 <= 1 && nd.act == HPV_ACT_TANH) {
         // elements the exchange buffers of the split whole-iteration kernels are sized for (the largest grid this batch can hold)
         m->xsync_elems = N / 400 + 1;
         // tagged-exchange granules: 2 words per exchanged double (tall elements: <= CUs x 25 doubles; SPLIT mode: 800 per element)
@@ -804,7 +820,7 @@ const char* hpv_mfma_variant(HpvMfma* m, int which) {
 }
 unsigned int* hpv_mfma_xiter(HpvMfma* m) { return m ? m->xiter : nullptr; }
 double* hpv_mfma_activation_store(HpvMfma* m) { return m ? m->ACTS : nullptr; }
-size_t hpv_mfma_activation_store_doubles(HpvMfma* m) { return m && m->ACTS ? (size_t)m->ntiles * m->L * m->ns * MF_KS * 64 : 0; }   // (the timing builds park their stamps there)
+size_t hpv_mfma_activation_store_doubles(HpvMfma* m) { return m && m->ACTS ? (size_t)m->ntiles * m->L * m->ns * m->ks * 64 : 0; }   // (the timing builds park their stamps there)
 // Workgroups per element of the fused reverse kernel: one when the shard has an element for every CU, more for the
 // small shards of a multi-GPU run (each workgroup walks 1/split of the element's 25 tiles).
 static int fused_split(HpvMfma* m, long n_elem) {

@@ -1,0 +1,487 @@
+// Taylor-mode MLP forward / reverse kernels for ANY uniform hidden width H = 4 m (instantiated: WIDE_WIDTHS of csrc/build.sh), every
+// channel set of the MFMA path, 1..4 hidden layers -- the MFMA path for the networks kernels_mfma.hip (H = 20) does not take.
+//
+// The reference's `Net_layer` is a free hyper-parameter (P1:236, P2:280-286, P3:46-51); until round 4 every hidden width other
+// than 20 ran on the generic VALU kernels (kernels_generic.hip) -- a 75x cliff behind the same class surface.  Structure =
+// the two-kernel MFMA path: k_fwd_wide writes the activation store [tile][layer][slot][KS][64] (512-byte
+// coalesced wave accesses), the projection runs as its own launch (k_project_tp / k_project_wg / k_project), k_bwd_wide reads
+// the store back, accumulates dW / db per wave in registers over its tiles and reduces them per workgroup into one gradient
+// row.  The tile arithmetic (16-row + 4-row MFMA decomposition of H) is hpv_wide_dev.h.
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "hpv_wide_dev.h"
+
+#define WF_BLOCK 256
+#define WF_WAVES 4
+
+// ------------------------------------------------------------------------------------------------
+// LDS maps
+// ------------------------------------------------------------------------------------------------
+template <int H, int L, int D>
+struct WideFwdLds {
+    using W = WD<H>;
+    static constexpr int LH = L - 1;
+    static constexpr int FR = 0;                         // forward fragments           [LH][FRAG]
+    static constexpr int BI = FR + LH * W::FRAG;         // hidden->hidden biases       [LH][H]
+    static constexpr int W1 = BI + LH * H;               // first-layer rows, first bias, head weights  [D + 2][H]
+    static constexpr int TOTAL = W1 + (D + 2) * H;
+};
+template <int H, int L, int D>
+struct WideBwdLds {
+    using W = WD<H>;
+    static constexpr int LH = L - 1;
+    static constexpr int TAB = 0;                               // per-wave transpose pair (one channel at a time) [WAVES][2][H][17]; epilogue: exchange
+    static constexpr int FR = TAB + WF_WAVES * 2 * W::TR;       // reverse fragments        [LH][FRAG]
+    static constexpr int W1 = FR + LH * W::FRAG;                // first-layer rows, head weights  [D + 1][H]
+    static constexpr int TOTAL = W1 + (D + 1) * H;
+    static_assert(WF_WAVES * 2 * W::TR >= WF_WAVES * 256, "the epilogue exchanges one accumulator (4 doubles per lane) per wave through the transpose region");
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int D, int NT1, int NT2, int ACT, int L, int H, bool SAVE>
+__global__ void __launch_bounds__(WF_BLOCK, (H <= 32 ? 2 : 1)) k_fwd_wide(MfmaArgs g) {
+    using W = WD<H>;
+    using M = WideFwdLds<H, L, D>;
+    constexpr int KS = W::KS, C = 1 + NT1 + NT2;
+    constexpr int NS = SlotCount<ACT, NT1, NT2>::value;
+    constexpr int SA1 = 1, SZC = 1 + (ACT == HPV_ACT_SIN ? 1 : 0), SZCC = SZC + NT1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = lane >> 4, pt = lane & 15;
+    const long wave = ((long)blockIdx.x * blockDim.x + tid) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const double* __restrict__ th = g.theta;
+
+    // the coordinates of the first tile are requested before the weight staging (one round trip for both)
+    double xn[D];
+    {
+        long p0 = wave * 16 + pt;
+        p0 = p0 < g.N ? p0 : g.N - 1;
+#pragma unroll
+        for (int c = 0; c < D; ++c) xn[c] = g.X[(long)c * g.N + p0];
+    }
+#pragma unroll
+    for (int i = 1; i < L; ++i) {
+        wide_stage_layer<H, true, WF_BLOCK>(th, g.woff[i], lds + M::FR + (i - 1) * W::FRAG, tid);
+        for (int j = tid; j < H; j += WF_BLOCK) lds[M::BI + (i - 1) * H + j] = th[g.boff[i] + j];
+    }
+    for (int f = tid; f < (D + 2) * H; f += WF_BLOCK) {
+        const int c = f / H, j = f - c * H;
+        lds[M::W1 + f] = th[(c < D ? g.woff[0] + c * H : (c == D ? g.boff[0] : g.woff[L])) + j];
+    }
+    __syncthreads();
+    const double bo = th[g.boff[L]];
+    const double* W1 = lds + M::W1;
+
+    for (long tile = wave; tile < g.ntiles; tile += nwaves) {
+        const long p = tile * 16 + pt;
+        const bool valid = p < g.N;
+        double x[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) x[c] = valid ? xn[c] : 0.0;
+        {
+            long pn = (tile + nwaves) * 16 + pt;
+            pn = pn < g.N ? pn : g.N - 1;
+#pragma unroll
+            for (int c = 0; c < D; ++c) xn[c] = g.X[(long)c * g.N + pn];
+        }
+        int lofs = lane;                       // opaque per tile: keeps the LDS fragment reads inside the loop
+        asm volatile("" : "+v"(lofs));
+        double h[C][KS];
+        double* sv = g.ACTS + (tile * L) * (long)(NS * KS * 64) + lane;
+
+        // ---- layer 1 (VALU): z = b + x W, z_c = W[c,:], z_cc = 0 ----
+        {
+            double z1[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                double z = W1[D * H + 4 * s + (lofs >> 4)];
+#pragma unroll
+                for (int c = 0; c < D; ++c) z = fma(x[c], W1[c * H + 4 * s + (lofs >> 4)], z);
+                z1[s] = z;
+            }
+            auto act1 = [&](auto fast) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    double a, a1, a2;
+                    act_fwd<ACT, decltype(fast)::value>(z1[s], a, a1, a2);
+                    h[0][s] = a;
+                    if constexpr (SAVE) {
+                        sv[(0 * KS + s) * 64] = a;
+                        if constexpr (ACT == HPV_ACT_SIN) sv[(SA1 * KS + s) * 64] = a1;
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT1; ++t) h[1 + t][s] = a1 * W1[(t < D ? t : 0) * H + 4 * s + (lofs >> 4)];   // T1 = coordinates 0..NT1-1
+#pragma unroll
+                    for (int b = 0; b < NT2; ++b) {
+                        const double zc = W1[(b < D ? b : 0) * H + 4 * s + (lofs >> 4)];                            // T2 = coordinates 0..NT2-1
+                        h[1 + NT1 + b][s] = a2 * zc * zc;
+                    }
+                }
+            };
+            if (act_wave_needs_safe<ACT>(z1)) act1(std::false_type{}); else act1(std::true_type{});
+        }
+        // ---- hidden -> hidden layers (MFMA) ----
+#pragma unroll
+        for (int i = 1; i < L; ++i) {
+            double z[C][KS];
+            wide_fwd_layer<H, C>(lds + M::FR + (i - 1) * W::FRAG, lds + M::BI + (i - 1) * H, lofs, h, z);
+            double* svl = sv + (long)i * (NS * KS * 64);
+            auto acti = [&](auto fast) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    double a, a1, a2;
+                    act_fwd<ACT, decltype(fast)::value>(z[0][s], a, a1, a2);
+                    h[0][s] = a;
+                    if constexpr (SAVE) {
+                        svl[(0 * KS + s) * 64] = a;
+                        if constexpr (ACT == HPV_ACT_SIN) svl[(SA1 * KS + s) * 64] = a1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < NT1; ++u) {
+                        if constexpr (SAVE) svl[((SZC + u) * KS + s) * 64] = z[1 + u][s];
+                        h[1 + u][s] = a1 * z[1 + u][s];
+                    }
+#pragma unroll
+                    for (int b = 0; b < NT2; ++b) {
+                        const double zcc = z[1 + NT1 + b][s], zc1 = z[1 + (b < NT1 ? b : 0)][s];
+                        if constexpr (SAVE) svl[((SZCC + b) * KS + s) * 64] = zcc;
+                        h[1 + NT1 + b][s] = a2 * zc1 * zc1 + a1 * zcc;
+                    }
+                }
+            };
+            if (act_wave_needs_safe<ACT>(z[0])) acti(std::false_type{}); else acti(std::true_type{});
+        }
+        // ---- linear head (VALU + the cross-row sums over the 4 neuron groups) ----
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            double v = 0.0;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) v = fma(h[ch][s], W1[(D + 1) * H + 4 * s + (lofs >> 4)], v);
+            v = xrow_sum16(v);
+            v = xrow_sum32(v);
+            if (ch == 0) v += bo;
+            if (q == 0 && valid) g.OUT[(long)ch * g.N + p] = v;
+            if (ch == 0 && g.data_off >= 0 && tile * 16 >= g.data_off) {
+                // lossb = w mean((u_d - u)^2) (P1:98, P2:122, P3:184): adjoint + per-tile partial sum, no extra launch
+                double dd = 0.0;
+                if (q == 0 && valid) {
+                    dd = g.ud[p - g.data_off] - v;
+                    if (g.data_write_gbar) g.gbar0[p] = g.data_scale * dd;
+                }
+                const double sq = row_sum16(dd * dd);
+                if (lane == 0) g.data_part[tile - g.data_off / 16] = sq;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reverse
+// ------------------------------------------------------------------------------------------------
+template <int D, int NT1, int NT2, int ACT, int L, int H>
+__global__ void __launch_bounds__(WF_BLOCK, 1) k_bwd_wide(MfmaArgs g) {
+    using W = WD<H>;
+    using M = WideBwdLds<H, L, D>;
+    constexpr int KS = W::KS, C = 1 + NT1 + NT2, LH = L > 1 ? L - 1 : 1;
+    constexpr int NS = SlotCount<ACT, NT1, NT2>::value;
+    constexpr int SZC = 1 + (ACT == HPV_ACT_SIN ? 1 : 0), SZCC = SZC + NT1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int q = lane >> 4, pt = lane & 15;
+    const long wave = ((long)blockIdx.x * blockDim.x + tid) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const double* __restrict__ th = g.theta;
+#pragma unroll
+    for (int i = 1; i < L; ++i) wide_stage_layer<H, false, WF_BLOCK>(th, g.woff[i], lds + M::FR + (i - 1) * W::FRAG, tid);
+    for (int f = tid; f < (D + 1) * H; f += WF_BLOCK) {
+        const int c = f / H, j = f - c * H;
+        lds[M::W1 + f] = th[(c < D ? g.woff[0] + c * H : g.woff[L]) + j];
+    }
+    __syncthreads();
+    const double* W1 = lds + M::W1;
+    double* TA = lds + M::TAB + wv * (2 * W::TR);
+    double* TB = TA + W::TR;
+
+    // gradient accumulators of this wave over all its tiles
+    WideDW<H> dW[LH];
+#pragma unroll
+    for (int i = 0; i < LH; ++i) dW[i].zero();
+    double db[L][KS], dW1[D][KS], dWo[KS], dbo = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        dWo[s] = 0.0;
+#pragma unroll
+        for (int i = 0; i < L; ++i) db[i][s] = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) dW1[c][s] = 0.0;
+    }
+    struct Slots {
+        double a[KS], a1s[KS];
+        double zc[NT1 > 0 ? NT1 : 1][KS];
+        double zcc[NT2 > 0 ? NT2 : 1][KS];
+    };
+    int lofs = lane;
+    auto load_slots = [&](const double* svl, bool first_layer, Slots& S) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            S.a[s] = svl[(0 * KS + s) * 64];
+            if constexpr (ACT == HPV_ACT_SIN) S.a1s[s] = svl[(1 * KS + s) * 64]; else S.a1s[s] = 0.0;
+#pragma unroll
+            for (int u = 0; u < NT1; ++u) S.zc[u][s] = first_layer ? W1[(u < D ? u : 0) * H + 4 * s + (lofs >> 4)] : svl[((SZC + u) * KS + s) * 64];
+#pragma unroll
+            for (int b = 0; b < NT2; ++b) S.zcc[b][s] = first_layer ? 0.0 : svl[((SZCC + b) * KS + s) * 64];
+        }
+    };
+    auto outputs_of = [&](const Slots& S, int ch, double (&hv)[KS]) {   // channel ch of the layer's outputs
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            double a1, a2, a3;
+            act_saved<ACT>(S.a[s], S.a1s[s], a1, a2, a3);
+            if (ch == 0) hv[s] = S.a[s];
+            else if (ch <= NT1) hv[s] = a1 * S.zc[(ch - 1) < NT1 ? (ch - 1) : 0][s];
+            else {
+                const int b = ch - 1 - NT1;
+                const double z1 = S.zc[b < NT1 ? b : 0][s];
+                hv[s] = a2 * z1 * z1 + a1 * S.zcc[b < NT2 ? b : 0][s];
+            }
+        }
+    };
+
+    for (long tile = wave; tile < g.ntiles; tile += nwaves) {
+        lofs = lane;
+        asm volatile("" : "+v"(lofs));   // opaque per tile: the LDS weight reads stay inside the loop
+        const long p = tile * 16 + pt;
+        const bool valid = p < g.N;
+        double x[D], gb[C];
+#pragma unroll
+        for (int c = 0; c < D; ++c) x[c] = valid ? g.X[(long)c * g.N + p] : 0.0;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) gb[ch] = valid ? g.GBAR[(long)ch * g.N + p] : 0.0;
+        const double* sv = g.ACTS + (tile * L) * (long)(NS * KS * 64) + lane;
+        Slots cur;
+        load_slots(sv + (long)(L - 1) * (NS * KS * 64), L == 1, cur);
+
+        double hbar[C][KS], zbar[C][KS];
+        // ---- linear head ----
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            double hv[KS];
+            outputs_of(cur, ch, hv);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                dWo[s] = fma(hv[s], gb[ch], dWo[s]);
+                hbar[ch][s] = gb[ch] * W1[D * H + 4 * s + (lofs >> 4)];
+            }
+        }
+        if (q == 0) dbo += gb[0];
+        // ---- hidden layers, last to first ----
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+            Slots prev;
+            if (i > 0) load_slots(sv + (long)(i - 1) * (NS * KS * 64), i == 1, prev);   // one layer ahead
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                double a1, a2, a3;
+                act_saved<ACT>(cur.a[s], cur.a1s[s], a1, a2, a3);
+                double zb = hbar[0][s] * a1;
+#pragma unroll
+                for (int u = 0; u < NT1; ++u) {
+                    zbar[1 + u][s] = hbar[1 + u][s] * a1;
+                    zb += hbar[1 + u][s] * a2 * cur.zc[u][s];
+                }
+#pragma unroll
+                for (int b = 0; b < NT2; ++b) {
+                    const int u = b < NT1 ? b : 0;
+                    const double hb = hbar[1 + NT1 + b][s];
+                    zbar[1 + NT1 + b][s] = hb * a1;
+                    zbar[1 + u][s] += 2.0 * hb * a2 * cur.zc[u][s];
+                    zb += hb * (a3 * cur.zc[u][s] * cur.zc[u][s] + a2 * cur.zcc[b][s]);
+                }
+                zbar[0][s] = zb;
+                db[i][s] += zb;
+            }
+            if (i == 0) {
+                // dW1[c][j] += x_c zbar[j] + [c in T1] zbar_c[j]
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                    for (int c = 0; c < D; ++c) dW1[c][s] += x[c] * zbar[0][s];
+#pragma unroll
+                    for (int u = 0; u < NT1; ++u) dW1[u < D ? u : 0][s] += zbar[1 + u][s];
+                }
+            } else {
+                // weight gradient: contraction over the tile's 16 points and over the channels; one channel's transpose pair in
+                // LDS at a time (the pairs of all channels of a 64-wide layer would be 4 x 87 KB)
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    double hv[KS];
+                    outputs_of(prev, ch, hv);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    wide_transpose_store<H>(TA, TB, q, pt, hv, zbar[ch]);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    wide_dw_accumulate<H>(TA, TB, lane, dW[i - 1]);
+                }
+                // hbar_in^T = W zbar^T
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) wide_hbar<H>(lds + M::FR + (i - 1) * W::FRAG, lofs, zbar[ch], hbar[ch]);
+                cur = prev;
+            }
+        }
+    }
+
+    // ---- epilogue: per-wave partials -> (LDS exchange, one accumulator group at a time) -> one gradient row per workgroup ----
+    // (per-wave rows in LDS, as k_bwd_mfma keeps them, do not fit: 4 x P doubles is 100 KB at H = 40 and 400 KB at H = 64)
+    double* row = g.GPART + (long)blockIdx.x * g.P;
+    double* EX = lds + M::TAB;
+    auto xsum4 = [&](int k) -> double { return EX[k] + EX[256 + k] + EX[512 + k] + EX[768 + k]; };   // fixed order over the waves
+    // v4d accumulators: every wave parks its 4 doubles per lane at EX[wv][r][lane]; thread (r, ln) sums the four waves
+    auto reduce_v4 = [&](const v4d& a, auto&& index_of) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) EX[wv * 256 + r * 64 + lane] = a[r];
+        __syncthreads();
+        const int r = tid >> 6, ln = tid & 63;
+        row[index_of(r, ln >> 4, ln & 15)] = xsum4(tid);
+    };
+    auto reduce_1 = [&](double a, auto&& index_of, bool quad_first) {
+        if (quad_first) a = quad4_sum(a);
+        __syncthreads();
+        EX[wv * 256 + lane] = a;
+        __syncthreads();
+        if (tid < 64) {
+            const int idx = index_of(tid >> 4, tid & 15);
+            if (idx >= 0) row[idx] = xsum4(tid);
+        }
+    };
+#pragma unroll
+    for (int i = 1; i < L; ++i) {
+        const int wo = g.woff[i];
+        const WideDW<H>& d = dW[i - 1];
+#pragma unroll
+        for (int ti = 0; ti < W::NL; ++ti)
+#pragma unroll
+            for (int to = 0; to < W::NL; ++to)
+                reduce_v4(d.big[ti][to], [&](int r, int qq, int pp) { return wo + (16 * ti + 4 * r + qq) * H + 16 * to + pp; });
+#pragma unroll
+        for (int u = 0; u < W::NR; ++u) {
+#pragma unroll
+            for (int t = 0; t < W::NL; ++t) {
+                reduce_1(d.s10[u][t], [&](int qq, int pp) { return wo + (16 * W::NL + 4 * u + qq) * H + 16 * t + pp; }, false);
+                reduce_1(d.s01[t][u], [&](int qq, int pp) { return wo + (16 * t + pp) * H + 16 * W::NL + 4 * u + qq; }, false);
+            }
+#pragma unroll
+            for (int u2 = 0; u2 < W::NR; ++u2)
+                reduce_1(d.cor[u][u2], [&](int qq, int pp) { return pp < 4 ? wo + (16 * W::NL + 4 * u + qq) * H + 16 * W::NL + 4 * u2 + pp : -1; }, true);
+        }
+    }
+    // per-lane partials: sum over the 16 point lanes of each neuron group, then over the waves -- all of them in one exchange:
+    // wave w parks its (L + D + 1) H + 1 sums at EX[w * NV ..] (4 NV <= 136 H doubles, the size of the transpose region)
+    {
+        constexpr int NV = (L + D + 1) * H + 1;
+        static_assert(WF_WAVES * NV <= WF_WAVES * 2 * W::TR, "vector partials fit the transpose region");
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int k = 0; k < L + D + 1; ++k) {
+                const double v = k < L ? db[k < L ? k : 0][s] : (k < L + D ? dW1[(k >= L && k - L < D) ? (k - L) : 0][s] : dWo[s]);
+                const double t = row_sum16(v);
+                if (pt == 0) EX[wv * NV + k * H + 4 * s + q] = t;
+            }
+        }
+        {
+            const double t = row_sum16(dbo);
+            if (lane == 0) EX[wv * NV + (L + D + 1) * H] = t;
+        }
+        __syncthreads();
+        for (int f = tid; f < NV; f += WF_BLOCK) {
+            const int k = f / H, j = f - k * H;
+            const int idx = k < L ? g.boff[k] + j : (k < L + D ? g.woff[0] + (k - L) * H + j : (k == L + D ? g.woff[L] + j : g.boff[L]));
+            row[idx] = EX[f] + EX[NV + f] + EX[2 * NV + f] + EX[3 * NV + f];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <typename K>
+static bool wide_set_lds(K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return false;
+    if (bytes <= 64 * 1024) return true;
+    const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return true;
+}
+
+template <int D, int NT1, int NT2, int ACT, int L, int H>
+static void run_fwd_wide(const MfmaArgs& a, int blocks, hipStream_t s) {
+    constexpr size_t bytes = (size_t)WideFwdLds<H, L, D>::TOTAL * sizeof(double);
+    if (a.save_act) hipLaunchKernelGGL((k_fwd_wide<D, NT1, NT2, ACT, L, H, true>), dim3(blocks), dim3(WF_BLOCK), bytes, s, a);
+    else hipLaunchKernelGGL((k_fwd_wide<D, NT1, NT2, ACT, L, H, false>), dim3(blocks), dim3(WF_BLOCK), bytes, s, a);
+}
+template <int D, int NT1, int NT2, int ACT, int L, int H>
+static void run_bwd_wide(const MfmaArgs& a, int blocks, hipStream_t s) {
+    constexpr size_t bytes = (size_t)WideBwdLds<H, L, D>::TOTAL * sizeof(double);
+    hipLaunchKernelGGL((k_bwd_wide<D, NT1, NT2, ACT, L, H>), dim3(blocks), dim3(WF_BLOCK), bytes, s, a);
+}
+
+template <int D, int NT1, int NT2, int ACT, int L, int H>
+static bool pick_wide(HpvMfma* m) {
+    constexpr size_t fb = (size_t)WideFwdLds<H, L, D>::TOTAL * sizeof(double), bb = (size_t)WideBwdLds<H, L, D>::TOTAL * sizeof(double);
+    if (!wide_set_lds(k_fwd_wide<D, NT1, NT2, ACT, L, H, true>, fb) || !wide_set_lds(k_fwd_wide<D, NT1, NT2, ACT, L, H, false>, fb) ||
+        !wide_set_lds(k_bwd_wide<D, NT1, NT2, ACT, L, H>, bb))
+        return false;
+    m->fwd = run_fwd_wide<D, NT1, NT2, ACT, L, H>;
+    m->bwd = run_bwd_wide<D, NT1, NT2, ACT, L, H>;
+    m->bwd_fused = nullptr;
+    int of = 1, ob = 1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, k_fwd_wide<D, NT1, NT2, ACT, L, H, true>, WF_BLOCK, fb);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_bwd_wide<D, NT1, NT2, ACT, L, H>, WF_BLOCK, bb);
+    m->occ_fwd = of > 0 ? of : 1;
+    m->occ_bwd = ob > 0 ? ob : 1;
+    const char* an = ACT == HPV_ACT_SIN ? "sin" : "tanh";
+    snprintf(m->vfwd, sizeof m->vfwd, "k_fwd_wide<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=%d>", D, NT1, NT2, an, L, H);
+    snprintf(m->vbwd, sizeof m->vbwd, "k_bwd_wide<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=%d>", D, NT1, NT2, an, L, H);
+    return true;
+}
+template <int D, int NT1, int NT2, int ACT, int H>
+static bool pick_wide_L(HpvMfma* m, int L) {
+    switch (L) {
+        case 1: return pick_wide<D, NT1, NT2, ACT, 1, H>(m);
+        case 2: return pick_wide<D, NT1, NT2, ACT, 2, H>(m);
+        case 3: return pick_wide<D, NT1, NT2, ACT, 3, H>(m);
+        case 4: return pick_wide<D, NT1, NT2, ACT, 4, H>(m);
+        default: return false;
+    }
+}
+template <int H>
+static bool pick_wide_key(HpvMfma* m, int key, int act, int L) {
+    if (act == HPV_ACT_SIN) {
+        if (key == 111) return pick_wide_L<1, 1, 1, HPV_ACT_SIN, H>(m, L);
+        if (key == 110) return pick_wide_L<1, 1, 0, HPV_ACT_SIN, H>(m, L);
+        if (key == 100) return pick_wide_L<1, 0, 0, HPV_ACT_SIN, H>(m, L);
+        return false;
+    }
+    if (key == 222) return pick_wide_L<2, 2, 2, HPV_ACT_TANH, H>(m, L);
+    if (key == 220) return pick_wide_L<2, 2, 0, HPV_ACT_TANH, H>(m, L);
+    if (key == 200) return pick_wide_L<2, 0, 0, HPV_ACT_TANH, H>(m, L);
+    if (key == 221) return pick_wide_L<2, 2, 1, HPV_ACT_TANH, H>(m, L);
+    return false;
+}
+
+// One translation unit per hidden width (csrc/build.sh compiles this file once per entry of WIDE_WIDTHS with -DHPV_WIDE_H=<H>:
+// 7 channel sets x 4 depths x 3 kernels each, in parallel); kernels_mfma.hip dispatches on H (hpv_wide_pick).
+#ifndef HPV_WIDE_H
+#error "compile with -DHPV_WIDE_H=<hidden width> (csrc/build.sh)"
+#endif
+#define WIDE_CAT_(a, b) a##b
+#define WIDE_CAT(a, b) WIDE_CAT_(a, b)
+bool WIDE_CAT(hpv_wide_pick_, HPV_WIDE_H)(HpvMfma* m, int key, int act, int L) { return pick_wide_key<HPV_WIDE_H>(m, key, act, L); }

@@ -39,12 +39,25 @@ def unpack(theta, layers):
     return ws, bs, theta[o:]
 
 
-MFMA_WIDTH = 20   # hidden width of the MFMA kernels (csrc/kernels_mfma.hip)
+MFMA_WIDTH = 20   # hidden width of the hand-tuned MFMA kernels (csrc/kernels_mfma.hip and the whole-iteration kernels)
+WIDE_WIDTHS = (24, 32, 40, 48, 64)   # hidden widths the width-generic MFMA kernels are instantiated for (csrc/kernels_wide.hip)
 
 
-def pad_plan(layers, extra=0, width=MFMA_WIDTH, max_hidden=4):
-    """Zero-padding of a narrow network onto the `width`-wide kernels.  Returns (padded_layers, index) with
-    theta_padded[index] = theta, or None when the network is not eligible (already `width` wide, wider, too deep).
+def device_width(hidden):
+    """The uniform hidden width the device runs a network with these hidden layer widths at: 20 when none is wider (the
+    whole-iteration kernels), else the smallest instantiated width that holds the widest layer; None beyond 64 (generic kernels)."""
+    w = max(hidden)
+    for cand in (MFMA_WIDTH,) + WIDE_WIDTHS:
+        if w <= cand:
+            return cand
+    return None
+
+
+def pad_plan(layers, extra=0, width=None, max_hidden=4):
+    """Zero-padding of a network onto kernels of ONE hidden width (`width`; default `device_width`: 20 for narrow networks --
+    the reference defaults are 5 wide, P2:280, P3:46 --, else the next instantiated width, also for non-uniform hidden
+    layers).  Returns (padded_layers, index) with theta_padded[index] = theta, or None when no padding is needed (every
+    hidden layer already has that width) or possible (too wide, too deep).
 
     The padding is exact, not an approximation: a padded neuron has zero incoming weights and bias, so it outputs
     act(0) = 0 (tanh and sin) with zero tangents, its outgoing weights are zero, and every gradient entry that belongs
@@ -53,7 +66,9 @@ def pad_plan(layers, extra=0, width=MFMA_WIDTH, max_hidden=4):
     hidden = layers[1:-1]
     if not (1 <= len(hidden) <= max_hidden) or layers[-1] != 1 or layers[0] > 2:
         return None
-    if any(w > width for w in hidden) or all(w == width for w in hidden):
+    if width is None:
+        width = device_width(hidden)
+    if width is None or any(w > width for w in hidden) or all(w == width for w in hidden):
         return None
     padded = [layers[0]] + [width] * len(hidden) + [1]
     idx, o = [], 0

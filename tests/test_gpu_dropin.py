@@ -59,6 +59,8 @@ def test_poisson1d_driver_order_fills_the_list_created_after_the_constructor():
     g = gold("poisson1d_small")
     a = p1_args(g)
     th = theta0(a[8], 11)
+    w = int(a[8][1])
+    th[w:2 * w] = 0.05 * np.arange(w)    # non-zero first bias: an odd sin network makes d loss / d b_out pure round-off, which Adam amplifies
     ns = {"args": a, "theta": th, "Opt_Niter": 31, "__name__": "mini_driver_1d"}
     exec(compile(DRIVER_1D, "<mini driver 1-D>", "exec"), ns)
     rec = ns["total_record"]

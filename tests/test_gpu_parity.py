@@ -201,7 +201,7 @@ def test_mfma_equals_generic_on_device():
 def test_mfma_unavailable_shape_raises():
     from hp_vpinns_amd import _lib
     with pytest.raises(_lib.HpvError):
-        _pair_2d("poisson2d_small", 1, layers=[2, 24, 24, 1], backend="mfma")   # wider than the MFMA kernels
+        _pair_2d("poisson2d_small", 1, layers=[2, 80, 80, 1], backend="mfma")   # wider than any MFMA kernel (20; 24..64: kernels_wide.hip)
 
 
 def test_device_tanh_accuracy():
