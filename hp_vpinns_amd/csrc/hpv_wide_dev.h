@@ -200,3 +200,82 @@ __device__ __forceinline__ void wide_dw_accumulate(const double* TA, const doubl
 #pragma unroll
         for (int u2 = 0; u2 < W::NR; ++u2) d.cor[u][u2] = __builtin_amdgcn_mfma_f64_4x4x4f64(cA[u], cB[u2], d.cor[u][u2], 0, 0, 0);
 }
+
+// Cross-wave reduction of the per-wave gradient accumulators into ONE row of the workgroup (fixed order over the waves: bitwise
+// reproducible).  EX = an LDS region of at least WAVES * max(256, (L + D + 1) H + 1) doubles that is free by now (the transpose
+// tiles).  One accumulator group at a time: a v4d accumulator is 4 doubles per lane = 256 per wave.
+template <int H, int L, int D, int WAVES>
+__device__ __forceinline__ void wide_epilogue(double* EX, const WideDW<H> (&dW)[(L > 1 ? L - 1 : 1)], const double (&db)[L][WD<H>::KS],
+                                              const double (&dW1)[D][WD<H>::KS], const double (&dWo)[WD<H>::KS], double dbo,
+                                              double* __restrict__ row, const int* woff, const int* boff) {
+    using W = WD<H>;
+    constexpr int KS = W::KS, BT = WAVES * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = lane >> 4, pt = lane & 15;
+    auto xsum = [&](int k, int stride) -> double {
+        double t = EX[k];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) t += EX[w * stride + k];
+        return t;
+    };
+    auto reduce_v4 = [&](const v4d& a, auto&& index_of) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) EX[wv * 256 + r * 64 + lane] = a[r];
+        __syncthreads();
+        for (int f = tid; f < 256; f += BT) row[index_of(f >> 6, (f & 63) >> 4, f & 15)] = xsum(f, 256);
+    };
+    auto reduce_1 = [&](double a, auto&& index_of, bool quad_first) {
+        if (quad_first) a = quad4_sum(a);
+        __syncthreads();
+        EX[wv * 256 + lane] = a;
+        __syncthreads();
+        if (tid < 64) {
+            const int idx = index_of(tid >> 4, tid & 15);
+            if (idx >= 0) row[idx] = xsum(tid, 256);
+        }
+    };
+#pragma unroll
+    for (int i = 1; i < L; ++i) {
+        const int wo = woff[i];
+        const WideDW<H>& d = dW[i - 1];
+#pragma unroll
+        for (int ti = 0; ti < W::NL; ++ti)
+#pragma unroll
+            for (int to = 0; to < W::NL; ++to)
+                reduce_v4(d.big[ti][to], [&](int r, int qq, int pp) { return wo + (16 * ti + 4 * r + qq) * H + 16 * to + pp; });
+#pragma unroll
+        for (int u = 0; u < W::NR; ++u) {
+#pragma unroll
+            for (int t = 0; t < W::NL; ++t) {
+                reduce_1(d.s10[u][t], [&](int qq, int pp) { return wo + (16 * W::NL + 4 * u + qq) * H + 16 * t + pp; }, false);
+                reduce_1(d.s01[t][u], [&](int qq, int pp) { return wo + (16 * t + pp) * H + 16 * W::NL + 4 * u + qq; }, false);
+            }
+#pragma unroll
+            for (int u2 = 0; u2 < W::NR; ++u2)
+                reduce_1(d.cor[u][u2], [&](int qq, int pp) { return pp < 4 ? wo + (16 * W::NL + 4 * u + qq) * H + 16 * W::NL + 4 * u2 + pp : -1; }, true);
+        }
+    }
+    // per-lane partials: sum over the 16 point lanes of each neuron group, then over the waves -- all of them in one exchange:
+    // wave w parks its (L + D + 1) H + 1 sums at EX[w * NV ..]
+    constexpr int NV = (L + D + 1) * H + 1;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int k = 0; k < L + D + 1; ++k) {
+            const double v = k < L ? db[k < L ? k : 0][s] : (k < L + D ? dW1[(k >= L && k - L < D) ? (k - L) : 0][s] : dWo[s]);
+            const double t = row_sum16(v);
+            if (pt == 0) EX[wv * NV + k * H + 4 * s + q] = t;
+        }
+    }
+    {
+        const double t = row_sum16(dbo);
+        if (lane == 0) EX[wv * NV + (L + D + 1) * H] = t;
+    }
+    __syncthreads();
+    for (int f = tid; f < NV; f += BT) {
+        const int k = f / H, j = f - k * H;
+        const int idx = k < L ? boff[k] + j : (k < L + D ? woff[0] + (k - L) * H + j : (k == L + D ? woff[L] + j : boff[L]));
+        row[idx] = xsum(f, NV);
+    }
+}

@@ -338,75 +338,7 @@ __global__ void __launch_bounds__(WF_BLOCK, 1) k_bwd_wide(MfmaArgs g) {
 
     // ---- epilogue: per-wave partials -> (LDS exchange, one accumulator group at a time) -> one gradient row per workgroup ----
     // (per-wave rows in LDS, as k_bwd_mfma keeps them, do not fit: 4 x P doubles is 100 KB at H = 40 and 400 KB at H = 64)
-    double* row = g.GPART + (long)blockIdx.x * g.P;
-    double* EX = lds + M::TAB;
-    auto xsum4 = [&](int k) -> double { return EX[k] + EX[256 + k] + EX[512 + k] + EX[768 + k]; };   // fixed order over the waves
-    // v4d accumulators: every wave parks its 4 doubles per lane at EX[wv][r][lane]; thread (r, ln) sums the four waves
-    auto reduce_v4 = [&](const v4d& a, auto&& index_of) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) EX[wv * 256 + r * 64 + lane] = a[r];
-        __syncthreads();
-        const int r = tid >> 6, ln = tid & 63;
-        row[index_of(r, ln >> 4, ln & 15)] = xsum4(tid);
-    };
-    auto reduce_1 = [&](double a, auto&& index_of, bool quad_first) {
-        if (quad_first) a = quad4_sum(a);
-        __syncthreads();
-        EX[wv * 256 + lane] = a;
-        __syncthreads();
-        if (tid < 64) {
-            const int idx = index_of(tid >> 4, tid & 15);
-            if (idx >= 0) row[idx] = xsum4(tid);
-        }
-    };
-#pragma unroll
-    for (int i = 1; i < L; ++i) {
-        const int wo = g.woff[i];
-        const WideDW<H>& d = dW[i - 1];
-#pragma unroll
-        for (int ti = 0; ti < W::NL; ++ti)
-#pragma unroll
-            for (int to = 0; to < W::NL; ++to)
-                reduce_v4(d.big[ti][to], [&](int r, int qq, int pp) { return wo + (16 * ti + 4 * r + qq) * H + 16 * to + pp; });
-#pragma unroll
-        for (int u = 0; u < W::NR; ++u) {
-#pragma unroll
-            for (int t = 0; t < W::NL; ++t) {
-                reduce_1(d.s10[u][t], [&](int qq, int pp) { return wo + (16 * W::NL + 4 * u + qq) * H + 16 * t + pp; }, false);
-                reduce_1(d.s01[t][u], [&](int qq, int pp) { return wo + (16 * t + pp) * H + 16 * W::NL + 4 * u + qq; }, false);
-            }
-#pragma unroll
-            for (int u2 = 0; u2 < W::NR; ++u2)
-                reduce_1(d.cor[u][u2], [&](int qq, int pp) { return pp < 4 ? wo + (16 * W::NL + 4 * u + qq) * H + 16 * W::NL + 4 * u2 + pp : -1; }, true);
-        }
-    }
-    // per-lane partials: sum over the 16 point lanes of each neuron group, then over the waves -- all of them in one exchange:
-    // wave w parks its (L + D + 1) H + 1 sums at EX[w * NV ..] (4 NV <= 136 H doubles, the size of the transpose region)
-    {
-        constexpr int NV = (L + D + 1) * H + 1;
-        static_assert(WF_WAVES * NV <= WF_WAVES * 2 * W::TR, "vector partials fit the transpose region");
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-#pragma unroll
-            for (int k = 0; k < L + D + 1; ++k) {
-                const double v = k < L ? db[k < L ? k : 0][s] : (k < L + D ? dW1[(k >= L && k - L < D) ? (k - L) : 0][s] : dWo[s]);
-                const double t = row_sum16(v);
-                if (pt == 0) EX[wv * NV + k * H + 4 * s + q] = t;
-            }
-        }
-        {
-            const double t = row_sum16(dbo);
-            if (lane == 0) EX[wv * NV + (L + D + 1) * H] = t;
-        }
-        __syncthreads();
-        for (int f = tid; f < NV; f += WF_BLOCK) {
-            const int k = f / H, j = f - k * H;
-            const int idx = k < L ? g.boff[k] + j : (k < L + D ? g.woff[0] + (k - L) * H + j : (k == L + D ? g.woff[L] + j : g.boff[L]));
-            row[idx] = EX[f] + EX[NV + f] + EX[2 * NV + f] + EX[3 * NV + f];
-        }
-    }
+    wide_epilogue<H, L, D, WF_WAVES>(lds + M::TAB, dW, db, dW1, dWo, dbo, g.GPART + (long)blockIdx.x * g.P, g.woff, g.boff);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -84,6 +84,6 @@ def test_one_dimensional_four_hidden_layers_reference_default_depth():
 
 def test_generic_fallback_warns_once_for_networks_beyond_every_mfma_kernel():
     with pytest.warns(UserWarning, match="generic kernels"):
-        o, m = _pair_2d("poisson2d_small", 1, layers=[2, 72, 72, 1])
+        o, m = _pair_2d("poisson2d_small", 1, layers=[2, 20, 20, 20, 20, 20, 1])     # five hidden layers: deeper than any MFMA kernel (1..4)
     assert m.backend() == "generic"
     _check_loss_grad(o, m)
