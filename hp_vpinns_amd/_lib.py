@@ -432,9 +432,10 @@ class Handle:
         self._h = None
 
     def pass_structure(self):
-        """'separate' | 'fused-reverse' | 'whole-iteration' | 'whole-iteration-split' | 'whole-iteration-tile' | 'whole-iteration-tall' (or None)."""
+        """'separate' | 'fused-reverse' | 'whole-iteration' | 'whole-iteration-split' | 'whole-iteration-tile' | 'whole-iteration-tall' |
+        'whole-iteration-element' (or None)."""
         return {0: "separate", 1: "fused-reverse", 2: "whole-iteration", 3: "whole-iteration-split",
-                4: "whole-iteration-tile", 5: "whole-iteration-tall"}.get(int(self.lib.hpv_pass_structure(self._h)))
+                4: "whole-iteration-tile", 5: "whole-iteration-tall", 6: "whole-iteration-element"}.get(int(self.lib.hpv_pass_structure(self._h)))
 
     def graphs_in_use(self):
         """hpv_step replays captured iteration graphs (False: eager launches, e.g. a collective that refused stream capture)."""

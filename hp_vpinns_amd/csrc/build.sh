@@ -9,6 +9,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $HPV_EXTRA_FLAGS"   # e.g. HPV_EXTRA_FLAGS=-DHPV_FZ_TIMING
 SRCS="kernels_generic kernels_mfma kernels_fused kernels_tall kernels_tile kernels_project hpv_api"
+ELEM_SHAPES="16,16,8,8 20,20,10,10 12,12,6,6"             # kernels_elem.hip: one object per element shape (= HPV_ELEM_SHAPES of hpv_mfma_dev.h)
 WIDE_WIDTHS="24 32 40 48 64"                            # kernels_wide.hip: one object per hidden width (= HPV_WIDE_WIDTHS of hpv_mfma.h)
 HOOKED="kernels_mfma kernels_fused kernels_tall hpv_api"        # the sources that contain test hooks (built twice)
 CHK="python3 ../../scripts/check_agpr.py"
@@ -94,6 +95,13 @@ for w in $WIDE_WIDTHS; do
     $HIPCC $FLAGS -DHPV_WIDE_H=$w -c kernels_wide.hip -o kernels_wide_$w.o & pids+=($!); names+=(kernels_wide_$w.o)
   fi
 done
+for sh in $ELEM_SHAPES; do
+  IFS=, read qx qy ntx nty <<< "$sh"
+  o=kernels_elem_${qx}_${qy}_${ntx}_${nty}.o
+  if stale $o kernels_elem.hip; then
+    $HIPCC $FLAGS -DHPV_ELEM_QX=$qx -DHPV_ELEM_QY=$qy -DHPV_ELEM_NTX=$ntx -DHPV_ELEM_NTY=$nty -c kernels_elem.hip -o $o & pids+=($!); names+=($o)
+  fi
+done
 fail=0
 for i in "${!pids[@]}"; do
   if ! wait ${pids[$i]}; then echo "build.sh: ERROR -- ${names[$i]} failed" >&2; rm -f ${names[$i]}; fail=1; fi
@@ -107,6 +115,7 @@ for f in $SRCS; do
   case " $HOOKED " in *" $f "*) TOBJS="$TOBJS $f.th.o";; *) TOBJS="$TOBJS $f.o";; esac
 done
 for w in $WIDE_WIDTHS; do OBJS="$OBJS kernels_wide_$w.o"; TOBJS="$TOBJS kernels_wide_$w.o"; done
+for sh in $ELEM_SHAPES; do o=kernels_elem_${sh//,/_}.o; OBJS="$OBJS $o"; TOBJS="$TOBJS $o"; done
 # -Bsymbolic: the two libraries may live in one process (the tests load both); each must bind its internal calls to itself
 $HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o ../libhpvpinn.so $OBJS
 $HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o ../libhpvpinn_testhooks.so $TOBJS

@@ -456,6 +456,10 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
                                             h->merged ? &fin : nullptr, &fin_done);
                 if (ifused) h->pass_structure = 4;
             }
+            if (!ifused) {   // any other instantiated element shape / 2-D channel set: the generic element-resident kernel (kernels_elem.hip)
+                ifused = hpv_mfma_iter_elem(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
+                if (ifused) h->pass_structure = 6;
+            }
             if (!ifused) {   // few tall elements (AdvDiff, 80x80 rule): many workgroups per element, partial sums exchanged (kernels_tall.hip)
                 const int ts = hpv_mfma_tall_split(h->mfma, h->pd, h->n_elem);
                 if (ts > 1 && h->n_elem * ts <= h->n_red_alloc &&

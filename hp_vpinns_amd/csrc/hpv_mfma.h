@@ -51,6 +51,10 @@ struct MfmaFinalize {
 bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
                         const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem, const MfmaFinalize* fin = nullptr,
                         bool* fin_done = nullptr);
+// The same for ANY instantiated tensor-product element shape and 2-D channel set (kernels_elem.hip): several tiles per wave, s of
+// every tile in registers, tangents recomputed in the reverse phase.
+bool hpv_mfma_iter_elem(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
+                        const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem);
 // Split whole-iteration kernels (SPLIT mode of k_iter_fused, k_iter_tall): the handle's sticky failure flag (device int, owned
 // by the caller) that a timed-out exchange sets; without one those modes are not used.  hpv_mfma_split_used: such a launch
 // happened since creation.

@@ -181,3 +181,10 @@ __device__ __forceinline__ double row_sum16(double v) {
     return v;
 }
 
+
+// kernels_elem.hip: the generic element-resident whole-iteration kernel, one translation unit per element shape
+// (= ELEM_SHAPES of csrc/build.sh); false: that (H, channel set, depth) is not instantiated or its LDS does not fit
+#define HPV_ELEM_SHAPES(X) X(16, 16, 8, 8) X(20, 20, 10, 10) X(12, 12, 6, 6)
+#define HPV_ELEM_DECL(qx, qy, ntx, nty) bool hpv_elem_launch_##qx##qy##_##ntx##_##nty(int H, int key, int L, const MfmaArgs& a, int blocks, hipStream_t s);
+HPV_ELEM_SHAPES(HPV_ELEM_DECL)
+#undef HPV_ELEM_DECL

@@ -53,7 +53,8 @@ __device__ __forceinline__ void wide_stage_layer(const double* __restrict__ th, 
 
 // z^T = W^T h^T for C channels (+ bias on the value channel): `frag` = this layer's forward fragments, `bias` = the layer's
 // bias vector in LDS (compact, [H]; a lane reads b[4 s + q]: four addresses per instruction, broadcast, conflict-free).
-template <int H, int C>
+// BIAS = false: no channel takes a bias (the tangent channels alone: the recompute of the element-resident kernel).
+template <int H, int C, bool BIAS = true>
 __device__ __forceinline__ void wide_fwd_layer(const double* frag, const double* bias, int lofs,
                                                const double (&h)[C][WD<H>::KS], double (&z)[C][WD<H>::KS]) {
     using W = WD<H>;
@@ -63,7 +64,7 @@ __device__ __forceinline__ void wide_fwd_layer(const double* frag, const double*
         v4d acc[C];
 #pragma unroll
         for (int ch = 0; ch < C; ++ch)
-            acc[ch] = ch == 0 ? v4d{bias[16 * t + q], bias[16 * t + 4 + q], bias[16 * t + 8 + q], bias[16 * t + 12 + q]} : v4d{0.0, 0.0, 0.0, 0.0};
+            acc[ch] = (BIAS && ch == 0) ? v4d{bias[16 * t + q], bias[16 * t + 4 + q], bias[16 * t + 8 + q], bias[16 * t + 12 + q]} : v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < W::KS; ++s) {
             const double a = frag[(t * W::KS + s) * 64 + lofs];
@@ -80,7 +81,7 @@ __device__ __forceinline__ void wide_fwd_layer(const double* frag, const double*
         const double* wr = frag + W::NL * W::KS * 64 + u * W::KS * 16 + q * 4 + (lofs & 3);
         double zz[C];
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) zz[ch] = ch == 0 ? bias[16 * W::NL + 4 * u + q] : 0.0;
+        for (int ch = 0; ch < C; ++ch) zz[ch] = (BIAS && ch == 0) ? bias[16 * W::NL + 4 * u + q] : 0.0;
 #pragma unroll
         for (int s = 0; s < W::KS; ++s) {
             const double a = wr[s * 16];

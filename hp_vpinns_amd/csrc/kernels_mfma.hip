@@ -861,6 +861,50 @@ void hpv_mfma_backward(HpvMfma* m, const double* theta, const double* X, const d
     if (rows) *rows = hpv_mfma_grad_rows(m);
 }
 
+// Whole training pass of a shard of elements of any instantiated shape in one launch (kernels_elem.hip).  Returns false when the
+// shape / channel set / width / layout is not covered; the caller then runs the separate kernels.
+bool hpv_mfma_iter_elem(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
+                        const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem) {
+    const ProjDesc& pd = pa.pd;
+    const NetDesc& nd = m->nd;
+    if (!m->iter_fused_ok || pd.edge || pd.nact || n_elem <= 0 || m->L < 2 || m->L > 3 || nd.d != 2 || nd.act != HPV_ACT_TANH) return false;
+    const int key = nd.d * 100 + nd.nT1 * 10 + nd.nT2;
+    const int nq = pd.qx * pd.qy, tpe = (nq + 15) / 16, tpw = (tpe + 3) / 4, slots = 4 * tpw, nfree = slots - tpe;
+    // batch layout [element points | pad to 16 | data points]
+    const long npad = ((long)n_elem * nq + 15) / 16 * 16;
+    const bool has_data = dt && dt->n_data > 0;
+    if (has_data ? (dt->data_off != npad || m->N != npad + dt->n_data) : (m->N != npad && m->N != n_elem * nq)) return false;
+    const long n_dt = has_data ? (dt->n_data + 15) / 16 : 0;
+    const long left = n_dt - n_elem * nfree;
+    const long blocks = n_elem + (left > 0 ? (left + slots - 1) / slots : 0);
+    if (blocks > hpv_mfma_grad_rows(m) && blocks > m->max_rows) return false;
+    MfmaArgs a = m->base;
+    a.theta = theta; a.X = X; a.GPART = GPART;
+    a.OUT = const_cast<double*>(pa.OUT);
+    a.data_off = -1;
+    if (has_data) {
+        a.data_off = dt->data_off; a.ud = dt->ud; a.gbar0 = dt->gbar0; a.data_part = dt->data_part;
+        a.data_scale = dt->scale; a.data_write_gbar = dt->write_gbar;
+    }
+    a.proj_n_elem = n_elem;
+    a.proj_split = 1;
+    a.pa = pa;
+    bool ok = false, known = false;
+#define HPV_ELEM_TRY(A_, B_, C_, D_)                                                           \
+    if (!known && pd.qx == A_ && pd.qy == B_ && pd.ntx == C_ && pd.nty == D_) {                 \
+        known = true;                                                                          \
+        ok = hpv_elem_launch_##A_##B_##_##C_##_##D_(m->H, key, m->L, a, (int)blocks, s);         \
+    }
+    HPV_ELEM_SHAPES(HPV_ELEM_TRY)
+#undef HPV_ELEM_TRY
+    if (!ok) return false;
+    m->last_split = false;
+    snprintf(m->variant, sizeof m->variant, "k_iter_elem<D=2,NT1=%d,NT2=%d,tanh,L=%d,H=%d,%dx%d/%dx%d,waves=4,tiles/wave=%d>", nd.nT1, nd.nT2,
+             m->L, m->H, pd.qx, pd.qy, pd.ntx, pd.nty, tpw);
+    if (rows) *rows = (int)blocks;
+    return true;
+}
+
 // Reverse pass with the per-element projection fused in front (element-block mode).  Returns false when not
 // applicable; the caller then launches projection and reverse pass separately.
 bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, const double* GBAR, double* GPART, int* rows,

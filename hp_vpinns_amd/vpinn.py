@@ -194,7 +194,8 @@ class _VPINNBase:
     def _finish(self):
         self.h.set_params(self._to_dev(self._init_params))
         self.h.backend_in_use()   # assembles the device batches; raises if a requested backend is unavailable
-        if self.backend() == "generic" and self._handle_args[1]["backend"] == _lib.BACKEND_AUTO and self.rank == 0:
+        if (self.backend() == "generic" and self._handle_args[1]["backend"] == _lib.BACKEND_AUTO and self.rank == 0
+                and self._handle_args[1]["scheme"] == _lib.SCHEME_VPINN):     # (the PINN branch picks its kernels at the first pass)
             import warnings
             warnings.warn(f"hp_vpinns_amd: layers {self.layers} are not covered by the MFMA kernels; this model runs on the "
                           "generic kernels, which are one to two orders of magnitude slower (see README.md, 'network shapes')")

@@ -196,7 +196,8 @@ int hpv_backend_in_use(hpv_handle h);                       /* HPV_BACKEND_GENER
  * exercise is the one that ran): 0 separate forward / projection / reverse launches, 1 forward + projection-fused reverse,
  * 2 element-resident whole-iteration kernel (20x20 / 10x10 Poisson-2D var_form 1), 3 the same in SPLIT mode (small shards),
  * 4 whole-iteration tile kernel (small elements of the other channel sets), 5 whole-iteration kernel for few tall elements
- * (80x80 points: many workgroups per element exchange partial residual sums); -1 before the first such pass. */
+ * (80x80 points: many workgroups per element exchange partial residual sums), 6 the generic element-resident whole-iteration
+ * kernel (any instantiated tensor-product element shape, e.g. 16x16 / 8x8; several tiles per wave); -1 before the first such pass. */
 int hpv_pass_structure(hpv_handle h);
 /* The kernel INSTANTIATION(s) of that pass by name, e.g. "k_iter_fused<L=3,SPLIT=false,QT=true>" (quarter-tile plan) vs
  * "k_iter_fused<L=3,SPLIT=false,QT=false>" (7/6/6/6 whole tiles: HPV_NO_QUARTER_TILE=1, or the build's AGPR guard tripped),
