@@ -383,7 +383,7 @@ static bool launch_iter_elem_key(int key, int L, const MfmaArgs& a, int blocks, 
 #if !defined(HPV_ELEM_QX) || !defined(HPV_ELEM_QY) || !defined(HPV_ELEM_NTX) || !defined(HPV_ELEM_NTY)
 #error "compile with -DHPV_ELEM_QX= -DHPV_ELEM_QY= -DHPV_ELEM_NTX= -DHPV_ELEM_NTY= (csrc/build.sh)"
 #endif
-#define EL_CAT5_(a, b, c, d, e) a##b##_##c##_##d##_##e
+#define EL_CAT5_(a, b, c, d, e) a##b##c##_##d##_##e
 #define EL_CAT5(a, b, c, d, e) EL_CAT5_(a, b, c, d, e)
 bool EL_CAT5(hpv_elem_launch_, HPV_ELEM_QX, HPV_ELEM_QY, HPV_ELEM_NTX, HPV_ELEM_NTY)(int H, int key, int L, const MfmaArgs& a, int blocks, hipStream_t s) {
     if (H == 20) return launch_iter_elem_key<20, HPV_ELEM_QX, HPV_ELEM_QY, HPV_ELEM_NTX, HPV_ELEM_NTY>(key, L, a, blocks, s);

@@ -11,6 +11,8 @@
 // HBM traffic per element = read the integrated channels + F, write the adjoint channels + R (channels no
 // term uses are neither read nor written; their GBAR rows are zeroed once by the host).  This is the kernel
 // judged against the HBM roofline on the scaled synthetic batch.
+#include <cstdlib>
+
 #include "hpv_internal.h"
 #include "hpv_project_wg.h"
 
@@ -27,6 +29,30 @@
 //              U[k][r] += m c sum_i AX[r][i] T[k][i]   (lane = k)
 //   adjoint :  V[k][i]  = sum_r AX[r][i] Rs[k][r]      (lane = k)     ->LDS->
 //              Gh[j][i] = c sum_k BY[k][j] V[k][i]     (lane = i)     -> coalesced stores
+// The one-hot streaming instantiation exists in two plans (A/B at run time: HPV_PJ_PIPE=0 selects the first):
+//   8 waves per workgroup, 4 waves per SIMD (124 VGPRs), a term's channel column loaded when the term starts;
+//   PIPE: 4 waves per workgroup, 3 workgroups per CU (168 VGPRs), the column of the NEXT term / next element group requested
+//         while this one's contractions run -- a column of loads in flight per wave all the time instead of load -> wait -> compute.
+// HPV_PJ_NT (compile time, scripts/build_variant.sh <name> -DHPV_PJ_NT=0): the streamed channel columns are read, and R
+// written, with non-temporal hints (each byte is touched once).
+#ifndef HPV_PJ_NT
+#define HPV_PJ_NT 1
+#endif
+__device__ __forceinline__ double pj_stream_load(const double* p) {
+#if HPV_PJ_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void pj_stream_store(double* p, double v) {
+#if HPV_PJ_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 struct ActiveCh {
     int n;                      // number of channels some term integrates
     int id[HPV_MAXC];           // their channel indices
@@ -38,8 +64,8 @@ struct ActiveCh {
 // channel column of a term is loaded when the term starts (124 VGPRs, 4 waves per SIMD, 2 x 63.6 KB LDS per CU):
 // measured 3.6 TB/s against 3.15 TB/s for the 202-VGPR / 2-waves-per-SIMD general variant on the 2^18-element batch
 // (5 waves per SIMD spills: 2.5 TB/s).
-template <int QX, int QY, int NTX, int NTY, int NA, bool EPS, int PJ_WAVES, bool OH = false>
-__global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : 1) k_project_tp(ProjDesc pd, ActiveCh ac, const double* __restrict__ OUT,
+template <int QX, int QY, int NTX, int NTY, int NA, bool EPS, int PJ_WAVES, bool OH = false, bool PIPE = false>
+__global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PIPE ? 3 : 1)) k_project_tp(ProjDesc pd, ActiveCh ac, const double* __restrict__ OUT,
                                                         double* __restrict__ GBAR, double* __restrict__ R,
                                                         const double* __restrict__ F, const double* __restrict__ coef,
                                                         long coef_stride, const double* __restrict__ wtx,
@@ -102,7 +128,20 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : 1) 
     const double sc = 2.0 / (double)NR;
 
     const long ngroups = (n_elem + EPW - 1) / EPW;
-    for (long grp = (long)blockIdx.x * PJ_WAVES + wv; grp < ngroups; grp += (long)gridDim.x * PJ_WAVES) {
+    constexpr bool LATE = OH && PJ_WAVES == 8;   // 4 waves/SIMD (124 VGPRs): the other waves hide the per-term round trip
+    static_assert(!PIPE || OH, "the pipelined plan is written for the one-hot term / channel structure");
+    const long gstride = (long)gridDim.x * PJ_WAVES;
+    // PIPE: `nxt` always holds the column the NEXT (term, group) step consumes; its loads were issued one step earlier
+    double nxt[PIPE ? QY : 1];
+    auto request = [&](long grp_, int t_) {
+        const long e_ = grp_ * EPW + slot;
+        const bool c_ = lane_ok && e_ < n_elem && li < QX && grp_ < ngroups;
+        const double* __restrict__ p_ = OUT + (c_ ? e_ : 0) * NQ + li + (long)ac.id[t_] * N;
+#pragma unroll
+        for (int j = 0; j < QY; ++j) nxt[PIPE ? j : 0] = c_ ? pj_stream_load(p_ + j * QX) : 0.0;
+    };
+    if constexpr (PIPE) request((long)blockIdx.x * PJ_WAVES + wv, 0);
+    for (long grp = (long)blockIdx.x * PJ_WAVES + wv; grp < ngroups; grp += gstride) {
         const long e = grp * EPW + slot;
         const bool ev = lane_ok && e < n_elem;
         const bool col = ev && li < QX;     // this lane owns quadrature column i = li
@@ -113,7 +152,6 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : 1) 
         double u[NTX];
 #pragma unroll
         for (int r = 0; r < NTX; ++r) u[r] = (row && F) ? -F[e * NR + li * NTX + r] : 0.0;
-        constexpr bool LATE = OH && PJ_WAVES == 8;   // 4 waves/SIMD (124 VGPRs): the other waves hide the per-term round trip
         double o[NA][QY];
         if constexpr (!LATE) {
 #pragma unroll
@@ -138,7 +176,11 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : 1) 
             double alpha_t = 1.0;
             if constexpr (OH) {
                 alpha_t = td.a0[ac.id[t]] + eps * td.a1[ac.id[t]];
-                if constexpr (LATE) {
+                if constexpr (PIPE) {
+#pragma unroll
+                    for (int j = 0; j < QY; ++j) gcol[j] = nxt[PIPE ? j : 0];
+                    if (t + 1 < NA) request(grp, t + 1); else request(grp + gstride, 0);     // in flight during this term's contractions
+                } else if constexpr (LATE) {
 #pragma unroll
                     for (int j = 0; j < QY; ++j) gcol[j] = col ? Oe[(long)ac.id[t] * N + j * QX] : 0.0;
                 } else {
@@ -192,7 +234,7 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : 1) 
         if (row) {
 #pragma unroll
             for (int r = 0; r < NTX; ++r) {
-                R[e * NR + li * NTX + r] = u[r];
+                if constexpr (OH) pj_stream_store(R + e * NR + li * NTX + r, u[r]); else R[e * NR + li * NTX + r] = u[r];
                 sq = fma(u[r], u[r], sq);
                 u[r] *= sc;
             }
@@ -290,7 +332,7 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : 1) 
     }
 }
 
-template <int QX, int QY, int NTX, int NTY, int NA, bool EPS, int PJ_WAVES, bool OH = false>
+template <int QX, int QY, int NTX, int NTY, int NA, bool EPS, int PJ_WAVES, bool OH = false, bool PIPE = false>
 static void launch_tp3(const ProjDesc& pd, const ActiveCh& ac, const double* OUT, double* GBAR, double* R, const double* F,
                        const double* coef, long coef_stride, const double* wtx, const double* wty, const double* eps_ptr,
                        double* loss_e, double* deps_e, long N, long n_elem, int do_adjoint, long ngroups, hipStream_t s) {
@@ -303,12 +345,12 @@ static void launch_tp3(const ProjDesc& pd, const ActiveCh& ac, const double* OUT
     if (lds > 65536) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)k_project_tp<QX, QY, NTX, NTY, NA, EPS, PJ_WAVES, OH>,
+            (void)hipFuncSetAttribute((const void*)k_project_tp<QX, QY, NTX, NTY, NA, EPS, PJ_WAVES, OH, PIPE>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((k_project_tp<QX, QY, NTX, NTY, NA, EPS, PJ_WAVES, OH>), dim3((unsigned)blocks), dim3(PJ_WAVES * 64), lds, s,
+    hipLaunchKernelGGL((k_project_tp<QX, QY, NTX, NTY, NA, EPS, PJ_WAVES, OH, PIPE>), dim3((unsigned)blocks), dim3(PJ_WAVES * 64), lds, s,
                        pd, ac, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, N, n_elem, do_adjoint);
 }
 
@@ -327,16 +369,19 @@ static bool launch_tp2(const ProjDesc& pd, const ActiveCh& ac, const double* OUT
     for (int t = 0; t < pd.nterms && onehot; ++t)
         for (int a = 0; a < NA; ++a)
             if (a != t && (pd.t[t].a0[ac.id[a]] != 0.0 || pd.t[t].a1[ac.id[a]] != 0.0)) onehot = false;
-#define HPV_GO(W_, OH_)                                                                                                  \
-    launch_tp3<QX, QY, NTX, NTY, NA, EPS, W_, OH_>(pd, ac, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, \
-                                                   N, n_elem, do_adjoint, ngroups, s)
+#define HPV_GO(W_, OH_, PIPE_)                                                                                           \
+    launch_tp3<QX, QY, NTX, NTY, NA, EPS, W_, OH_, PIPE_>(pd, ac, OUT, GBAR, R, F, coef, coef_stride, wtx, wty, eps_ptr, loss_e, deps_e, \
+                                                          N, n_elem, do_adjoint, ngroups, s)
     if constexpr (!EPS && NA >= 2) {
         if (onehot) {
-            if (ngroups <= 1024) HPV_GO(1, true); else HPV_GO(8, true);
+            static const bool no_pipe = getenv("HPV_PJ_PIPE") && getenv("HPV_PJ_PIPE")[0] == '0';     // (A/B switch)
+            if (ngroups <= 1024) HPV_GO(1, true, false);
+            else if (no_pipe) HPV_GO(8, true, false);
+            else HPV_GO(4, true, true);
             return true;
         }
     }
-    if (ngroups <= 1024) HPV_GO(1, false); else HPV_GO(4, false);
+    if (ngroups <= 1024) HPV_GO(1, false, false); else HPV_GO(4, false, false);
 #undef HPV_GO
     return true;
 }
