@@ -29,10 +29,13 @@
 //              U[k][r] += m c sum_i AX[r][i] T[k][i]   (lane = k)
 //   adjoint :  V[k][i]  = sum_r AX[r][i] Rs[k][r]      (lane = k)     ->LDS->
 //              Gh[j][i] = c sum_k BY[k][j] V[k][i]     (lane = i)     -> coalesced stores
-// The one-hot streaming instantiation exists in two plans (A/B at run time: HPV_PJ_PIPE=0 selects the first):
-//   8 waves per workgroup, 4 waves per SIMD (124 VGPRs), a term's channel column loaded when the term starts;
-//   PIPE: 4 waves per workgroup, 3 workgroups per CU (168 VGPRs), the column of the NEXT term / next element group requested
-//         while this one's contractions run -- a column of loads in flight per wave all the time instead of load -> wait -> compute.
+// The one-hot streaming instantiation exists in two plans (A/B at run time: HPV_PJ_PIPE=1 selects the second):
+//   default: 8 waves per workgroup, 4 waves per SIMD (126 VGPRs), a term's channel column loaded when the term starts;
+//   PIPE:    4 waves per workgroup, 3 workgroups per CU (168 VGPRs), the column of the NEXT term / next element group requested
+//            while this one's contractions run.  Measured SLOWER on the 2^18-element batch (round 4: 2.99-3.05 TB/s against
+//            3.48-3.50): at 168 registers the kernel spills 8 doubles, scratch reloads count in vmcnt like every vector load,
+//            so each reload waits for the whole prefetch (s_waitcnt vmcnt(0) in the middle of the contractions) -- the overlap
+//            the plan exists for does not happen, and three waves per SIMD hide less than four.  Kept for A/B runs.
 // HPV_PJ_NT (compile time, scripts/build_variant.sh <name> -DHPV_PJ_NT=0): the streamed channel columns are read, and R
 // written, with non-temporal hints (each byte is touched once).
 #ifndef HPV_PJ_NT
@@ -152,6 +155,11 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PI
         double u[NTX];
 #pragma unroll
         for (int r = 0; r < NTX; ++r) u[r] = (row && F) ? -F[e * NR + li * NTX + r] : 0.0;
+        // the term coefficients are requested HERE, ahead of any prefetch of the next column: vector loads return in order, and a
+        // wait for a coefficient issued behind the prefetch (s_waitcnt vmcnt(0)) would wait for the prefetch as well
+        double cf[OH ? NA : HPV_MAXT];
+#pragma unroll
+        for (int t = 0; t < (OH ? NA : HPV_MAXT); ++t) cf[t] = (ev && (OH || t < nterms)) ? coef[(long)t * coef_stride + e] : 0.0;
         double o[NA][QY];
         if constexpr (!LATE) {
 #pragma unroll
@@ -215,7 +223,7 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PI
             // (c) x-contraction, lane = residual row k
             if (row) {
                 const double* axt = AXT + td.dx * (NTX * QX);
-                const double c = coef[(long)t * coef_stride + e] * (td.eps_mult ? eps : 1.0) * alpha_t;
+                const double c = cf[t] * (td.eps_mult ? eps : 1.0) * alpha_t;
                 double trow[QX], acc[NTX];
 #pragma unroll
                 for (int i = 0; i < QX; ++i) trow[i] = Tb[slot * (NTY * LDT) + li * LDT + i];
@@ -272,7 +280,7 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PI
             // (e) Gh[j][i] = c sum_k BY[k][j] V[k][i], lane = column i; scattered onto the integrated channels
             if (col) {
                 const double* by = BYs + td.dy * (NTY * QY);
-                const double c = coef[(long)t * coef_stride + e];
+                const double c = cf[t];
                 const double m = td.eps_mult ? eps : 1.0;
                 double vcol[NTY], gh[QY];
 #pragma unroll
@@ -374,9 +382,9 @@ static bool launch_tp2(const ProjDesc& pd, const ActiveCh& ac, const double* OUT
                                                           N, n_elem, do_adjoint, ngroups, s)
     if constexpr (!EPS && NA >= 2) {
         if (onehot) {
-            static const bool no_pipe = getenv("HPV_PJ_PIPE") && getenv("HPV_PJ_PIPE")[0] == '0';     // (A/B switch)
+            static const bool pipe = getenv("HPV_PJ_PIPE") && getenv("HPV_PJ_PIPE")[0] == '1';     // (A/B switch)
             if (ngroups <= 1024) HPV_GO(1, true, false);
-            else if (no_pipe) HPV_GO(8, true, false);
+            else if (!pipe) HPV_GO(8, true, false);
             else HPV_GO(4, true, true);
             return true;
         }

@@ -35,9 +35,13 @@ def test_config4_reaches_1e_2_relative_l2():
         losses.append(l)
         if l < best:
             best, best_theta = l, m.get_params()
+    # the LAST iterate is asserted too (advisor, round 3: keep a like-for-like figure next to the best-checkpoint one): a plain
+    # run's final parameters are within 2x of the best checkpoint's bar at this length (5e-3 .. 1.6e-2 from 25 000 on)
+    err_last = m.rel_l2_error(s["X_test"], s["u_test"])
+    assert err_last <= 2e-2, (err_last, losses)
     m.set_params(best_theta)
     err = m.rel_l2_error(s["X_test"], s["u_test"])
-    assert err <= 1e-2, (err, losses)
+    assert err <= 1e-2, (err, err_last, losses)
     assert best < 2e-4 * l0 and np.median(losses) < 1e-3 * l0, (best / l0, losses)
 
 
