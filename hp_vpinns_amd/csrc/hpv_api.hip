@@ -335,7 +335,7 @@ int assemble_batches(hpv_ctx* h) {
             hpv_mfma_set_split_ok(h->mfma, h->shared_elem_ok);
             if ((rc = alloc_batch(h, h->var, h->nd_var, Ntot, true))) return rc;
             if (h->var.ACT) { (void)hipFree(h->var.ACT); h->var.ACT = nullptr; }   // the MFMA path has its own store
-            const int rows = hpv_mfma_max_rows(h->mfma, h->n_elem);
+            const int rows = hpv_mfma_max_rows(h->mfma, h->n_elem, (nd + 15) / 16);
             if ((rc = dalloc(h, &h->var.GPART, (size_t)rows * h->P))) return rc;
             h->var.rows = hpv_mfma_grad_rows(h->mfma);
             std::vector<double> X((size_t)d * Ntot, 0.0);
@@ -445,8 +445,14 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
         bool ifused = false;
         if (backward && use_mfma) {
             tstart(h, 2);
-            ifused = hpv_mfma_iter_fused(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
-            if (ifused) h->pass_structure = hpv_mfma_sync_failed_possible(h->mfma) ? 3 : 2;
+            if (hpv_mfma_prefers_elem(h->mfma)) {      // HPV_FUSE=e (A/B runs): the generic element-resident kernel first
+                ifused = hpv_mfma_iter_elem(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
+                if (ifused) h->pass_structure = 6;
+            }
+            if (!ifused) {
+                ifused = hpv_mfma_iter_fused(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
+                if (ifused) h->pass_structure = hpv_mfma_sync_failed_possible(h->mfma) ? 3 : 2;
+            }
             if (!ifused) {   // small elements of the other channel sets (1-D, AdvDiff, var_form 0): kernels_tile.hip
                 // (a one-workgroup grid finishes the iteration itself: packed buffer, Adam, loss history)
                 MfmaFinalize fin{adam_args(h), h->d_RB, h->cfg.lossb_weight, h->n_data, (h->n_data + 15) / 16, h->has_eps,

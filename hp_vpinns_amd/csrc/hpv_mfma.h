@@ -72,9 +72,10 @@ bool hpv_mfma_iter_tall(HpvMfma* m, const double* theta, const double* X, double
 // Names of the kernel instantiations (hpv_kernel_variant): which = 0 the whole-iteration kernel most recently launched, 1 the
 // separate forward kernel, 2 the separate reverse kernel, 3 the reverse kernel with the projection fused in
 const char* hpv_mfma_variant(HpvMfma* m, int which);
+bool hpv_mfma_prefers_elem(HpvMfma* m);             // HPV_FUSE=e: the generic element-resident kernel before the hand-tuned ones
 unsigned int* hpv_mfma_xiter(HpvMfma* m);         // launch counter of the tagged exchange (advanced by k_finalize behind a shared-element launch)
 // "ok" | "no-quarter-tile" (AGPR guard tripped in the QT instantiation) | "absent" (guard tripped: kernel compiled out)
 const char* hpv_fused_build_state();
 const char* hpv_tall_build_state();
 bool hpv_mfma_sync_failed_possible(HpvMfma* m);   // the last whole-iteration launch ran in SPLIT mode
-int hpv_mfma_max_rows(HpvMfma* m, long n_elem);
+int hpv_mfma_max_rows(HpvMfma* m, long n_elem, long n_data_tiles = 0);

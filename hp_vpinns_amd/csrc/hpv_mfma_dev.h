@@ -50,6 +50,7 @@ struct MfmaArgs {
     unsigned int* xiter;         // launches so far: the tag of a launch is *xiter + 1; workgroup 0 advances it at its end
     // single-workgroup grids (the reference's own 1-element 1-D default, BASELINE config 1): the whole-iteration tile kernel
     // finishes the iteration itself -- packed buffer, TF1 Adam, loss history -- instead of a dependent k_finalize launch
+    int elem_waves;       // k_iter_elem: wavefronts per workgroup (4 or 8; kernels_elem.hip)
     int tall_qt;          // k_iter_tall: the quarter-tile plan (every workgroup's tile count is 0 or 1 mod 4, see kernels_tall.hip)
     int fin_mode;         // 0: k_finalize follows; 1: packed buffer only; 2: packed buffer + Adam update
     AdamArgs fin_ad;
@@ -88,6 +89,8 @@ struct HpvMfma {
     bool fuse_bwd = true, iter_fused_ok = true, iter_fused_force = false;
     // 's' keeps small shards on the forward + split reverse kernels (the whole-iteration kernel's split mode off)
     bool iter_split_ok = true;
+    // 'e' tries the generic element-resident kernel (kernels_elem.hip) BEFORE the hand-tuned whole-iteration kernels (A/B runs, tests)
+    bool prefer_elem = false;
     int* xerr = nullptr;                   // NOT owned: the handle's sticky failure flag (hpv_mfma_set_err_flag)
     int xdebug_skip = 0;
     unsigned long long* xg = nullptr;      // tagged-exchange granules (owned)

@@ -342,10 +342,10 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_elem(MfmaArgs g) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-#define EL_WAVES 4
-
-template <int D, int NT1, int NT2, int ACT, int L, int H, int QX, int QY, int NTX, int NTY>
-static bool launch_iter_elem(const MfmaArgs& a, int blocks, hipStream_t s) {
+// Wavefronts per workgroup: 4 (one per SIMD, 512 registers each) or 8 (two per SIMD, 256 registers each: half the tiles per wave,
+// the two waves of a SIMD cover each other's LDS / MFMA-result latencies).  HPV_ELEM_WAVES=4|8 forces one for A/B runs.
+template <int D, int NT1, int NT2, int ACT, int L, int H, int QX, int QY, int NTX, int NTY, int EL_WAVES>
+static bool launch_iter_elem_w(const MfmaArgs& a, int blocks, hipStream_t s) {
     using M = ElLds<D, NT1, NT2, L, H, QX, QY, NTX, NTY, EL_WAVES>;
     constexpr size_t bytes = (size_t)M::TOTAL * sizeof(double);
     if (bytes > 160 * 1024) return false;
@@ -360,6 +360,14 @@ static bool launch_iter_elem(const MfmaArgs& a, int blocks, hipStream_t s) {
     }
     hipLaunchKernelGGL((k_iter_elem<D, NT1, NT2, ACT, L, H, QX, QY, NTX, NTY, EL_WAVES>), dim3(blocks), dim3(EL_WAVES * 64), bytes, s, a);
     return true;
+}
+template <int D, int NT1, int NT2, int ACT, int L, int H, int QX, int QY, int NTX, int NTY>
+static bool launch_iter_elem(const MfmaArgs& a, int blocks, hipStream_t s) {
+    constexpr int TPE = (QX * QY + 15) / 16;
+    if constexpr (H <= 24 && TPE >= 8) {      // (wider layers need more than 256 registers per wave in the reverse phase)
+        if (a.elem_waves == 8) return launch_iter_elem_w<D, NT1, NT2, ACT, L, H, QX, QY, NTX, NTY, 8>(a, blocks, s);
+    }
+    return launch_iter_elem_w<D, NT1, NT2, ACT, L, H, QX, QY, NTX, NTY, 4>(a, blocks, s);
 }
 
 template <int H, int QX, int QY, int NTX, int NTY>

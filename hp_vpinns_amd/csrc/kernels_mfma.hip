@@ -796,6 +796,7 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
         m->iter_fused_ok = !(e && (e[0] == 'n' || e[0] == 'b'));
         m->iter_fused_force = e && e[0] == 'i';
         m->iter_split_ok = !(e && e[0] == 's');
+        m->prefer_elem = e && e[0] == 'e';
     }
     MfmaArgs& a = m->base;
     a = MfmaArgs{};
@@ -819,6 +820,7 @@ const char* hpv_mfma_variant(HpvMfma* m, int which) {
     return which == 0 ? m->variant : (which == 1 ? m->vfwd : (which == 2 ? m->vbwd : m->vbwd_fused));
 }
 unsigned int* hpv_mfma_xiter(HpvMfma* m) { return m ? m->xiter : nullptr; }
+bool hpv_mfma_prefers_elem(HpvMfma* m) { return m && m->prefer_elem; }
 double* hpv_mfma_activation_store(HpvMfma* m) { return m ? m->ACTS : nullptr; }
 size_t hpv_mfma_activation_store_doubles(HpvMfma* m) { return m && m->ACTS ? (size_t)m->ntiles * m->L * m->ns * m->ks * 64 : 0; }   // (the timing builds park their stamps there)
 // Workgroups per element of the fused reverse kernel: one when the shard has an element for every CU, more for the
@@ -829,8 +831,10 @@ static int fused_split(HpvMfma* m, long n_elem) {
     return split;
 }
 // rows the caller must allocate: the element-block mode writes one row per workgroup
-int hpv_mfma_max_rows(HpvMfma* m, long n_elem) {
+int hpv_mfma_max_rows(HpvMfma* m, long n_elem, long n_data_tiles) {
     int r = hpv_mfma_grad_rows(m);
+    // kernels_elem.hip: one row per element plus one per 8 .. 16 boundary / data tiles no element wave has a free slot for
+    if (n_elem + n_data_tiles / 8 + 2 > r && n_elem <= 65536) r = (int)(n_elem + n_data_tiles / 8 + 2);
     const long fused_rows = n_elem * fused_split(m, n_elem);
     if (m->bwd_fused && fused_rows > r && fused_rows <= 65536) r = (int)fused_rows;
     if (n_elem > r && n_elem <= 65536) r = (int)n_elem;      // the whole-iteration kernel writes one row per element
@@ -869,7 +873,22 @@ bool hpv_mfma_iter_elem(HpvMfma* m, const double* theta, const double* X, double
     const NetDesc& nd = m->nd;
     if (!m->iter_fused_ok || pd.edge || pd.nact || n_elem <= 0 || m->L < 2 || m->L > 3 || nd.d != 2 || nd.act != HPV_ACT_TANH) return false;
     const int key = nd.d * 100 + nd.nT1 * 10 + nd.nT2;
-    const int nq = pd.qx * pd.qy, tpe = (nq + 15) / 16, tpw = (tpe + 3) / 4, slots = 4 * tpw, nfree = slots - tpe;
+    // Where this structure is the DEFAULT (measured, profiles/r04_element_shapes.md: 16x16-element grids, us per iteration, this
+    // kernel with 4 / 8 waves against the separate launches): few channel-layers or small elements -- [2,20,20,1] var_form 1
+    // 52.6 / 46.1 vs 54.1, one channel (var_form 2) 45.0 / 40.4 vs 60.9, 12x12 points 39.6 / 43.5 vs 56.0.  With three or more
+    // channels through three hidden layers the compiler-scheduled tile bodies at one or two waves per SIMD lose to the
+    // hand-scheduled two-kernel path (16x16 points, var_form 1: 80.6 / 75.2 vs 69.4; five channels 118 / 132 vs 92.6), and so
+    // do wider layers (H = 32: 164 vs 110, register spills): those run it only on request (HPV_FUSE=e).
+    const int C_ = 1 + nd.nT1 + nd.nT2, tpe_ = (pd.qx * pd.qy + 15) / 16;
+    const bool light = C_ == 1 || C_ * m->L <= 6;
+    if (!m->prefer_elem && !(m->H <= 24 && (light || tpe_ <= 9))) return false;
+    // wavefronts per workgroup (kernels_elem.hip): two per SIMD for the light channel sets, where 256 registers per wave suffice
+    int waves = (m->H <= 24 && tpe_ >= 8 && light) ? 8 : 4;
+    if (const char* e = getenv("HPV_ELEM_WAVES")) {      // (A/B switch, read per launch / capture)
+        if (atoi(e) == 4) waves = 4;
+        if (atoi(e) == 8 && m->H <= 24 && tpe_ >= 8) waves = 8;
+    }
+    const int nq = pd.qx * pd.qy, tpe = (nq + 15) / 16, tpw = (tpe + waves - 1) / waves, slots = waves * tpw, nfree = slots - tpe;
     // batch layout [element points | pad to 16 | data points]
     const long npad = ((long)n_elem * nq + 15) / 16 * 16;
     const bool has_data = dt && dt->n_data > 0;
@@ -889,6 +908,7 @@ bool hpv_mfma_iter_elem(HpvMfma* m, const double* theta, const double* X, double
     a.proj_n_elem = n_elem;
     a.proj_split = 1;
     a.pa = pa;
+    a.elem_waves = waves;
     bool ok = false, known = false;
 #define HPV_ELEM_TRY(A_, B_, C_, D_)                                                           \
     if (!known && pd.qx == A_ && pd.qy == B_ && pd.ntx == C_ && pd.nty == D_) {                 \
@@ -899,8 +919,8 @@ bool hpv_mfma_iter_elem(HpvMfma* m, const double* theta, const double* X, double
 #undef HPV_ELEM_TRY
     if (!ok) return false;
     m->last_split = false;
-    snprintf(m->variant, sizeof m->variant, "k_iter_elem<D=2,NT1=%d,NT2=%d,tanh,L=%d,H=%d,%dx%d/%dx%d,waves=4,tiles/wave=%d>", nd.nT1, nd.nT2,
-             m->L, m->H, pd.qx, pd.qy, pd.ntx, pd.nty, tpw);
+    snprintf(m->variant, sizeof m->variant, "k_iter_elem<D=2,NT1=%d,NT2=%d,tanh,L=%d,H=%d,%dx%d/%dx%d,waves=%d,tiles/wave=%d>", nd.nT1, nd.nT2,
+             m->L, m->H, pd.qx, pd.qy, pd.ntx, pd.nty, waves, tpw);
     if (rows) *rows = (int)blocks;
     return true;
 }

@@ -18,6 +18,14 @@ from test_gpu_parity import TOL, TRAJ_TOL
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _element_resident_kernel_first(monkeypatch, request):
+    """HPV_FUSE=e: the generic element-resident kernel wherever it is instantiated, so that EVERY instantiation is checked against
+    the oracle -- by default it runs only where it is the faster structure (test_default_policy... below)."""
+    if "default_policy" not in request.node.name:
+        monkeypatch.setenv("HPV_FUSE", "e")
+
+
 def _p2(q, nt, nex, ney, nb=13):
     from hp_vpinns_amd.drivers import poisson2d
     s = poisson2d.setup(N_el_x=nex, N_el_y=ney, N_test_x=nt, N_test_y=nt, N_quad=q, N_bound=nb, with_test_grid=False)
@@ -92,7 +100,7 @@ def test_config4_shape_other_forms_run_element_resident_and_equal_the_separate_l
             l3s, gs = m2.loss_and_grad()
             assert m2.h.pass_structure() == "separate"
         finally:
-            del os.environ["HPV_FUSE"]
+            os.environ["HPV_FUSE"] = "e"
         assert rel(gm, gs) < 1e-11 and rel(l3m, l3s) < 1e-12
 
 
@@ -116,3 +124,21 @@ def test_more_boundary_tiles_than_free_slots_go_to_extra_workgroups():
     th = theta0(L, 15)
     o, m = OracleVPINN2D(*a, init_params=th), VPINN2D(*a, init_params=th)
     _check(o, m, 2 * 36, "12x12/6x6")
+
+
+def test_default_policy_picks_the_faster_structure_per_shape():
+    """Without HPV_FUSE the element-resident kernel is the default where it measured faster than the separate launches (few
+    channel-layers, small elements: profiles/r04_element_shapes.md) and the separate launches elsewhere."""
+    from hp_vpinns_amd.vpinn import VPINN2D
+    assert "HPV_FUSE" not in os.environ
+    for (q, nt, L, vf, want, waves) in [(12, 6, [2, 20, 20, 20, 1], 1, "whole-iteration-element", 4),
+                                        (16, 8, [2, 20, 20, 1], 1, "whole-iteration-element", 8),
+                                        (20, 10, [2, 20, 20, 20, 1], 2, "whole-iteration-element", 8),
+                                        (16, 8, [2, 20, 20, 20, 1], 1, "separate", None),
+                                        (16, 8, [2, 32, 32, 32, 1], 1, "separate", None)]:
+        a = _p2(q, nt, 3, 3) + (L,)
+        m = VPINN2D(*a, var_form=vf, init_params=theta0(L, 3))
+        m.loss_and_grad()
+        assert m.h.pass_structure() == want, (q, L, vf, m.h.pass_structure(), m.h.kernel_variant())
+        if waves:
+            assert f"waves={waves}" in m.h.kernel_variant(), m.h.kernel_variant()
