@@ -104,6 +104,10 @@ struct hpv_ctx {
     // in-library exchange of the packed buffer between the ranks of a node (hpv_p2p_*)
     P2PArgs pp{};
     bool p2p_on = false;
+    // one-workgroup grids (config 1): hpv_step asks for `persist_want` iterations in one launch; the tile kernel says how many it ran
+    int persist_want = 1, persist_done = 1;
+    bool persist_probed = false;
+    bool persist_seen = false;   // the most recent training pass ended inside the tile kernel (in-kernel finalize): persistent launches possible
     int pass_structure = -1;   // see hpv_pass_structure
     char variant[320] = "";    // see hpv_kernel_variant
     double* d_inbox = nullptr;
@@ -458,6 +462,8 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
                 MfmaFinalize fin{adam_args(h), h->d_RB, h->cfg.lossb_weight, h->n_data, (h->n_data + 15) / 16, h->has_eps,
                                  adam_state_doubles(h->P) / 2};
                 if (!fuse_adam) fin.ad.theta = nullptr;
+                fin.n_iters = fuse_adam ? h->persist_want : 1;
+                fin.iters_done = &h->persist_done;
                 ifused = hpv_mfma_iter_tile(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem,
                                             h->merged ? &fin : nullptr, &fin_done);
                 if (ifused) h->pass_structure = 4;
@@ -550,6 +556,7 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
         (void)hipStreamWaitEvent(smain, h->ev_join, 0);
     }
     const AdamArgs ad = adam_args(h);
+    if (backward && fuse_adam) h->persist_seen = fin_done;
     if (!fin_done)
     launch_finalize(backward && h->var.N > 0 ? h->var.GPART : nullptr, h->var.rows,
                     backward && h->n_data > 0 && !h->merged ? h->data.GPART : nullptr, h->data.rows,
@@ -1109,6 +1116,27 @@ int hpv_loss_and_grad(hpv_handle h, double* loss3, double* grad) {
 // n_iters training iterations enqueued on the handle's stream (graph replays where possible), no synchronisation
 static int enqueue_iterations(hpv_ctx* h, int n_iters) {
     int rc;
+    // one-workgroup grids whose kernel finishes the iteration itself: the remaining iterations in ONE persistent launch
+    // (k_iter_tile<.., PERSIST>; no graph needed -- there is one launch)
+    const bool persist_on = getenv("HPV_PERSIST") && getenv("HPV_PERSIST")[0] == '1';     // opt-in (kernels_tile.hip, tile_body)
+    if (persist_on && !h->persist_probed && n_iters > 1 && !h->rccl_on && !h->p2p_on && h->cfg.scheme == HPV_SCHEME_VPINN) {
+        // (the first training pass of a handle tells whether its grid is one such workgroup: one eager iteration)
+        if ((rc = enqueue_pass(h, true, true))) return rc;
+        h->persist_probed = true;
+        h->nupd_host += 1;
+        n_iters -= 1;
+    }
+    if (persist_on && h->persist_seen && n_iters > 1 && !h->rccl_on && !h->p2p_on && !h->timing && h->cfg.scheme == HPV_SCHEME_VPINN) {
+        h->persist_want = n_iters;
+        h->persist_done = 1;
+        rc = enqueue_pass(h, true, true);
+        h->persist_want = 1;
+        if (rc) return rc;
+        const int did = h->persist_seen ? h->persist_done : 1;
+        h->nupd_host += did;
+        if (did >= n_iters) return 0;
+        n_iters -= did;
+    }
     if (h->use_graph && h->own_stream && !h->timing && n_iters > 0 && h->cfg.scheme == HPV_SCHEME_VPINN) {
         if ((rc = check_ready(h))) return rc;
         // n = a * HPV_GRAPH_ITERS + r: a replays of the K-iteration graph and ONE replay of an r-iteration graph (captured

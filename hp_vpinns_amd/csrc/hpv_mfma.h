@@ -47,6 +47,8 @@ struct MfmaFinalize {
     double* RB;
     double lossb_weight;
     int n_data, n_data_part, has_eps, ncopies;
+    int n_iters = 1;              // iterations the caller wants back to back (a one-workgroup grid may run them in ONE persistent launch)
+    int* iters_done = nullptr;    // out: iterations this launch performs (1, or n_iters on the persistent path)
 };
 bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
                         const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem, const MfmaFinalize* fin = nullptr,

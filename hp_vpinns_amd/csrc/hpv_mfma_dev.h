@@ -52,6 +52,7 @@ struct MfmaArgs {
     // finishes the iteration itself -- packed buffer, TF1 Adam, loss history -- instead of a dependent k_finalize launch
     int elem_waves;       // k_iter_elem: wavefronts per workgroup (4 or 8; kernels_elem.hip)
     int tall_qt;          // k_iter_tall: the quarter-tile plan (every workgroup's tile count is 0 or 1 mod 4, see kernels_tall.hip)
+    int persist_iters;    // k_iter_tile<.., PERSIST>: whole iterations per launch (one-workgroup grids)
     int fin_mode;         // 0: k_finalize follows; 1: packed buffer only; 2: packed buffer + Adam update
     AdamArgs fin_ad;
     double* fin_RB;       // [grad (P) | d eps | lossv | w*lossb | msq | pad]

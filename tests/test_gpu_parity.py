@@ -1150,3 +1150,28 @@ def test_single_workgroup_grid_finishes_the_iteration_in_the_kernel():
         o.adam_step()
         lo.append(float(o.loss_parts()[0]))
     assert rel(hist[:, 0], lo) < TRAJ_TOL and rel(m.get_params(), o.get_params()) < TRAJ_TOL
+
+
+def test_persistent_single_workgroup_launch_is_the_same_iteration(monkeypatch):
+    """HPV_PERSIST=1 (opt-in; measured no faster: kernels_tile.hip, tile_body): MANY iterations of the one-workgroup grid of config 1
+    in ONE launch -- the same body function behind a call.  Loss history, parameters, Adam moments and beta powers must equal the
+    one-launch-per-iteration run to round-off (two compilations of the same body), the recorded iterations must be all there, and
+    early-stop chunking on top of it must keep the reference's semantics."""
+    from hp_vpinns_amd.vpinn import VPINN1D
+    a = p1_args(gold("poisson1d_cfg1"), layers=[1, 20, 20, 20, 1])
+    th = theta0(a[8], 41)
+    th[20:40] = 0.03 * np.arange(20)
+    ref = VPINN1D(*a, init_params=th)
+    h_ref = ref._step_record(37)[0]
+    ref._step(100, False)
+    monkeypatch.setenv("HPV_PERSIST", "1")
+    m = VPINN1D(*a, init_params=th)
+    h = m._step_record(37)[0]
+    assert "persistent" in m.h.kernel_variant(), m.h.kernel_variant()
+    m._step(100, False)
+    assert m.h.updates_applied() == 137
+    assert rel(h, h_ref) < 1e-12 and rel(m.h.get_state(), ref.h.get_state()) < 1e-11
+    rec = []
+    m2 = VPINN1D(*a, init_params=th, total_record=rec)
+    m2.train(41, 0.0)
+    assert [int(r[0]) for r in rec] == [0, 10, 20, 30, 40] and rel([r[1] for r in rec], h_ref[[0, 10, 20, 30], 0].tolist() + [rec[-1][1]]) < 1e-12
