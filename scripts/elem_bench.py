@@ -27,12 +27,16 @@ def both(build):
     m = build()
     us, v, ps = timeit(m), m.h.kernel_variant(), m.h.pass_structure()
     del m
+    prev = os.environ.get("HPV_FUSE")
     os.environ["HPV_FUSE"] = "n"
     try:
         m = build()
         us2, v2 = timeit(m), m.h.kernel_variant()
     finally:
-        del os.environ["HPV_FUSE"]
+        if prev is None:
+            del os.environ["HPV_FUSE"]
+        else:
+            os.environ["HPV_FUSE"] = prev
     return us, v, ps, us2, v2
 
 

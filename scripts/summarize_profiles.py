@@ -38,12 +38,14 @@ def pmc(d):
 stats("stats")
 stats("stats_c5")
 stats("stats_c5n")
+stats("stats_w32")
 stats("stats_b")
 stats("stats_proj1")
 stats("stats_proj0")
 TITLES = (("", "bench (config 4), default path: whole-iteration kernel"),
           ("_c5", "config 5 (AdvDiff 8 x 80x80 points), default path: tall-element whole-iteration kernel"),
           ("_c5n", "config 5, HPV_FUSE=n: round 2's launches (forward -> activation store -> row-split projection -> reverse)"), ("_b", "bench (config 4), HPV_FUSE=b: forward + projection-fused reverse kernel"),
+          ("_w32", "config-4 grid with [2,32,32,32,1]: the width-generic kernels k_fwd_wide / k_bwd_wide + k_project_tp"),
           ("_proj1", "projection kernel, residual + adjoint, 2^18-element batch"), ("_proj0", "projection kernel, residual only, 2^18-element batch"))
 for tagp, title in TITLES:
     fe, wr = pmc("pmc_fetch" + tagp), pmc("pmc_write" + tagp)
@@ -56,7 +58,7 @@ for tagp, title in TITLES:
             f_, w_ = fe.get(k, {}).get("FETCH_SIZE", 0.0), wr.get(k, {}).get("WRITE_SIZE", 0.0)
             if f_ + w_ > 1.0:
                 print(f"| `{k}` | {f_:.0f} | {w_:.0f} | {(2 * f_ + w_) * 1024:.3e} |")
-for tagp, title in (("", "default path"), ("_c5", "config 5, tall-element kernel"), ("2", "default path, second pass"), ("_b", "HPV_FUSE=b")):
+for tagp, title in (("", "default path"), ("_c5", "config 5, tall-element kernel"), ("_w32", "config-4 grid, 32-wide network"), ("2", "default path, second pass"), ("_b", "HPV_FUSE=b")):
     sq = pmc("pmc_sq" + tagp)
     if sq:
         print(f"\n### SQ counters per launch (bench, {title})\n")
