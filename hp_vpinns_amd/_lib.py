@@ -33,7 +33,7 @@ EXPORTS = [
     "hpv_eval_channels", "hpv_bench_residual",
     "hpv_set_collocation_shard", "hpv_rccl_unique_id", "hpv_rccl_connect", "hpv_rccl_selftest", "hpv_rccl_disconnect", "hpv_exchange_in_use",
     "hpv_rccl_available", "hpv_graphs_in_use", "hpv_updates_applied", "hpv_set_shared_element_kernels", "hpv_shared_element_kernels",
-    "hpv_kernel_variant", "hpv_build_info", "hpv_rccl_abandon",
+    "hpv_kernel_variant", "hpv_build_info", "hpv_rccl_abandon", "hpv_bench_residual_checksums",
 ]
 
 
@@ -153,6 +153,7 @@ def load():
     lib.hpv_rccl_disconnect.argtypes = [h]
     lib.hpv_exchange_in_use.argtypes = [h]
     lib.hpv_rccl_abandon.argtypes = [h]
+    lib.hpv_bench_residual_checksums.argtypes = [h, C.c_long, C.c_int, _dp]
     lib.hpv_kernel_variant.argtypes = [h, C.c_char_p, C.c_size_t]
     lib.hpv_build_info.argtypes = []
     lib.hpv_build_info.restype = C.c_char_p
@@ -495,6 +496,12 @@ class Handle:
         a, a1, ref = np.empty_like(x), np.empty_like(x), np.empty_like(x)
         self._chk(self.lib.hpv_debug_activation(self._h, _p(x), x.size, _p(a), _p(a1), _p(ref)))
         return a, a1, ref
+
+    def bench_checksums(self, n_elem, do_adjoint=True):
+        """Checksums of one stand-alone projection launch on the seeded synthetic batch (hpv_bench_residual_checksums)."""
+        out = np.empty(6)
+        self._chk(self.lib.hpv_bench_residual_checksums(self._h, int(n_elem), 1 if do_adjoint else 0, _p(out)))
+        return out
 
     def bench_projection(self, n_elem, reps=10, do_adjoint=True):
         ms, by = C.c_double(), C.c_double()

@@ -1725,7 +1725,15 @@ int hpv_bench_projection(hpv_handle h, long n_elem, int reps, double* avg_ms, do
     return hpv_bench_residual(h, n_elem, reps, 1, avg_ms, bytes_per_launch);
 }
 
+static int bench_residual_impl(hpv_handle h, long n_elem, int reps, int do_adjoint, double* avg_ms, double* bytes_per_launch, double* sums);
 int hpv_bench_residual(hpv_handle h, long n_elem, int reps, int do_adjoint, double* avg_ms, double* bytes_per_launch) {
+    return bench_residual_impl(h, n_elem, reps, do_adjoint, avg_ms, bytes_per_launch, nullptr);
+}
+int hpv_bench_residual_checksums(hpv_handle h, long n_elem, int do_adjoint, double* sums6) {
+    if (!sums6) return -1;
+    return bench_residual_impl(h, n_elem, 1, do_adjoint, nullptr, nullptr, sums6);
+}
+static int bench_residual_impl(hpv_handle h, long n_elem, int reps, int do_adjoint, double* avg_ms, double* bytes_per_launch, double* sums) {
     if (!h) return -1;
     if (!h->have_quad || !h->have_tables) return fail(h, -3, "set quadrature and tables first");
     if (n_elem < 1 || reps < 1) return fail(h, -1, "bad arguments");
@@ -1770,6 +1778,16 @@ int hpv_bench_residual(hpv_handle h, long n_elem, int reps, int do_adjoint, doub
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = fail(h, -2, "projection bench failed: %s", hipGetErrorString(e));
+        if (!rc && sums) {      // what the launch produced, condensed: sum R, sum R^2, sum loss_e, sum |gbar|, sum gbar^2, sum over e of e-weighted loss
+            std::vector<double> hr((size_t)n_elem * NR), hl((size_t)n_elem), hg(do_adjoint ? (size_t)C * N : 0);
+            (void)hipMemcpy(hr.data(), R, hr.size() * sizeof(double), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hl.data(), le, hl.size() * sizeof(double), hipMemcpyDeviceToHost);
+            if (do_adjoint) (void)hipMemcpy(hg.data(), GB, hg.size() * sizeof(double), hipMemcpyDeviceToHost);
+            for (int i = 0; i < 6; ++i) sums[i] = 0.0;
+            for (double v : hr) { sums[0] += v; sums[1] += v * v; }
+            for (size_t i = 0; i < hl.size(); ++i) { sums[2] += hl[i]; sums[5] += hl[i] * (double)(i % 97); }
+            for (double v : hg) { sums[3] += std::fabs(v); sums[4] += v * v; }
+        }
     }
     // algorithmic bytes: read the integrated channels + F, write R (8 (C_u N + 2 N_R)); with the adjoint
     // also write the adjoint channels

@@ -11,6 +11,7 @@
 // HBM traffic per element = read the integrated channels + F, write the adjoint channels + R (channels no
 // term uses are neither read nor written; their GBAR rows are zeroed once by the host).  This is the kernel
 // judged against the HBM roofline on the scaled synthetic batch.
+#include <algorithm>
 #include <cstdlib>
 
 #include "hpv_internal.h"
@@ -340,6 +341,175 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PI
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streaming residual kernel (round 4): the one-hot two-term form (Poisson-2D var_form 1) on LARGE batches, residual only
+// (R = U - F and the element loss: the launch whose bytes SURVEY.md 8(d) counts, 8 (C_u N + 2 N_R)).
+//
+// k_project_tp keeps a lane's quadrature column in REGISTERS: 124 VGPRs cap it at 4 waves per SIMD, every wave alternates
+// "20 loads -> wait the full loaded latency -> 1 600 cycles of contractions", and 16 B... per-lane 8-byte loads of 160-byte
+// row segments touch 8-10 cache lines per instruction: 3.5 TB/s.  Here the data path and the arithmetic are decoupled:
+//   * a workgroup (4 waves) owns batches of NB consecutive elements = two contiguous runs of NB Q doubles (one per channel);
+//     every thread fetches them with 16-byte loads (fully coalesced, whole cache lines) into REGISTERS for the NEXT batch while
+//     the contractions of the current one run from LDS -- the registers are the second buffer, nothing waits in the middle of a batch;
+//   * contractions read the integrand from LDS ("a lane owns a column" still: lane (e, t, i) takes T_t[.][i], conflict-free),
+//     tables broadcast from LDS, one LDS hand-off T between the contractions, lane (e, k, r-half) finishes both terms of its
+//     residual entries and stores R straight from registers (a batch's R is one contiguous run);
+//   * 75 KB of LDS per workgroup -> two workgroups per CU cover each other's barriers.
+// ------------------------------------------------------------------------------------------------
+template <int QX, int QY, int NTX, int NTY, int NB>
+struct RsLds {
+    static constexpr int NQ = QX * QY, NR = NTX * NTY, LDT = QX + 1;
+    static constexpr int BYT = 0;                            // [2 terms][QY][NTY]   w_y phi^(dy_t)[k][j], j-major
+    static constexpr int AXT = BYT + 2 * QY * NTY;           // [2 terms][QX][NTX]   w_x phi^(dx_t)[r][i], i-major
+    static constexpr int G = AXT + 2 * QX * NTX;             // [2 channels][NB][NQ] the batch's integrand channels
+    static constexpr int T = G + 2 * NB * NQ;                // [NB][2][NTY][LDT]
+    static constexpr int SQ = T + NB * 2 * NTY * LDT;        // [NB * 2 * NTY] partial squares
+    static constexpr int TOTAL = SQ + NB * 2 * NTY + 16;
+};
+
+template <int QX, int QY, int NTX, int NTY, int NB>
+__global__ void __launch_bounds__(256, 2) k_residual_stream(ProjDesc pd, int ch0, int ch1, const double* __restrict__ OUT,
+                                                            double* __restrict__ R, const double* __restrict__ F,
+                                                            const double* __restrict__ coef, long coef_stride,
+                                                            const double* __restrict__ wtx, const double* __restrict__ wty,
+                                                            double* __restrict__ loss_e, long N, long n_elem) {
+    using M = RsLds<QX, QY, NTX, NTY, NB>;
+    constexpr int NQ = QX * QY, NR = NTX * NTY, LDT = QX + 1, BT = 256;
+    constexpr int RUN = NB * NQ;                              // doubles per channel and batch (contiguous in memory)
+    constexpr int NLD = (2 * RUN / 2 + BT - 1) / BT;          // 16-byte loads per thread and batch
+    static_assert(NQ % 2 == 0 && NB * 2 * QX <= BT && NB * NTY * 2 <= BT && NTX % 2 == 0, "lane maps");
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    // tables of the two terms (their derivative orders are launch constants), transposed for broadcast reads along the output index
+    for (int i = tid; i < 2 * QY * NTY; i += BT) {
+        const int t = i / (QY * NTY), j = (i / NTY) % QY, k = i % NTY;
+        sm[M::BYT + i] = wty[(long)pd.t[t].dy * NTY * QY + k * QY + j];
+    }
+    for (int i = tid; i < 2 * QX * NTX; i += BT) {
+        const int t = i / (QX * NTX), c = (i / NTX) % QX, r = i % NTX;
+        sm[M::AXT + i] = wtx[(long)pd.t[t].dx * NTX * QX + r * QX + c];
+    }
+    const double al0 = pd.t[0].a0[ch0], al1 = pd.t[1].a0[ch1];
+    const long nbatch = (n_elem + NB - 1) / NB;
+    const double* __restrict__ C0 = OUT + (long)ch0 * N;
+    const double* __restrict__ C1 = OUT + (long)ch1 * N;
+    const long ntot = n_elem * NQ;
+    v2d nx[NLD];
+    auto request = [&](long b) {        // the two runs of batch b, 16 bytes per thread and load (clamped at the end of the arrays)
+        const long base = b * RUN;
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            const int idx = 2 * (p * BT + tid);              // 0 .. 2 RUN - 2: first run = channel 0, second = channel 1
+            const bool second = idx >= RUN;
+            long o = base + (second ? idx - RUN : idx);
+            if (o > ntot - 2) o = ntot - 2;
+            nx[p] = (idx < 2 * RUN && b < nbatch) ? __builtin_nontemporal_load((const v2d*)((second ? C1 : C0) + o)) : v2d{0.0, 0.0};
+        }
+    };
+    long b = blockIdx.x;
+    request(b);
+    // lane maps
+    const int ye = tid / (2 * QX), yt = (tid / QX) % 2, yi = tid % QX;                 // y-contraction: (element, term, column)
+    const bool yon = tid < NB * 2 * QX;
+    const int xe = tid / (NTY * 2), xk = (tid / 2) % NTY, xh = tid % 2;                // x-contraction: (element, row k, half of the r range)
+    const bool xon = tid < NB * NTY * 2;
+    constexpr int RH = NTX / 2;
+    __syncthreads();
+    for (; b < nbatch; b += gridDim.x) {
+        // park the batch in LDS (the previous batch's readers are behind the barrier at the loop's end)
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            const int idx = 2 * (p * BT + tid);
+            if (idx < 2 * RUN) *(v2d*)(sm + M::G + idx) = nx[p];
+        }
+        // this batch's right-hand side rows and coefficients (small; requested BEFORE the prefetch: loads return in order)
+        const long e_x = b * NB + xe;
+        const bool xv = xon && e_x < n_elem;
+        double u[RH], c0 = 0.0, c1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < RH; ++r) u[r] = (xv && F) ? -F[e_x * NR + xk * NTX + xh * RH + r] : 0.0;
+        if (xv) { c0 = coef[e_x] * al0; c1 = coef[coef_stride + e_x] * al1; }
+        __syncthreads();
+        request(b + gridDim.x);                              // in flight during everything below
+        // y-contraction: T_t[k][i] = sum_j BY_t[k][j] G_t[j][i], lane = (e, t, i)
+        if (yon) {
+            const double* g = sm + M::G + yt * RUN + ye * NQ + yi;
+            const double* byt = sm + M::BYT + yt * (QY * NTY);
+            double acc[NTY];
+#pragma unroll
+            for (int k = 0; k < NTY; ++k) acc[k] = 0.0;
+#pragma unroll
+            for (int j = 0; j < QY; ++j) {
+                const double gv = g[j * QX];
+#pragma unroll
+                for (int k = 0; k < NTY; ++k) acc[k] = fma(byt[j * NTY + k], gv, acc[k]);
+            }
+            double* tt = sm + M::T + ((ye * 2 + yt) * NTY) * LDT + yi;
+#pragma unroll
+            for (int k = 0; k < NTY; ++k) tt[k * LDT] = acc[k];
+        }
+        __syncthreads();
+        // x-contraction, both terms: U[k][r] = sum_t c_t sum_i AX_t[r][i] T_t[k][i], lane = (e, k, half of r)
+        double sq = 0.0;
+        if (xon) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const double* tr = sm + M::T + ((xe * 2 + t) * NTY + xk) * LDT;
+                const double* axt = sm + M::AXT + t * (QX * NTX) + xh * RH;
+                double acc[RH];
+#pragma unroll
+                for (int r = 0; r < RH; ++r) acc[r] = 0.0;
+#pragma unroll
+                for (int i = 0; i < QX; ++i) {
+                    const double tv = tr[i];
+#pragma unroll
+                    for (int r = 0; r < RH; ++r) acc[r] = fma(axt[i * NTX + r], tv, acc[r]);
+                }
+                const double c = t == 0 ? c0 : c1;
+#pragma unroll
+                for (int r = 0; r < RH; ++r) u[r] = fma(c, acc[r], u[r]);
+            }
+            if (xv) {
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    __builtin_nontemporal_store(u[r], R + e_x * NR + xk * NTX + xh * RH + r);
+                    sq = fma(u[r], u[r], sq);
+                }
+            }
+            sm[M::SQ + tid] = sq;
+        }
+        __syncthreads();
+        if (tid < NB && b * NB + tid < n_elem) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NTY * 2; ++i) s += sm[M::SQ + tid * (NTY * 2) + i];
+            loss_e[b * NB + tid] = s / (double)NR;
+        }
+    }
+}
+
+template <int QX, int QY, int NTX, int NTY>
+static bool launch_residual_stream(const ProjDesc& pd, const ActiveCh& ac, const double* OUT, double* R, const double* F, const double* coef,
+                                   long coef_stride, const double* wtx, const double* wty, double* loss_e, long N, long n_elem, hipStream_t s) {
+    constexpr int NB = 6;
+    using M = RsLds<QX, QY, NTX, NTY, NB>;
+    constexpr size_t lds = (size_t)M::TOTAL * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_residual_stream<QX, QY, NTX, NTY, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        attr_set = true;
+    }
+    const long nbatch = (n_elem + NB - 1) / NB;
+    const unsigned blocks = (unsigned)std::min<long>(nbatch, 512);          // two resident workgroups per CU, each streams its batches
+    hipLaunchKernelGGL((k_residual_stream<QX, QY, NTX, NTY, NB>), dim3(blocks), dim3(256), lds, s, pd, ac.id[0], ac.id[1], OUT, R, F, coef,
+                       coef_stride, wtx, wty, loss_e, N, n_elem);
+    return true;
+}
+
 template <int QX, int QY, int NTX, int NTY, int NA, bool EPS, int PJ_WAVES, bool OH = false, bool PIPE = false>
 static void launch_tp3(const ProjDesc& pd, const ActiveCh& ac, const double* OUT, double* GBAR, double* R, const double* F,
                        const double* coef, long coef_stride, const double* wtx, const double* wty, const double* eps_ptr,
@@ -382,7 +552,15 @@ static bool launch_tp2(const ProjDesc& pd, const ActiveCh& ac, const double* OUT
                                                           N, n_elem, do_adjoint, ngroups, s)
     if constexpr (!EPS && NA >= 2) {
         if (onehot) {
-            static const bool pipe = getenv("HPV_PJ_PIPE") && getenv("HPV_PJ_PIPE")[0] == '1';     // (A/B switch)
+            const bool pipe = getenv("HPV_PJ_PIPE") && getenv("HPV_PJ_PIPE")[0] == '1';     // (A/B switch)
+            const bool no_stream = getenv("HPV_PJ_STREAM") && getenv("HPV_PJ_STREAM")[0] == '0';     // (A/B switch)
+            if constexpr (NA == 2 && QX == 20 && QY == 20 && NTX == 10 && NTY == 10) {
+                // large batches, residual only, unit channel weights: the streaming kernel (LDS-staged, register double-buffered)
+                if (!do_adjoint && !no_stream && n_elem >= 4096 && N == n_elem * (long)(QX * QY) && pd.t[0].a1[ac.id[0]] == 0.0 &&
+                    pd.t[1].a1[ac.id[1]] == 0.0 && !pd.t[0].eps_mult && !pd.t[1].eps_mult &&
+                    launch_residual_stream<QX, QY, NTX, NTY>(pd, ac, OUT, R, F, coef, coef_stride, wtx, wty, loss_e, N, n_elem, s))
+                    return true;
+            }
             if (ngroups <= 1024) HPV_GO(1, true, false);
             else if (!pipe) HPV_GO(8, true, false);
             else HPV_GO(4, true, true);

@@ -243,6 +243,10 @@ int hpv_bench_projection(hpv_handle h, long n_elem, int reps, double* avg_ms, do
 /* Same with the adjoint half switchable: do_adjoint = 0 is the residual-only launch whose algorithmic bytes are
  * SURVEY.md 8(d)'s 8 (C_u N + 2 N_R) (read the integrated channels and F, write R). */
 int hpv_bench_residual(hpv_handle h, long n_elem, int reps, int do_adjoint, double* avg_ms, double* bytes_per_launch);
+/* One such launch on the same seeded synthetic data, condensed to checksums {sum R, sum R^2, sum loss_e, sum |gbar|, sum gbar^2,
+ * sum_e (e mod 97) loss_e}: lets tests compare the kernel plans that serve large batches (streaming / column-in-registers)
+ * with each other and with the general projection kernel on the SAME data. */
+int hpv_bench_residual_checksums(hpv_handle h, long n_elem, int do_adjoint, double* sums6);
 
 #ifdef __cplusplus
 }

@@ -1175,3 +1175,30 @@ def test_persistent_single_workgroup_launch_is_the_same_iteration(monkeypatch):
     m2 = VPINN1D(*a, init_params=th, total_record=rec)
     m2.train(41, 0.0)
     assert [int(r[0]) for r in rec] == [0, 10, 20, 30, 40] and rel([r[1] for r in rec], h_ref[[0, 10, 20, 30], 0].tolist() + [rec[-1][1]]) < 1e-12
+
+
+def test_large_batch_projection_plans_agree(monkeypatch):
+    """The stand-alone projection on a LARGE synthetic batch (the HBM-roofline measurement of SURVEY.md 8d) has three plans:
+    the streaming residual kernel (LDS-staged batches of 6 elements, register double-buffered: residual only), the
+    column-in-registers kernel k_project_tp, and the general k_project.  On the same seeded data they must give the same R and
+    element losses (sums of the same terms in different orders) -- incl. a batch size that is not a multiple of 6 or 3."""
+    from hp_vpinns_amd import _lib
+    from hp_vpinns_amd.quadrature import GaussLobattoJacobiWeights
+    from hp_vpinns_amd.testfcn import tables_1d
+    x, w = GaussLobattoJacobiWeights(20, 0, 0)
+
+    def sums(adj, backend=_lib.BACKEND_AUTO, n=10007):
+        h = _lib.Handle(_lib.PDE_POISSON2D, 1, _lib.ACT_TANH, [2, 20, 20, 20, 1], lossb_weight=10, backend=backend)
+        h.set_quadrature(x, w, x, w)
+        h.set_tables(tables_1d(10, x), tables_1d(10, x))
+        return h.bench_checksums(n, adj)
+
+    s_stream = sums(False)
+    monkeypatch.setenv("HPV_PJ_STREAM", "0")
+    s_tp = sums(False)
+    s_gen = sums(False, _lib.BACKEND_GENERIC)
+    assert np.all(np.isfinite(s_stream)) and s_stream[1] > 0
+    assert rel(s_stream[[0, 1, 2, 5]], s_tp[[0, 1, 2, 5]]) < 1e-12, (s_stream, s_tp)
+    assert rel(s_tp[[0, 1, 2, 5]], s_gen[[0, 1, 2, 5]]) < 1e-12, (s_tp, s_gen)
+    a_tp, a_gen = sums(True), sums(True, _lib.BACKEND_GENERIC)
+    assert rel(a_tp, a_gen) < 1e-12 and a_tp[4] > 0
