@@ -37,10 +37,11 @@
 //            3.48-3.50): at 168 registers the kernel spills 8 doubles, scratch reloads count in vmcnt like every vector load,
 //            so each reload waits for the whole prefetch (s_waitcnt vmcnt(0) in the middle of the contractions) -- the overlap
 //            the plan exists for does not happen, and three waves per SIMD hide less than four.  Kept for A/B runs.
-// HPV_PJ_NT (compile time, scripts/build_variant.sh <name> -DHPV_PJ_NT=0): the streamed channel columns are read, and R
-// written, with non-temporal hints (each byte is touched once).
+// HPV_PJ_NT (compile time, scripts/build_variant.sh <name> -DHPV_PJ_NT=1): the streamed channel columns are read, and R
+// written, with non-temporal hints (each byte is touched once).  Measured (round 4): no gain (46-47 % vs 47.5-48.7 % of 8 TB/s
+// without) and +5 % written bytes by PMC (8-byte nt stores with an 80-byte lane stride are not merged into whole lines): off.
 #ifndef HPV_PJ_NT
-#define HPV_PJ_NT 1
+#define HPV_PJ_NT 0
 #endif
 __device__ __forceinline__ double pj_stream_load(const double* p) {
 #if HPV_PJ_NT
@@ -358,15 +359,17 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PI
 // ------------------------------------------------------------------------------------------------
 template <int QX, int QY, int NTX, int NTY, int NB>
 struct RsLds {
-    static constexpr int NQ = QX * QY, NR = NTX * NTY, LDT = QX + 1;
-    static constexpr int BYT = 0;                            // [2 terms][QY][NTY]   w_y phi^(dy_t)[k][j], j-major
-    static constexpr int AXT = BYT + 2 * QY * NTY;           // [2 terms][QX][NTX]   w_x phi^(dx_t)[r][i], i-major
-    static constexpr int G = AXT + 2 * QX * NTX;             // [2 channels][NB][NQ] the batch's integrand channels
+    static constexpr int NQ = QX * QY, NR = NTX * NTY, LDT = QX + 2;          // (even leading dimension: 16-byte row reads)
+    static constexpr int G = 0;                              // [2 channels][NB][NQ] the batch's integrand channels
     static constexpr int T = G + 2 * NB * NQ;                // [NB][2][NTY][LDT]
-    static constexpr int SQ = T + NB * 2 * NTY * LDT;        // [NB * 2 * NTY] partial squares
-    static constexpr int TOTAL = SQ + NB * 2 * NTY + 16;
+    static constexpr int SQ = T + NB * 2 * NTY * LDT;        // [NB][NTY][2] partial squares
+    static constexpr int TOTAL = SQ + NB * NTY * 2 + 16;
 };
 
+// Tables: NOT in LDS.  Every table value a wave needs in a contraction step is wave-uniform (the wave's term in the y-contraction,
+// its half of the r range in the x-contraction are functions of the wave index), so the tables are read from global memory at
+// uniform addresses -- scalar loads into SGPRs, an SGPR operand per FMA: no LDS read, no VGPR, no wait in front of every FMA (the
+// LDS-table version of this kernel spent 19 k cycles per batch in 195 exposed ds_read -> s_waitcnt -> fma round trips).
 template <int QX, int QY, int NTX, int NTY, int NB>
 __global__ void __launch_bounds__(256, 2) k_residual_stream(ProjDesc pd, int ch0, int ch1, const double* __restrict__ OUT,
                                                             double* __restrict__ R, const double* __restrict__ F,
@@ -374,48 +377,54 @@ __global__ void __launch_bounds__(256, 2) k_residual_stream(ProjDesc pd, int ch0
                                                             const double* __restrict__ wtx, const double* __restrict__ wty,
                                                             double* __restrict__ loss_e, long N, long n_elem) {
     using M = RsLds<QX, QY, NTX, NTY, NB>;
-    constexpr int NQ = QX * QY, NR = NTX * NTY, LDT = QX + 1, BT = 256;
+    constexpr int NQ = QX * QY, NR = NTX * NTY, LDT = M::LDT, BT = 256;
     constexpr int RUN = NB * NQ;                              // doubles per channel and batch (contiguous in memory)
     constexpr int NLD = (2 * RUN / 2 + BT - 1) / BT;          // 16-byte loads per thread and batch
-    static_assert(NQ % 2 == 0 && NB * 2 * QX <= BT && NB * NTY * 2 <= BT && NTX % 2 == 0, "lane maps");
+    constexpr int RH = NTX / 2;
+    static_assert(NQ % 2 == 0 && NB * QX <= 128 && NB * NTY <= 64 && NTX % 2 == 0 && QX % 2 == 0, "lane maps");
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     typedef double v2d __attribute__((ext_vector_type(2)));
-    // tables of the two terms (their derivative orders are launch constants), transposed for broadcast reads along the output index
-    for (int i = tid; i < 2 * QY * NTY; i += BT) {
-        const int t = i / (QY * NTY), j = (i / NTY) % QY, k = i % NTY;
-        sm[M::BYT + i] = wty[(long)pd.t[t].dy * NTY * QY + k * QY + j];
-    }
-    for (int i = tid; i < 2 * QX * NTX; i += BT) {
-        const int t = i / (QX * NTX), c = (i / NTX) % QX, r = i % NTX;
-        sm[M::AXT + i] = wtx[(long)pd.t[t].dx * NTX * QX + r * QX + c];
-    }
     const double al0 = pd.t[0].a0[ch0], al1 = pd.t[1].a0[ch1];
     const long nbatch = (n_elem + NB - 1) / NB;
     const double* __restrict__ C0 = OUT + (long)ch0 * N;
     const double* __restrict__ C1 = OUT + (long)ch1 * N;
     const long ntot = n_elem * NQ;
+    // lane maps.  y-contraction: waves 0, 1 take term 0, waves 2, 3 term 1; the 128 lanes of a pair = (element, column) of NB x QX.
+    // x-contraction: wave 0 takes the first half of the r range, wave 1 the second; its lanes = (element, row k); waves 2, 3 rest.
+    const int yt = wv >> 1;
+    const int yl = (wv & 1) * 64 + lane, ye = yl / QX, yi = yl % QX;
+    const bool yon = yl < NB * QX;
+    const int xh = wv & 1, xe = lane / NTY, xk = lane % NTY;
+    const bool xon = wv < 2 && lane < NB * NTY;
+    const double* __restrict__ byt = wty + (long)pd.t[yt].dy * NTY * QY;                 // [k][j]  (wave-uniform address)
+    const double* __restrict__ ax0 = wtx + (long)pd.t[0].dx * NTX * QX + xh * RH * QX;   // [r][i] of this wave's r range
+    const double* __restrict__ ax1 = wtx + (long)pd.t[1].dx * NTX * QX + xh * RH * QX;
     v2d nx[NLD];
+    double nf[RH], nc0, nc1;            // this lane's right-hand-side entries and term coefficients of the prefetched batch
     auto request = [&](long b) {        // the two runs of batch b, 16 bytes per thread and load (clamped at the end of the arrays)
         const long base = b * RUN;
+        {   // unconditional loads from clamped addresses: a conditional load is a branch with a wait of its own
+            long e_ = b * NB + (xon ? xe : 0);
+            e_ = e_ < n_elem ? e_ : n_elem - 1;
+            const double* fp = (F ? F : OUT) + e_ * NR + (xon ? xk : 0) * NTX + xh * RH;
+#pragma unroll
+            for (int r = 0; r < RH; ++r) nf[r] = fp[r];
+            nc0 = coef[e_];
+            nc1 = coef[coef_stride + e_];
+        }
 #pragma unroll
         for (int p = 0; p < NLD; ++p) {
             const int idx = 2 * (p * BT + tid);              // 0 .. 2 RUN - 2: first run = channel 0, second = channel 1
             const bool second = idx >= RUN;
             long o = base + (second ? idx - RUN : idx);
             if (o > ntot - 2) o = ntot - 2;
-            nx[p] = (idx < 2 * RUN && b < nbatch) ? __builtin_nontemporal_load((const v2d*)((second ? C1 : C0) + o)) : v2d{0.0, 0.0};
+            nx[p] = (idx < 2 * RUN && b < nbatch) ? *(const v2d*)((second ? C1 : C0) + o) : v2d{0.0, 0.0};
         }
     };
     long b = blockIdx.x;
     request(b);
-    // lane maps
-    const int ye = tid / (2 * QX), yt = (tid / QX) % 2, yi = tid % QX;                 // y-contraction: (element, term, column)
-    const bool yon = tid < NB * 2 * QX;
-    const int xe = tid / (NTY * 2), xk = (tid / 2) % NTY, xh = tid % 2;                // x-contraction: (element, row k, half of the r range)
-    const bool xon = tid < NB * NTY * 2;
-    constexpr int RH = NTX / 2;
-    __syncthreads();
     for (; b < nbatch; b += gridDim.x) {
         // park the batch in LDS (the previous batch's readers are behind the barrier at the loop's end)
 #pragma unroll
@@ -423,63 +432,59 @@ __global__ void __launch_bounds__(256, 2) k_residual_stream(ProjDesc pd, int ch0
             const int idx = 2 * (p * BT + tid);
             if (idx < 2 * RUN) *(v2d*)(sm + M::G + idx) = nx[p];
         }
-        // this batch's right-hand side rows and coefficients (small; requested BEFORE the prefetch: loads return in order)
         const long e_x = b * NB + xe;
         const bool xv = xon && e_x < n_elem;
-        double u[RH], c0 = 0.0, c1 = 0.0;
+        double u[RH];
 #pragma unroll
-        for (int r = 0; r < RH; ++r) u[r] = (xv && F) ? -F[e_x * NR + xk * NTX + xh * RH + r] : 0.0;
-        if (xv) { c0 = coef[e_x] * al0; c1 = coef[coef_stride + e_x] * al1; }
-        __syncthreads();
+        for (int r = 0; r < RH; ++r) u[r] = F ? -nf[r] : 0.0;
+        const double c0 = nc0 * al0, c1 = nc1 * al1;
+        pj_lds_barrier();      // LDS hand-off only (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also wait for the prefetch
         request(b + gridDim.x);                              // in flight during everything below
-        // y-contraction: T_t[k][i] = sum_j BY_t[k][j] G_t[j][i], lane = (e, t, i)
+        // y-contraction: T_t[k][i] = sum_j BY_t[k][j] G_t[j][i], lane = (element, column) of the wave pair's term
         if (yon) {
             const double* g = sm + M::G + yt * RUN + ye * NQ + yi;
-            const double* byt = sm + M::BYT + yt * (QY * NTY);
-            double acc[NTY];
+            double gv[QY];
 #pragma unroll
-            for (int k = 0; k < NTY; ++k) acc[k] = 0.0;
-#pragma unroll
-            for (int j = 0; j < QY; ++j) {
-                const double gv = g[j * QX];
-#pragma unroll
-                for (int k = 0; k < NTY; ++k) acc[k] = fma(byt[j * NTY + k], gv, acc[k]);
-            }
+            for (int j = 0; j < QY; ++j) gv[j] = g[j * QX];
             double* tt = sm + M::T + ((ye * 2 + yt) * NTY) * LDT + yi;
 #pragma unroll
-            for (int k = 0; k < NTY; ++k) tt[k * LDT] = acc[k];
+            for (int k = 0; k < NTY; ++k) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < QY; ++j) acc = fma(byt[k * QY + j], gv[j], acc);      // table value: SGPR operand
+                tt[k * LDT] = acc;
+            }
         }
-        __syncthreads();
-        // x-contraction, both terms: U[k][r] = sum_t c_t sum_i AX_t[r][i] T_t[k][i], lane = (e, k, half of r)
-        double sq = 0.0;
+        pj_lds_barrier();
+        // x-contraction, both terms: U[k][r] = sum_t c_t sum_i AX_t[r][i] T_t[k][i], lane = (element, row k), wave = half of r
         if (xon) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const double* tr = sm + M::T + ((xe * 2 + t) * NTY + xk) * LDT;
-                const double* axt = sm + M::AXT + t * (QX * NTX) + xh * RH;
-                double acc[RH];
+                const double* __restrict__ ax = t == 0 ? ax0 : ax1;
+                double tv[QX];
 #pragma unroll
-                for (int r = 0; r < RH; ++r) acc[r] = 0.0;
-#pragma unroll
-                for (int i = 0; i < QX; ++i) {
-                    const double tv = tr[i];
-#pragma unroll
-                    for (int r = 0; r < RH; ++r) acc[r] = fma(axt[i * NTX + r], tv, acc[r]);
-                }
+                for (int i = 0; i < QX; i += 2) { const v2d w = *(const v2d*)(tr + i); tv[i] = w[0]; tv[i + 1] = w[1]; }
                 const double c = t == 0 ? c0 : c1;
 #pragma unroll
-                for (int r = 0; r < RH; ++r) u[r] = fma(c, acc[r], u[r]);
+                for (int r = 0; r < RH; ++r) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < QX; ++i) acc = fma(ax[r * QX + i], tv[i], acc);   // table value: SGPR operand
+                    u[r] = fma(c, acc, u[r]);
+                }
             }
+            double sq = 0.0;
             if (xv) {
 #pragma unroll
                 for (int r = 0; r < RH; ++r) {
-                    __builtin_nontemporal_store(u[r], R + e_x * NR + xk * NTX + xh * RH + r);
+                    R[e_x * NR + xk * NTX + xh * RH + r] = u[r];
                     sq = fma(u[r], u[r], sq);
                 }
             }
-            sm[M::SQ + tid] = sq;
+            sm[M::SQ + (xe * NTY + xk) * 2 + xh] = sq;
         }
-        __syncthreads();
+        pj_lds_barrier();
         if (tid < NB && b * NB + tid < n_elem) {
             double s = 0.0;
 #pragma unroll
