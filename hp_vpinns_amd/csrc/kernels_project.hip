@@ -40,6 +40,12 @@
 // HPV_PJ_NT (compile time, scripts/build_variant.sh <name> -DHPV_PJ_NT=1): the streamed channel columns are read, and R
 // written, with non-temporal hints (each byte is touched once).  Measured (round 4): no gain (46-47 % vs 47.5-48.7 % of 8 TB/s
 // without) and +5 % written bytes by PMC (8-byte nt stores with an 80-byte lane stride are not merged into whole lines): off.
+// HPV_PJ_SGPR (compile time, default 1): the one-hot 8-wave instantiation of k_project_tp reads its test-function tables from
+// global memory at wave-uniform addresses -- scalar loads, an SGPR operand per FMA -- instead of LDS broadcast reads (800 ds_read
+// per element group with an s_waitcnt in front of the FMAs that use them).
+#ifndef HPV_PJ_SGPR
+#define HPV_PJ_SGPR 1
+#endif
 #ifndef HPV_PJ_NT
 #define HPV_PJ_NT 0
 #endif
@@ -134,6 +140,7 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PI
 
     const long ngroups = (n_elem + EPW - 1) / EPW;
     constexpr bool LATE = OH && PJ_WAVES == 8;   // 4 waves/SIMD (124 VGPRs): the other waves hide the per-term round trip
+    constexpr bool SGT = OH && PJ_WAVES == 8 && !PIPE && (HPV_PJ_SGPR != 0);   // tables as SGPR operands (scalar loads), not LDS reads
     static_assert(!PIPE || OH, "the pipelined plan is written for the one-hot term / channel structure");
     const long gstride = (long)gridDim.x * PJ_WAVES;
     // PIPE: `nxt` always holds the column the NEXT (term, group) step consumes; its loads were issued one step earlier
@@ -211,13 +218,21 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PI
             // (b) y-contraction, lane = column i
             if (col) {
                 const double* byt = BYT + td.dy * (NTY * QY);
+                const double* __restrict__ byg = wty + (long)td.dy * (NTY * QY);      // [k][j], wave-uniform
                 double acc[NTY];
 #pragma unroll
                 for (int k = 0; k < NTY; ++k) acc[k] = 0.0;
+                if constexpr (SGT) {
+#pragma unroll
+                    for (int k = 0; k < NTY; ++k)
+#pragma unroll
+                        for (int j = 0; j < QY; ++j) acc[k] = fma(byg[k * QY + j], gcol[j], acc[k]);
+                } else {
 #pragma unroll
                 for (int j = 0; j < QY; ++j)
 #pragma unroll
                     for (int k = 0; k < NTY; ++k) acc[k] = fma(byt[j * NTY + k], gcol[j], acc[k]);
+                }
 #pragma unroll
                 for (int k = 0; k < NTY; ++k) Tb[slot * (NTY * LDT) + k * LDT + li] = acc[k];
             }
@@ -225,16 +240,24 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PI
             // (c) x-contraction, lane = residual row k
             if (row) {
                 const double* axt = AXT + td.dx * (NTX * QX);
+                const double* __restrict__ axg = wtx + (long)td.dx * (NTX * QX);      // [r][i], wave-uniform
                 const double c = cf[t] * (td.eps_mult ? eps : 1.0) * alpha_t;
                 double trow[QX], acc[NTX];
 #pragma unroll
                 for (int i = 0; i < QX; ++i) trow[i] = Tb[slot * (NTY * LDT) + li * LDT + i];
 #pragma unroll
                 for (int r = 0; r < NTX; ++r) acc[r] = 0.0;
+                if constexpr (SGT) {
+#pragma unroll
+                    for (int r = 0; r < NTX; ++r)
+#pragma unroll
+                        for (int i = 0; i < QX; ++i) acc[r] = fma(axg[r * QX + i], trow[i], acc[r]);
+                } else {
 #pragma unroll
                 for (int i = 0; i < QX; ++i)
 #pragma unroll
                     for (int r = 0; r < NTX; ++r) acc[r] = fma(axt[i * NTX + r], trow[i], acc[r]);
+                }
 #pragma unroll
                 for (int r = 0; r < NTX; ++r) u[r] = fma(c, acc[r], u[r]);
             }
@@ -267,7 +290,7 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PI
             pj_wave_sync();
             // (d) V[k][i] = sum_r AX[r][i] Rs[k][r], lane = row k
             if (row) {
-                const double* ax = AXs + td.dx * (NTX * QX);
+                const double* ax = SGT ? wtx + (long)td.dx * (NTX * QX) : AXs + td.dx * (NTX * QX);
                 double acc[QX];
 #pragma unroll
                 for (int i = 0; i < QX; ++i) acc[i] = 0.0;
@@ -281,7 +304,7 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PI
             pj_wave_sync();
             // (e) Gh[j][i] = c sum_k BY[k][j] V[k][i], lane = column i; scattered onto the integrated channels
             if (col) {
-                const double* by = BYs + td.dy * (NTY * QY);
+                const double* by = SGT ? wty + (long)td.dy * (NTY * QY) : BYs + td.dy * (NTY * QY);
                 const double c = cf[t];
                 const double m = td.eps_mult ? eps : 1.0;
                 double vcol[NTY], gh[QY];
@@ -558,7 +581,9 @@ static bool launch_tp2(const ProjDesc& pd, const ActiveCh& ac, const double* OUT
     if constexpr (!EPS && NA >= 2) {
         if (onehot) {
             const bool pipe = getenv("HPV_PJ_PIPE") && getenv("HPV_PJ_PIPE")[0] == '1';     // (A/B switch)
-            const bool no_stream = getenv("HPV_PJ_STREAM") && getenv("HPV_PJ_STREAM")[0] == '0';     // (A/B switch)
+            // (opt-in A/B switch: with its tables as SGPR operands k_project_tp reaches the same 4.4-4.5 TB/s as the streaming kernel
+            //  on the 2^18-element batch -- and serves the adjoint half as well)
+            const bool no_stream = !(getenv("HPV_PJ_STREAM") && getenv("HPV_PJ_STREAM")[0] == '1');
             if constexpr (NA == 2 && QX == 20 && QY == 20 && NTX == 10 && NTY == 10) {
                 // large batches, residual only, unit channel weights: the streaming kernel (LDS-staged, register double-buffered)
                 if (!do_adjoint && !no_stream && n_elem >= 4096 && N == n_elem * (long)(QX * QY) && pd.t[0].a1[ac.id[0]] == 0.0 &&

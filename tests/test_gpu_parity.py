@@ -1193,8 +1193,9 @@ def test_large_batch_projection_plans_agree(monkeypatch):
         h.set_tables(tables_1d(10, x), tables_1d(10, x))
         return h.bench_checksums(n, adj)
 
+    monkeypatch.setenv("HPV_PJ_STREAM", "1")        # (opt-in: equal speed to k_project_tp since that kernel's tables are SGPR operands)
     s_stream = sums(False)
-    monkeypatch.setenv("HPV_PJ_STREAM", "0")
+    monkeypatch.delenv("HPV_PJ_STREAM")
     s_tp = sums(False)
     s_gen = sums(False, _lib.BACKEND_GENERIC)
     assert np.all(np.isfinite(s_stream)) and s_stream[1] > 0
