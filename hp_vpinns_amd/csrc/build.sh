@@ -8,17 +8,17 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $HPV_EXTRA_FLAGS"   # e.g. HPV_EXTRA_FLAGS=-DHPV_FZ_TIMING
-SRCS="kernels_generic kernels_mfma kernels_fused kernels_tall kernels_tile kernels_project hpv_api"
+SRCS="kernels_generic kernels_mfma kernels_fused kernels_tall kernels_tile kernels_project hpv_api hpv_exchange hpv_bench"
 ELEM_SHAPES="16,16,8,8 20,20,10,10 12,12,6,6"             # kernels_elem.hip: one object per element shape (= HPV_ELEM_SHAPES of hpv_mfma_dev.h)
 WIDE_WIDTHS="24 32 40 48 64"                            # kernels_wide.hip: one object per hidden width (= HPV_WIDE_WIDTHS of hpv_mfma.h)
-HOOKED="kernels_mfma kernels_fused kernels_tall hpv_api"        # the sources that contain test hooks (built twice)
+HOOKED="kernels_mfma kernels_fused kernels_tall hpv_api hpv_exchange"        # the sources that contain test hooks (built twice)
 CHK="python3 ../../scripts/check_agpr.py"
 # objects are cached by mtime; a change of flags must invalidate them (.flags remembers what the objects were built with)
 if [ "$(cat .flags 2>/dev/null)" != "$FLAGS|$HPV_FUSED_EXTRA" ]; then rm -f *.o; echo "$FLAGS|$HPV_FUSED_EXTRA" > .flags; fi
 
 stale() {   # stale <object> <source>: the object is missing or older than its source / any header
   [ ! -f "$1" ] && return 0
-  for d in "$2" hpv_internal.h hpv_mfma.h hpv_mfma_dev.h hpv_wide_dev.h hpv_project_wg.h hpv_math.h hpv_fused_dev.h ../../include/hpvpinn.h; do
+  for d in "$2" hpv_ctx.h hpv_internal.h hpv_mfma.h hpv_mfma_dev.h hpv_wide_dev.h hpv_project_wg.h hpv_math.h hpv_fused_dev.h ../../include/hpvpinn.h; do
     [ -f "$d" ] && [ "$d" -nt "$1" ] && return 0
   done
   return 1

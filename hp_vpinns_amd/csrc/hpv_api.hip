@@ -1,206 +1,12 @@
 // C-ABI of libhpvpinn.so (include/hpvpinn.h): host orchestration of one hp-VPINN training
-// handle = one GPU's shard of elements + a replica of the network parameters.
-#include <dlfcn.h>
-#include <unistd.h>
-#include <rccl/rccl.h>   // types and prototypes only: the library is dlopen'ed on first multi-GPU use (no link-time dependency)
+// handle = one GPU's shard of elements + a replica of the network parameters.  (The multi-GPU exchanges live in hpv_exchange.hip,
+// the timing / benchmark / debug hooks in hpv_bench.hip; hpv_ctx.h holds the handle and the helpers they share.)
+#include "hpv_ctx.h"
 
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <string>
-#include <vector>
+using namespace hpvd;
 
-#include "hpv_internal.h"
-#include "hpv_mfma.h"
-#include "hpv_project_wg.h"
-
-namespace {
-
+namespace hpvd {
 std::string g_create_error;
-
-struct Batch {
-    long N = 0;
-    NetDesc nd{};
-    double* X = nullptr;     // [d][N]
-    double* ACT = nullptr;   // saved slots of every hidden layer
-    double* OUT = nullptr;   // [C][N]
-    double* GBAR = nullptr;  // [C][N]
-    double* GPART = nullptr; // [rows][P] partial parameter gradients
-    int rows = 0;
-    size_t act_doubles = 0;
-};
-
-struct TimerClass {
-    std::vector<hipEvent_t> ev;  // start/stop pairs
-    size_t used = 0;
-    double total_ms = 0.0;
-    long launches = 0;
-};
-
-}  // namespace
-
-struct hpv_ctx {
-    hpv_config cfg{};
-    std::string err;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int dim = 1;
-    int P = 0, Ptot = 0, has_eps = 0;
-    NetDesc nd_var{}, nd_val{};
-    ProjDesc pd{};
-    int backend = HPV_BACKEND_GENERIC;
-    // quadrature / tables (host copies + device weighted tables)
-    std::vector<double> xi, wx, yi, wy;
-    int qx = 0, qy = 1, ntx = 0, nty = 1;
-    double *d_wtx = nullptr, *d_wty = nullptr, *d_edge_dphi = nullptr;
-    bool have_quad = false, have_tables = false, have_elems = false, have_params = false;
-    // elements
-    int nex = 0, ney = 1, e_begin = 0, e_end = 0;
-    long n_elem = 0;
-    double *d_coef = nullptr, *d_edge_coef = nullptr, *d_F = nullptr, *d_R = nullptr, *d_loss_e = nullptr,
-           *d_deps_e = nullptr;
-    std::vector<double> F_all;
-    bool have_F = false;
-    std::vector<int> nact_all;     // active test functions per element of the whole grid (empty: all); see hpv_set_active_tests
-    int* d_nact = nullptr;         // ... of the owned elements
-    Batch var, data, edge, pred;
-    // host copies of the point sets; the device batches are (re)assembled lazily (assemble_batches)
-    std::vector<double> Xq_host;   // [dim][Nq] quadrature points of the owned elements
-    std::vector<double> Xd_host;   // [n_data][dim] boundary / data points
-    long Nq = 0;
-    bool batch_dirty = true;
-    bool merged = false;           // MFMA path: data points ride as extra tiles of the quadrature batch
-    long data_off = 0;             // first data point inside the merged batch
-    double* d_udata = nullptr;
-    double* d_data_part = nullptr;
-    int n_data = 0;
-    // parameters / optimizer
-    double *d_theta = nullptr, *d_m = nullptr, *d_v = nullptr, *d_state = nullptr, *d_RB = nullptr;
-    double* d_hist = nullptr;   // [HPV_HIST_CAP][4] loss / epsilon history (AdamArgs)
-    int* d_hist_idx = nullptr;
-    unsigned long long* d_nupd = nullptr;   // updates applied so far (AdamArgs::n_upd)
-    bool shared_elem_ok = true; // hpv_set_shared_element_kernels
-    long long nupd_host = 0;    // updates ENQUEUED so far (equals *d_nupd once the stream is idle unless a run failed)
-    int n_fallbacks = 0;        // runs finished on the barrier-free structures after an exchange timeout (after_exchange_timeout)
-    int* d_xerr = nullptr;      // sticky failure flag: a SPLIT-mode element barrier timed out (kernels_fused.hip); see sync_check
-    // mfma path (one object per batch: quadrature points, boundary/data points, element edges)
-    HpvMfma* mfma = nullptr;
-    HpvMfma* mfma_data = nullptr;
-    HpvMfma* mfma_edge = nullptr;
-    HpvMfma* mfma_pred = nullptr;
-    // strong-form PINN branch (scheme == PINNs): collocation batch with the 5 Laplacian channels
-    NetDesc nd_pinn{};
-    Batch colloc;
-    HpvMfma* mfma_colloc = nullptr;
-    double *d_fcol = nullptr, *d_col_part = nullptr;
-    int n_col = 0;
-    long n_col_total = 0;      // collocation points of ALL shards (the mean of P2:124 runs over them)
-    double* d_jac = nullptr;   // |J_e| of the owned elements (RHS assembly, hpv_assemble_rhs)
-    // in-library exchange of the packed buffer between the ranks of a node (hpv_p2p_*)
-    P2PArgs pp{};
-    bool p2p_on = false;
-    // one-workgroup grids (config 1): hpv_step asks for `persist_want` iterations in one launch; the tile kernel says how many it ran
-    int persist_want = 1, persist_done = 1;
-    bool persist_probed = false;
-    bool persist_seen = false;   // the most recent training pass ended inside the tile kernel (in-kernel finalize): persistent launches possible
-    int pass_structure = -1;   // see hpv_pass_structure
-    char variant[320] = "";    // see hpv_kernel_variant
-    double* d_inbox = nullptr;
-    unsigned long long* d_flag = nullptr;
-    unsigned long long* d_p2p_counter = nullptr;
-    int* d_p2p_err = nullptr;
-    void* p2p_maps[2 * HPV_P2P_MAX] = {};
-    // in-library RCCL all-reduce of the packed buffer (hpv_rccl_*): the multi-GPU default
-    ncclComm_t rccl_comm = nullptr;
-    bool rccl_on = false;
-    int rccl_world = 1, rccl_rank = 0;
-    // hpv_rccl_abandon (the ONE entry point that may be called from another thread while a call is inside the library): the
-    // caller has given up waiting for a blocking hpv_rccl_connect / hpv_rccl_selftest that runs on a helper thread.  The
-    // abandoned call then never touches the handle again: a communicator that comes up late is destroyed, rccl_on stays false
-    std::atomic<int> rccl_abandoned{0};
-    double* d_upart = nullptr; // partial residual sums of the row-split projection (few tall elements)
-    int proj_split = 1;        // workgroups per element there; loss_e / deps_e hold n_elem * proj_split entries
-    long n_red_alloc = 0;      // entries loss_e / deps_e were allocated with (>= every launch structure's count)
-    long n_loss_entries = 0;   // entries the most recent pass wrote (what the finalize kernel sums)
-    // timing
-    bool timing = false;
-    TimerClass timers[3];
-    // whole-iteration hipGraph (forward + projection + backward || boundary branch -> finalize -> Adam)
-    hipStream_t stream2 = nullptr;       // side stream: the boundary/data branch runs beside the main branch
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool side_active = false;            // true only while capturing
-    bool use_graph = true;
-    hipGraphExec_t g_stepK = nullptr;    // HPV_GRAPH_ITERS iterations per replay (fewer inter-graph gaps)
-    hipGraphExec_t g_rem[8] = {};        // g_rem[r]: r iterations (the remainder of a call), captured at first use
-};
-
-static void p2p_release(hpv_ctx* h);
-static void rccl_release(hpv_ctx* h);
-static int sync_check(hpv_ctx* h);
-static int p2p_check(hpv_ctx* h);
-
-namespace {
-
-// RCCL entry points resolved at run time.  A copy that is already loaded (torch ships one) is reused, so that one
-// process never runs two collective libraries.
-struct RcclApi {
-    void* lib = nullptr;
-    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-    decltype(&ncclCommInitRank) CommInitRank = nullptr;
-    decltype(&ncclAllReduce) AllReduce = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    bool ok = false;
-    std::string why;     // what went wrong, captured where it went wrong (dlerror() is one-shot and goes stale)
-};
-RcclApi& rccl_api() {
-    static RcclApi api;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        const char* names[] = {"librccl.so.1", "librccl.so"};
-        for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-        for (const char* n : names)
-            if (!api.lib) {
-                api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-                if (!api.lib) { const char* e = dlerror(); api.why = e ? e : "dlopen failed"; }
-            }
-        if (!api.lib) return;
-        api.why.clear();
-        auto sym = [&](const char* name) -> void* {
-            void* p = dlsym(api.lib, name);
-            if (!p && api.why.empty()) { const char* e = dlerror(); api.why = e ? e : (std::string("symbol missing: ") + name); }
-            return p;
-        };
-        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
-        api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
-        api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
-        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
-        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
-        api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy && api.GetErrorString;
-    });
-    return api;
-}
-
-// ncclAllReduce as the library issues it.  -DHPV_TEST_HOOKS builds (libhpvpinn_testhooks.so) can make it fail on demand --
-// HPV_TEST_RCCL_FAIL="capture": every call on a capturing stream fails (a collective that refuses stream capture);
-// HPV_TEST_RCCL_FAIL="eager:k": the k-th call outside a capture fails (k >= 1) -- the product library has no such switch.
-ncclResult_t rccl_allreduce(hpv_ctx* h, void* buf, size_t n, hipStream_t s) {
-#ifdef HPV_TEST_HOOKS
-    if (const char* e = getenv("HPV_TEST_RCCL_FAIL")) {
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(s, &st);
-        static long eager_calls = 0;
-        if (!strncmp(e, "capture", 7)) { if (st == hipStreamCaptureStatusActive) return ncclInvalidUsage; }
-        else if (!strncmp(e, "eager:", 6) && st != hipStreamCaptureStatusActive) { if (++eager_calls == atol(e + 6)) return ncclSystemError; }
-    }
-#endif
-    return rccl_api().AllReduce(buf, buf, n, ncclDouble, ncclSum, h->rccl_comm, s);
-}
 
 int fail(hpv_ctx* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -212,26 +18,24 @@ int fail(hpv_ctx* h, int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIPCHK(h, call)                                                                            \
-    do {                                                                                           \
-        hipError_t e_ = (call);                                                                    \
-        if (e_ != hipSuccess) return fail(h, -2, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-
-template <typename T>
-int dalloc(hpv_ctx* h, T** p, size_t n) {
-    if (*p) { (void)hipFree(*p); *p = nullptr; }
-    if (n == 0) return 0;
-    HIPCHK(h, hipMalloc((void**)p, n * sizeof(T)));
-    return 0;
-}
-
 int upload(hpv_ctx* h, double* dst, const double* src, size_t n) {
     if (n == 0) return 0;
     HIPCHK(h, hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
+
+void drop_graph(hpv_ctx* h) {
+    if (h->g_stepK) { (void)hipGraphExecDestroy(h->g_stepK); h->g_stepK = nullptr; }
+    for (hipGraphExec_t& g : h->g_rem) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+}
+}  // namespace hpvd
+
+static int sync_check(hpv_ctx* h);
+
+
+
+namespace {
 
 void free_batch(Batch& b) {
     if (b.X) (void)hipFree(b.X);
@@ -627,7 +431,7 @@ int enqueue_pass_x(hpv_ctx* h, bool backward, bool fuse_adam) {
         int rc = enqueue_pass(h, backward, false);
         if (rc) return rc;
         ncclResult_t r = rccl_allreduce(h, h->d_RB, (size_t)h->Ptot + 4, h->stream);
-        if (r != ncclSuccess) return fail(h, -6, "ncclAllReduce failed: %s", rccl_api().GetErrorString(r));
+        if (r != ncclSuccess) return fail(h, -6, "ncclAllReduce failed: %s", rccl_error_string(r));
         if (backward && fuse_adam) launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(h, -2, "adam launch failed: %s", hipGetErrorString(e));
@@ -644,10 +448,6 @@ int enqueue_pass_x(hpv_ctx* h, bool backward, bool fuse_adam) {
 }
 
 #define HPV_GRAPH_ITERS 8
-void drop_graph(hpv_ctx* h) {
-    if (h->g_stepK) { (void)hipGraphExecDestroy(h->g_stepK); h->g_stepK = nullptr; }
-    for (hipGraphExec_t& g : h->g_rem) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
-}
 
 // Capture `iters` whole training iterations (incl. the Adam updates) into an executable graph.
 int build_step_graph(hpv_ctx* h, int iters, hipGraphExec_t* out) {
@@ -1215,14 +1015,6 @@ static int after_exchange_timeout(hpv_ctx* h, int n) {
     return (int)done;
 }
 
-// after a synchronisation point: did an exchange give up waiting for a peer?
-static int p2p_check(hpv_ctx* h) {
-    if (!h->p2p_on) return 0;
-    int err = 0;
-    HIPCHK(h, hipMemcpy(&err, h->d_p2p_err, sizeof(int), hipMemcpyDeviceToHost));
-    if (err) return fail(h, -5, "in-library exchange: a peer did not arrive (rank %d of %d)", h->pp.rank, h->pp.world);
-    return 0;
-}
 
 int hpv_step(hpv_handle h, int n_iters, double* loss3_after) {
     if (!h) return -1;
@@ -1420,180 +1212,6 @@ int hpv_test_tables(hpv_handle h, int ntest, const double* xi, int q, double* ta
     return rc;
 }
 
-// ---- in-library exchange (multi-GPU, one process per GPU on one node) ----
-static void p2p_release(hpv_ctx* h) {
-    for (void*& m : h->p2p_maps) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
-    if (h->d_inbox) (void)hipFree(h->d_inbox);
-    if (h->d_flag) (void)hipFree(h->d_flag);
-    if (h->d_p2p_counter) (void)hipFree(h->d_p2p_counter);
-    if (h->d_p2p_err) (void)hipFree(h->d_p2p_err);
-    h->d_inbox = nullptr; h->d_flag = nullptr; h->d_p2p_counter = nullptr; h->d_p2p_err = nullptr;
-    h->p2p_on = false;
-}
-
-int hpv_p2p_export(hpv_handle h, int world, int rank, void* handles128) {
-    if (!h || !handles128 || world < 1 || world > HPV_P2P_MAX || rank < 0 || rank >= world) return -1;
-    if (!h->have_params) return fail(h, -3, "hpv_set_params has not been called");
-    p2p_release(h);
-    drop_graph(h);
-    const int n = h->Ptot + 4;
-    const size_t nb = (size_t)2 * world * n * sizeof(double), fb = (size_t)2 * world * sizeof(unsigned long long);
-    // uncached (fine-grained) device memory: peers write it over xGMI while this rank polls it
-    if (hipExtMallocWithFlags((void**)&h->d_inbox, nb, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); HIPCHK(h, hipMalloc((void**)&h->d_inbox, nb)); }
-    if (hipExtMallocWithFlags((void**)&h->d_flag, fb, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); HIPCHK(h, hipMalloc((void**)&h->d_flag, fb)); }
-    HIPCHK(h, hipMalloc((void**)&h->d_p2p_counter, sizeof(unsigned long long)));
-    HIPCHK(h, hipMalloc((void**)&h->d_p2p_err, sizeof(int)));
-    HIPCHK(h, hipMemset(h->d_inbox, 0, nb));
-    HIPCHK(h, hipMemset(h->d_flag, 0, fb));
-    HIPCHK(h, hipMemset(h->d_p2p_counter, 0, sizeof(unsigned long long)));
-    HIPCHK(h, hipMemset(h->d_p2p_err, 0, sizeof(int)));
-    HIPCHK(h, hipDeviceSynchronize());
-    hipIpcMemHandle_t hi, hf;
-    HIPCHK(h, hipIpcGetMemHandle(&hi, h->d_inbox));
-    HIPCHK(h, hipIpcGetMemHandle(&hf, h->d_flag));
-    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
-    memcpy(handles128, &hi, 64);
-    memcpy((char*)handles128 + 64, &hf, 64);
-    h->pp = P2PArgs{};
-    h->pp.world = world; h->pp.rank = rank; h->pp.n = n;
-    h->pp.counter = h->d_p2p_counter; h->pp.err = h->d_p2p_err;
-    {   // wall-clock budget of one exchange wait (ranks may be skewed by host work); HPV_P2P_TIMEOUT_MS overrides
-        double ms = 20000.0;
-        if (const char* e = getenv("HPV_P2P_TIMEOUT_MS")) { const double v = atof(e); if (v > 0.0) ms = v; }
-        h->pp.timeout_ticks = (unsigned long long)(ms * 1e5);
-    }
-    return 0;
-}
-
-int hpv_p2p_connect(hpv_handle h, const void* handles) {
-    if (!h || !handles || !h->d_inbox) return -1;
-    const int W = h->pp.world, me = h->pp.rank;
-    for (int r = 0; r < W; ++r) {
-        if (r == me) { h->pp.inbox[r] = h->d_inbox; h->pp.flag[r] = h->d_flag; continue; }
-        hipIpcMemHandle_t hi, hf;
-        memcpy(&hi, (const char*)handles + (size_t)r * 128, 64);
-        memcpy(&hf, (const char*)handles + (size_t)r * 128 + 64, 64);
-        void *pi = nullptr, *pf = nullptr;
-        hipError_t e = hipIpcOpenMemHandle(&pi, hi, hipIpcMemLazyEnablePeerAccess);
-        if (e == hipSuccess) e = hipIpcOpenMemHandle(&pf, hf, hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) { (void)hipGetLastError(); p2p_release(h); return fail(h, -2, "hipIpcOpenMemHandle (rank %d): %s", r, hipGetErrorString(e)); }
-        h->p2p_maps[2 * r] = pi; h->p2p_maps[2 * r + 1] = pf;
-        h->pp.inbox[r] = (double*)pi; h->pp.flag[r] = (unsigned long long*)pf;
-    }
-    drop_graph(h);
-    h->p2p_on = true;
-    return 0;
-}
-
-int hpv_p2p_disconnect(hpv_handle h) {
-    if (!h) return -1;
-    (void)hipStreamSynchronize(h->stream);
-    drop_graph(h);
-    p2p_release(h);
-    return 0;
-}
-
-// Known-answer exchange: RB[i] = (rank + 1) + 1e-3 i on every rank -> out[i] = W (W + 1) / 2 + W 1e-3 i; status = the
-// device-side timeout flag.  Collective: every rank must call it the same number of times.
-int hpv_p2p_selftest(hpv_handle h, double* out, size_t n, int* timed_out) {
-    if (!h || !out || !timed_out || !h->p2p_on || n != (size_t)h->pp.n) return -1;
-    std::vector<double> v(n);
-    for (size_t i = 0; i < n; ++i) v[i] = (double)(h->pp.rank + 1) + 1e-3 * (double)i;
-    int rc = upload(h, h->d_RB, v.data(), n);
-    if (rc) return rc;
-    launch_p2p_exchange(h->pp, h->d_RB, nullptr, h->P, h->Ptot, h->stream);
-    HIPCHK(h, hipMemcpyAsync(out, h->d_RB, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(timed_out, h->d_p2p_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return 0;
-}
-
-// ---- in-library RCCL all-reduce (multi-GPU default: one process per GPU, communicator owned by the handle) ----
-static void rccl_release(hpv_ctx* h) {
-    if (h->rccl_comm) { (void)rccl_api().CommDestroy(h->rccl_comm); h->rccl_comm = nullptr; }
-    h->rccl_on = false;
-}
-
-int hpv_rccl_available(void) { return rccl_api().ok ? 1 : 0; }
-
-int hpv_rccl_unique_id(hpv_handle h, void* id128) {
-    if (!h || !id128) return -1;
-    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
-    if (!rccl_api().ok) return fail(h, -6, "librccl.so could not be loaded: %s", rccl_api().why.c_str());
-    ncclUniqueId id;
-    ncclResult_t r = rccl_api().GetUniqueId(&id);
-    if (r != ncclSuccess) return fail(h, -6, "ncclGetUniqueId failed: %s", rccl_api().GetErrorString(r));
-    memcpy(id128, &id, 128);
-    return 0;
-}
-
-int hpv_rccl_connect(hpv_handle h, int world, int rank, const void* id128) {
-    if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return -1;
-    if (h->rccl_abandoned.load()) return fail(h, -6, "this handle abandoned an RCCL call earlier (hpv_rccl_abandon)");
-    if (!rccl_api().ok) return fail(h, -6, "librccl.so could not be loaded: %s", rccl_api().why.c_str());
-    if (!h->have_params) return fail(h, -3, "hpv_set_params has not been called");
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    drop_graph(h);
-    rccl_release(h);
-    ncclUniqueId id;
-    memcpy(&id, id128, 128);
-    // The blocking part.  The caller may run this on a helper thread and stop waiting (hpv_rccl_abandon): from here on nothing of
-    // the handle is touched unless the token is still clear -- a communicator that comes up late is destroyed again and the
-    // handle stays unconnected (advisor, round 3: a late success used to set rccl_on in the middle of the fallback's training).
-    ncclComm_t comm = nullptr;
-#ifdef HPV_TEST_HOOKS
-    if (const char* e = getenv("HPV_TEST_RCCL_CONNECT_DELAY_MS")) usleep((useconds_t)(atof(e) * 1000.0));
-#endif
-    ncclResult_t r = rccl_api().CommInitRank(&comm, world, id, rank);
-    if (h->rccl_abandoned.load()) {
-        if (r == ncclSuccess && comm) (void)rccl_api().CommDestroy(comm);
-        return -6;
-    }
-    if (r != ncclSuccess) return fail(h, -6, "ncclCommInitRank failed: %s", rccl_api().GetErrorString(r));
-    h->rccl_comm = comm;
-    h->rccl_world = world; h->rccl_rank = rank;
-    h->rccl_on = true;
-    return 0;
-}
-
-// The caller gave up waiting for a hpv_rccl_connect / hpv_rccl_selftest that blocks on another thread.  Thread-safe (the only
-// entry point that is); the abandoned call returns -6 without touching the handle again.  A connect that was abandoned leaves
-// the handle usable (unconnected); after an abandoned self-test the stream may be blocked behind a collective that never
-// completes -- the caller must not use this handle any more (the Python classes build a fresh one).
-int hpv_rccl_abandon(hpv_handle h) {
-    if (!h) return -1;
-    h->rccl_abandoned.store(1);
-    return 0;
-}
-
-int hpv_rccl_disconnect(hpv_handle h) {
-    if (!h) return -1;
-    (void)hipStreamSynchronize(h->stream);
-    drop_graph(h);
-    rccl_release(h);
-    return 0;
-}
-
-// Known-answer all-reduce: RB[i] = (rank + 1) + 1e-3 i on every rank -> out[i] = W (W + 1) / 2 + W 1e-3 i.  Collective.
-int hpv_rccl_selftest(hpv_handle h, double* out, size_t n) {
-    if (!h || !out || !h->rccl_on || n != (size_t)h->Ptot + 4) return -1;
-    HIPCHK(h, hipSetDevice(h->cfg.device));   // (may run on a helper thread of the caller: the current device is per thread)
-    std::vector<double> v(n);
-    for (size_t i = 0; i < n; ++i) v[i] = (double)(h->rccl_rank + 1) + 1e-3 * (double)i;
-    int rc = upload(h, h->d_RB, v.data(), n);
-    if (rc) return rc;
-    ncclResult_t r = rccl_allreduce(h, h->d_RB, n, h->stream);
-    if (h->rccl_abandoned.load()) return -6;      // the caller stopped waiting: the handle is no longer ours to touch
-    if (r != ncclSuccess) return fail(h, -6, "ncclAllReduce failed: %s", rccl_api().GetErrorString(r));
-    hipError_t e1 = hipMemcpyAsync(out, h->d_RB, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-    hipError_t e2 = e1 == hipSuccess ? hipStreamSynchronize(h->stream) : e1;
-    if (h->rccl_abandoned.load()) return -6;
-    if (e2 != hipSuccess) return fail(h, -2, "rccl self-test copy failed: %s", hipGetErrorString(e2));
-    return 0;
-}
-
-int hpv_exchange_in_use(hpv_handle h) { return !h ? -1 : (h->rccl_on ? 1 : (h->p2p_on ? 2 : 0)); }
 
 int hpv_get_residuals(hpv_handle h, double* R, size_t n) {
     if (!h || !R) return -1;
@@ -1682,121 +1300,6 @@ int hpv_backend_in_use(hpv_handle h) {
         if (rc) return rc;
     }
     return h->backend;
-}
-
-int hpv_debug_activation(hpv_handle h, const double* x, int n, double* a, double* a1, double* ref) {
-    if (!h || !x || !a || !a1 || !ref || n < 1) return -1;
-    double* d = nullptr;
-    int rc = dalloc(h, &d, (size_t)4 * n);
-    if (rc) return rc;
-    rc = upload(h, d, x, (size_t)n);
-    if (!rc) {
-        launch_debug_act(h->cfg.act, d, n, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, h->stream);
-        hipError_t e = hipMemcpyAsync(a, d + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(a1, d + 2 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(ref, d + 3 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        if (e != hipSuccess) rc = fail(h, -2, "debug_activation failed: %s", hipGetErrorString(e));
-    }
-    (void)hipFree(d);
-    return rc;
-}
-
-int hpv_enable_timing(hpv_handle h, int on) {
-    if (!h) return -1;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->timing = on != 0;
-    for (auto& t : h->timers) { t.used = 0; t.total_ms = 0.0; t.launches = 0; }
-    return 0;
-}
-
-int hpv_kernel_time_ms(hpv_handle h, int which, double* avg_ms, long* launches) {
-    if (!h || which < 0 || which > 2) return -1;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    TimerClass& t = h->timers[which];
-    for (size_t i = 0; i < t.used; i += 2) { float ms = 0; (void)hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]); t.total_ms += ms; }
-    t.used = 0;
-    if (avg_ms) *avg_ms = t.launches ? t.total_ms / (double)t.launches : 0.0;
-    if (launches) *launches = t.launches;
-    return 0;
-}
-
-int hpv_bench_projection(hpv_handle h, long n_elem, int reps, double* avg_ms, double* bytes_per_launch) {
-    return hpv_bench_residual(h, n_elem, reps, 1, avg_ms, bytes_per_launch);
-}
-
-static int bench_residual_impl(hpv_handle h, long n_elem, int reps, int do_adjoint, double* avg_ms, double* bytes_per_launch, double* sums);
-int hpv_bench_residual(hpv_handle h, long n_elem, int reps, int do_adjoint, double* avg_ms, double* bytes_per_launch) {
-    return bench_residual_impl(h, n_elem, reps, do_adjoint, avg_ms, bytes_per_launch, nullptr);
-}
-int hpv_bench_residual_checksums(hpv_handle h, long n_elem, int do_adjoint, double* sums6) {
-    if (!sums6) return -1;
-    return bench_residual_impl(h, n_elem, 1, do_adjoint, nullptr, nullptr, sums6);
-}
-static int bench_residual_impl(hpv_handle h, long n_elem, int reps, int do_adjoint, double* avg_ms, double* bytes_per_launch, double* sums) {
-    if (!h) return -1;
-    if (!h->have_quad || !h->have_tables) return fail(h, -3, "set quadrature and tables first");
-    if (n_elem < 1 || reps < 1) return fail(h, -1, "bad arguments");
-    const ProjDesc& pd = h->pd;
-    const long NQ = (long)pd.qx * pd.qy, NR = (long)pd.ntx * pd.nty, N = n_elem * NQ;
-    const int C = pd.C;
-    double *OUT = nullptr, *GB = nullptr, *R = nullptr, *F = nullptr, *coef = nullptr, *le = nullptr, *de = nullptr;
-    int rc = 0;
-    rc |= dalloc(h, &OUT, (size_t)C * N); rc |= dalloc(h, &GB, (size_t)C * N);
-    rc |= dalloc(h, &R, (size_t)n_elem * NR); rc |= dalloc(h, &F, (size_t)n_elem * NR);
-    rc |= dalloc(h, &coef, (size_t)pd.nterms * n_elem); rc |= dalloc(h, &le, (size_t)n_elem); rc |= dalloc(h, &de, (size_t)n_elem);
-    if (!rc) {
-        // deterministic pseudo-random fill on the host in chunks (seeded LCG -> uniform(-1,1))
-        std::vector<double> buf((size_t)1 << 20);
-        unsigned long long s = 1234;
-        auto fill = [&](double* dst, size_t n) {
-            for (size_t o = 0; o < n; o += buf.size()) {
-                size_t m = std::min(buf.size(), n - o);
-                for (size_t i = 0; i < m; ++i) { s = s * 6364136223846793005ULL + 1442695040888963407ULL; buf[i] = (double)(long long)(s >> 11) / 4503599627370496.0 - 1.0; }
-                (void)hipMemcpy(dst + o, buf.data(), m * sizeof(double), hipMemcpyHostToDevice);
-            }
-        };
-        fill(OUT, (size_t)C * N); fill(F, (size_t)n_elem * NR);
-        std::vector<double> c((size_t)pd.nterms * n_elem, 0.25);
-        (void)hipMemcpy(coef, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice);
-        const double* eps_ptr = h->has_eps ? h->d_theta + h->P : nullptr;
-        ProjDesc p2 = pd; p2.edge = 0;
-        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        (void)hipMemset(GB, 0, (size_t)C * N * sizeof(double));
-        auto go = [&]() {
-            if (h->cfg.backend == HPV_BACKEND_GENERIC ||
-                !launch_project_tp(p2, OUT, GB, R, F, coef, n_elem, h->d_wtx, h->d_wty, eps_ptr, le, de, N, n_elem, do_adjoint ? 1 : 0, h->stream))
-                launch_project(p2, OUT, GB, R, F, coef, n_elem, h->d_wtx, h->d_wty, eps_ptr, le, de, N, n_elem, do_adjoint ? 1 : 0, nullptr, nullptr, nullptr, nullptr, h->stream);
-        };
-        go();
-        (void)hipEventRecord(e0, h->stream);
-        for (int i = 0; i < reps; ++i) go();
-        (void)hipEventRecord(e1, h->stream);
-        (void)hipStreamSynchronize(h->stream);
-        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
-        if (avg_ms) *avg_ms = ms / reps;
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) rc = fail(h, -2, "projection bench failed: %s", hipGetErrorString(e));
-        if (!rc && sums) {      // what the launch produced, condensed: sum R, sum R^2, sum loss_e, sum |gbar|, sum gbar^2, sum over e of e-weighted loss
-            std::vector<double> hr((size_t)n_elem * NR), hl((size_t)n_elem), hg(do_adjoint ? (size_t)C * N : 0);
-            (void)hipMemcpy(hr.data(), R, hr.size() * sizeof(double), hipMemcpyDeviceToHost);
-            (void)hipMemcpy(hl.data(), le, hl.size() * sizeof(double), hipMemcpyDeviceToHost);
-            if (do_adjoint) (void)hipMemcpy(hg.data(), GB, hg.size() * sizeof(double), hipMemcpyDeviceToHost);
-            for (int i = 0; i < 6; ++i) sums[i] = 0.0;
-            for (double v : hr) { sums[0] += v; sums[1] += v * v; }
-            for (size_t i = 0; i < hl.size(); ++i) { sums[2] += hl[i]; sums[5] += hl[i] * (double)(i % 97); }
-            for (double v : hg) { sums[3] += std::fabs(v); sums[4] += v * v; }
-        }
-    }
-    // algorithmic bytes: read the integrated channels + F, write R (8 (C_u N + 2 N_R)); with the adjoint
-    // also write the adjoint channels
-    int cu = 0;
-    for (int ch = 0; ch < C; ++ch) { bool used = false; for (int t = 0; t < pd.nterms; ++t) if (pd.t[t].a0[ch] != 0.0 || pd.t[t].a1[ch] != 0.0) used = true; cu += used; }
-    if (bytes_per_launch) *bytes_per_launch = 8.0 * ((do_adjoint ? 2.0 : 1.0) * cu * (double)N + 2.0 * (double)n_elem * NR);
-    double* ptrs[] = {OUT, GB, R, F, coef, le, de};
-    for (double* p : ptrs) if (p) (void)hipFree(p);
-    return rc;
 }
 
 }  // extern "C"

@@ -1,4 +1,4 @@
-// Internal descriptors shared by the host orchestration (hpv_api.hip) and the kernels.
+// Internal descriptors shared by the host orchestration (hpv_api.hip, hpv_exchange.hip, hpv_bench.hip) and the kernels.
 // Everything here is plain-old-data passed to kernels by value (kernarg segment).
 #pragma once
 #include <hip/hip_runtime.h>

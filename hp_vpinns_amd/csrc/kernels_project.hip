@@ -40,7 +40,7 @@
 // HPV_PJ_NT (compile time, scripts/build_variant.sh <name> -DHPV_PJ_NT=1): the streamed channel columns are read, and R
 // written, with non-temporal hints (each byte is touched once).  Measured (round 4): no gain (46-47 % vs 47.5-48.7 % of 8 TB/s
 // without) and +5 % written bytes by PMC (8-byte nt stores with an 80-byte lane stride are not merged into whole lines): off.
-// HPV_PJ_SGPR (compile time, default 1): the one-hot 8-wave instantiation of k_project_tp reads its test-function tables from
+// HPV_PJ_SGPR (compile time, default 1): k_project_tp reads its test-function tables from
 // global memory at wave-uniform addresses -- scalar loads, an SGPR operand per FMA -- instead of LDS broadcast reads (800 ds_read
 // per element group with an s_waitcnt in front of the FMAs that use them).
 #ifndef HPV_PJ_SGPR
@@ -97,11 +97,12 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PI
     // index (independent accumulators, wide broadcast reads, many LDS reads in flight).  The transposed copies
     // are derived here; ALL global loads of the staging are issued before the first LDS store (one L2 round
     // trip instead of one per loop iteration -- the staging was most of the kernel's latency at 256 elements).
+    constexpr bool SGT = !PIPE && (HPV_PJ_SGPR != 0);   // tables as SGPR operands (scalar loads at uniform addresses), not LDS reads
     double* AXs = sm;                      // [3][NTX][QX]  w_x phi^(d)[r][i]
     double* BYs = AXs + 3 * NTX * QX;      // [3][NTY][QY]  w_y phi^(d)[k][j]
     double* AXT = BYs + 3 * NTY * QY;      // [3][QX][NTX]
     double* BYT = AXT + 3 * NTX * QX;      // [3][QY][NTY]
-    {
+    if constexpr (!SGT) {      // (with SGPR tables nothing is staged: the kernel starts with its first element group's loads)
         constexpr int NAX = 3 * NTX * QX, NBY = 3 * NTY * QY;
         constexpr int ITA = (NAX + PJ_BLOCK - 1) / PJ_BLOCK, ITB = (NBY + PJ_BLOCK - 1) / PJ_BLOCK;
         double va[ITA], vb[ITB];
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PI
             }
         }
     }
-    __syncthreads();
+    if constexpr (!SGT) __syncthreads();
     double* Tb = BYT + 3 * NTY * QY + wv * WAVE_DOUBLES;   // [EPW][NTY][LDT]  transpose tile (T, then V)
     double* Rd = Tb + TB_D;                                // [64] slot-wise reductions
     const int slot = lane / LPE, li = lane % LPE;
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PI
 
     const long ngroups = (n_elem + EPW - 1) / EPW;
     constexpr bool LATE = OH && PJ_WAVES == 8;   // 4 waves/SIMD (124 VGPRs): the other waves hide the per-term round trip
-    constexpr bool SGT = OH && PJ_WAVES == 8 && !PIPE && (HPV_PJ_SGPR != 0);   // tables as SGPR operands (scalar loads), not LDS reads
+
     static_assert(!PIPE || OH, "the pipelined plan is written for the one-hot term / channel structure");
     const long gstride = (long)gridDim.x * PJ_WAVES;
     // PIPE: `nxt` always holds the column the NEXT (term, group) step consumes; its loads were issued one step earlier
