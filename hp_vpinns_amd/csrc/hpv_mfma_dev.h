@@ -73,6 +73,7 @@ struct HpvMfma {
     long N, ntiles;
     int L;
     int H = MF_H;      // uniform hidden width (20: kernels_mfma.hip and the whole-iteration kernels; other widths: kernels_wide.hip)
+    bool store_s_only = false;   // kernels_wide.hip: the forward kernel stores s (and cos) only, the reverse kernel recomputes the tangents
     int ks = MF_KS;    // values per lane, channel and layer = H / 4 (the activation store is [tile][layer][slot][ks][64])
     int ns;            // saved slots per layer
     double* ACTS = nullptr;

@@ -848,7 +848,7 @@ int hpv_mfma_max_rows(HpvMfma* m, long n_elem, long n_data_tiles) {
 void hpv_mfma_forward(HpvMfma* m, const double* theta, const double* X, double* OUT, int save_act, hipStream_t s,
                       const MfmaDataTerm* dt) {
     MfmaArgs a = m->base;
-    a.theta = theta; a.X = X; a.OUT = OUT; a.save_act = save_act;
+    a.theta = theta; a.X = X; a.OUT = OUT; a.save_act = (save_act && m->store_s_only) ? 2 : save_act;
     a.data_off = -1;
     if (dt && dt->n_data > 0) {
         a.data_off = dt->data_off; a.ud = dt->ud; a.gbar0 = dt->gbar0; a.data_part = dt->data_part;

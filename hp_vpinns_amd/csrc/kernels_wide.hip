@@ -42,13 +42,17 @@ struct WideBwdLds {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int D, int NT1, int NT2, int ACT, int L, int H, bool SAVE>
+// SAVE: 0 nothing (forward-only evaluation), 1 every slot of the activation store (s, [cos], z_c, z_cc), 2 only s (and cos): the
+// reverse kernel k_bwd_wide_rc then recomputes the tangent pre-activations on the MFMA pipe -- a third of the store's bytes for
+// three channels (the forward kernel is HBM-write-bound on the store: 182 MB, 4.2 TB/s at H = 32 on the config-4 grid)
+template <int D, int NT1, int NT2, int ACT, int L, int H, int SAVE>
 __global__ void __launch_bounds__(WF_BLOCK, (H <= 32 ? 2 : 1)) k_fwd_wide(MfmaArgs g) {
     using W = WD<H>;
     using M = WideFwdLds<H, L, D>;
     constexpr int KS = W::KS, C = 1 + NT1 + NT2;
-    constexpr int NS = SlotCount<ACT, NT1, NT2>::value;
+    constexpr int NS = SAVE == 2 ? (ACT == HPV_ACT_SIN ? 2 : 1) : SlotCount<ACT, NT1, NT2>::value;      // slots per layer in the store
     constexpr int SA1 = 1, SZC = 1 + (ACT == HPV_ACT_SIN ? 1 : 0), SZCC = SZC + NT1;
+    constexpr bool SAVE_T = SAVE == 1;       // tangent pre-activations stored too
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = lane >> 4, pt = lane & 15;
@@ -110,7 +114,7 @@ __global__ void __launch_bounds__(WF_BLOCK, (H <= 32 ? 2 : 1)) k_fwd_wide(MfmaAr
                     double a, a1, a2;
                     act_fwd<ACT, decltype(fast)::value>(z1[s], a, a1, a2);
                     h[0][s] = a;
-                    if constexpr (SAVE) {
+                    if constexpr (SAVE != 0) {
                         sv[(0 * KS + s) * 64] = a;
                         if constexpr (ACT == HPV_ACT_SIN) sv[(SA1 * KS + s) * 64] = a1;
                     }
@@ -137,19 +141,19 @@ __global__ void __launch_bounds__(WF_BLOCK, (H <= 32 ? 2 : 1)) k_fwd_wide(MfmaAr
                     double a, a1, a2;
                     act_fwd<ACT, decltype(fast)::value>(z[0][s], a, a1, a2);
                     h[0][s] = a;
-                    if constexpr (SAVE) {
+                    if constexpr (SAVE != 0) {
                         svl[(0 * KS + s) * 64] = a;
                         if constexpr (ACT == HPV_ACT_SIN) svl[(SA1 * KS + s) * 64] = a1;
                     }
 #pragma unroll
                     for (int u = 0; u < NT1; ++u) {
-                        if constexpr (SAVE) svl[((SZC + u) * KS + s) * 64] = z[1 + u][s];
+                        if constexpr (SAVE_T) svl[((SZC + u) * KS + s) * 64] = z[1 + u][s];
                         h[1 + u][s] = a1 * z[1 + u][s];
                     }
 #pragma unroll
                     for (int b = 0; b < NT2; ++b) {
                         const double zcc = z[1 + NT1 + b][s], zc1 = z[1 + (b < NT1 ? b : 0)][s];
-                        if constexpr (SAVE) svl[((SZCC + b) * KS + s) * 64] = zcc;
+                        if constexpr (SAVE_T) svl[((SZCC + b) * KS + s) * 64] = zcc;
                         h[1 + NT1 + b][s] = a2 * zc1 * zc1 + a1 * zcc;
                     }
                 }
@@ -342,6 +346,191 @@ __global__ void __launch_bounds__(WF_BLOCK, 1) k_bwd_wide(MfmaArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// reverse, tangents recomputed (the store holds s -- and cos -- only; k_fwd_wide<.., SAVE = 2>)
+// ------------------------------------------------------------------------------------------------
+template <int H, int L, int D>
+struct WideBwdRcLds {
+    using W = WD<H>;
+    static constexpr int LH = L - 1;
+    static constexpr int TAB = 0;                               // per-wave transpose pair [WAVES][2][H][17]; epilogue: exchange
+    static constexpr int FR = TAB + WF_WAVES * 2 * W::TR;       // reverse fragments        [LH][FRAG]
+    static constexpr int FF = FR + LH * W::FRAG;                // forward fragments (the recompute)  [LH][FRAG]
+    static constexpr int W1 = FF + LH * W::FRAG;                // first-layer rows, head weights  [D + 1][H]
+    static constexpr int TOTAL = W1 + (D + 1) * H;
+};
+
+template <int D, int NT1, int NT2, int ACT, int L, int H>
+__global__ void __launch_bounds__(WF_BLOCK, 1) k_bwd_wide_rc(MfmaArgs g) {
+    using W = WD<H>;
+    using M = WideBwdRcLds<H, L, D>;
+    constexpr int KS = W::KS, C = 1 + NT1 + NT2, CT = NT1 + NT2, LH = L > 1 ? L - 1 : 1;
+    constexpr int NS = ACT == HPV_ACT_SIN ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int q = lane >> 4, pt = lane & 15;
+    const long wave = ((long)blockIdx.x * blockDim.x + tid) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const double* __restrict__ th = g.theta;
+#pragma unroll
+    for (int i = 1; i < L; ++i) {
+        wide_stage_layer<H, false, WF_BLOCK>(th, g.woff[i], lds + M::FR + (i - 1) * W::FRAG, tid);
+        wide_stage_layer<H, true, WF_BLOCK>(th, g.woff[i], lds + M::FF + (i - 1) * W::FRAG, tid);
+    }
+    for (int f = tid; f < (D + 1) * H; f += WF_BLOCK) {
+        const int c = f / H, j = f - c * H;
+        lds[M::W1 + f] = th[(c < D ? g.woff[0] + c * H : g.woff[L]) + j];
+    }
+    __syncthreads();
+    const double* W1 = lds + M::W1;
+    double* TA = lds + M::TAB + wv * (2 * W::TR);
+    double* TB = TA + W::TR;
+    WideDW<H> dW[LH];
+#pragma unroll
+    for (int i = 0; i < LH; ++i) dW[i].zero();
+    double db[L][KS], dW1[D][KS], dWo[KS], dbo = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        dWo[s] = 0.0;
+#pragma unroll
+        for (int i = 0; i < L; ++i) db[i][s] = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) dW1[c][s] = 0.0;
+    }
+    for (long tile = wave; tile < g.ntiles; tile += nwaves) {
+        int lofs = lane;
+        asm volatile("" : "+v"(lofs));   // opaque per tile: the LDS weight reads stay inside the loop
+        const int ql = lofs >> 4;
+        const long p = tile * 16 + pt;
+        const bool valid = p < g.N;
+        double x[D], gb[C];
+#pragma unroll
+        for (int c = 0; c < D; ++c) x[c] = valid ? g.X[(long)c * g.N + p] : 0.0;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) gb[ch] = valid ? g.GBAR[(long)ch * g.N + p] : 0.0;
+        // s (and cos) of every hidden layer: ONE batch of coalesced loads per tile
+        const double* sv = g.ACTS + (tile * L) * (long)(NS * KS * 64) + lane;
+        double S[L][KS], S1[ACT == HPV_ACT_SIN ? L : 1][KS];
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                S[i][s] = sv[(long)i * (NS * KS * 64) + s * 64];
+                if constexpr (ACT == HPV_ACT_SIN) S1[i][s] = sv[(long)i * (NS * KS * 64) + (KS + s) * 64];
+            }
+        // tangent pre-activations of every layer, recomputed on the MFMA pipe
+        double zc[L][NT1 > 0 ? NT1 : 1][KS], zcc[L][NT2 > 0 ? NT2 : 1][KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int u = 0; u < NT1; ++u) zc[0][u][s] = W1[(u < D ? u : 0) * H + 4 * s + ql];
+#pragma unroll
+            for (int b = 0; b < NT2; ++b) zcc[0][b][s] = 0.0;
+        }
+        if constexpr (CT > 0) {
+            double hc[CT > 0 ? CT : 1][KS];
+#pragma unroll
+            for (int i = 0; i < L - 1; ++i) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    double a1, a2, a3;
+                    act_saved<ACT>(S[i][s], ACT == HPV_ACT_SIN ? S1[ACT == HPV_ACT_SIN ? i : 0][s] : 0.0, a1, a2, a3);
+#pragma unroll
+                    for (int u = 0; u < NT1; ++u) hc[u][s] = a1 * zc[i][u][s];
+#pragma unroll
+                    for (int b = 0; b < NT2; ++b) {
+                        const double z1 = zc[i][b < NT1 ? b : 0][s];
+                        hc[NT1 + b][s] = a2 * z1 * z1 + a1 * zcc[i][b][s];
+                    }
+                }
+                double zt[CT > 0 ? CT : 1][KS];
+                wide_fwd_layer<H, (CT > 0 ? CT : 1), false>(lds + M::FF + i * W::FRAG, nullptr, lofs, hc, zt);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                    for (int u = 0; u < NT1; ++u) zc[i + 1][u][s] = zt[u][s];
+#pragma unroll
+                    for (int b = 0; b < NT2; ++b) zcc[i + 1][b][s] = zt[NT1 + b][s];
+                }
+            }
+        }
+        auto outputs_of = [&](int i, int ch, double (&hv)[KS]) {   // channel ch of layer i's outputs
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                double a1, a2, a3;
+                act_saved<ACT>(S[i][s], ACT == HPV_ACT_SIN ? S1[ACT == HPV_ACT_SIN ? i : 0][s] : 0.0, a1, a2, a3);
+                if (ch == 0) hv[s] = S[i][s];
+                else if (ch <= NT1) hv[s] = a1 * zc[i][(ch - 1) < NT1 ? (ch - 1) : 0][s];
+                else {
+                    const int b = ch - 1 - NT1;
+                    const double z1 = zc[i][b < NT1 ? b : 0][s];
+                    hv[s] = a2 * z1 * z1 + a1 * zcc[i][b < NT2 ? b : 0][s];
+                }
+            }
+        };
+        double hbar[C][KS], zbar[C][KS];
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            double hv[KS];
+            outputs_of(L - 1, ch, hv);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                dWo[s] = fma(hv[s], gb[ch], dWo[s]);
+                hbar[ch][s] = gb[ch] * W1[D * H + 4 * s + ql];
+            }
+        }
+        if (q == 0) dbo += gb[0];
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                double a1, a2, a3;
+                act_saved<ACT>(S[i][s], ACT == HPV_ACT_SIN ? S1[ACT == HPV_ACT_SIN ? i : 0][s] : 0.0, a1, a2, a3);
+                double zb = hbar[0][s] * a1;
+#pragma unroll
+                for (int u = 0; u < NT1; ++u) {
+                    zbar[1 + u][s] = hbar[1 + u][s] * a1;
+                    zb += hbar[1 + u][s] * a2 * zc[i][u][s];
+                }
+#pragma unroll
+                for (int b = 0; b < NT2; ++b) {
+                    const int u = b < NT1 ? b : 0;
+                    const double hb = hbar[1 + NT1 + b][s];
+                    zbar[1 + NT1 + b][s] = hb * a1;
+                    zbar[1 + u][s] += 2.0 * hb * a2 * zc[i][u][s];
+                    zb += hb * (a3 * zc[i][u][s] * zc[i][u][s] + a2 * zcc[i][b][s]);
+                }
+                zbar[0][s] = zb;
+                db[i][s] += zb;
+            }
+            if (i == 0) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                    for (int c = 0; c < D; ++c) dW1[c][s] += x[c] * zbar[0][s];
+#pragma unroll
+                    for (int u = 0; u < NT1; ++u) dW1[u < D ? u : 0][s] += zbar[1 + u][s];
+                }
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    double hv[KS];
+                    outputs_of(i - 1, ch, hv);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    wide_transpose_store<H>(TA, TB, q, pt, hv, zbar[ch]);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    wide_dw_accumulate<H>(TA, TB, lane, dW[i - 1]);
+                }
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) wide_hbar<H>(lds + M::FR + (i - 1) * W::FRAG, lofs, zbar[ch], hbar[ch]);
+            }
+        }
+    }
+    wide_epilogue<H, L, D, WF_WAVES>(lds + M::TAB, dW, db, dW1, dWo, dbo, g.GPART + (long)blockIdx.x * g.P, g.woff, g.boff);
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 template <typename K>
@@ -356,8 +545,9 @@ static bool wide_set_lds(K kernel, size_t bytes) {
 template <int D, int NT1, int NT2, int ACT, int L, int H>
 static void run_fwd_wide(const MfmaArgs& a, int blocks, hipStream_t s) {
     constexpr size_t bytes = (size_t)WideFwdLds<H, L, D>::TOTAL * sizeof(double);
-    if (a.save_act) hipLaunchKernelGGL((k_fwd_wide<D, NT1, NT2, ACT, L, H, true>), dim3(blocks), dim3(WF_BLOCK), bytes, s, a);
-    else hipLaunchKernelGGL((k_fwd_wide<D, NT1, NT2, ACT, L, H, false>), dim3(blocks), dim3(WF_BLOCK), bytes, s, a);
+    if (a.save_act == 2) hipLaunchKernelGGL((k_fwd_wide<D, NT1, NT2, ACT, L, H, 2>), dim3(blocks), dim3(WF_BLOCK), bytes, s, a);
+    else if (a.save_act) hipLaunchKernelGGL((k_fwd_wide<D, NT1, NT2, ACT, L, H, 1>), dim3(blocks), dim3(WF_BLOCK), bytes, s, a);
+    else hipLaunchKernelGGL((k_fwd_wide<D, NT1, NT2, ACT, L, H, 0>), dim3(blocks), dim3(WF_BLOCK), bytes, s, a);
 }
 template <int D, int NT1, int NT2, int ACT, int L, int H>
 static void run_bwd_wide(const MfmaArgs& a, int blocks, hipStream_t s) {
@@ -366,22 +556,42 @@ static void run_bwd_wide(const MfmaArgs& a, int blocks, hipStream_t s) {
 }
 
 template <int D, int NT1, int NT2, int ACT, int L, int H>
+static void run_bwd_wide_rc(const MfmaArgs& a, int blocks, hipStream_t s) {
+    constexpr size_t bytes = (size_t)WideBwdRcLds<H, L, D>::TOTAL * sizeof(double);
+    hipLaunchKernelGGL((k_bwd_wide_rc<D, NT1, NT2, ACT, L, H>), dim3(blocks), dim3(WF_BLOCK), bytes, s, a);
+}
+
+template <int D, int NT1, int NT2, int ACT, int L, int H>
 static bool pick_wide(HpvMfma* m) {
     constexpr size_t fb = (size_t)WideFwdLds<H, L, D>::TOTAL * sizeof(double), bb = (size_t)WideBwdLds<H, L, D>::TOTAL * sizeof(double);
-    if (!wide_set_lds(k_fwd_wide<D, NT1, NT2, ACT, L, H, true>, fb) || !wide_set_lds(k_fwd_wide<D, NT1, NT2, ACT, L, H, false>, fb) ||
+    if (!wide_set_lds(k_fwd_wide<D, NT1, NT2, ACT, L, H, 1>, fb) || !wide_set_lds(k_fwd_wide<D, NT1, NT2, ACT, L, H, 0>, fb) ||
         !wide_set_lds(k_bwd_wide<D, NT1, NT2, ACT, L, H>, bb))
         return false;
     m->fwd = run_fwd_wide<D, NT1, NT2, ACT, L, H>;
     m->bwd = run_bwd_wide<D, NT1, NT2, ACT, L, H>;
+    m->store_s_only = false;
+    // s-only store + tangent recompute in the reverse kernel (where tangents exist, H <= 32, forward fragments fit beside the
+    // reverse ones): OPT-IN, HPV_WIDE_RC=1.  Measured slower than the full store on every case tried (round 4, us per iteration,
+    // recompute / full store: config-4 grid H = 24 125.1 / 112.9, H = 32 192.9 / 149.2; 1-D 16 elements [1,32,32,32,32,1]
+    // 60.2 / 48.6): the forward kernel's store shrinks to a third, but the reverse kernel -- the compiler-scheduled recompute at
+    // one wave per SIMD, 380 B of scratch at H = 32 -- loses more than the forward kernel gains.
+    if constexpr (H <= 32 && L >= 2 && NT1 + NT2 > 0) {
+        constexpr size_t rb = (size_t)WideBwdRcLds<H, L, D>::TOTAL * sizeof(double);
+        const char* e = getenv("HPV_WIDE_RC");
+        if ((e && e[0] == '1') && wide_set_lds(k_fwd_wide<D, NT1, NT2, ACT, L, H, 2>, fb) && wide_set_lds(k_bwd_wide_rc<D, NT1, NT2, ACT, L, H>, rb)) {
+            m->bwd = run_bwd_wide_rc<D, NT1, NT2, ACT, L, H>;
+            m->store_s_only = true;
+        }
+    }
     m->bwd_fused = nullptr;
     int of = 1, ob = 1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, k_fwd_wide<D, NT1, NT2, ACT, L, H, true>, WF_BLOCK, fb);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, k_fwd_wide<D, NT1, NT2, ACT, L, H, 1>, WF_BLOCK, fb);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_bwd_wide<D, NT1, NT2, ACT, L, H>, WF_BLOCK, bb);
     m->occ_fwd = of > 0 ? of : 1;
     m->occ_bwd = ob > 0 ? ob : 1;
     const char* an = ACT == HPV_ACT_SIN ? "sin" : "tanh";
     snprintf(m->vfwd, sizeof m->vfwd, "k_fwd_wide<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=%d>", D, NT1, NT2, an, L, H);
-    snprintf(m->vbwd, sizeof m->vbwd, "k_bwd_wide<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=%d>", D, NT1, NT2, an, L, H);
+    snprintf(m->vbwd, sizeof m->vbwd, "%s<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=%d>", m->store_s_only ? "k_bwd_wide_rc" : "k_bwd_wide", D, NT1, NT2, an, L, H);
     return true;
 }
 template <int D, int NT1, int NT2, int ACT, int H>
