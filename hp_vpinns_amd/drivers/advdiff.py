@@ -95,13 +95,28 @@ def build_model(s, Net_layer, var_form=0, LR=0.001, init_params=None, backend="a
                         **kw)                                    # P3:488-489
 
 
+def export_mat(path, s, u_record, u_records_iterhis, total_record, total_time_train):
+    """The reference's `<case>_record.mat` (P3:500-508): test grid, exact solution, element grids, the best prediction of the last
+    tenth of the run, the records [iteration, loss, epsilon, 1] and the training time.  (The reference issues one `savemat` per
+    variable into the same open file, which leaves only fragments readable; here ONE call writes all eight variables under the
+    reference's names.)"""
+    import scipy.io
+    rec = np.array([[float(r[0]), float(r[1]), float(np.ravel(r[2])[0]), float(r[3])] for r in total_record]) if len(total_record) else np.zeros((0, 4))
+    scipy.io.savemat(path, {"x_test": s["XT_test"], "u_test": s["u_test"], "grid_x": s["grid_x"], "grid_t": s["grid_t"],
+                            "u_pred": np.zeros((0, 1)) if u_record is None else u_record,
+                            "u_pred_his": np.asarray(u_records_iterhis, dtype=np.float64) if len(u_records_iterhis) else np.zeros((0, 1)),
+                            "total": rec, "total_time_train": float(total_time_train)})
+
+
 def run(LR=0.001, Opt_Niter=1500 + 1, Opt_tresh=2e-11, var_form=0, Net_layer=None, N_el_x=1, N_el_t=1, N_test_x=5,
-        N_test_t=5, N_quad=10, N_bound=80, init_params=None, backend="auto", verbose=True):
+        N_test_t=5, N_quad=10, N_bound=80, init_params=None, backend="auto", verbose=True, mat_path=None):
     """P3:31-54 hyper-parameters (reference defaults) -> identified epsilon, prediction, L2 error."""
     Net_layer = [2] + [5] * 3 + [1] if Net_layer is None else Net_layer        # P3:46
     s = setup(N_el_x, N_el_t, N_test_x, N_test_t, N_quad, N_bound)
     model = build_model(s, Net_layer, var_form, LR, init_params, backend)
     error_record, total_record, u_record, u_his, t_train = model.train(Opt_Niter, Opt_tresh)   # P3:493-494
+    if mat_path is not None:                                                    # P3:500-508
+        export_mat(mat_path, s, u_record, u_his, total_record, t_train)
     u_pred = model.predict()
     err = np.linalg.norm(s["u_test"] - u_pred, 2) / np.linalg.norm(s["u_test"], 2)
     eps_id = float(model.epsilon[0])
@@ -118,5 +133,7 @@ if __name__ == "__main__":
     ap.add_argument("--quad", type=int, default=10)
     ap.add_argument("--width", type=int, default=5)
     ap.add_argument("--var-form", type=int, default=0)
+    ap.add_argument("--mat", default=None, help="write the reference's <case>_record.mat here (P3:500-508)")
     a = ap.parse_args()
-    run(Opt_Niter=a.iters, N_el_x=a.elements_x, N_quad=a.quad, var_form=a.var_form, Net_layer=[2] + [a.width] * 3 + [1])
+    run(Opt_Niter=a.iters, N_el_x=a.elements_x, N_quad=a.quad, var_form=a.var_form, Net_layer=[2] + [a.width] * 3 + [1],
+        mat_path=a.mat)

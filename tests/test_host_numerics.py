@@ -181,3 +181,19 @@ def test_recorded_run_indices_and_stop_without_a_device():
     recs, stop = m._recorded_run(0, 30, 6.5)                 # losses at iterations 0, 10, 20: 10, 6.9, 3.8 -> stop at 20
     assert [r[0] for r in recs] == [0, 10, 20] and stop == 20
     assert m.calls == [("record", 30), ("set_state", "state"), ("step", 21)]
+
+
+def test_advdiff_mat_export_holds_the_reference_variables(tmp_path):
+    """drivers.advdiff.export_mat: the eight variables of the reference's `hpPINN_ADE_Iden_record.mat` (P3:500-508) in one file."""
+    import scipy.io
+    from hp_vpinns_amd.drivers import advdiff
+    s = dict(XT_test=np.random.rand(7, 2), u_test=np.random.rand(7, 1), grid_x=np.array([-1.0, 1.0]), grid_t=np.array([0.0, 1.0]))
+    total = [np.array([10 * i, 1.0 / (i + 1), np.array([1.0 - 0.01 * i]), 1], dtype=object) for i in range(5)]
+    path = str(tmp_path / "rec.mat")
+    advdiff.export_mat(path, s, np.ones((7, 1)), [], total, 1.25)
+    m = scipy.io.loadmat(path)
+    assert set(["x_test", "u_test", "grid_x", "grid_t", "u_pred", "u_pred_his", "total", "total_time_train"]) <= set(m)
+    assert m["total"].shape == (5, 4) and abs(m["total"][3, 1] - 0.25) < 1e-15 and abs(m["total"][4, 2] - 0.96) < 1e-15
+    assert m["u_pred"].shape == (7, 1) and float(m["total_time_train"]) == 1.25
+    advdiff.export_mat(path, s, None, [], [], 0.0)           # (a run that never reached its last tenth)
+    assert scipy.io.loadmat(path)["total"].shape == (0, 4)
