@@ -314,7 +314,14 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
                 // specialised tensor-product kernel for the hot element shapes unless the generic backend is forced
                 // (needs GBAR's unused channels pre-zeroed: true for every batch, see alloc_batch)
                 const char* pname = "k_project";
-                if (h->cfg.backend != HPV_BACKEND_GENERIC &&
+                // few elements (at most two per CU) of a 2-D shape: one workgroup per element before "a lane owns a line"
+                const bool small_grid = h->dim == 2 && h->n_elem <= 512 && h->proj_split == 1 && !h->pd.nact;
+                if (h->cfg.backend != HPV_BACKEND_GENERIC && small_grid && getenv("HPV_PJ_WG_SMALL") == nullptr &&
+                    launch_project_wg(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
+                                      eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT,
+                                      h->d_edge_dphi, h->d_edge_coef, h->edge.GBAR, h->stream, nullptr))
+                    pname = "k_project_wg";
+                else if (h->cfg.backend != HPV_BACKEND_GENERIC &&
                     launch_project_tp(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
                                       eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->stream))
                     pname = "k_project_tp";

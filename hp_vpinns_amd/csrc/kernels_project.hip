@@ -691,6 +691,13 @@ bool launch_project_wg(const ProjDesc& pd, const double* OUT, double* GBAR, doub
                                                n_elem, do_adjoint, edge_u, edge_dphi, edge_coef, edge_gbar, s);
     HPV_WG(80, 1, 60, 1)     // Poisson-1D reference rule: N_Quad = 80, N_testfcn = 60 (P1:237-238; BASELINE configs 1, 2)
     HPV_WG(80, 80, 5, 5)     // AdvDiff with the 80-point rule per direction (BASELINE config 5)
+    // small grids of the 2-D shapes (round 4): one 1024-thread workgroup per element spreads a few hundred elements over all CUs,
+    // where "a lane owns a line" (k_project_tp: 3-6 elements per WAVE) leaves most of the chip idle -- the caller prefers this
+    // launch when the shard has at most two elements per CU
+    HPV_WG(20, 20, 10, 10)
+    HPV_WG(10, 10, 5, 5)
+    HPV_WG(16, 16, 8, 8)
+    HPV_WG(12, 12, 6, 6)
 #undef HPV_WG
     return false;
 }

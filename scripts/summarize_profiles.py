@@ -45,7 +45,7 @@ stats("stats_proj0")
 TITLES = (("", "bench (config 4), default path: whole-iteration kernel"),
           ("_c5", "config 5 (AdvDiff 8 x 80x80 points), default path: tall-element whole-iteration kernel"),
           ("_c5n", "config 5, HPV_FUSE=n: round 2's launches (forward -> activation store -> row-split projection -> reverse)"), ("_b", "bench (config 4), HPV_FUSE=b: forward + projection-fused reverse kernel"),
-          ("_w32", "config-4 grid with [2,32,32,32,1]: the width-generic kernels k_fwd_wide / k_bwd_wide + k_project_tp"),
+          ("_w32", "config-4 grid with [2,32,32,32,1]: the width-generic kernels k_fwd_wide / k_bwd_wide + k_project_wg"),
           ("_proj1", "projection kernel, residual + adjoint, 2^18-element batch"), ("_proj0", "projection kernel, residual only, 2^18-element batch"))
 for tagp, title in TITLES:
     fe, wr = pmc("pmc_fetch" + tagp), pmc("pmc_write" + tagp)

@@ -665,9 +665,16 @@ def test_full_size_config4_properties():
     try:
         mw = poisson2d.build_model(s, L, init_params=th)
         l3w, gw = mw.loss_and_grad()
+        assert "k_project_wg<20x20/10x10>" in mw.h.kernel_variant()      # 256 elements: one workgroup per element
+        os.environ["HPV_PJ_WG_SMALL"] = "0"                               # ... against "a lane owns a line" on the same grid
+        mt = poisson2d.build_model(s, L, init_params=th)
+        l3t, gt = mt.loss_and_grad()
+        assert "k_project_tp<20x20/10x10>" in mt.h.kernel_variant()
     finally:
         del os.environ["HPV_FUSE"]
+        os.environ.pop("HPV_PJ_WG_SMALL", None)
     assert rel(gw, g) < 1e-11 and rel(l3w, l3) < 1e-13
+    assert rel(gt, g) < 1e-11 and rel(l3t, l3) < 1e-13
     from hp_vpinns_amd import _lib
     from hp_vpinns_amd.testfcn import tables_1d
     from hp_vpinns_amd.vpinn import _tensor_rule
