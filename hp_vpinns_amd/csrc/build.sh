@@ -46,14 +46,14 @@ compile_one() {   # compile_one <source stem> <object> <extra flags>
   if [ $f = kernels_fused ]; then
     XF="$HPV_FUSED_EXTRA"           # (A/B builds: flags for this file only, scripts/build_variant.sh --fused-only)
     $HIPCC $FLAGS $XF $extra -S --cuda-device-only $f.hip -o $asm 2>$asm.err || { cat $asm.err >&2; return 1; }
-    # (instantiations: <L, SPLIT, QT>; the quarter-tile one sits closest to the hand-managed range and has its own fallback)
-    g=0; guard $asm k_iter_fusedILi3ELb0ELb0 106 k_iter_fusedILi3ELb1ELb0 106 k_iter_fusedILi2ELb0ELb0 156 k_iter_fusedILi2ELb1ELb0 156 || g=$?
+    # (instantiations: <L, SPLIT, QT, GS = false>: the GS = true ones hand-manage no registers; the quarter-tile one sits closest to the hand-managed range and has its own fallback)
+    g=0; guard $asm k_iter_fusedILi3ELb0ELb0ELb0E 106 k_iter_fusedILi3ELb1ELb0ELb0E 106 k_iter_fusedILi2ELb0ELb0ELb0E 156 k_iter_fusedILi2ELb1ELb0ELb0E 156 || g=$?
     [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check $f.hip" >&2; return 1; }
     if [ $g -eq 1 ]; then
       echo "build.sh: WARNING -- AGPR guard tripped in $f.hip: building without k_iter_fused (fallback = HPV_FUSE=b structure)" >&2
       XF="$XF -DHPV_AGPR_GUARD_TRIPPED"
     else
-      g=0; guard $asm k_iter_fusedILi3ELb0ELb1 106 k_iter_fusedILi2ELb0ELb1 156 || g=$?
+      g=0; guard $asm k_iter_fusedILi3ELb0ELb1ELb0E 106 k_iter_fusedILi2ELb0ELb1ELb0E 156 || g=$?
       [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check the quarter-tile instantiation of $f.hip" >&2; return 1; }
       if [ $g -eq 1 ]; then
         echo "build.sh: WARNING -- AGPR guard tripped in the quarter-tile instantiation of k_iter_fused: building with 7 / 6 / 6 / 6 whole tiles per wave" >&2

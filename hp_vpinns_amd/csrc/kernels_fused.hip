@@ -59,6 +59,8 @@ struct FzLds {
     static constexpr int W1O = WRB + LH * MF_KS * 16;      // [4][5][64]   W1[0][4s+q], W1[1][4s+q], Wo[4s+q], b1[4s+q]
     static constexpr int CH = W1O + 4 * MF_KS * 64;        // [2][400]     u_x, u_y of the element -> their adjoints
     static constexpr int PK = CH + 2 * FZ_NQ;              // [6][L*5][64] parked s: slot w = tile 0 of wave w, slots 4, 5 = tile 1 of waves 0, 1
+    static constexpr int XS = PK;                          // GS (slots 0..3 of PK are free then): [x | y | u_d][400 + 16] coordinates of the element and of the data tile
+    static constexpr int XLD = FZ_NQ + 16;
     static constexpr int PZ = PK + 6 * L * MF_KS * 64;     // [4][LH*5][32] QT: the quarter tiles' tangent pre-activations of the layers >= 2 (tangent lanes, compact)
     static constexpr int TR = PZ + FZ_WAVES * LH * MF_KS * 32;   // phase P: projection scratch | phase R: per-wave transpose tiles | epilogue rows
     static constexpr int TR_WAVE = FZ_C * 2 * MF_TRB * MF_LD;
@@ -71,6 +73,7 @@ struct FzLds {
     static constexpr int S = U + FZ_NR;                    // [2][NTY][QX]
     static constexpr int RED = S + 2 * FZ_NTY * FZ_QX;     // [16]
     static_assert(RED + 16 - TR <= FZ_WAVES * TR_WAVE, "projection scratch fits the transpose region");
+    static_assert(3 * XLD <= 4 * L * MF_KS * 64, "the staged coordinates fit the parking slots the GS plan leaves free");
     static constexpr int total(int P) { return TR + (FZ_WAVES * TR_WAVE > FZ_WAVES * P ? FZ_WAVES * TR_WAVE : FZ_WAVES * P); }
 };
 
@@ -86,7 +89,15 @@ struct FzLds {
 // products then run ONCE for the packed operand instead of once per channel (a third of a full tile's MFMA work, same weight
 // fragments), the channels of a point meet through DPP row shifts in the element-wise steps, and the boundary / data points
 // ride in the slots that would be idle, so no wave owns a seventh tile any more.
-template <int L, bool SPLIT = false, bool QT = false>
+//
+// GS (round 4, opt-in: measured slower, see launch_iter_fused_L): what the reverse pass needs of a whole tile -- s of every hidden layer AND the tangent pre-activations z_x, z_y of the
+// layers >= 2 (35 doubles per lane at L = 3) -- travels through device memory instead of being parked in AGPRs / LDS and recomputed:
+// the forward pass stores it (16-byte lane-contiguous stores into the handle's activation store, [tile][pair][lane][2]), the
+// reverse pass requests tile k + 1's while it works on tile k.  The kernel is bound by the fp64 datapath and leaves 8 TB/s of HBM
+// (and the 256 MB memory-side cache, which holds the whole 110 MB) idle; the recompute was 1 600 of a reverse tile's 7 650 datapath
+// cycles plus the AGPR shuffles around it.  Every workgroup reads back only what its own waves wrote (same CU, same L2): no fences.
+typedef double v2d __attribute__((ext_vector_type(2)));
+template <int L, bool SPLIT = false, bool QT = false, bool GS = false>
 __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     static_assert(!(SPLIT && QT), "the quarter-tile scheme is for whole elements");
     using M = FzLds<L>;
@@ -186,10 +197,6 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     // the element's projection constants, requested now so that no global latency sits inside phase P
     const double pc0 = pa.coef[e], pc1 = pa.coef[pa.coef_stride + e];
     const double pF = (pa.F && tid < FZ_NR) ? pa.F[e * FZ_NR + tid] : 0.0;
-    FZ_STAMP(0);
-    __syncthreads();
-    FZ_STAMP(1);
-
     // ---- tile list of this wave: element tiles wv, wv+4, .., and possibly one boundary/data tile `dtile` ----
     const int lg = SPLIT ? __builtin_ctz(split) : 0;                             // split is 2, 4 or 8
     const int tbase = SPLIT ? (part * FZ_TPE) >> lg : 0;                         // this workgroup's tile range of the element
@@ -215,6 +222,25 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         if (g.ntiles - g.proj_n_elem * FZ_TPE <= g.proj_n_elem * n_free)
             dtile = mine ? g.proj_n_elem * FZ_TPE + e * n_free + before : g.ntiles;
     }
+    if constexpr (GS) {
+        // the coordinates of the element's points and of the workgroup's boundary / data tile (+ its targets) to LDS: the tile loops
+        // then hold no global load besides the saved values' -- a wait for a coordinate would be a wait for every store / request
+        // issued before it (in-order vmcnt)
+        for (int i = tid; i < FZ_NQ; i += FZ_BLOCK) {
+            lds[M::XS + i] = g.X[e * FZ_NQ + i];
+            lds[M::XS + M::XLD + i] = g.X[g.N + e * FZ_NQ + i];
+        }
+        if (tid < 16) {
+            const long pd_ = dtile * 16 + tid;
+            const bool vd = dtile < g.ntiles && pd_ < g.N;
+            lds[M::XS + FZ_NQ + tid] = vd ? g.X[pd_] : 0.0;
+            lds[M::XS + M::XLD + FZ_NQ + tid] = vd ? g.X[g.N + pd_] : 0.0;
+            lds[M::XS + 2 * M::XLD + tid] = vd ? g.ud[pd_ - g.data_off] : 0.0;
+        }
+    }
+    FZ_STAMP(0);
+    __syncthreads();
+    FZ_STAMP(1);
     const bool has_d = !QT && (wv == (tend - tbase) % FZ_WAVES) && dtile < g.ntiles;     // (QT: the data points ride in the quarter tile)
     const int n_own = n_el + (has_d ? 1 : 0);
     auto tile_of = [&](int k) -> long { return k < n_el ? e * FZ_TPE + tbase + wv + (long)k * FZ_WAVES : dtile; };
@@ -223,8 +249,13 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     // AGPRs a[ABASE + (k-1) * 2 NSV ..] (see acc_put)
     constexpr int NREG = FZ_MAXT - 2;  // tiles whose s live in AGPRs; the first one (waves 0, 1: two) of a wave is parked in LDS
     constexpr int ABASE = 256 - NREG * 2 * NSV;
-    asm volatile("" ::: "a255");       // the kernel owns all 256 AGPRs
-    const int n_lds = QT ? 1 : (wv <= 1 ? 2 : 1);       // (QT: slots 4, 5 of the parking area hold the quarter tiles' s)
+    if constexpr (!GS) asm volatile("" ::: "a255");       // the kernel owns all 256 AGPRs
+    const int n_lds = GS ? 0 : QT ? 1 : (wv <= 1 ? 2 : 1);       // (QT: slots 4, 5 of the parking area hold the quarter tiles' s)
+    // GS: pairs per tile and lane -- {z_x, z_y}[layer >= 2][k-step], then s two by two; a tile's block of the activation store
+    constexpr int NZP = (L > 1 ? L - 1 : 0) * MF_KS, NSP = (NSV + 1) / 2, NP = NZP + NSP;
+    constexpr long GS_STRIDE = (long)L * 3 * MF_KS * 64;         // doubles per tile of the activation store (3 slots: kernels_mfma.hip)
+    static_assert(NP * 128 <= GS_STRIDE, "a tile's pairs fit its block of the activation store");
+    auto gs_ptr = [&](long tile) -> v2d* { return reinterpret_cast<v2d*>(g.ACTS + tile * GS_STRIDE) + lane; };
     double* PKw = lds + M::PK + wv * (NSV * 64) + lane;
     double* PKw2 = lds + M::PK + (4 + (wv & 1)) * (NSV * 64) + lane;
     double gdat = 0.0;           // adjoint of u at the data tile's point (boundary term, P2:122)
@@ -251,7 +282,11 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     [[maybe_unused]] double* PKZ = lds + M::PZ + wv * ((L > 1 ? L - 1 : 1) * MF_KS * 32);   // tangent pre-activations, the 32 tangent lanes only
     [[maybe_unused]] const int q_cz = q * 8 + (qcs == 2 ? 4 : 0) + qj;
     [[maybe_unused]] double gdat_q = 0.0, qx0 = 0.0, qx1 = 0.0, qud = 0.0;
-    if constexpr (QT) {                     // (requested before the whole tiles: consumed after them)
+    [[maybe_unused]] const int q_xs = qcs == 3 ? FZ_NQ + 4 * wv + qj : q_lp;      // GS: the slot's point in the staged coordinates
+    if constexpr (QT && GS) {
+        qx0 = lds[M::XS + q_xs]; qx1 = lds[M::XS + M::XLD + q_xs];
+        qud = q_vdat ? lds[M::XS + 2 * M::XLD + 4 * wv + qj] : 0.0;
+    } else if constexpr (QT) {              // (requested before the whole tiles: consumed after them)
         qx0 = g.X[q_p]; qx1 = g.X[g.N + q_p];
         qud = q_vdat ? g.ud[q_pdat - g.data_off] : 0.0;
     }
@@ -263,7 +298,12 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         x[0] = g.X[pc]; x[1] = g.X[g.N + pc];
     };
     auto stash = [&](int k, const double (&sv)[NSV]) {
-        if (k < n_lds) {     // wave-uniform
+        if constexpr (GS) {
+            v2d* zs = gs_ptr(tile_of(k)) + NZP * 64;
+#pragma unroll
+            for (int j = 0; j < NSV / 2; ++j) zs[j * 64] = v2d{sv[2 * j], sv[2 * j + 1]};
+            if constexpr (NSV & 1) reinterpret_cast<double*>(zs + (NSV / 2) * 64 - lane)[lane] = sv[NSV - 1];   // (odd count: the last one alone, 8-byte lanes)
+        } else if (k < n_lds) {     // wave-uniform
             double* pk = k == 0 ? PKw : PKw2;
 #pragma unroll
             for (int j = 0; j < NSV; ++j) pk[j * 64] = sv[j];
@@ -286,13 +326,24 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         double xx[NT][2];
         bool valid[NT];
         long pp[NT];
+        if constexpr (GS) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            valid[t] = vn[t]; pp[t] = pn[t];
-            xx[t][0] = valid[t] ? xn[t][0] : 0.0; xx[t][1] = valid[t] ? xn[t][1] : 0.0;
+            for (int t = 0; t < NT; ++t) {
+                const int k = k0 + t;
+                const int lp = k < n_el ? (tbase + wv + k * FZ_WAVES) * 16 + pt : FZ_NQ + pt;
+                pp[t] = tile_of(k) * 16 + pt;
+                valid[t] = pp[t] < g.N;
+                xx[t][0] = lds[M::XS + lp]; xx[t][1] = lds[M::XS + M::XLD + lp];       // (points beyond the batch were staged as 0)
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                valid[t] = vn[t]; pp[t] = pn[t];
+                xx[t][0] = valid[t] ? xn[t][0] : 0.0; xx[t][1] = valid[t] ? xn[t][1] : 0.0;
+            }
+            load_x(k0 + NT, xn[0], vn[0], pn[0]);       // the next trip's coordinates travel while this one computes
+            load_x(k0 + NT + 1, xn[1], vn[1], pn[1]);
         }
-        load_x(k0 + NT, xn[0], vn[0], pn[0]);       // the next trip's coordinates travel while this one computes
-        load_x(k0 + NT + 1, xn[1], vn[1], pn[1]);
         int lofs = lane;
         asm volatile("" : "+v"(lofs));       // opaque: the LDS fragment reads stay inside the loop
         double h[NT][FZ_C][MF_KS], sv[NT][NSV];
@@ -326,6 +377,14 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                 fz_layer<true>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, lds + M::BH + (i - 1) * MF_KS * 64, lofs, h[t][0], z[t][0]);
                 fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[t][1], z[t][1]);
                 fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[t][2], z[t][2]);
+            }
+            if constexpr (GS) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    v2d* zs = gs_ptr(tile_of(k0 + t)) + (i - 1) * MF_KS * 64;
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s) zs[s * 64] = v2d{z[t][1][s], z[t][2][s]};
+                }
             }
             [[maybe_unused]] double QZ[MF_KS];
             if constexpr (WQ)
@@ -386,7 +445,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                 }
             } else {
                 // lossb = w mean((u_d - u)^2) (P2:122,127): adjoint of u kept in a register, per-tile partial sum to memory
-                const double dd = valid[t] ? g.ud[pp[t] - g.data_off] - o[0] : 0.0;
+                double udv;
+                if constexpr (GS) udv = lds[M::XS + 2 * M::XLD + pt]; else udv = valid[t] ? g.ud[pp[t] - g.data_off] : 0.0;
+                const double dd = valid[t] ? udv - o[0] : 0.0;
                 gdat = g.data_scale * dd;
                 const double sq = row_sum16(dd * dd);
                 if (lane == 0) g.data_part[pp[t] / 16 - g.data_off / 16] = sq;
@@ -410,8 +471,10 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             }
         }
     };
-    load_x(0, xn[0], vn[0], pn[0]);
-    load_x(1, xn[1], vn[1], pn[1]);
+    if constexpr (!GS) {
+        load_x(0, xn[0], vn[0], pn[0]);
+        load_x(1, xn[1], vn[1], pn[1]);
+    }
     int k0 = 0;
     if constexpr (QT) {      // six whole tiles: two trips of two, then the last two with the quarter tile beside them
         static_assert((FZ_TPE - 1) / FZ_WAVES == 6, "trip plan of the QT instantiation");
@@ -439,8 +502,23 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             return;      // (the launch counter is advanced by the kernel that FOLLOWS this launch: k_finalize, hpv_fused_dev.h)
         }
     }
-    __syncthreads();
+    // (GS: an LDS-only barrier -- the stores of the saved values need no acknowledgement here: the wave that wrote them reads them back)
+    if constexpr (GS && !SPLIT) pj_lds_barrier(); else __syncthreads();
     FZ_STAMP(3);
+    // GS: the first reverse tile's pairs travel during the projection phase
+    [[maybe_unused]] v2d BA[GS ? NP : 1], BB[GS ? NP : 1];
+    [[maybe_unused]] auto request = [&](int k, v2d (&B)[GS ? NP : 1]) {
+        if constexpr (GS) {
+            const v2d* zs = gs_ptr(tile_of(k));
+            constexpr int NF = NZP + NSV / 2;      // full pairs
+#pragma unroll
+            for (int j = 0; j < NF; ++j) B[j] = zs[j * 64];
+            // (an odd s count: the last value alone -- a 16-byte load whose upper half nobody reads makes the compiler wait for the
+            //  whole request as soon as it reuses that register)
+            if constexpr (NSV & 1) B[NF] = v2d{reinterpret_cast<const double*>(zs + NF * 64 - lane)[lane], 0.0};
+        }
+    };
+    if constexpr (GS) { if (n_own > 0) request(0, BA); }
     if constexpr (QT) {      // lossb partial of the workgroup's boundary / data tile: the four waves' quarters (P2:122,127)
         if (tid == 0 && dtile < g.ntiles)
             g.data_part[dtile - g.data_off / 16] = (lds[M::RED + 8] + lds[M::RED + 9]) + (lds[M::RED + 10] + lds[M::RED + 11]);
@@ -531,19 +609,28 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     long long fz_seg[2 + 2 * L], fz_last = clock64();
     for (int i = 0; i < 2 + 2 * L; ++i) fz_seg[i] = 0;
 #endif
-#pragma unroll 1
-    for (int k = 0; k < n_own; ++k) {
+    // one reverse tile; GS: `B` = the tile's pairs, requested a tile ahead
+    auto rev_tile = [&](int k, [[maybe_unused]] const v2d (&B)[GS ? NP : 1]) {
 #ifdef HPV_FZ_TIMING
         fz_last = clock64();
 #endif
-        const long tile = tile_of(k);
-        const long p = tile * 16 + pt;
-        const bool valid = p < g.N;
-        const double x0 = valid ? g.X[p] : 0.0, x1 = valid ? g.X[g.N + p] : 0.0;
+        double x0, x1;
+        if constexpr (GS) {
+            const int lp = k < n_el ? (tbase + wv + k * FZ_WAVES) * 16 + pt : FZ_NQ + pt;
+            x0 = lds[M::XS + lp]; x1 = lds[M::XS + M::XLD + lp];
+        } else {
+            const long tile = tile_of(k);
+            const long p = tile * 16 + pt;
+            const bool valid = p < g.N;
+            x0 = valid ? g.X[p] : 0.0; x1 = valid ? g.X[g.N + p] : 0.0;
+        }
         int lofs = lane;
         asm volatile("" : "+v"(lofs));
         double sv[NSV];
-        if (k < n_lds) {
+        if constexpr (GS) {
+#pragma unroll
+            for (int j = 0; j < NSV; ++j) sv[j] = B[NZP + j / 2][j & 1];
+        } else if (k < n_lds) {
             const double* pk = k == 0 ? PKw : PKw2;
 #pragma unroll
             for (int j = 0; j < NSV; ++j) sv[j] = pk[j * 64];
@@ -565,6 +652,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             gb[0] = gdat; gb[1] = 0.0; gb[2] = 0.0;
         }
         // tangent pre-activations of every hidden layer: layer 0 has z_c = W1[c,:]; layer i: z_c = (sigma'(z_{i-1}) z_c,{i-1}) W_i
+        // (GS: read back; otherwise recomputed from s on the matrix pipe)
         double zc[L][2][MF_KS];
 #define ZC(I, CC, SS) zc[(I)][(CC)][(SS)]
 #pragma unroll
@@ -574,14 +662,19 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         }
 #pragma unroll
         for (int i = 1; i < L; ++i) {
-            double hx[MF_KS], hy[MF_KS];
+            if constexpr (GS) {
 #pragma unroll
-            for (int s = 0; s < MF_KS; ++s) {
-                const double a = sv[(i - 1) * MF_KS + s], a1 = 1.0 - a * a;
-                hx[s] = a1 * ZC(i - 1, 0, s); hy[s] = a1 * ZC(i - 1, 1, s);
+                for (int s = 0; s < MF_KS; ++s) { zc[i][0][s] = B[(i - 1) * MF_KS + s][0]; zc[i][1][s] = B[(i - 1) * MF_KS + s][1]; }
+            } else {
+                double hx[MF_KS], hy[MF_KS];
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+                    const double a = sv[(i - 1) * MF_KS + s], a1 = 1.0 - a * a;
+                    hx[s] = a1 * ZC(i - 1, 0, s); hy[s] = a1 * ZC(i - 1, 1, s);
+                }
+                fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, hx, zc[i][0]);
+                fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, hy, zc[i][1]);
             }
-            fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, hx, zc[i][0]);
-            fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, hy, zc[i][1]);
         }
 
         FZ_SEG(0);
@@ -591,7 +684,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         for (int s = 0; s < MF_KS; ++s) {
             const double a = sv[(L - 1) * MF_KS + s], a1 = 1.0 - a * a;
             const double wo = lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
-            dWo[s] = fma(a, gb[0], dWo[s]);
+            if (k >= n_el) dWo[s] = fma(a, gb[0], dWo[s]);       // (wave-uniform; element tiles have no adjoint of the value channel)
             dWo[s] = fma(a1 * zc[L - 1][0][s], gb[1], dWo[s]);
             dWo[s] = fma(a1 * zc[L - 1][1][s], gb[2], dWo[s]);
             hbar[0][s] = gb[0] * wo; hbar[1][s] = gb[1] * wo; hbar[2][s] = gb[2] * wo;
@@ -676,14 +769,33 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             }
         }
         FZ_SEG(1 + 2 * L);
+    };
+#undef ZC
+    if constexpr (GS) {
+        // two tiles per trip of the loop (ping-pong buffers: no register copies), tile k + 1's pairs in flight during tile k
+#pragma unroll 1
+        for (int k = 0; k < n_own; k += 2) {
+            // (requests are unconditional -- past the wave's last tile they repeat it: a branch around a request would make the
+            //  compiler's wait for the OTHER buffer a wait for everything in flight)
+            request(k + 1 < n_own ? k + 1 : n_own - 1, BB);
+            rev_tile(k, BA);
+            __builtin_amdgcn_sched_barrier(0);       // (nothing of tile k + 1 -- it would wait for the request above -- moves up into tile k)
+            if (k + 1 < n_own) {
+                request(k + 2 < n_own ? k + 2 : n_own - 1, BA);
+                rev_tile(k + 1, BB);
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < n_own; ++k) rev_tile(k, BA);
     }
 
-#undef ZC
     if constexpr (QT) {
         // ---- the packed quarter tile, reverse: the whole-tile steps above for ONE packed operand (every slot's adjoint at once) ----
         int lofs = lane;
         asm volatile("" : "+v"(lofs));
-        const double X0 = g.X[q_p], X1 = g.X[g.N + q_p];     // (consumed at the very end: first-layer weight gradient)
+        double X0, X1;                                         // (consumed at the very end: first-layer weight gradient)
+        if constexpr (GS) { X0 = lds[M::XS + q_xs]; X1 = lds[M::XS + M::XLD + q_xs]; } else { X0 = g.X[q_p]; X1 = g.X[g.N + q_p]; }
         double AAq[NSV];
 #pragma unroll
         for (int j = 0; j < NSV; ++j) AAq[j] = PKQ[j * 32 + q_ci];
@@ -1282,15 +1394,21 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int L, bool SPLIT, bool QT = false>
+template <int L, bool SPLIT, bool QT = false, bool GS = false>
 static void launch_iter_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
     const size_t bytes = (size_t)FzLds<L>::total(a.P) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_iter_fused<L, SPLIT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        (void)hipFuncSetAttribute((const void*)k_iter_fused<L, SPLIT, QT, GS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_iter_fused<L, SPLIT, QT>), dim3(blocks), dim3(FZ_BLOCK), bytes, s, a);
+    hipLaunchKernelGGL((k_iter_fused<L, SPLIT, QT, GS>), dim3(blocks), dim3(FZ_BLOCK), bytes, s, a);
+}
+// (GS_: the saved values travel through the activation store instead of AGPRs / LDS + recompute; HPV_FUSED_GSTASH=1 opts in)
+template <bool SPLIT, bool QT>
+static void launch_iter_fused_L(int L, bool gs, const MfmaArgs& a, int blocks, hipStream_t s) {
+    if (gs) { if (L == 2) launch_iter_fused<2, SPLIT, QT, true>(a, blocks, s); else launch_iter_fused<3, SPLIT, QT, true>(a, blocks, s); }
+    else    { if (L == 2) launch_iter_fused<2, SPLIT, QT, false>(a, blocks, s); else launch_iter_fused<3, SPLIT, QT, false>(a, blocks, s); }
 }
 
 template <int L>
@@ -1377,20 +1495,26 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     a.xiter = m->xiter;
     a.pa = pa;
     m->last_split = split > 1;
+    // GS is opt-in (HPV_FUSED_GSTASH=1): measured 67.8 against 60.6 us at config 4 -- the reverse phase does shrink (73.1 k -> 60.9 k
+    // cycles) but the forward phase pays for its stores (42.9 k -> 49.4 k: the four waves' bursts share one 64 B/clk path), and with
+    // 220 MB of extra traffic per iteration the chip clocks 10 % lower (1.94 against 2.16 GHz); profiles/r04_notes.md
+    const char* ge = getenv("HPV_FUSED_GSTASH");
+    const bool gs = a.ACTS != nullptr && ge && ge[0] == '1';
+    const char* gsn = gs ? "true" : "false";
     if (split > 1) {
         m->split_used = true;
-        snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=true,QT=false> split=%d", m->L, split);
-        if (m->L == 2) launch_iter_fused<2, true>(a, (int)blocks, s); else launch_iter_fused<3, true>(a, (int)blocks, s);
+        snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=true,QT=false,GS=%s> split=%d", m->L, gsn, split);
+        launch_iter_fused_L<true, false>(m->L, gs, a, (int)blocks, s);
 #ifdef HPV_AGPR_GUARD_TRIPPED_QT                    // csrc/build.sh: the compiler's registers reached the stash of the QT instantiation
-    } else if (true) {
+    } else if (!gs) {
 #else
     } else if (getenv("HPV_NO_QUARTER_TILE")) {      // (A/B switch: seven whole tiles for the first wave, read per launch / capture)
 #endif
-        snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=false,QT=false>", m->L);
-        if (m->L == 2) launch_iter_fused<2, false>(a, (int)blocks, s); else launch_iter_fused<3, false>(a, (int)blocks, s);
+        snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=false,QT=false,GS=%s>", m->L, gsn);
+        launch_iter_fused_L<false, false>(m->L, gs, a, (int)blocks, s);
     } else {
-        snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=false,QT=true>", m->L);
-        if (m->L == 2) launch_iter_fused<2, false, true>(a, (int)blocks, s); else launch_iter_fused<3, false, true>(a, (int)blocks, s);
+        snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=false,QT=true,GS=%s>", m->L, gsn);
+        launch_iter_fused_L<false, true>(m->L, gs, a, (int)blocks, s);
     }
     if (rows) *rows = (int)blocks;
     return true;

@@ -52,7 +52,7 @@ def test_bench_driver_style_single_gpu_line():
     assert out["n_gpus"] == 1 and out["steps"] == 20 and out["config"]["pass_structure"] == "whole-iteration"
     bi = out["config"]["build"]
     assert bi["test_hooks"] == "0" and bi["k_iter_fused"] in ("ok", "no-quarter-tile")
-    assert out["config"]["kernel_variant"] == "k_iter_fused<L=3,SPLIT=false,QT=%s>" % ("true" if bi["k_iter_fused"] == "ok" else "false")
+    assert out["config"]["kernel_variant"] == "k_iter_fused<L=3,SPLIT=false,QT=%s,GS=false>" % ("true" if bi["k_iter_fused"] == "ok" else "false")
     t = out["timing"]
     assert t["windows"] == 25 and t["untimed_warmup_iterations"] * out["ms_per_step"] * 1e-3 >= 0.2
     assert t["min_it_per_s"] <= out["value"] <= t["max_it_per_s"]

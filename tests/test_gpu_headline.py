@@ -97,7 +97,7 @@ def test_config4_full_size_against_the_oracle():
     # build's AGPR guard compiled it out (hpv_build_info says so; csrc/build.sh)
     bi = m.h.build_info()
     assert m.h.pass_structure() == ("whole-iteration" if bi["k_iter_fused"] != "absent" else "fused-reverse")
-    want = {"ok": "k_iter_fused<L=3,SPLIT=false,QT=true>", "no-quarter-tile": "k_iter_fused<L=3,SPLIT=false,QT=false>"}.get(bi["k_iter_fused"])
+    want = {"ok": "k_iter_fused<L=3,SPLIT=false,QT=true,GS=false>", "no-quarter-tile": "k_iter_fused<L=3,SPLIT=false,QT=false,GS=false>"}.get(bi["k_iter_fused"])
     if want is not None:
         assert m.h.kernel_variant() == want, (m.h.kernel_variant(), bi)
     assert bi["test_hooks"] == "0"
@@ -196,3 +196,36 @@ def test_quarter_tile_plan_against_whole_tiles(cfg):
         assert state == "no-quarter-tile" and q[7] == w[7]
     assert rel(q[0], w[0]) < 1e-13 and rel(q[1], w[1]) < 1e-12 and rel(q[2], w[2]) < 1e-12
     assert rel(q[3], w[3]) < 1e-9 and rel(q[5], w[5]) < 1e-9 and rel(q[4] + 1.0, w[4] + 1.0) < 1e-10
+
+
+@pytest.mark.parametrize("case", ["cfg4", "cfg4_two_hidden", "shard64"])
+def test_saved_values_through_device_memory_against_the_register_stash(case):
+    """k_iter_fused<.., GS>: s and the tangent pre-activations of every whole tile go through the activation store (written by the
+    forward phase, requested a tile ahead by the reverse phase) instead of AGPRs / LDS + a recompute on the matrix pipe (opt-in,
+    HPV_FUSED_GSTASH=1: measured slower).  Against the default register-stash instantiation on the full config-4 grid, with two hidden layers, and on a 64-element
+    shard (SPLIT mode: two workgroups per element): loss triple, gradient, residuals, and a 50-step trajectory."""
+    import os
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    n = 8 if case == "shard64" else 16
+    L = [2, 20, 20, 1] if case == "cfg4_two_hidden" else [2, 20, 20, 20, 1]
+    s = poisson2d.setup(N_el_x=n, N_el_y=n, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
+    th = xavier_init(L, 17)
+
+    def run():
+        m = poisson2d.build_model(s, L, init_params=th)
+        l3, g = m.loss_and_grad()
+        r = m.h.residuals(n * n * 100)
+        hist, _ = m._step_record(50)
+        return l3, g, r, hist, m.get_params(), m.h.kernel_variant()
+
+    b = run()
+    os.environ["HPV_FUSED_GSTASH"] = "1"
+    try:
+        a = run()
+    finally:
+        del os.environ["HPV_FUSED_GSTASH"]
+    assert "GS=true" in a[5] and "GS=false" in b[5], (a[5], b[5])
+    assert ("SPLIT=true" in a[5]) == (case == "shard64")
+    assert rel(a[0], b[0]) < 1e-13 and rel(a[1], b[1]) < 1e-12 and rel(a[2], b[2]) < 1e-12
+    assert rel(a[3], b[3]) < 1e-9 and rel(a[4], b[4]) < 1e-9
