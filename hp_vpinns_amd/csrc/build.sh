@@ -46,18 +46,30 @@ compile_one() {   # compile_one <source stem> <object> <extra flags>
   if [ $f = kernels_fused ]; then
     XF="$HPV_FUSED_EXTRA"           # (A/B builds: flags for this file only, scripts/build_variant.sh --fused-only)
     $HIPCC $FLAGS $XF $extra -S --cuda-device-only $f.hip -o $asm 2>$asm.err || { cat $asm.err >&2; return 1; }
-    # (instantiations: <L, SPLIT, QT, GS = false>: the GS = true ones hand-manage no registers; the quarter-tile one sits closest to the hand-managed range and has its own fallback)
-    g=0; guard $asm k_iter_fusedILi3ELb0ELb0ELb0E 106 k_iter_fusedILi3ELb1ELb0ELb0E 106 k_iter_fusedILi2ELb0ELb0ELb0E 156 k_iter_fusedILi2ELb1ELb0ELb0E 156 || g=$?
+    # (instantiations: <L, SPLIT, QT, GS = false, element shape>: the GS = true ones hand-manage no registers; the hand-managed
+    #  range starts at 256 - (tiles per wave - 2) x 10 L registers; the quarter-tile one sits closest to it and has its own fallback)
+    local S=ELi20ELi20ELi10ELi10E
+    g=0; guard $asm k_iter_fusedILi3ELb0ELb0ELb0${S} 106 k_iter_fusedILi3ELb1ELb0ELb0${S} 106 k_iter_fusedILi2ELb0ELb0ELb0${S} 156 k_iter_fusedILi2ELb1ELb0ELb0${S} 156 || g=$?
     [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check $f.hip" >&2; return 1; }
     if [ $g -eq 1 ]; then
       echo "build.sh: WARNING -- AGPR guard tripped in $f.hip: building without k_iter_fused (fallback = HPV_FUSE=b structure)" >&2
       XF="$XF -DHPV_AGPR_GUARD_TRIPPED"
     else
-      g=0; guard $asm k_iter_fusedILi3ELb0ELb1ELb0E 106 k_iter_fusedILi2ELb0ELb1ELb0E 156 || g=$?
+      g=0; guard $asm k_iter_fusedILi3ELb0ELb1ELb0${S} 106 k_iter_fusedILi2ELb0ELb1ELb0${S} 156 || g=$?
       [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check the quarter-tile instantiation of $f.hip" >&2; return 1; }
       if [ $g -eq 1 ]; then
         echo "build.sh: WARNING -- AGPR guard tripped in the quarter-tile instantiation of k_iter_fused: building with 7 / 6 / 6 / 6 whole tiles per wave" >&2
         XF="$XF -DHPV_AGPR_GUARD_TRIPPED_QT"
+      fi
+      # the other element shapes (FZ_SHAPES of kernels_fused.hip): 16x16 / 8x8 (5 tiles per wave), 12x12 / 6x6 (3)
+      local S16=ELi16ELi16ELi8ELi8E S12=ELi12ELi12ELi6ELi6E
+      g=0; guard $asm k_iter_fusedILi3ELb0ELb0ELb0${S16} 166 k_iter_fusedILi3ELb1ELb0ELb0${S16} 166 k_iter_fusedILi2ELb0ELb0ELb0${S16} 196 k_iter_fusedILi2ELb1ELb0ELb0${S16} 196 \
+                       k_iter_fusedILi3ELb0ELb0ELb0${S12} 226 k_iter_fusedILi3ELb1ELb0ELb0${S12} 226 k_iter_fusedILi3ELb0ELb1ELb0${S12} 226 \
+                       k_iter_fusedILi2ELb0ELb0ELb0${S12} 236 k_iter_fusedILi2ELb1ELb0ELb0${S12} 236 k_iter_fusedILi2ELb0ELb1ELb0${S12} 236 || g=$?
+      [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check the extra element shapes of $f.hip" >&2; return 1; }
+      if [ $g -eq 1 ]; then
+        echo "build.sh: WARNING -- AGPR guard tripped in an extra element shape of k_iter_fused: those shapes run on the other structures" >&2
+        XF="$XF -DHPV_FZ_NO_EXTRA_SHAPES"
       fi
     fi
   fi

@@ -26,15 +26,17 @@
 
 #define FZ_WAVES 4
 #define FZ_BLOCK (FZ_WAVES * 64)
-#define FZ_MAXT 7          // tiles per wave: ceil(25 / 4), or 6 + one boundary/data tile
-#define FZ_QX 20
-#define FZ_QY 20
-#define FZ_NTX 10
-#define FZ_NTY 10
-#define FZ_NQ (FZ_QX * FZ_QY)
-#define FZ_NR (FZ_NTX * FZ_NTY)
-#define FZ_TPE (FZ_NQ / 16)
 #define FZ_C 3             // u, u_x, u_y
+// The element shape (QX x QY quadrature points, NTX x NTY test functions) is a template parameter of the kernel (round 4; it was
+// written for 20x20 / 10x10 alone); FZ_SHAPE_CONSTS names the derived constants inside a template body.  Needed of a shape: whole
+// 16-point tiles (QX QY % 16 == 0) and a tile count of 0 or 1 mod 4 (the parking plan below gives waves 2, 3 one LDS slot each).
+#define FZ_SHAPE_CONSTS                                                                                              \
+    static constexpr int FZ_QX = QX_, FZ_QY = QY_, FZ_NTX = NTX_, FZ_NTY = NTY_, FZ_NQ = QX_ * QY_, FZ_NR = NTX_ * NTY_; \
+    static constexpr int FZ_TPE = FZ_NQ / 16;                                                                        \
+    static constexpr int FZ_MAXT = FZ_TPE / 4 + 1;      /* tiles per wave: ceil(TPE / 4), or TPE / 4 + one boundary/data tile */ \
+    static_assert(FZ_NQ % 16 == 0 && FZ_TPE % 4 <= 1, "element shape not covered by the whole-iteration kernel");
+// instantiated shapes (host dispatch, build guard of csrc/build.sh): X(QX, QY, NTX, NTY)
+#define FZ_SHAPES(X) X(20, 20, 10, 10) X(16, 16, 8, 8) X(12, 12, 6, 6)
 
 // Build with -DHPV_FZ_TIMING to make the kernel record the duration of its phases (staging, forward, barrier wait,
 // projection, reverse, barrier wait, epilogue) per wave into MfmaArgs::OUT; scripts/fz_timing.py prints them.
@@ -48,8 +50,9 @@
 #define FZ_SEG(I)
 #endif
 
-template <int L>
+template <int L, int QX_, int QY_, int NTX_, int NTY_>
 struct FzLds {
+    FZ_SHAPE_CONSTS
     static constexpr int LH = L > 1 ? L - 1 : 0;
     static constexpr int WT = 0;                           // [LH][5][64]  forward A fragments  W[4s+q][out = pt]
     static constexpr int BH = WT + LH * MF_KS * 64;        // [LH][5][64]  bias fragments       b[4s+q]
@@ -97,10 +100,11 @@ struct FzLds {
 // (and the 256 MB memory-side cache, which holds the whole 110 MB) idle; the recompute was 1 600 of a reverse tile's 7 650 datapath
 // cycles plus the AGPR shuffles around it.  Every workgroup reads back only what its own waves wrote (same CU, same L2): no fences.
 typedef double v2d __attribute__((ext_vector_type(2)));
-template <int L, bool SPLIT = false, bool QT = false, bool GS = false>
+template <int L, bool SPLIT, bool QT, bool GS, int QX_, int QY_, int NTX_, int NTY_>
 __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     static_assert(!(SPLIT && QT), "the quarter-tile scheme is for whole elements");
-    using M = FzLds<L>;
+    FZ_SHAPE_CONSTS
+    using M = FzLds<L, QX_, QY_, NTX_, NTY_>;
     constexpr int LH = L > 1 ? L - 1 : 1;
     constexpr int NSV = L * MF_KS;                 // saved doubles per lane and tile
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -309,7 +313,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             for (int j = 0; j < NSV; ++j) pk[j * 64] = sv[j];
         } else {
             switch (k - n_lds) {
-#define FZ_STASH(K) case K: acc_put_all<ABASE + K * 2 * NSV, NSV>(sv); break;
+#define FZ_STASH(K) case K: if constexpr (K < NREG) acc_put_all<ABASE + K * 2 * NSV, NSV>(sv); break;
                 FZ_STASH(0) FZ_STASH(1) FZ_STASH(2) FZ_STASH(3) FZ_STASH(4)
 #undef FZ_STASH
             }
@@ -477,7 +481,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     }
     int k0 = 0;
     if constexpr (QT) {      // six whole tiles: two trips of two, then the last two with the quarter tile beside them
-        static_assert((FZ_TPE - 1) / FZ_WAVES == 6, "trip plan of the QT instantiation");
+        static_assert((FZ_TPE - 1) / FZ_WAVES >= 2 && ((FZ_TPE - 1) / FZ_WAVES) % 2 == 0, "trip plan of the QT instantiation: pairs of whole tiles");
 #pragma unroll 1
         for (; k0 + 3 < n_own; k0 += 2) fwd_trip(k0, std::integral_constant<int, 2>{}, std::false_type{});
         fwd_trip(k0, std::integral_constant<int, 2>{}, std::true_type{});
@@ -636,7 +640,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             for (int j = 0; j < NSV; ++j) sv[j] = pk[j * 64];
         } else {
             switch (k - n_lds) {
-#define FZ_FETCH(K) case K: acc_get_all<ABASE + K * 2 * NSV, NSV>(sv); break;
+#define FZ_FETCH(K) case K: if constexpr (K < NREG) acc_get_all<ABASE + K * 2 * NSV, NSV>(sv); break;
                 FZ_FETCH(0) FZ_FETCH(1) FZ_FETCH(2) FZ_FETCH(3) FZ_FETCH(4)
 #undef FZ_FETCH
                 default:
@@ -1394,21 +1398,53 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int L, bool SPLIT, bool QT = false, bool GS = false>
+template <int L, bool SPLIT, bool QT, bool GS, int QX_, int QY_, int NTX_, int NTY_>
 static void launch_iter_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
-    const size_t bytes = (size_t)FzLds<L>::total(a.P) * sizeof(double);
+    const size_t bytes = (size_t)FzLds<L, QX_, QY_, NTX_, NTY_>::total(a.P) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_iter_fused<L, SPLIT, QT, GS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        (void)hipFuncSetAttribute((const void*)k_iter_fused<L, SPLIT, QT, GS, QX_, QY_, NTX_, NTY_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_iter_fused<L, SPLIT, QT, GS>), dim3(blocks), dim3(FZ_BLOCK), bytes, s, a);
+    hipLaunchKernelGGL((k_iter_fused<L, SPLIT, QT, GS, QX_, QY_, NTX_, NTY_>), dim3(blocks), dim3(FZ_BLOCK), bytes, s, a);
 }
-// (GS_: the saved values travel through the activation store instead of AGPRs / LDS + recompute; HPV_FUSED_GSTASH=1 opts in)
-template <bool SPLIT, bool QT>
-static void launch_iter_fused_L(int L, bool gs, const MfmaArgs& a, int blocks, hipStream_t s) {
-    if (gs) { if (L == 2) launch_iter_fused<2, SPLIT, QT, true>(a, blocks, s); else launch_iter_fused<3, SPLIT, QT, true>(a, blocks, s); }
-    else    { if (L == 2) launch_iter_fused<2, SPLIT, QT, false>(a, blocks, s); else launch_iter_fused<3, SPLIT, QT, false>(a, blocks, s); }
+// One element shape: plan 0 = SPLIT, 1 = whole tiles, 2 = quarter tiles (shapes with 1 mod 4 tiles).  false: not instantiated.
+// (GS: the saved values travel through the activation store instead of AGPRs / LDS + recompute; HPV_FUSED_GSTASH=1 opts in; built
+//  for the 20x20 / 10x10 shape only)
+template <int QX_, int QY_, int NTX_, int NTY_>
+static bool launch_iter_fused_shape(int L, int plan, bool gs, const MfmaArgs& a, int blocks, hipStream_t s) {
+    constexpr bool HAS_QT = ((QX_ * QY_ / 16) % 4) == 1, HAS_GS = QX_ == 20;
+#define FZ_GO(L_, SPLIT_, QT_, GS_) launch_iter_fused<L_, SPLIT_, QT_, GS_, QX_, QY_, NTX_, NTY_>(a, blocks, s)
+    if (L != 2 && L != 3) return false;
+    if (gs) {
+        if constexpr (HAS_GS) {
+            if (plan == 0) { if (L == 2) FZ_GO(2, true, false, true); else FZ_GO(3, true, false, true); }
+            else if (plan == 1) { if (L == 2) FZ_GO(2, false, false, true); else FZ_GO(3, false, false, true); }
+            else { if (L == 2) FZ_GO(2, false, true, true); else FZ_GO(3, false, true, true); }
+            return true;
+        } else return false;
+    }
+    if (plan == 0) { if (L == 2) FZ_GO(2, true, false, false); else FZ_GO(3, true, false, false); }
+    else if (plan == 1) { if (L == 2) FZ_GO(2, false, false, false); else FZ_GO(3, false, false, false); }
+    else {
+        if constexpr (HAS_QT) { if (L == 2) FZ_GO(2, false, true, false); else FZ_GO(3, false, true, false); }
+        else return false;
+    }
+#undef FZ_GO
+    return true;
+}
+static bool launch_iter_fused_any(const ProjDesc& pd, int L, int plan, bool gs, const MfmaArgs& a, int blocks, hipStream_t s) {
+#define FZ_TRY(A_, B_, C_, D_) \
+    if (pd.qx == A_ && pd.qy == B_ && pd.ntx == C_ && pd.nty == D_) return launch_iter_fused_shape<A_, B_, C_, D_>(L, plan, gs, a, blocks, s);
+    FZ_SHAPES(FZ_TRY)
+#undef FZ_TRY
+    return false;
+}
+static bool fused_shape_ok(const ProjDesc& pd) {
+#define FZ_TRY(A_, B_, C_, D_) if (pd.qx == A_ && pd.qy == B_ && pd.ntx == C_ && pd.nty == D_) return true;
+    FZ_SHAPES(FZ_TRY)
+#undef FZ_TRY
+    return false;
 }
 
 template <int L>
@@ -1432,7 +1468,12 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     if (m->H != MF_H) return false;      // written for 20-wide layers (other widths: kernels_wide.hip)
     if (!(nd.d == 2 && nd.nT1 == 2 && nd.nT2 == 0 && nd.act == HPV_ACT_TANH) || m->L < 2 || m->L > 3) return false;
     const bool small = pd.qx == SM_QX && pd.qy == SM_QY && pd.ntx == SM_NTX && pd.nty == SM_NTY;
-    if (!(pd.qx == FZ_QX && pd.qy == FZ_QY && pd.ntx == FZ_NTX && pd.nty == FZ_NTY) && !small) return false;
+    if (!fused_shape_ok(pd) && !small) return false;
+    const int NQ = pd.qx * pd.qy, TPE = NQ / 16;              // points and 16-point tiles of an element
+    const bool has_qt = TPE % 4 == 1, base_shape = pd.qx == 20;
+#ifdef HPV_FZ_NO_EXTRA_SHAPES     // csrc/build.sh: the AGPR guard tripped in an instantiation of a shape other than 20x20 / 10x10
+    if (!base_shape && !small) return false;
+#endif
     if (pd.edge || pd.has_eps || pd.nterms != 2 || pd.nact) return false;
     for (int t = 0; t < 2; ++t)          // one-hot: term t integrates exactly channel 1 + t with weight 1
         for (int ch = 0; ch < HPV_MAXC; ++ch)
@@ -1441,6 +1482,10 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
 #ifdef HPV_AGPR_GUARD_TRIPPED     // csrc/build.sh: the compiler's registers reached the hand-managed AGPR range of k_iter_fused
     if (!small) return false;
 #endif
+    // shapes other than the headline one: one workgroup per element pays the launch-once phases (staging, projection, epilogue:
+    // ~7 us) per element -- on grids of many small elements the separate launches amortise them better (scripts/elem_bench.py:
+    // 1 024 elements of 12x12 points 106 against 99 us, of 16x16 points 158 against 163; 256 elements 30.7 / 48.9 against 49.3 / 60.5)
+    if (!base_shape && !small && n_elem > (long)(TPE < 16 ? 3 : 6) * m->n_cus) return false;
     if (small) {
         // batch layout [element points | pad to 16 | data points]; at most one boundary/data tile per workgroup
         const long npad = (n_elem * SM_NQ + 15) / 16 * 16;
@@ -1471,10 +1516,10 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     if (n_elem * 2 <= m->n_cus && !m->iter_fused_force) {
         if (!m->xerr || !m->xg || !m->xiter || !m->iter_split_ok) return false;
         while (split < 8 && n_elem * split * 2 <= m->n_cus) split *= 2;
-        if (n_elem * split > m->n_cus || n_elem > m->xsync_elems || (size_t)n_elem * 2 * FZ_NQ * 2 > m->xg_words) return false;
+        if (n_elem * split > m->n_cus || n_elem > m->xsync_elems || (size_t)n_elem * 2 * NQ * 2 > m->xg_words) return false;
     }
     const long blocks = n_elem * split;
-    const long rest = m->ntiles - n_elem * FZ_TPE;                  // pad + boundary/data tiles: at most one per workgroup
+    const long rest = m->ntiles - n_elem * TPE;                  // pad + boundary/data tiles: at most one per workgroup
     if (rest < 0 || rest > blocks) return false;
     if (blocks > hpv_mfma_grad_rows(m) && blocks > m->max_rows) return false;
     MfmaArgs a = m->base;
@@ -1494,28 +1539,24 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     a.xg = m->xg;
     a.xiter = m->xiter;
     a.pa = pa;
-    m->last_split = split > 1;
     // GS is opt-in (HPV_FUSED_GSTASH=1): measured 67.8 against 60.6 us at config 4 -- the reverse phase does shrink (73.1 k -> 60.9 k
     // cycles) but the forward phase pays for its stores (42.9 k -> 49.4 k: the four waves' bursts share one 64 B/clk path), and with
     // 220 MB of extra traffic per iteration the chip clocks 10 % lower (1.94 against 2.16 GHz); profiles/r04_notes.md
     const char* ge = getenv("HPV_FUSED_GSTASH");
-    const bool gs = a.ACTS != nullptr && ge && ge[0] == '1';
-    const char* gsn = gs ? "true" : "false";
-    if (split > 1) {
-        m->split_used = true;
-        snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=true,QT=false,GS=%s> split=%d", m->L, gsn, split);
-        launch_iter_fused_L<true, false>(m->L, gs, a, (int)blocks, s);
+    const bool gs = base_shape && a.ACTS != nullptr && ge && ge[0] == '1';
+    int plan = 2;
+    if (split > 1) plan = 0;
 #ifdef HPV_AGPR_GUARD_TRIPPED_QT                    // csrc/build.sh: the compiler's registers reached the stash of the QT instantiation
-    } else if (!gs) {
-#else
-    } else if (getenv("HPV_NO_QUARTER_TILE")) {      // (A/B switch: seven whole tiles for the first wave, read per launch / capture)
+    else if (!gs) plan = 1;
 #endif
-        snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=false,QT=false,GS=%s>", m->L, gsn);
-        launch_iter_fused_L<false, false>(m->L, gs, a, (int)blocks, s);
-    } else {
-        snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=false,QT=true,GS=%s>", m->L, gsn);
-        launch_iter_fused_L<false, true>(m->L, gs, a, (int)blocks, s);
-    }
+    else if (!has_qt || getenv("HPV_NO_QUARTER_TILE")) plan = 1;      // (A/B switch: whole tiles only, read per launch / capture)
+    if (!launch_iter_fused_any(pd, m->L, plan, gs, a, (int)blocks, s)) return false;
+    m->last_split = split > 1;
+    if (split > 1) m->split_used = true;
+    char shp[40] = "";
+    if (!base_shape) snprintf(shp, sizeof shp, ",%dx%d/%dx%d", pd.qx, pd.qy, pd.ntx, pd.nty);
+    if (split > 1) snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=true,QT=false,GS=%s%s> split=%d", m->L, gs ? "true" : "false", shp, split);
+    else snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=false,QT=%s,GS=%s%s>", m->L, plan == 2 ? "true" : "false", gs ? "true" : "false", shp);
     if (rows) *rows = (int)blocks;
     return true;
 }

@@ -763,7 +763,7 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
     }
     if (need_store && H == MF_H && nd.d == 2 && nd.nT1 == 2 && nd.nT2 <= 1 && nd.act == HPV_ACT_TANH) {
         // elements the exchange buffers of the split whole-iteration kernels are sized for (the largest grid this batch can hold)
-        m->xsync_elems = N / 400 + 1;
+        m->xsync_elems = N / 144 + 1;       // (the smallest element shape of the whole-iteration kernels: 12x12 points)
         // tagged-exchange granules: 2 words per exchanged double (tall elements: <= CUs x 25 doubles; SPLIT mode: 800 per element)
         m->xg_words = (size_t)2 * 800 * (size_t)std::min<long>(m->xsync_elems, 512);
         if (hipMalloc((void**)&m->xg, m->xg_words * sizeof(unsigned long long)) == hipSuccess &&

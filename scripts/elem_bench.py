@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Iteration time of element shapes / variational forms the hand-tuned whole-iteration kernels do not take: the generic
-element-resident kernel (csrc/kernels_elem.hip, one launch + finalize) against the separate launches (HPV_FUSE=n: forward ->
-activation store -> projection -> reverse -> finalize).  Prints a markdown table (profiles/r04_element_shapes.md)."""
+"""Iteration time of element shapes / variational forms other than the five BASELINE configs': the default dispatch (the
+whole-iteration kernel k_iter_fused for the two-term forms on 16x16 / 8x8 and 12x12 / 6x6 elements since round 4, otherwise the
+faster of the next two) against the generic element-resident kernel (csrc/kernels_elem.hip, HPV_FUSE=e) and the separate launches
+(HPV_FUSE=n: forward -> activation store -> projection -> reverse -> finalize).  Prints a markdown table."""
 import os
 import sys
 import time
@@ -23,35 +24,44 @@ def timeit(m, n=400):
     return 1e6 * best
 
 
-def both(build):
-    m = build()
-    us, v, ps = timeit(m), m.h.kernel_variant(), m.h.pass_structure()
-    del m
+def with_fuse(val, build):
     prev = os.environ.get("HPV_FUSE")
-    os.environ["HPV_FUSE"] = "n"
+    if val is None:
+        os.environ.pop("HPV_FUSE", None)
+    else:
+        os.environ["HPV_FUSE"] = val
     try:
         m = build()
-        us2, v2 = timeit(m), m.h.kernel_variant()
+        return timeit(m), m.h.kernel_variant(), m.h.pass_structure()
     finally:
         if prev is None:
-            del os.environ["HPV_FUSE"]
+            os.environ.pop("HPV_FUSE", None)
         else:
             os.environ["HPV_FUSE"] = prev
-    return us, v, ps, us2, v2
+
+
+def both(build):
+    """default dispatch, the generic element-resident kernel forced (HPV_FUSE=e), the separate launches (HPV_FUSE=n)"""
+    us, v, ps = with_fuse(None, build)
+    use, ve, pse = with_fuse("e", build)
+    usn, vn, _ = with_fuse("n", build)
+    return us, v, ps, use, (ve if pse == "whole-iteration-element" else "-"), usn
 
 
 rows = []
-for (q, nt, ne, L, vf) in [(16, 8, 16, [2, 20, 20, 20, 1], 1), (16, 8, 16, [2, 20, 20, 20, 1], 0), (16, 8, 16, [2, 20, 20, 1], 1),
-                           (12, 6, 16, [2, 20, 20, 20, 1], 1), (20, 10, 16, [2, 20, 20, 20, 1], 0), (20, 10, 16, [2, 20, 20, 20, 1], 2),
-                           (16, 8, 16, [2, 32, 32, 32, 1], 1), (16, 8, 32, [2, 20, 20, 20, 1], 1)]:
-    s = poisson2d.setup(N_el_x=ne, N_el_y=ne, N_test_x=nt, N_test_y=nt, N_quad=q, with_test_grid=False)
+for (q, nt, nex, ney, L, vf) in [(16, 8, 16, 16, [2, 20, 20, 20, 1], 1), (16, 8, 16, 16, [2, 20, 20, 1], 1), (16, 8, 16, 4, [2, 20, 20, 20, 1], 1),
+                                (12, 6, 16, 16, [2, 20, 20, 20, 1], 1), (12, 6, 16, 16, [2, 20, 20, 1], 1), (12, 6, 16, 4, [2, 20, 20, 20, 1], 1),
+                                (16, 8, 32, 32, [2, 20, 20, 20, 1], 1), (12, 6, 32, 32, [2, 20, 20, 20, 1], 1),
+                                (16, 8, 16, 16, [2, 20, 20, 20, 1], 0), (20, 10, 16, 16, [2, 20, 20, 20, 1], 0), (20, 10, 16, 16, [2, 20, 20, 20, 1], 2),
+                                (16, 8, 16, 16, [2, 32, 32, 32, 1], 1)]:
+    s = poisson2d.setup(N_el_x=nex, N_el_y=ney, N_test_x=nt, N_test_y=nt, N_quad=q, with_test_grid=False)
     r = both(lambda: poisson2d.build_model(s, L, var_form=vf, init_params=xavier_init(L, 1234)))
-    rows.append((f"Poisson-2D var_form {vf}, {ne}x{ne} elements, {q}x{q} points, {nt}x{nt} test fcns, {L}", ne * ne * q * q) + r)
+    rows.append((f"Poisson-2D var_form {vf}, {nex}x{ney} elements, {q}x{q} points, {nt}x{nt} test fcns, {L}", nex * ney * q * q) + r)
 L = [2, 20, 20, 20, 1]
 s = advdiff.setup(N_el_x=16, N_el_t=16, N_test_x=8, N_test_t=8, N_quad=16, with_test_grid=False)
 for vf in (0, 1):
     r = both(lambda: advdiff.build_model(s, L, var_form=vf, init_params=xavier_init(L, 1234, extra=[1.0])))
     rows.append((f"AdvDiff var_form {vf} (trainable epsilon), 16x16 elements, 16x16 points, 8x8 test fcns, {L}", 256 * 256) + r)
-print("| problem | points | us / iteration | separate launches (HPV_FUSE=n) | ratio | kernel |\n|---|---|---|---|---|---|")
-for name, npt, us, v, ps, us2, v2 in rows:
-    print(f"| {name} | {npt} | {us:.1f} ({ps}) | {us2:.1f} | {us2 / us:.2f} | `{v}` |")
+print("| problem | points | default: us / iteration | kernel | generic element-resident kernel (HPV_FUSE=e) | separate launches (HPV_FUSE=n) |\n|---|---|---|---|---|---|")
+for name, npt, us, v, ps, use, ve, usn in rows:
+    print(f"| {name} | {npt} | **{us:.1f}** ({ps}) | `{v}` | {use:.1f} `{ve}` | {usn:.1f} |")

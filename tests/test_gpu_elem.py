@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 def _element_resident_kernel_first(monkeypatch, request):
     """HPV_FUSE=e: the generic element-resident kernel wherever it is instantiated, so that EVERY instantiation is checked against
     the oracle -- by default it runs only where it is the faster structure (test_default_policy... below)."""
-    if "default_policy" not in request.node.name:
+    if "default_policy" not in request.node.name and "hand_tuned" not in request.node.name:
         monkeypatch.setenv("HPV_FUSE", "e")
 
 
@@ -126,15 +126,63 @@ def test_more_boundary_tiles_than_free_slots_go_to_extra_workgroups():
     _check(o, m, 2 * 36, "12x12/6x6")
 
 
+@pytest.mark.parametrize("q,nt", [(16, 8), (12, 6)])
+@pytest.mark.parametrize("nhid", [2, 3])
+@pytest.mark.parametrize("grid", ["full", "shard"])
+def test_hand_tuned_whole_iteration_kernel_on_other_element_shapes(q, nt, nhid, grid):
+    """k_iter_fused takes the element shape as a template parameter since round 4: 16x16 / 8x8 (16 tiles: 4 per wave, one wave also
+    the boundary tile) and 12x12 / 6x6 (9 tiles: 2 per wave + a quarter tile) under the default two-term form run on it by default --
+    a 16x16-element grid with one workgroup per element, a small shard with several workgroups per element (SPLIT mode).  Against the
+    oracle (loss triple, gradient, residuals, trajectory) and against the whole-tile plan where the shape has quarter tiles."""
+    from hp_vpinns_amd.vpinn import VPINN2D
+    from oracle.vpinn_oracle import OracleVPINN2D
+    assert "HPV_FUSE" not in os.environ
+    L = [2] + [20] * nhid + [1]
+    nex, ney = (16, 16) if grid == "full" else (5, 3)
+    a = _p2(q, nt, nex, ney, nb=13 if grid == "shard" else 40) + (L,)
+    th = theta0(L, 71)
+    o, m = OracleVPINN2D(*a, init_params=th), VPINN2D(*a, init_params=th)
+    o.vectorized = True
+    l3o, go = o.loss_and_grad()
+    l3m, gm = m.loss_and_grad()
+    v = m.h.kernel_variant()
+    assert m.h.pass_structure() == ("whole-iteration-split" if grid == "shard" else "whole-iteration"), m.h.pass_structure()
+    assert f",{q}x{q}/{nt}x{nt}>" in v and v.startswith("k_iter_fused<L=%d," % nhid), v
+    assert ("SPLIT=true" in v) == (grid == "shard"), v
+    assert ("QT=true" in v) == (grid == "full" and q == 12), v
+    assert rel(l3m, l3o) < TOL and rel(gm, go) < TOL, (l3m, l3o, rel(gm, go))
+    assert rel(m.h.residuals(nex * ney * nt * nt), o.last["R"].reshape(-1)) < TOL
+    l3b, gb = m.loss_and_grad()
+    assert np.array_equal(gb, gm) and np.array_equal(l3b, l3m)
+    lo, lm = [], []
+    for _ in range(6):
+        o.adam_step()
+        lo.append(float(o.loss_parts()[0]))
+        lm.append(float(m._step(1, True)[0]))
+    assert rel(lm, lo) < TRAJ_TOL and rel(m.get_params(), o.get_params()) < TRAJ_TOL
+    if "QT=true" in v:
+        os.environ["HPV_NO_QUARTER_TILE"] = "1"
+        try:
+            w = VPINN2D(*a, init_params=th)
+            l3w, gw = w.loss_and_grad()
+            assert "QT=false" in w.h.kernel_variant()
+        finally:
+            del os.environ["HPV_NO_QUARTER_TILE"]
+        assert rel(gw, gm) < 1e-11 and rel(l3w, l3m) < 1e-12
+
+
 def test_default_policy_picks_the_faster_structure_per_shape():
-    """Without HPV_FUSE the element-resident kernel is the default where it measured faster than the separate launches (few
-    channel-layers, small elements: profiles/r04_element_shapes.md) and the separate launches elsewhere."""
+    """Without HPV_FUSE: the two-term forms on 16x16 / 8x8 and 12x12 / 6x6 elements run on k_iter_fused; the generic element-resident
+    kernel is the default where it measured faster than the separate launches (few channel-layers: profiles/r04_element_shapes.md)
+    and the separate launches elsewhere."""
     from hp_vpinns_amd.vpinn import VPINN2D
     assert "HPV_FUSE" not in os.environ
-    for (q, nt, L, vf, want, waves) in [(12, 6, [2, 20, 20, 20, 1], 1, "whole-iteration-element", 4),
-                                        (16, 8, [2, 20, 20, 1], 1, "whole-iteration-element", 8),
+    for (q, nt, L, vf, want, waves) in [(12, 6, [2, 20, 20, 20, 1], 1, "whole-iteration-split", None),
+                                        (16, 8, [2, 20, 20, 1], 1, "whole-iteration-split", None),
+                                        (16, 8, [2, 20, 20, 20, 1], 1, "whole-iteration-split", None),
+                                        (12, 6, [2, 20, 20, 20, 1], 2, "whole-iteration-element", 8),
                                         (20, 10, [2, 20, 20, 20, 1], 2, "whole-iteration-element", 8),
-                                        (16, 8, [2, 20, 20, 20, 1], 1, "separate", None),
+                                        (16, 8, [2, 20, 20, 20, 1], 0, "separate", None),
                                         (16, 8, [2, 32, 32, 32, 1], 1, "separate", None)]:
         a = _p2(q, nt, 3, 3) + (L,)
         m = VPINN2D(*a, var_form=vf, init_params=theta0(L, 3))
