@@ -365,6 +365,64 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
     // =============================================================================================
     // phase P: partial projection of this workgroup's points, exchange, residual, adjoint at its points
     // =============================================================================================
+    // parking place of tile 0's recomputed tangent pre-activations: the transpose region (idle until the reverse pass) behind the
+    // gathered partial sums; the four waves' blocks straddle the per-wave transpose tiles, so everybody reads its block back BEFORE
+    // the barrier that ends phase P
+    // (the quarter-tile instantiations only: the other ones sit too close to the hand-managed AGPR range for a second copy of the
+    //  tile body; -DHPV_TALL_NO_EARLY: A/B)
+#ifdef HPV_TALL_NO_EARLY
+    constexpr bool EARLY0 = false;
+#else
+    constexpr bool EARLY0 = QT;
+#endif
+    constexpr int NPARK = (L - 1) * (NT1 + NT2) * MF_KS;
+    static_assert(64 * NR + TA_WAVES * NPARK * 64 <= TA_WAVES * M::TR_WAVE, "gathered sums + parked tangents fit the transpose region");
+    double* PARK = lds + M::TR + 64 * NR + wv * (NPARK * 64) + lane;     // (behind the gathered sums: at most 64 partners x NR)
+    // s of tile k back from the stash and its tangent pre-activations recomputed on the matrix pipe.  Tile 0's are produced BEFORE
+    // the gather of the exchange (they need nothing of the projection): the wait for the partners' partial sums (10 k cycles per
+    // launch) covers them
+    auto fetch_sv = [&](int k, double (&sv)[NSV]) {
+        switch (k) {
+#define TA_FETCH(K) case K: if constexpr (K < NSLOT) acc_get_all<ABASE + K * 2 * NSV, NSV>(sv); break;
+            TA_FETCH(0) TA_FETCH(1) TA_FETCH(2) TA_FETCH(3)
+#undef TA_FETCH
+            default:
+#pragma unroll
+                for (int j = 0; j < NSV; ++j) sv[j] = 0.0;
+        }
+    };
+    auto tangents = [&](int lofs, bool recompute, const double (&sv)[NSV], double (&zc)[L][NT1 > 0 ? NT1 : 1][MF_KS], double (&zcc)[L][NT2 > 0 ? NT2 : 1][MF_KS]) {
+        // tangent pre-activations of every hidden layer, recomputed: layer 0 has z_c = W1[c,:], z_cc = 0;
+        // layer i: z_c = (s' z_c)_{i-1} W_i, z_cc = (s'' z_c^2 + s' z_cc)_{i-1} W_i
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+#pragma unroll
+            for (int u = 0; u < NT1; ++u) zc[0][u][s] = lds[M::W1O + (u * MF_KS + s) * 64 + lofs];
+#pragma unroll
+            for (int b = 0; b < NT2; ++b) zcc[0][b][s] = 0.0;
+        }
+        if (!recompute) return;      // (wave-uniform) tile 0: its tangents were read back from the parking place before the loop
+#pragma unroll
+        for (int i = 1; i < L; ++i) {
+            double hx[NT1 > 0 ? NT1 : 1][MF_KS], hcc[NT2 > 0 ? NT2 : 1][MF_KS];
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+                const double a = sv[(i - 1) * MF_KS + s], a1 = 1.0 - a * a, a2 = -2.0 * a * a1;
+#pragma unroll
+                for (int u = 0; u < NT1; ++u) hx[u][s] = a1 * zc[i - 1][u][s];
+#pragma unroll
+                for (int b = 0; b < NT2; ++b)
+                    hcc[b][s] = a2 * zc[i - 1][b][s] * zc[i - 1][b][s] + (i > 1 ? a1 * zcc[i - 1][b][s] : 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < NT1; ++u)
+                fz_layer<false>(WTl + (i - 1) * MF_KS * 64, WRl + (i - 1) * MF_KS * 16, nullptr, lofs, hx[u], zc[i][u]);
+#pragma unroll
+            for (int b = 0; b < NT2; ++b)
+                fz_layer<false>(WTl + (i - 1) * MF_KS * 64, WRl + (i - 1) * MF_KS * 16, nullptr, lofs, hcc[b], zcc[i][b]);
+        }
+    };
+    double zc[L][NT1 > 0 ? NT1 : 1][MF_KS], zcc[L][NT2 > 0 ? NT2 : 1][MF_KS];       // tile 0's, between the parking place and the reverse pass
     const int np = n_mine * 16;                       // this workgroup's points: qe = 16 tbase + lp, lp < np
     const long qe0 = 16L * tbase;
     {
@@ -448,6 +506,22 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
         }
         }
         TA_STAMP(4);
+        if (EARLY0 && n_own > 0) {         // (wave-uniform)
+            double sv_[NSV], zc_[L][NT1 > 0 ? NT1 : 1][MF_KS], zcc_[L][NT2 > 0 ? NT2 : 1][MF_KS];
+            int lofs = lane;
+            asm volatile("" : "+v"(lofs));
+            fetch_sv(0, sv_);
+            tangents(lofs, true, sv_, zc_, zcc_);
+#pragma unroll
+            for (int i = 1; i < L; ++i)
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+#pragma unroll
+                    for (int u = 0; u < NT1; ++u) PARK[(((i - 1) * (NT1 + NT2) + u) * MF_KS + s) * 64] = zc_[i][u][s];
+#pragma unroll
+                    for (int b = 0; b < NT2; ++b) PARK[(((i - 1) * (NT1 + NT2) + NT1 + b) * MF_KS + s) * 64] = zcc_[i][b][s];
+                }
+        }
         {
             // the S x NR partial sums of the element, straight into LDS (the transpose region is idle between the phases)
             constexpr int NITG = (64 * NR * 2 + TA_BLOCK - 1) / TA_BLOCK;
@@ -517,6 +591,17 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
             deps = pj_wave_sum(deps);
             if (lane == 0) lds[M::RED + wv] = deps;
         }
+        if (EARLY0 && n_own > 0) {         // tile 0's tangents back from the parking place (before the barrier: the reverse pass reuses the region)
+#pragma unroll
+            for (int i = 1; i < L; ++i)
+#pragma unroll
+                for (int s = 0; s < MF_KS; ++s) {
+#pragma unroll
+                    for (int u = 0; u < NT1; ++u) zc[i][u][s] = PARK[(((i - 1) * (NT1 + NT2) + u) * MF_KS + s) * 64];
+#pragma unroll
+                    for (int b = 0; b < NT2; ++b) zcc[i][b][s] = PARK[(((i - 1) * (NT1 + NT2) + NT1 + b) * MF_KS + s) * 64];
+                }
+        }
         __syncthreads();
         if (pd.has_eps && tid == 0)
             pa.deps_e[wg_slot] = (lds[M::RED] + lds[M::RED + 1]) + (lds[M::RED + 2] + lds[M::RED + 3]);
@@ -539,23 +624,18 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
         for (int i = 0; i < L; ++i) db[i][s] = 0.0;
     }
 
-#pragma unroll 1
-    for (int k = 0; k < n_own; ++k) {
+    // one reverse tile; EARLY_ (tile 0): zc0 / zcc0 hold its tangents of the layers >= 2, read back from the parking place
+    auto rev_tile = [&](int k, auto EARLY_, [[maybe_unused]] const double (&zc0)[L][NT1 > 0 ? NT1 : 1][MF_KS],
+                        [[maybe_unused]] const double (&zcc0)[L][NT2 > 0 ? NT2 : 1][MF_KS]) {
+        constexpr bool EARLY = decltype(EARLY_)::value;
         const long tile = tile_of(k);
         const long p = tile * 16 + pt;
         const bool valid = p < g.N;
         const double x0 = valid ? g.X[p] : 0.0, x1 = valid ? g.X[g.N + p] : 0.0;
         int lofs = lane;
         asm volatile("" : "+v"(lofs));
-        double sv[NSV];
-        switch (k) {
-#define TA_FETCH(K) case K: if constexpr (K < NSLOT) acc_get_all<ABASE + K * 2 * NSV, NSV>(sv); break;
-            TA_FETCH(0) TA_FETCH(1) TA_FETCH(2) TA_FETCH(3)
-#undef TA_FETCH
-            default:
-#pragma unroll
-                for (int j = 0; j < NSV; ++j) sv[j] = 0.0;
-        }
+        double sv[NSV], zc[L][NT1 > 0 ? NT1 : 1][MF_KS], zcc[L][NT2 > 0 ? NT2 : 1][MF_KS];
+        fetch_sv(k, sv);
         double gb[C];
         if (k < n_el) {
             const int lp = lp_of(k);
@@ -566,34 +646,17 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
             for (int ch = 0; ch < C; ++ch) gb[ch] = 0.0;
             gb[0] = gdat;
         }
-        // tangent pre-activations of every hidden layer, recomputed: layer 0 has z_c = W1[c,:], z_cc = 0;
-        // layer i: z_c = (s' z_c)_{i-1} W_i, z_cc = (s'' z_c^2 + s' z_cc)_{i-1} W_i
-        double zc[L][NT1 > 0 ? NT1 : 1][MF_KS], zcc[L][NT2 > 0 ? NT2 : 1][MF_KS];
+        tangents(lofs, !EARLY, sv, zc, zcc);
+        if constexpr (EARLY) {
 #pragma unroll
-        for (int s = 0; s < MF_KS; ++s) {
+            for (int i = 1; i < L; ++i)
 #pragma unroll
-            for (int u = 0; u < NT1; ++u) zc[0][u][s] = lds[M::W1O + (u * MF_KS + s) * 64 + lofs];
+                for (int s = 0; s < MF_KS; ++s) {
 #pragma unroll
-            for (int b = 0; b < NT2; ++b) zcc[0][b][s] = 0.0;
-        }
+                    for (int u = 0; u < NT1; ++u) zc[i][u][s] = zc0[i][u][s];
 #pragma unroll
-        for (int i = 1; i < L; ++i) {
-            double hx[NT1 > 0 ? NT1 : 1][MF_KS], hcc[NT2 > 0 ? NT2 : 1][MF_KS];
-#pragma unroll
-            for (int s = 0; s < MF_KS; ++s) {
-                const double a = sv[(i - 1) * MF_KS + s], a1 = 1.0 - a * a, a2 = -2.0 * a * a1;
-#pragma unroll
-                for (int u = 0; u < NT1; ++u) hx[u][s] = a1 * zc[i - 1][u][s];
-#pragma unroll
-                for (int b = 0; b < NT2; ++b)
-                    hcc[b][s] = a2 * zc[i - 1][b][s] * zc[i - 1][b][s] + (i > 1 ? a1 * zcc[i - 1][b][s] : 0.0);
-            }
-#pragma unroll
-            for (int u = 0; u < NT1; ++u)
-                fz_layer<false>(WTl + (i - 1) * MF_KS * 64, WRl + (i - 1) * MF_KS * 16, nullptr, lofs, hx[u], zc[i][u]);
-#pragma unroll
-            for (int b = 0; b < NT2; ++b)
-                fz_layer<false>(WTl + (i - 1) * MF_KS * 64, WRl + (i - 1) * MF_KS * 16, nullptr, lofs, hcc[b], zcc[i][b]);
+                    for (int b = 0; b < NT2; ++b) zcc[i][b][s] = zcc0[i][b][s];
+                }
         }
         // channel ch of layer i's outputs (compile-time i, ch after unrolling)
         auto hv_of = [&](int i, int ch, int s) -> double {
@@ -700,6 +763,14 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
                 }
             }
         }
+    };
+    if constexpr (EARLY0) {
+        if (n_own > 0) rev_tile(0, std::true_type{}, zc, zcc);
+#pragma unroll 1
+        for (int k = 1; k < n_own; ++k) rev_tile(k, std::false_type{}, zc, zcc);
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < n_own; ++k) rev_tile(k, std::false_type{}, zc, zcc);
     }
 
     if (QT && q_kind != 0) {
