@@ -123,6 +123,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
 
     // ---- stage every weight fragment and the projection tables ----
     constexpr int TNX = FZ_NTX, TNY = FZ_NTY, TQX = FZ_QX, TQY = FZ_QY;
+    const int rnx = pa.pd.ntx, rny = pa.pd.nty, rnr = rnx * rny;      // the run's test functions per direction (<= NTX, NTY)
     static_assert(FZ_NTX * FZ_QX == FZ_NTY * FZ_QY, "table staging walks both tables with one index");
     {
         // layer index as a compile-time constant (kernarg offsets become scalar loads instead of a dependent vector load per
@@ -162,8 +163,11 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         for (int it = 0; it < ITT; ++it) {
             const int f = it * FZ_BLOCK + tid, fc = f < NTAB ? f : 0;
             const int tt_ = fc / (TNX * TQX), ti_ = fc % (TNX * TQX);
-            vax[it] = pa.wtx[(long)(tt_ ? dx1 : dx0) * TNX * TQX + ti_];
-            vby[it] = pa.wty[(long)(tt_ ? dy1 : dy0) * TNY * TQY + ti_];
+            // (fewer test functions than the instantiation's NTX x NTY: the tables of the missing ones are zero -- their residuals are
+            //  exactly 0 and leave the sums alone; R, F and the means below use the run's own counts rnx, rny)
+            const int rr_ = ti_ / TQX, ii_ = ti_ % TQX;
+            vax[it] = rr_ < rnx ? pa.wtx[((long)(tt_ ? dx1 : dx0) * rnx + rr_) * TQX + ii_] : 0.0;
+            vby[it] = rr_ < rny ? pa.wty[((long)(tt_ ? dy1 : dy0) * rny + rr_) * TQY + ii_] : 0.0;
         }
 #pragma unroll
         for (int i_ = 1; i_ < L; ++i_) {
@@ -200,7 +204,10 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     if constexpr (SPLIT) { xsticky = *g.xerr; xtag = *g.xiter + 1u; }
     // the element's projection constants, requested now so that no global latency sits inside phase P
     const double pc0 = pa.coef[e], pc1 = pa.coef[pa.coef_stride + e];
-    const double pF = (pa.F && tid < FZ_NR) ? pa.F[e * FZ_NR + tid] : 0.0;
+    const int ro_k = tid / FZ_NTX, ro_r = tid % FZ_NTX;                 // residual (k, r) of thread tid < NR, and whether the run has it
+    const bool ro_on = tid < FZ_NR && ro_k < rny && ro_r < rnx;
+    const long ro_idx = e * rnr + ro_k * rnx + ro_r;
+    const double pF = (pa.F && ro_on) ? pa.F[ro_idx] : 0.0;
     // ---- tile list of this wave: element tiles wv, wv+4, .., and possibly one boundary/data tile `dtile` ----
     const int lg = SPLIT ? __builtin_ctz(split) : 0;                             // split is 2, 4 or 8
     const int tbase = SPLIT ? (part * FZ_TPE) >> lg : 0;                         // this workgroup's tile range of the element
@@ -559,7 +566,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         if (tid < FZ_NR) {
             const double u = (lds[M::UP + tid] + lds[M::UP + FZ_NR + tid]) - pF;
             lds[M::U + tid] = u;
-            pa.R[e * FZ_NR + tid] = u;
+            if (ro_on) pa.R[ro_idx] = u;
             sq = u * u;
         }
         if (wv < 2) {
@@ -567,9 +574,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             if (lane == 0) lds[M::RED + wv] = sq;
         }
         __syncthreads();
-        if (tid == 0) pa.loss_e[e] = (lds[M::RED] + lds[M::RED + 1]) / (double)FZ_NR;
+        if (tid == 0) pa.loss_e[e] = (lds[M::RED] + lds[M::RED + 1]) / (double)rnr;
         // adjoint: S_t[k][i] = (2/NR) c_t sum_r AX_t[r][i] U[k][r];  Gbar_t[j][i] = sum_k BY_t[k][j] S_t[k][i]
-        const double sc = 2.0 / (double)FZ_NR;
+        const double sc = 2.0 / (double)rnr;
         for (int o = tid; o < 2 * FZ_NTY * FZ_QX; o += FZ_BLOCK) {
             const int t = o / (FZ_NTY * FZ_QX), kk = (o / FZ_QX) % FZ_NTY, i = o % FZ_QX;
             const double* ax = lds + M::AX + t * FZ_NTX * FZ_QX + i;
@@ -1028,6 +1035,7 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
 
     // ---- stage weight fragments and projection tables ----
     constexpr int TNX = SM_NTX, TNY = SM_NTY, TQX = SM_QX, TQY = SM_QY;
+    const int rnx = pa.pd.ntx, rny = pa.pd.nty, rnr = rnx * rny;      // the run's test functions per direction (<= NTX, NTY: see k_iter_fused)
     static_assert(SM_NTX * SM_QX == SM_NTY * SM_QY, "table staging walks both tables with one index");
     {
         // layer index as a compile-time constant (kernarg offsets become scalar loads instead of a dependent vector load per
@@ -1067,8 +1075,11 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
         for (int it = 0; it < ITT; ++it) {
             const int f = it * SM_BLOCK + tid, fc = f < NTAB ? f : 0;
             const int tt_ = fc / (TNX * TQX), ti_ = fc % (TNX * TQX);
-            vax[it] = pa.wtx[(long)(tt_ ? dx1 : dx0) * TNX * TQX + ti_];
-            vby[it] = pa.wty[(long)(tt_ ? dy1 : dy0) * TNY * TQY + ti_];
+            // (fewer test functions than the instantiation's NTX x NTY: the tables of the missing ones are zero -- their residuals are
+            //  exactly 0 and leave the sums alone; R, F and the means below use the run's own counts rnx, rny)
+            const int rr_ = ti_ / TQX, ii_ = ti_ % TQX;
+            vax[it] = rr_ < rnx ? pa.wtx[((long)(tt_ ? dx1 : dx0) * rnx + rr_) * TQX + ii_] : 0.0;
+            vby[it] = rr_ < rny ? pa.wty[((long)(tt_ ? dy1 : dy0) * rny + rr_) * TQY + ii_] : 0.0;
         }
 #pragma unroll
         for (int i_ = 1; i_ < L; ++i_) {
@@ -1099,7 +1110,10 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
     }
     const double bo = th[g.boff[L]];
     const double pc0 = pa.coef[e], pc1 = pa.coef[pa.coef_stride + e];
-    const double pF = (pa.F && tid < SM_NR) ? pa.F[e * SM_NR + tid] : 0.0;
+    const int ro_k = tid / SM_NTX, ro_r = tid % SM_NTX;
+    const bool ro_on = tid < SM_NR && ro_k < rny && ro_r < rnx;
+    const long ro_idx = e * rnr + ro_k * rnx + ro_r;
+    const double pF = (pa.F && ro_on) ? pa.F[ro_idx] : 0.0;
 
     // ---- this wave's tile: waves 0..6 element tile wv, wave 7 the boundary/data tile blockIdx.x (if there is one) ----
     const bool is_el = wv < SM_TPE;
@@ -1200,7 +1214,7 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
         if (tid < SM_NR) {
             const double u = (lds[M::UP + tid] + lds[M::UP + SM_NR + tid]) - pF;
             lds[M::U + tid] = u;
-            pa.R[e * SM_NR + tid] = u;
+            if (ro_on) pa.R[ro_idx] = u;
             sq = u * u;
         }
         if (wv == 0) {
@@ -1208,8 +1222,8 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
             if (lane == 0) lds[M::RED] = sq;
         }
         __syncthreads();
-        if (tid == 0) pa.loss_e[e] = lds[M::RED] / (double)SM_NR;
-        const double sc = 2.0 / (double)SM_NR;
+        if (tid == 0) pa.loss_e[e] = lds[M::RED] / (double)rnr;
+        const double sc = 2.0 / (double)rnr;
         for (int o = tid; o < 2 * SM_NTY * SM_QX; o += SM_BLOCK) {
             const int t = o / (SM_NTY * SM_QX), kk = (o / SM_QX) % SM_NTY, i = o % SM_QX;
             const double* ax = lds + M::AX + t * SM_NTX * SM_QX + i;
@@ -1435,13 +1449,13 @@ static bool launch_iter_fused_shape(int L, int plan, bool gs, const MfmaArgs& a,
 }
 static bool launch_iter_fused_any(const ProjDesc& pd, int L, int plan, bool gs, const MfmaArgs& a, int blocks, hipStream_t s) {
 #define FZ_TRY(A_, B_, C_, D_) \
-    if (pd.qx == A_ && pd.qy == B_ && pd.ntx == C_ && pd.nty == D_) return launch_iter_fused_shape<A_, B_, C_, D_>(L, plan, gs, a, blocks, s);
+    if (pd.qx == A_ && pd.qy == B_ && pd.ntx <= C_ && pd.nty <= D_) return launch_iter_fused_shape<A_, B_, C_, D_>(L, plan, gs, a, blocks, s);
     FZ_SHAPES(FZ_TRY)
 #undef FZ_TRY
     return false;
 }
 static bool fused_shape_ok(const ProjDesc& pd) {
-#define FZ_TRY(A_, B_, C_, D_) if (pd.qx == A_ && pd.qy == B_ && pd.ntx == C_ && pd.nty == D_) return true;
+#define FZ_TRY(A_, B_, C_, D_) if (pd.qx == A_ && pd.qy == B_ && pd.ntx >= 1 && pd.ntx <= C_ && pd.nty >= 1 && pd.nty <= D_) return true;
     FZ_SHAPES(FZ_TRY)
 #undef FZ_TRY
     return false;
@@ -1467,12 +1481,13 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     if (!m->iter_fused_ok) return false;
     if (m->H != MF_H) return false;      // written for 20-wide layers (other widths: kernels_wide.hip)
     if (!(nd.d == 2 && nd.nT1 == 2 && nd.nT2 == 0 && nd.act == HPV_ACT_TANH) || m->L < 2 || m->L > 3) return false;
-    const bool small = pd.qx == SM_QX && pd.qy == SM_QY && pd.ntx == SM_NTX && pd.nty == SM_NTY;
+    const bool small = pd.qx == SM_QX && pd.qy == SM_QY && pd.ntx >= 1 && pd.ntx <= SM_NTX && pd.nty >= 1 && pd.nty <= SM_NTY;
     if (!fused_shape_ok(pd) && !small) return false;
     const int NQ = pd.qx * pd.qy, TPE = NQ / 16;              // points and 16-point tiles of an element
-    const bool has_qt = TPE % 4 == 1, base_shape = pd.qx == 20;
+    const bool has_qt = TPE % 4 == 1, q20 = pd.qx == 20 && pd.qy == 20;
+    const bool base_shape = q20 && pd.ntx == 10 && pd.nty == 10;           // BASELINE config 4 itself
 #ifdef HPV_FZ_NO_EXTRA_SHAPES     // csrc/build.sh: the AGPR guard tripped in an instantiation of a shape other than 20x20 / 10x10
-    if (!base_shape && !small) return false;
+    if (!q20 && !small) return false;
 #endif
     if (pd.edge || pd.has_eps || pd.nterms != 2 || pd.nact) return false;
     for (int t = 0; t < 2; ++t)          // one-hot: term t integrates exactly channel 1 + t with weight 1
@@ -1485,7 +1500,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     // shapes other than the headline one: one workgroup per element pays the launch-once phases (staging, projection, epilogue:
     // ~7 us) per element -- on grids of many small elements the separate launches amortise them better (scripts/elem_bench.py:
     // 1 024 elements of 12x12 points 106 against 99 us, of 16x16 points 158 against 163; 256 elements 30.7 / 48.9 against 49.3 / 60.5)
-    if (!base_shape && !small && n_elem > (long)(TPE < 16 ? 3 : 6) * m->n_cus) return false;
+    if (!q20 && !small && n_elem > (long)(TPE < 16 ? 3 : 6) * m->n_cus) return false;
     if (small) {
         // batch layout [element points | pad to 16 | data points]; at most one boundary/data tile per workgroup
         const long npad = (n_elem * SM_NQ + 15) / 16 * 16;
@@ -1505,7 +1520,8 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
         a.proj_split = 1;
         a.pa = pa;
         m->last_split = false;
-        snprintf(m->variant, sizeof m->variant, "k_iter_small<L=%d>", m->L);
+        if (pd.ntx == SM_NTX && pd.nty == SM_NTY) snprintf(m->variant, sizeof m->variant, "k_iter_small<L=%d>", m->L);
+        else snprintf(m->variant, sizeof m->variant, "k_iter_small<L=%d,10x10/%dx%d>", m->L, pd.ntx, pd.nty);
         if (m->L == 2) launch_iter_small<2>(a, (int)n_elem, s); else launch_iter_small<3>(a, (int)n_elem, s);
         if (rows) *rows = (int)n_elem;
         return true;
@@ -1543,7 +1559,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     // cycles) but the forward phase pays for its stores (42.9 k -> 49.4 k: the four waves' bursts share one 64 B/clk path), and with
     // 220 MB of extra traffic per iteration the chip clocks 10 % lower (1.94 against 2.16 GHz); profiles/r04_notes.md
     const char* ge = getenv("HPV_FUSED_GSTASH");
-    const bool gs = base_shape && a.ACTS != nullptr && ge && ge[0] == '1';
+    const bool gs = q20 && a.ACTS != nullptr && ge && ge[0] == '1';
     int plan = 2;
     if (split > 1) plan = 0;
 #ifdef HPV_AGPR_GUARD_TRIPPED_QT                    // csrc/build.sh: the compiler's registers reached the stash of the QT instantiation

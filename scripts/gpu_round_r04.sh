@@ -42,8 +42,8 @@ echo >> $OUT/summary.md; echo "### iterations/sec of the five BASELINE configs (
 python scripts/config_bench.py 2>/dev/null | grep "^|" >> $OUT/summary.md
 echo >> $OUT/summary.md; echo "### networks of other widths / depths (scripts/wide_bench.py)" >> $OUT/summary.md; echo >> $OUT/summary.md
 python scripts/wide_bench.py 2>/dev/null | grep "^|" >> $OUT/summary.md
-echo >> $OUT/summary.md; echo "### other element shapes / variational forms: generic element-resident kernel forced (HPV_FUSE=e) vs separate launches (scripts/elem_bench.py)" >> $OUT/summary.md; echo >> $OUT/summary.md
-HPV_FUSE=e python scripts/elem_bench.py 2>/dev/null | grep "^|" >> $OUT/summary.md
+echo >> $OUT/summary.md; echo "### other element shapes / variational forms: default dispatch vs the generic element-resident kernel (HPV_FUSE=e) vs the separate launches (scripts/elem_bench.py)" >> $OUT/summary.md; echo >> $OUT/summary.md
+python scripts/elem_bench.py 2>/dev/null | grep "^|" >> $OUT/summary.md
 echo >> $OUT/summary.md; echo "### shards of config 4 one GPU of N owns (SPLIT mode), no communication" >> $OUT/summary.md; echo >> $OUT/summary.md
 python scripts/shard_bench.py 2>/dev/null | sed 's/^/    /' >> $OUT/summary.md
 echo >> $OUT/summary.md; echo "### iteration tail of the multi-GPU launches on one GPU (scripts/exchange_overhead.py)" >> $OUT/summary.md; echo >> $OUT/summary.md

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 def _element_resident_kernel_first(monkeypatch, request):
     """HPV_FUSE=e: the generic element-resident kernel wherever it is instantiated, so that EVERY instantiation is checked against
     the oracle -- by default it runs only where it is the faster structure (test_default_policy... below)."""
-    if "default_policy" not in request.node.name and "hand_tuned" not in request.node.name:
+    if "default_policy" not in request.node.name and "hand_tuned" not in request.node.name:     # (those run the default dispatch)
         monkeypatch.setenv("HPV_FUSE", "e")
 
 
@@ -169,6 +169,40 @@ def test_hand_tuned_whole_iteration_kernel_on_other_element_shapes(q, nt, nhid, 
         finally:
             del os.environ["HPV_NO_QUARTER_TILE"]
         assert rel(gw, gm) < 1e-11 and rel(l3w, l3m) < 1e-12
+
+
+@pytest.mark.parametrize("q,ntx,nty,nex,ney", [(20, 7, 5, 16, 16), (20, 10, 6, 5, 3), (20, 1, 1, 4, 4), (16, 5, 5, 16, 16), (16, 8, 3, 5, 3),
+                                               (12, 4, 6, 16, 16), (12, 2, 5, 4, 2), (10, 3, 4, 8, 8), (10, 5, 2, 4, 4), (10, 1, 3, 3, 3)])
+def test_hand_tuned_kernels_with_fewer_test_functions_than_instantiated(q, ntx, nty, nex, ney):
+    """N_test_x / N_test_y are free hyper-parameters (P2:283-286): the whole-iteration kernels are instantiated per quadrature rule
+    with the largest test-function counts (20x20 / 10x10, 16x16 / 8x8, 12x12 / 6x6, 10x10 / 5x5) and take any smaller counts at run
+    time -- the missing functions' tables are zero, R / F / the means use the run's own counts.  Full grids and small shards,
+    N_test_x != N_test_y, down to one test function; against the oracle."""
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.vpinn import VPINN2D
+    from oracle.vpinn_oracle import OracleVPINN2D
+    assert "HPV_FUSE" not in os.environ
+    L = [2, 20, 20, 20, 1]
+    s = poisson2d.setup(N_el_x=nex, N_el_y=ney, N_test_x=ntx, N_test_y=nty, N_quad=q, N_bound=17, with_test_grid=False)
+    a = (s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"], s["WXY_quad_train"], None,
+         s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"], s["X_u_train"], s["u_train"], L)
+    assert s["F_ext_total"].shape == (nex, ney, nty, ntx)
+    th = theta0(L, 123)
+    o, m = OracleVPINN2D(*a, init_params=th), VPINN2D(*a, init_params=th)
+    o.vectorized = True
+    l3o, go = o.loss_and_grad()
+    l3m, gm = m.loss_and_grad()
+    v = m.h.kernel_variant()
+    assert m.h.pass_structure().startswith("whole-iteration"), (m.h.pass_structure(), v)
+    assert (v.startswith("k_iter_small<") if q == 10 else v.startswith("k_iter_fused<")) and f"{q}x{q}/{ntx}x{nty}" in v, v
+    assert rel(l3m, l3o) < TOL and rel(gm, go) < TOL, (l3m, l3o, rel(gm, go))
+    assert rel(m.h.residuals(nex * ney * ntx * nty), o.last["R"].reshape(-1)) < TOL
+    lo, lm = [], []
+    for _ in range(5):
+        o.adam_step()
+        lo.append(float(o.loss_parts()[0]))
+        lm.append(float(m._step(1, True)[0]))
+    assert rel(lm, lo) < TRAJ_TOL and rel(m.get_params(), o.get_params()) < TRAJ_TOL
 
 
 def test_default_policy_picks_the_faster_structure_per_shape():
