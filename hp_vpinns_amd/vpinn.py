@@ -550,6 +550,11 @@ class VPINN1D(_VPINNBase):
         self.F_ext_total = np.zeros((self.Nelement, self.N_test, 1))
         for e, f in enumerate(Fe):
             self.F_ext_total[e, :f.size, 0] = f
+        # The element-resident 1-D kernel is instantiated for the reference's own rule (80 points, 60 test functions: P1:237-238).
+        # Fewer test functions (N_testfcn is a free hyper-parameter) run on it as a p-refinement with equal counts: the device
+        # gets the first 60 test functions (phi_k does not depend on how many follow), F padded with zeros, and the count per
+        # element -- the same mechanism as the ragged lists above.
+        self._N_test_dev = 60 if (self.xquad.size == 80 and self.N_test < 60) else self.N_test
         self.grid = np.asarray(grid, dtype=np.float64)
         self.var_form, self.LR, self.lossb_weight = var_form, LR, lossb_weight
         self._total_record_arg = total_record
@@ -562,14 +567,19 @@ class VPINN1D(_VPINNBase):
             xi = self.xquad.reshape(-1)
             self.h.set_quadrature(xi, self.wquad.reshape(-1))
             edge = None
+            nt = self._N_test_dev
             if var_form == 3:
-                d1b = dTest_fcn(self.N_test, np.array([-1.0, 1.0]))[0]     # (N_test, 2): phi'(-1), phi'(1)  (P1:79)
+                d1b = dTest_fcn(nt, np.array([-1.0, 1.0]))[0]     # (N_test, 2): phi'(-1), phi'(1)  (P1:79)
                 edge = np.ascontiguousarray(d1b)
-            self.h.set_tables(tables_1d(self.N_test, xi), None, edge)
+            self.h.set_tables(tables_1d(nt, xi), None, edge)
             eb, ee = shard_range(self.Nelement, self.rank, self.world)
             self.h.set_elements(self.grid, None, eb, ee)
-            self.h.set_rhs(self.F_ext_total.reshape(-1))
-            if np.any(self._n_active != self.N_test):
+            Fd = self.F_ext_total
+            if nt != self.N_test:
+                Fd = np.zeros((self.Nelement, nt, 1))
+                Fd[:, :self.N_test] = self.F_ext_total
+            self.h.set_rhs(Fd.reshape(-1))
+            if np.any(self._n_active != nt):
                 self.h.set_active_tests(self._n_active)
             if self.rank == 0:
                 self.h.set_data(self.x, self.u.reshape(-1))

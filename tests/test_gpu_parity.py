@@ -1061,6 +1061,33 @@ def test_poisson1d_per_element_test_function_counts(vf, backend):
     assert abs(m2.loss_and_grad()[0][0] - m.loss_and_grad()[0][0]) > 1e-6
 
 
+@pytest.mark.parametrize("nt", [40, 5])
+@pytest.mark.parametrize("vf", [1, 2])
+def test_poisson1d_fewer_test_functions_run_on_the_element_resident_kernel(nt, vf):
+    """N_testfcn is a free hyper-parameter of the 1-D driver (P1:238).  With the reference's 80-point rule, any count below the
+    instantiated 60 runs on the whole-iteration tile kernel as a p-refinement with equal counts (vpinn.py pads tables and F, the
+    library divides by the count): loss, gradient, residuals and a trajectory against the oracle built with the count itself."""
+    from hp_vpinns_amd.drivers import poisson1d
+    from hp_vpinns_amd.init import xavier_init
+    from hp_vpinns_amd.vpinn import VPINN1D
+    from oracle.vpinn_oracle import OracleVPINN1D
+    s = poisson1d.setup(N_Element=3, N_testfcn_total=[nt] * 3)
+    L = [1, 20, 20, 20, 1]
+    th = xavier_init(L, 32)
+    th[L[1]:2 * L[1]] = 0.1
+    args = (s["X_u_train"], s["u_train"], s["X_quad_train"], s["W_quad_train"], s["F_ext_total"], s["grid"], s["X_test"],
+            s["u_test"], L, s["X_f_train"], s["f_train"])
+    m = VPINN1D(*args, var_form=vf, init_params=th)
+    o = OracleVPINN1D(*args, var_form=vf, init_params=th)
+    assert m.N_test == nt and o.N_test == nt
+    _check_loss_grad(o, m)
+    assert m.h.pass_structure() == "whole-iteration-tile", m.h.kernel_variant()
+    r = m.h.residuals(3 * 60).reshape(3, 60)
+    assert np.all(r[:, nt:] == 0.0) and np.count_nonzero(r[:, :nt]) >= 3 * nt - 3
+    assert abs(float(m.loss_and_grad()[0][2]) - float(np.mean(r[:, :nt] ** 2, axis=1).sum())) < 1e-10 * max(1.0, float(np.abs(r).max()) ** 2)   # lossv = sum_e mean over ITS nt residuals
+    _check_traj(o, m, n=8)
+
+
 @pytest.mark.parametrize("backend", ["auto", "generic"])
 def test_poisson1d_shards_with_test_function_counts(backend):
     """What the ranks of a multi-GPU run own: the element range [e_begin, e_end) with F and the per-element test-function
