@@ -64,6 +64,38 @@ def _tensor_rule(X_quad, W_quad):
     return xi, wx, yi, wy
 
 
+# Quadrature rules the element-resident whole-iteration kernels are instantiated for: (points per direction, largest test-function
+# count per direction).  2-D two-term forms: csrc/kernels_fused.hip (k_iter_small, FZ_SHAPES); 1-D: csrc/kernels_tile.hip.
+_RULES_2D = ((10, 5), (12, 6), (16, 8), (20, 10))
+_RULE_1D = (80, 60)
+_RULE_PAD_MAX_ELEMS = 1536        # beyond ~6 elements per CU the kernels hand shapes other than 20 / 10 points to the separate launches
+
+
+def _pad_rule(xi, w, q_dev):
+    """N_quad is a free hyper-parameter (P1:237, P2:282, P3:47).  A rule with fewer points than an instantiated one is handed to the
+    device padded with ZERO-WEIGHT points (at the last node): the tables the kernels contract with are w * phi, so a padded point
+    adds exact zeros to every residual and receives a zero adjoint -- the integrals and their gradients are those of the rule itself,
+    and the problem runs on the element-resident kernel of the next instantiated rule instead of the general launches."""
+    n = q_dev - xi.size
+    if n <= 0:
+        return xi, w
+    return np.concatenate([xi, np.full(n, xi[-1])]), np.concatenate([w, np.zeros(n)])
+
+
+def _device_rule_2d(xi, wx, yi, wy, ntx, nty, n_elem, exact_counts=False, rules=_RULES_2D):
+    """The (possibly padded) 2-D rule for the device; `exact_counts`: only instantiations with exactly these test-function counts."""
+    if xi.size != yi.size or os.environ.get("HPV_NO_RULE_PADDING"):
+        return xi, wx, yi, wy
+    for q_dev, nt_max in rules:
+        counts_ok = (ntx == nt_max and nty == nt_max) if exact_counts else max(ntx, nty) <= nt_max
+        if xi.size <= q_dev and counts_ok:
+            if xi.size < q_dev and (q_dev in (10, 20) or n_elem <= _RULE_PAD_MAX_ELEMS):
+                xi, wx = _pad_rule(xi, wx, q_dev)
+                yi, wy = _pad_rule(yi, wy, q_dev)
+            break
+    return xi, wx, yi, wy
+
+
 def _caller_globals(depth=2):
     """Module globals of whoever called the public method `depth - 1` frames above this function."""
     try:
@@ -563,9 +595,17 @@ class VPINN1D(_VPINNBase):
             raise ValueError("grid must have Nelement+1 entries")
         self._create(layers, var_form, LR, lossb_weight, 1.0, init_params, seed, backend, device)
 
+        hidden = self.layers[1:-1]
+        pad_rule = (backend != "generic" and var_form in (1, 2) and self.xquad.size < _RULE_1D[0] and self.N_test <= _RULE_1D[1]
+                    and max(hidden) <= 20 and 2 <= len(hidden) <= 4 and not os.environ.get("HPV_NO_RULE_PADDING"))
+        if pad_rule:
+            self._N_test_dev = _RULE_1D[1]
+
         def populate():
-            xi = self.xquad.reshape(-1)
-            self.h.set_quadrature(xi, self.wquad.reshape(-1))
+            xi, wq = self.xquad.reshape(-1), self.wquad.reshape(-1)
+            if pad_rule:
+                xi, wq = _pad_rule(xi, wq, _RULE_1D[0])
+            self.h.set_quadrature(xi, wq)
             edge = None
             nt = self._N_test_dev
             if var_form == 3:
@@ -663,6 +703,9 @@ class VPINN2D(_VPINNBase):
                 self.h.set_collocation(Xf[cb:ce], ff[cb:ce], n_total=Xf.shape[0])
             else:
                 xi, wx, yi, wy = _tensor_rule(X_quad, W_quad)
+                hidden = self.layers[1:-1]
+                if backend != "generic" and var_form == 1 and max(hidden) <= 20 and 2 <= len(hidden) <= 3:
+                    xi, wx, yi, wy = _device_rule_2d(xi, wx, yi, wy, self.Ntestx, self.Ntesty, self.Nelementx * self.Nelementy)
                 self.h.set_quadrature(xi, wx, yi, wy)
                 self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntesty, yi))
                 eb, ee = shard_range(self.Nelementx * self.Nelementy, self.rank, self.world)
@@ -732,6 +775,10 @@ class VPINNAdvDiff(_VPINNBase):
 
         def populate():
             xi, wx, ti, wt = _tensor_rule(XT_quad, W_quad)
+            hidden = self.layers[1:-1]
+            if backend != "generic" and max(hidden) <= 20 and 2 <= len(hidden) <= 3 and xi.size < 10:     # (the 10x10 / 5x5 tile kernel)
+                xi, wx, ti, wt = _device_rule_2d(xi, wx, ti, wt, self.Ntestx, self.Ntestt, self.Nelementx * self.Nelementt, exact_counts=True,
+                                                 rules=_RULES_2D[:1])
             self.h.set_quadrature(xi, wx, ti, wt)
             self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntestt, ti))
             eb, ee = shard_range(self.Nelementx * self.Nelementt, self.rank, self.world)

@@ -65,3 +65,19 @@ for vf in (0, 1):
 print("| problem | points | default: us / iteration | kernel | generic element-resident kernel (HPV_FUSE=e) | separate launches (HPV_FUSE=n) |\n|---|---|---|---|---|---|")
 for name, npt, us, v, ps, use, ve, usn in rows:
     print(f"| {name} | {npt} | **{us:.1f}** ({ps}) | `{v}` | {use:.1f} `{ve}` | {usn:.1f} |")
+
+# quadrature rules / test-function counts between the instantiated ones: the rule goes to the device padded with zero-weight
+# points (vpinn._pad_rule), the counts are run-time values of the kernels -- against the same problem on the general launches
+print()
+print("| problem (Poisson-2D var_form 1, [2, 20, 20, 20, 1]) | default: us / iteration | kernel | rule as it is (HPV_NO_RULE_PADDING=1) | kernels |\n|---|---|---|---|---|")
+for (q, nt, ne) in [(14, 7, 16), (18, 9, 16), (11, 5, 16), (7, 4, 16), (20, 7, 16), (16, 5, 16)]:
+    L = [2, 20, 20, 20, 1]
+    s = poisson2d.setup(N_el_x=ne, N_el_y=ne, N_test_x=nt, N_test_y=nt, N_quad=q, with_test_grid=False)
+    build = lambda: poisson2d.build_model(s, L, var_form=1, init_params=xavier_init(L, 1234))
+    us, v, ps = with_fuse(None, build)
+    os.environ["HPV_NO_RULE_PADDING"] = "1"
+    try:
+        us2, v2, _ = with_fuse(None, build)
+    finally:
+        del os.environ["HPV_NO_RULE_PADDING"]
+    print(f"| {ne}x{ne} elements, {q}x{q} points, {nt}x{nt} test fcns | **{us:.1f}** | `{v}` | {us2:.1f} | `{v2}` |")

@@ -205,6 +205,81 @@ def test_hand_tuned_kernels_with_fewer_test_functions_than_instantiated(q, ntx, 
     assert rel(lm, lo) < TRAJ_TOL and rel(m.get_params(), o.get_params()) < TRAJ_TOL
 
 
+@pytest.mark.parametrize("q,nt,nex,want", [(14, 7, 16, "k_iter_fused<L=3,SPLIT=false,QT=false,GS=false,16x16/7x7>"),
+                                          (18, 9, 4, "20x20/9x9> split"), (11, 6, 16, "12x12/6x6>"), (7, 4, 8, "k_iter_small<L=3,10x10/4x4>")])
+def test_hand_tuned_kernels_with_smaller_quadrature_rules_than_instantiated(q, nt, nex, want):
+    """N_quad is a free hyper-parameter (P2:282).  A rule with fewer points than an instantiated one goes to the device padded with
+    zero-weight points (vpinn._pad_rule): exact zeros in every integral and adjoint, and the problem runs on the element-resident
+    kernel of the next rule.  Oracle = the reference's graph on the rule itself."""
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.vpinn import VPINN2D
+    from oracle.vpinn_oracle import OracleVPINN2D
+    assert "HPV_FUSE" not in os.environ
+    L = [2, 20, 20, 20, 1]
+    s = poisson2d.setup(N_el_x=nex, N_el_y=nex, N_test_x=nt, N_test_y=nt, N_quad=q, N_bound=17, with_test_grid=False)
+    assert s["XY_quad_train"].shape == (q * q, 2)
+    a = (s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"], s["WXY_quad_train"], None,
+         s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"], s["X_u_train"], s["u_train"], L)
+    th = theta0(L, 124)
+    o, m = OracleVPINN2D(*a, init_params=th), VPINN2D(*a, init_params=th)
+    o.vectorized = True
+    l3o, go = o.loss_and_grad()
+    l3m, gm = m.loss_and_grad()
+    assert want in m.h.kernel_variant(), m.h.kernel_variant()
+    assert rel(l3m, l3o) < TOL and rel(gm, go) < TOL, (l3m, l3o, rel(gm, go))
+    assert rel(m.h.residuals(nex * nex * nt * nt), o.last["R"].reshape(-1)) < TOL
+    lo, lm = [], []
+    for _ in range(5):
+        o.adam_step()
+        lo.append(float(o.loss_parts()[0]))
+        lm.append(float(m._step(1, True)[0]))
+    assert rel(lm, lo) < TRAJ_TOL and rel(m.get_params(), o.get_params()) < TRAJ_TOL
+    os.environ["HPV_NO_RULE_PADDING"] = "1"           # the rule as it is: the general launches, same numbers
+    try:
+        m2 = VPINN2D(*a, init_params=th)
+        l3u, gu = m2.loss_and_grad()
+        assert not m2.h.pass_structure().startswith("whole-iteration"), m2.h.kernel_variant()
+    finally:
+        del os.environ["HPV_NO_RULE_PADDING"]
+    assert rel(l3u, l3m) < 1e-12 and rel(gu, gm) < 1e-10
+
+
+def test_hand_tuned_kernels_smaller_rules_1d_and_advdiff():
+    """The same for the 1-D driver (N_Quad = 40, 20 test functions: the 80 / 60 tile kernel) and AdvDiff (8x8 points, 5x5 test
+    functions: the 10x10 / 5x5 tile kernel, trainable epsilon)."""
+    from hp_vpinns_amd.drivers import advdiff, poisson1d
+    from hp_vpinns_amd.init import xavier_init
+    from hp_vpinns_amd.vpinn import VPINN1D, VPINNAdvDiff
+    from oracle.vpinn_oracle import OracleVPINN1D, OracleVPINNAdvDiff
+    assert "HPV_FUSE" not in os.environ
+    s = poisson1d.setup(N_Element=4, N_testfcn=20, N_Quad=40)
+    L = [1, 20, 20, 20, 1]
+    th = xavier_init(L, 33)
+    th[L[1]:2 * L[1]] = 0.1
+    args = (s["X_u_train"], s["u_train"], s["X_quad_train"], s["W_quad_train"], s["F_ext_total"], s["grid"], s["X_test"],
+            s["u_test"], L, s["X_f_train"], s["f_train"])
+    o, m = OracleVPINN1D(*args, init_params=th), VPINN1D(*args, init_params=th)
+    l3o, go = o.loss_and_grad()
+    l3m, gm = m.loss_and_grad()
+    assert m.h.pass_structure() == "whole-iteration-tile" and "80x1/60x1" in m.h.kernel_variant(), m.h.kernel_variant()
+    assert rel(l3m, l3o) < TOL and rel(gm, go) < TOL
+    L = [2, 20, 20, 20, 1]
+    a = _p3(8, 5, 4, 2) + (L, None, None)
+    th = theta0(L, 9, extra=[0.8])
+    o, m = OracleVPINNAdvDiff(*a, init_params=th), VPINNAdvDiff(*a, init_params=th)
+    o.vectorized = True
+    l3o, go = o.loss_and_grad()
+    l3m, gm = m.loss_and_grad()
+    assert m.h.pass_structure() == "whole-iteration-tile" and "10x10/5x5" in m.h.kernel_variant(), m.h.kernel_variant()
+    assert rel(l3m, l3o) < TOL and rel(gm, go) < TOL
+    lo, lm = [], []
+    for _ in range(5):
+        o.adam_step()
+        lo.append(float(o.loss_parts()[0]))
+        lm.append(float(m._step(1, True)[0]))
+    assert rel(lm, lo) < TRAJ_TOL and rel(m.get_params(), o.get_params()) < TRAJ_TOL
+
+
 def test_default_policy_picks_the_faster_structure_per_shape():
     """Without HPV_FUSE: the two-term forms on 16x16 / 8x8 and 12x12 / 6x6 elements run on k_iter_fused; the generic element-resident
     kernel is the default where it measured faster than the separate launches (few channel-layers: profiles/r04_element_shapes.md)
