@@ -882,6 +882,9 @@ bool hpv_mfma_iter_elem(HpvMfma* m, const double* theta, const double* X, double
     const int C_ = 1 + nd.nT1 + nd.nT2, tpe_ = (pd.qx * pd.qy + 15) / 16;
     const bool light = C_ == 1 || C_ * m->L <= 6;
     if (!m->prefer_elem && !(m->H <= 24 && (light || tpe_ <= 9))) return false;
+    // many small elements: one workgroup per element pays its launch-once phases per element, the separate launches amortise them
+    // (1 024 elements of 12x12 points: 138 against 99 us)
+    if (!m->prefer_elem && tpe_ <= 9 && !light && n_elem > 3L * m->n_cus) return false;
     // wavefronts per workgroup (kernels_elem.hip): two per SIMD for the light channel sets, where 256 registers per wave suffice
     int waves = (m->H <= 24 && tpe_ >= 8 && light) ? 8 : 4;
     if (const char* e = getenv("HPV_ELEM_WAVES")) {      // (A/B switch, read per launch / capture)
