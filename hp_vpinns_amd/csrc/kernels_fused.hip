@@ -112,8 +112,12 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): tile counts and branches on it stay scalar
     const int q = lane >> 4, pt = lane & 15;
     const int split = SPLIT ? g.proj_split : 1;
-    const long e = SPLIT ? (long)(blockIdx.x >> __builtin_ctz(split)) : (long)blockIdx.x;     // split is 2, 4 or 8
-    const int part = SPLIT ? (int)(blockIdx.x & (split - 1)) : 0;
+    // SPLIT: the partners of an element are the workgroups b, b + n_elem, b + 2 n_elem, ..: workgroups are dealt to the XCDs round-robin
+    // (observed: XCC id == blockIdx % 8), so with an element count that 8 divides -- the shards of a multi-GPU run -- the partners share
+    // an XCD and their exchange is served by one L2 (1.56 against 2.39 us per exchange, profiles/r04_xchg_probe.txt).  A speed choice
+    // only: nothing depends on the placement.
+    const long e = SPLIT ? (long)(blockIdx.x % (unsigned)g.proj_n_elem) : (long)blockIdx.x;
+    const int part = SPLIT ? (int)(blockIdx.x / (unsigned)g.proj_n_elem) : 0;
     const double* __restrict__ th = g.theta;
     const ProjArgs& pa = g.pa;
 #ifdef HPV_FZ_TIMING
