@@ -64,6 +64,7 @@ compile_one() {   # compile_one <source stem> <object> <extra flags>
       # the other element shapes (FZ_SHAPES of kernels_fused.hip): 16x16 / 8x8 (5 tiles per wave), 12x12 / 6x6 (3)
       local S16=ELi16ELi16ELi8ELi8E S12=ELi12ELi12ELi6ELi6E
       g=0; guard $asm k_iter_fusedILi3ELb0ELb0ELb0${S16} 166 k_iter_fusedILi3ELb1ELb0ELb0${S16} 166 k_iter_fusedILi2ELb0ELb0ELb0${S16} 196 k_iter_fusedILi2ELb1ELb0ELb0${S16} 196 \
+                       k_iter_fusedILi3ELb0ELb1ELb0${S16} 166 k_iter_fusedILi2ELb0ELb1ELb0${S16} 196 \
                        k_iter_fusedILi3ELb0ELb0ELb0${S12} 226 k_iter_fusedILi3ELb1ELb0ELb0${S12} 226 k_iter_fusedILi3ELb0ELb1ELb0${S12} 226 \
                        k_iter_fusedILi2ELb0ELb0ELb0${S12} 236 k_iter_fusedILi2ELb1ELb0ELb0${S12} 236 k_iter_fusedILi2ELb0ELb1ELb0${S12} 236 || g=$?
       [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check the extra element shapes of $f.hip" >&2; return 1; }

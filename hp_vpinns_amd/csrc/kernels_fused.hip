@@ -216,10 +216,15 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     const int lg = SPLIT ? __builtin_ctz(split) : 0;                             // split is 2, 4 or 8
     const int tbase = SPLIT ? (part * FZ_TPE) >> lg : 0;                         // this workgroup's tile range of the element
     const int tend = SPLIT ? ((part + 1) * FZ_TPE) >> lg : FZ_TPE;
-    const int n_el = QT ? (FZ_TPE - 1) / FZ_WAVES
+    // DQ: a shape whose tiles divide by four (16x16 points: 4 + 4 + 4 + 4) has no tile to cut in quarters, but one wave owns the
+    // workgroup's boundary / data tile as a fifth -- the same 25 % imbalance.  Its "quarter-tile" instantiation packs ONLY the data
+    // points (slot c = 3 of every wave's operand, four points each); the element-point slots are switched off (no channel
+    // written, zero adjoint), so every wave owns TPE / 4 whole tiles + a packed operand.
+    constexpr bool DQ = QT && FZ_TPE % FZ_WAVES == 0;
+    const int n_el = QT ? (DQ ? FZ_TPE / FZ_WAVES : (FZ_TPE - 1) / FZ_WAVES)
                         : SPLIT ? (tend - tbase - wv + FZ_WAVES - 1 > 0 ? (tend - tbase - wv + FZ_WAVES - 1) / FZ_WAVES : 0)
                                 : (FZ_TPE - wv + FZ_WAVES - 1) / FZ_WAVES;
-    static_assert(!QT || (FZ_TPE - 1) % FZ_WAVES == 0, "QT: 24 whole tiles over four waves + one tile in quarters");
+    static_assert(!QT || (FZ_TPE - 1) % FZ_WAVES == 0 || DQ, "QT: 24 whole tiles over four waves + one tile in quarters");
     // The boundary/data tiles behind the elements go one per workgroup to the first wave with the fewest element tiles
     // (25 tiles over 4 waves: wave 1).  SPLIT: only to workgroups in which that wave has a free slot compared with its
     // neighbours (tile count not a multiple of 4) -- otherwise the adopted tile is a whole extra forward + reverse that the
@@ -475,7 +480,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             for (int s = 0; s < MF_KS; ++s) v += QH[s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
             v = xrow_sum16(v);
             v = xrow_sum32(v);
-            if (q == 0 && q_tan) lds[M::CH + (qcs - 1) * FZ_NQ + q_lp] = v;
+            if (!DQ && q == 0 && q_tan) lds[M::CH + (qcs - 1) * FZ_NQ + q_lp] = v;
             const double dd = q_vdat ? qud - (v + bo) : 0.0;
             gdat_q = g.data_scale * dd;
             const double sq = row_sum16(q == 0 ? dd * dd : 0.0);
@@ -492,7 +497,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     }
     int k0 = 0;
     if constexpr (QT) {      // six whole tiles: two trips of two, then the last two with the quarter tile beside them
-        static_assert((FZ_TPE - 1) / FZ_WAVES >= 2 && ((FZ_TPE - 1) / FZ_WAVES) % 2 == 0, "trip plan of the QT instantiation: pairs of whole tiles");
+        static_assert((FZ_TPE - (DQ ? 0 : 1)) / FZ_WAVES >= 2 && ((FZ_TPE - (DQ ? 0 : 1)) / FZ_WAVES) % 2 == 0, "trip plan of the QT instantiation: pairs of whole tiles");
 #pragma unroll 1
         for (; k0 + 3 < n_own; k0 += 2) fwd_trip(k0, std::integral_constant<int, 2>{}, std::false_type{});
         fwd_trip(k0, std::integral_constant<int, 2>{}, std::true_type{});
@@ -819,7 +824,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         const double mval = q_tan ? 0.0 : 1.0;                        // value-like slots (element value, data point)
         // adjoint of the slot's output: d/dx, d/dy slots from the projection, the data slot from the boundary term, value slot none
         const double gch = lds[M::CH + (q_tan ? (qcs - 1) * FZ_NQ : 0) + q_lp];
-        const double GB = q_tan ? gch : (qcs == 3 ? gdat_q : 0.0);
+        const double GB = q_tan ? (DQ ? 0.0 : gch) : (qcs == 3 ? gdat_q : 0.0);
         // packed layer inputs H_i from s and the tangent pre-activations (tangent slots; 0 elsewhere) the forward pass left in LDS
         double Hq[L][MF_KS], ZCq[L][MF_KS];
 #pragma unroll
@@ -1431,7 +1436,7 @@ static void launch_iter_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
 //  for the 20x20 / 10x10 shape only)
 template <int QX_, int QY_, int NTX_, int NTY_>
 static bool launch_iter_fused_shape(int L, int plan, bool gs, const MfmaArgs& a, int blocks, hipStream_t s) {
-    constexpr bool HAS_QT = ((QX_ * QY_ / 16) % 4) == 1, HAS_GS = QX_ == 20;
+    constexpr bool HAS_QT = ((QX_ * QY_ / 16) % 4) <= 1 && QX_ * QY_ / 16 >= 8, HAS_GS = QX_ == 20;     // (0 mod 4: the data-quarter plan)
 #define FZ_GO(L_, SPLIT_, QT_, GS_) launch_iter_fused<L_, SPLIT_, QT_, GS_, QX_, QY_, NTX_, NTY_>(a, blocks, s)
     if (L != 2 && L != 3) return false;
     if (gs) {
@@ -1488,7 +1493,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     const bool small = pd.qx == SM_QX && pd.qy == SM_QY && pd.ntx >= 1 && pd.ntx <= SM_NTX && pd.nty >= 1 && pd.nty <= SM_NTY;
     if (!fused_shape_ok(pd) && !small) return false;
     const int NQ = pd.qx * pd.qy, TPE = NQ / 16;              // points and 16-point tiles of an element
-    const bool has_qt = TPE % 4 == 1, q20 = pd.qx == 20 && pd.qy == 20;
+    const bool has_qt = TPE % 4 <= 1 && TPE >= 8, q20 = pd.qx == 20 && pd.qy == 20;
     const bool base_shape = q20 && pd.ntx == 10 && pd.nty == 10;           // BASELINE config 4 itself
 #ifdef HPV_FZ_NO_EXTRA_SHAPES     // csrc/build.sh: the AGPR guard tripped in an instantiation of a shape other than 20x20 / 10x10
     if (!q20 && !small) return false;

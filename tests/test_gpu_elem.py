@@ -130,8 +130,8 @@ def test_more_boundary_tiles_than_free_slots_go_to_extra_workgroups():
 @pytest.mark.parametrize("nhid", [2, 3])
 @pytest.mark.parametrize("grid", ["full", "shard"])
 def test_hand_tuned_whole_iteration_kernel_on_other_element_shapes(q, nt, nhid, grid):
-    """k_iter_fused takes the element shape as a template parameter since round 4: 16x16 / 8x8 (16 tiles: 4 per wave, one wave also
-    the boundary tile) and 12x12 / 6x6 (9 tiles: 2 per wave + a quarter tile) under the default two-term form run on it by default --
+    """k_iter_fused takes the element shape as a template parameter since round 4: 16x16 / 8x8 (16 tiles: 4 per wave + the boundary
+    tile's points as a packed operand of four per wave) and 12x12 / 6x6 (9 tiles: 2 per wave + a quarter tile) under the default two-term form run on it by default --
     a 16x16-element grid with one workgroup per element, a small shard with several workgroups per element (SPLIT mode).  Against the
     oracle (loss triple, gradient, residuals, trajectory) and against the whole-tile plan where the shape has quarter tiles."""
     from hp_vpinns_amd.vpinn import VPINN2D
@@ -149,7 +149,7 @@ def test_hand_tuned_whole_iteration_kernel_on_other_element_shapes(q, nt, nhid, 
     assert m.h.pass_structure() == ("whole-iteration-split" if grid == "shard" else "whole-iteration"), m.h.pass_structure()
     assert f",{q}x{q}/{nt}x{nt}>" in v and v.startswith("k_iter_fused<L=%d," % nhid), v
     assert ("SPLIT=true" in v) == (grid == "shard"), v
-    assert ("QT=true" in v) == (grid == "full" and q == 12), v
+    assert ("QT=true" in v) == (grid == "full"), v        # (12x12: a quarter of the 9th tile per wave; 16x16: the data points only)
     assert rel(l3m, l3o) < TOL and rel(gm, go) < TOL, (l3m, l3o, rel(gm, go))
     assert rel(m.h.residuals(nex * ney * nt * nt), o.last["R"].reshape(-1)) < TOL
     l3b, gb = m.loss_and_grad()
@@ -205,7 +205,7 @@ def test_hand_tuned_kernels_with_fewer_test_functions_than_instantiated(q, ntx, 
     assert rel(lm, lo) < TRAJ_TOL and rel(m.get_params(), o.get_params()) < TRAJ_TOL
 
 
-@pytest.mark.parametrize("q,nt,nex,want", [(14, 7, 16, "k_iter_fused<L=3,SPLIT=false,QT=false,GS=false,16x16/7x7>"),
+@pytest.mark.parametrize("q,nt,nex,want", [(14, 7, 16, "k_iter_fused<L=3,SPLIT=false,QT=true,GS=false,16x16/7x7>"),
                                           (18, 9, 4, "20x20/9x9> split"), (11, 6, 16, "12x12/6x6>"), (7, 4, 8, "k_iter_small<L=3,10x10/4x4>")])
 def test_hand_tuned_kernels_with_smaller_quadrature_rules_than_instantiated(q, nt, nex, want):
     """N_quad is a free hyper-parameter (P2:282).  A rule with fewer points than an instantiated one goes to the device padded with
