@@ -194,7 +194,8 @@ int hpv_get_residuals(hpv_handle h, double* R, size_t n);   /* R of the owned el
 int hpv_backend_in_use(hpv_handle h);                       /* HPV_BACKEND_GENERIC or HPV_BACKEND_MFMA */
 /* Launch structure of the most recent reverse-mode pass over the quadrature batch (tests assert that the kernel they mean to
  * exercise is the one that ran): 0 separate forward / projection / reverse launches, 1 forward + projection-fused reverse,
- * 2 element-resident whole-iteration kernel (20x20 / 10x10 Poisson-2D var_form 1), 3 the same in SPLIT mode (small shards),
+ * 2 element-resident whole-iteration kernel (Poisson-2D var_form 1 on 20x20-, 16x16-, 12x12- or 10x10-point elements with up to
+ * 10x10 / 8x8 / 6x6 / 5x5 test functions), 3 the same in SPLIT mode (small shards),
  * 4 whole-iteration tile kernel (small elements of the other channel sets), 5 whole-iteration kernel for few tall elements
  * (80x80 points: many workgroups per element exchange partial residual sums), 6 the generic element-resident whole-iteration
  * kernel (any instantiated tensor-product element shape, e.g. 16x16 / 8x8; several tiles per wave); -1 before the first such pass. */
