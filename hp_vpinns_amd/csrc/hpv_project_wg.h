@@ -99,8 +99,11 @@ struct ProjTableRegs {
     int nterms_loaded = HPV_MAXT;
     // besides the tables: -F of the element (the initial value of U) and, lane t < 4 of the block, one of the four scalars
     // {coef[0][e], coef[1][e], epsilon, active test count}
+    // (the run may have FEWER test functions per direction than the instantiation -- N_test is a free hyper-parameter, P2:283-286:
+    //  the tables of the missing ones are zero, so their residuals are exactly 0; F, R and the means use the run's counts)
     __device__ __forceinline__ void load(const ProjArgs& pa, long e) {
         nterms_loaded = pa.pd.nterms;
+        const int rnx = pa.pd.ntx, rny = pa.pd.nty;
 #pragma unroll
         for (int t = 0; t < HPV_MAXT; ++t) {
             const bool on = t < pa.pd.nterms;           // (workgroup-uniform: an unused term costs no loads)
@@ -108,18 +111,19 @@ struct ProjTableRegs {
 #pragma unroll
             for (int it = 0; it < ITX; ++it) {
                 const int i = it * PW_BLOCK + (int)threadIdx.x;
-                ax[t][it] = on ? pa.wtx[(long)dx * NTX * QX + (i < NTX * QX ? i : 0)] : 0.0;
+                ax[t][it] = (on && i < NTX * QX && i / QX < rnx) ? pa.wtx[((long)dx * rnx + i / QX) * QX + i % QX] : 0.0;
             }
 #pragma unroll
             for (int it = 0; it < ITY; ++it) {
                 const int i = it * PW_BLOCK + (int)threadIdx.x;
-                by[t][it] = on ? pa.wty[(long)dy * NTY * QY + (i < NTY * QY ? i : 0)] : 0.0;
+                by[t][it] = (on && i < NTY * QY && i / QY < rny) ? pa.wty[((long)dy * rny + i / QY) * QY + i % QY] : 0.0;
             }
         }
 #pragma unroll
         for (int it = 0; it < ITR; ++it) {
             const int idx = it * PW_BLOCK + (int)threadIdx.x;
-            fr[it] = (pa.F && idx < NR) ? -pa.F[e * NR + idx] : 0.0;
+            const int k_ = idx / NTX, r_ = idx % NTX;
+            fr[it] = (pa.F && idx < NR && k_ < rny && r_ < rnx) ? -pa.F[e * (rnx * rny) + k_ * rnx + r_] : 0.0;
         }
         const int t4 = (int)threadIdx.x;
         sc4 = 0.0;
@@ -189,6 +193,7 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
     constexpr int NQ = QX * QY, NR = NTX * NTY, LDG = QX + 1;
     constexpr int NIT = (NQ + PW_BLOCK - 1) / PW_BLOCK;
     constexpr int AXLD = PRE ? QX + 1 : QX;      // (the pre-staged tables have padded rows, see ProjTableRegs)
+    const int rnx = pd.ntx, rny = pd.nty, rnr = rnx * rny;     // the run's test functions per direction (<= NTX, NTY: see ProjTableRegs)
     double* G = sm;                              // [QY][LDG]
     double* AXl = G + QY * LDG;                  // [HPV_MAXT][NTX][AXLD]  every term's w_x phi^(dx)
     double* BYl = AXl + HPV_MAXT * NTX * (QX + 1);   // [HPV_MAXT][NTY][QY]  every term's w_y phi^(dy)
@@ -219,7 +224,8 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
 #pragma unroll
         for (int it = 0; it < ITR; ++it) {
             const int idx = it * PW_BLOCK + tid;
-            fr[it] = (F && idx < NR) ? -F[e * NR + idx] : 0.0;
+            const int k_ = idx / NTX, r_ = idx % NTX;
+            fr[it] = (F && idx < NR && k_ < rny && r_ < rnx) ? -F[e * rnr + k_ * rnx + r_] : 0.0;
         }
 #pragma unroll
         for (int t = 0; t < HPV_MAXT; ++t) cf[t] = coef[(long)(t < nterms ? t : 0) * coef_stride + e];
@@ -231,12 +237,12 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
 #pragma unroll
             for (int it = 0; it < ITX; ++it) {
                 const int i = it * PW_BLOCK + tid;
-                tax[t][it] = wtx[(long)dx * NTX * QX + (i < NTX * QX ? i : 0)];
+                tax[t][it] = (i < NTX * QX && i / QX < rnx) ? wtx[((long)dx * rnx + i / QX) * QX + i % QX] : 0.0;
             }
 #pragma unroll
             for (int it = 0; it < ITY; ++it) {
                 const int i = it * PW_BLOCK + tid;
-                tby[t][it] = wty[(long)dy * NTY * QY + (i < NTY * QY ? i : 0)];
+                tby[t][it] = (i < NTY * QY && i / QY < rny) ? wty[((long)dy * rny + i / QY) * QY + i % QY] : 0.0;
             }
         }
 #pragma unroll
@@ -353,12 +359,14 @@ __device__ __forceinline__ void project_element_wg(const ProjArgs& pa, const lon
         __syncthreads();
     }
     const int nax = PRE ? (int)red[48 + HPV_MAXT + 1] : (pd.nact ? pd.nact[e] : NTX);   // active test functions (p-refinement, P1:67)
-    const double NRa = (double)(nax * NTY);
+    const bool counted = pd.nact != nullptr;     // (per-element counts, P1:66-67: 1-D, rnx = NTX)
+    const double NRa = counted ? (double)(nax * NTY) : (double)rnr;
     double sq = 0.0;
     for (int o = tid; o < NR; o += PW_BLOCK) {
-        const double u = (o % NTX) < nax ? U[o] : 0.0;
+        const int k_ = o / NTX, r_ = o % NTX;
+        const double u = r_ < nax ? U[o] : 0.0;
         U[o] = u;                                         // (each entry is read and written by its own thread only)
-        R[e * NR + o] = u;
+        if (k_ < rny && r_ < rnx) R[e * rnr + k_ * rnx + r_] = u;
         sq = fma(u, u, sq);
     }
     sq = pj_wave_sum(sq);

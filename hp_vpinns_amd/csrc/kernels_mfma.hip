@@ -914,7 +914,7 @@ bool hpv_mfma_iter_elem(HpvMfma* m, const double* theta, const double* X, double
     a.elem_waves = waves;
     bool ok = false, known = false;
 #define HPV_ELEM_TRY(A_, B_, C_, D_)                                                           \
-    if (!known && pd.qx == A_ && pd.qy == B_ && pd.ntx == C_ && pd.nty == D_) {                 \
+    if (!known && pd.qx == A_ && pd.qy == B_ && pd.ntx >= 1 && pd.ntx <= C_ && pd.nty >= 1 && pd.nty <= D_) {                 \
         known = true;                                                                          \
         ok = hpv_elem_launch_##A_##B_##_##C_##_##D_(m->H, key, m->L, a, (int)blocks, s);         \
     }
@@ -934,7 +934,7 @@ bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, c
                              hipStream_t s, const ProjArgs& pa, long n_elem) {
     const ProjDesc& pd = pa.pd;
     if (!m->bwd_fused || !m->fuse_bwd || pd.edge || pd.nact || n_elem <= 0) return false;
-    if (!(pd.qx == 20 && pd.qy == 20 && pd.ntx == 10 && pd.nty == 10)) return false;
+    if (!(pd.qx == 20 && pd.qy == 20 && pd.ntx >= 1 && pd.ntx <= 10 && pd.nty >= 1 && pd.nty <= 10)) return false;   // (counts: run-time values)
     const long tpe = (20 * 20) / 16;
     const long rest = m->ntiles - n_elem * tpe;                 // pad + data tiles: at most one per workgroup
     const int split = fused_split(m, n_elem);

@@ -650,7 +650,7 @@ bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double
     if (!m->iter_fused_ok || pd.edge || n_elem <= 0 || m->L < 2 || m->L > 4 || m->H != MF_H) { TL_WHY(1); return false; }
     const int key = nd.d * 100 + nd.nT1 * 10 + nd.nT2;
     const bool shape1d = pd.qx == 80 && pd.qy == 1 && pd.ntx == 60 && pd.nty == 1 && nd.act == HPV_ACT_SIN && (key == 111 || key == 110);
-    const bool shape2d = pd.qx == 10 && pd.qy == 10 && pd.ntx == 5 && pd.nty == 5 && nd.act == HPV_ACT_TANH &&
+    const bool shape2d = pd.qx == 10 && pd.qy == 10 && pd.ntx >= 1 && pd.ntx <= 5 && pd.nty >= 1 && pd.nty <= 5 && nd.act == HPV_ACT_TANH &&
                          (key == 200 || key == 220 || key == 221 || key == 222) && m->L <= 3;
     if (!shape1d && !shape2d) { TL_WHY(2); return false; }
     const int waves = shape1d ? 6 : 8, nq = pd.qx * pd.qy, tpe = (nq + 15) / 16;

@@ -280,6 +280,37 @@ def test_hand_tuned_kernels_smaller_rules_1d_and_advdiff():
     assert rel(lm, lo) < TRAJ_TOL and rel(m.get_params(), o.get_params()) < TRAJ_TOL
 
 
+@pytest.mark.parametrize("fuse", ["e", "n", "b"])
+@pytest.mark.parametrize("q,ntx,nty,vf", [(20, 7, 5, 0), (20, 4, 9, 2), (16, 5, 5, 0), (16, 8, 3, 1), (12, 4, 6, 2), (10, 3, 4, 0)])
+def test_run_time_test_function_counts_on_every_projection_structure_hand_tuned_or_not(q, ntx, nty, vf, fuse, monkeypatch):
+    """The workgroup-per-element projection (hpv_project_wg.h: inside k_iter_elem / k_iter_tile, fused into the reverse kernel, and
+    as k_project_wg) takes test-function counts below its instantiation's at run time, under every variational form:
+    HPV_FUSE = e (generic element-resident kernel), n (separate launches), b (projection fused into the reverse kernel)."""
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.vpinn import VPINN2D
+    from oracle.vpinn_oracle import OracleVPINN2D
+    monkeypatch.setenv("HPV_FUSE", fuse)
+    L = [2, 20, 20, 20, 1]
+    s = poisson2d.setup(N_el_x=4, N_el_y=3, N_test_x=ntx, N_test_y=nty, N_quad=q, N_bound=17, with_test_grid=False)
+    a = (s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"], s["WXY_quad_train"], None,
+         s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"], s["X_u_train"], s["u_train"], L)
+    th = theta0(L, 125)
+    o, m = OracleVPINN2D(*a, var_form=vf, init_params=th), VPINN2D(*a, var_form=vf, init_params=th)
+    o.vectorized = True
+    l3o, go = o.loss_and_grad()
+    l3m, gm = m.loss_and_grad()
+    v = m.h.kernel_variant()
+    assert "k_project<" not in v and "generic" not in v, v          # never the general projection / VALU kernels
+    assert rel(l3m, l3o) < TOL and rel(gm, go) < TOL, (v, l3m, l3o, rel(gm, go))
+    assert rel(m.h.residuals(12 * ntx * nty), o.last["R"].reshape(-1)) < TOL
+    lo, lm = [], []
+    for _ in range(4):
+        o.adam_step()
+        lo.append(float(o.loss_parts()[0]))
+        lm.append(float(m._step(1, True)[0]))
+    assert rel(lm, lo) < TRAJ_TOL and rel(m.get_params(), o.get_params()) < TRAJ_TOL
+
+
 def test_default_policy_picks_the_faster_structure_per_shape():
     """Without HPV_FUSE: the two-term forms on 16x16 / 8x8 and 12x12 / 6x6 elements run on k_iter_fused; the generic element-resident
     kernel is the default where it measured faster than the separate launches (few channel-layers: profiles/r04_element_shapes.md)
