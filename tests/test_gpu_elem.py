@@ -171,8 +171,8 @@ def test_hand_tuned_whole_iteration_kernel_on_other_element_shapes(q, nt, nhid, 
         assert rel(gw, gm) < 1e-11 and rel(l3w, l3m) < 1e-12
 
 
-@pytest.mark.parametrize("q,ntx,nty,nex,ney", [(20, 7, 5, 16, 16), (20, 10, 6, 5, 3), (20, 1, 1, 4, 4), (16, 5, 5, 16, 16), (16, 8, 3, 5, 3),
-                                               (12, 4, 6, 16, 16), (12, 2, 5, 4, 2), (10, 3, 4, 8, 8), (10, 5, 2, 4, 4), (10, 1, 3, 3, 3)])
+@pytest.mark.parametrize("q,ntx,nty,nex,ney", [(20, 7, 5, 16, 16), (20, 10, 6, 5, 3), (20, 1, 1, 4, 4), (16, 5, 5, 16, 8), (16, 8, 3, 5, 3),
+                                               (12, 4, 6, 16, 8), (12, 2, 5, 4, 2), (10, 3, 4, 8, 8), (10, 5, 2, 4, 4), (10, 1, 3, 3, 3)])
 def test_hand_tuned_kernels_with_fewer_test_functions_than_instantiated(q, ntx, nty, nex, ney):
     """N_test_x / N_test_y are free hyper-parameters (P2:283-286): the whole-iteration kernels are instantiated per quadrature rule
     with the largest test-function counts (20x20 / 10x10, 16x16 / 8x8, 12x12 / 6x6, 10x10 / 5x5) and take any smaller counts at run
