@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
 #endif
 
     // ---- stage every weight fragment and the projection tables ----
-    constexpr int TNX = FZ_NTX, TNY = FZ_NTY, TQX = FZ_QX, TQY = FZ_QY;
+    [[maybe_unused]] constexpr int TNX = FZ_NTX, TNY = FZ_NTY, TQX = FZ_QX, TQY = FZ_QY;
     const int rnx = pa.pd.ntx, rny = pa.pd.nty, rnr = rnx * rny;      // the run's test functions per direction (<= NTX, NTY)
     static_assert(FZ_NTX * FZ_QX == FZ_NTY * FZ_QY, "table staging walks both tables with one index");
     {
@@ -1043,7 +1043,7 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
 #endif
 
     // ---- stage weight fragments and projection tables ----
-    constexpr int TNX = SM_NTX, TNY = SM_NTY, TQX = SM_QX, TQY = SM_QY;
+    [[maybe_unused]] constexpr int TNX = SM_NTX, TNY = SM_NTY, TQX = SM_QX, TQY = SM_QY;
     const int rnx = pa.pd.ntx, rny = pa.pd.nty, rnr = rnx * rny;      // the run's test functions per direction (<= NTX, NTY: see k_iter_fused)
     static_assert(SM_NTX * SM_QX == SM_NTY * SM_QY, "table staging walks both tables with one index");
     {
