@@ -708,6 +708,8 @@ static bool pick_L(HpvMfma* m, int L) {
         case 2: return pick<D, NT1, NT2, ACT, 2>(m);
         case 3: return pick<D, NT1, NT2, ACT, 3>(m);
         case 4: return pick<D, NT1, NT2, ACT, 4>(m);
+        case 5: return pick<D, NT1, NT2, ACT, 5>(m);
+        case 6: return pick<D, NT1, NT2, ACT, 6>(m);
         default: return false;
     }
 }
@@ -724,8 +726,8 @@ bool hpv_wide_pick(HpvMfma* m, int H, int key, int act, int L) {
 HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_store) {
     auto no = [&](const char* msg) -> HpvMfma* { if (why) *why = msg; return nullptr; };
     const int L = nd.nl - 1;
-    if (L < 1 || L > 4) return no("1..4 hidden layers are covered");
     const int H = nd.width[1];
+    if (L < 1 || L > 6 || (L > 4 && H != MF_H)) return no("1..6 hidden layers are covered at width <= 20, 1..4 at the other widths");
     for (int l = 1; l <= L; ++l)
         if (nd.width[l] != H) return no("all hidden layers must have the same width (the Python classes zero-pad to one)");
     for (int u = 0; u < nd.nT1; ++u) if (nd.t1dim[u] != u) return no("tangent channels must be coordinates 0..nT1-1");

@@ -53,7 +53,7 @@ def device_width(hidden):
     return None
 
 
-def pad_plan(layers, extra=0, width=None, max_hidden=4):
+def pad_plan(layers, extra=0, width=None, max_hidden=None):
     """Zero-padding of a network onto kernels of ONE hidden width (`width`; default `device_width`: 20 for narrow networks --
     the reference defaults are 5 wide, P2:280, P3:46 --, else the next instantiated width, also for non-uniform hidden
     layers).  Returns (padded_layers, index) with theta_padded[index] = theta, or None when no padding is needed (every
@@ -64,10 +64,14 @@ def pad_plan(layers, extra=0, width=None, max_hidden=4):
     to padding is exactly zero (h_pad = 0 kills dW rows, hbar_pad = 0 kills dW columns and db) -- TF1 Adam leaves them
     at zero.  Sums only gain exact-zero terms."""
     hidden = layers[1:-1]
-    if not (1 <= len(hidden) <= max_hidden) or layers[-1] != 1 or layers[0] > 2:
+    if not hidden or layers[-1] != 1 or layers[0] > 2:
         return None
     if width is None:
         width = device_width(hidden)
+    if max_hidden is None:          # depths the MFMA kernels are instantiated for: 6 at width 20 (kernels_mfma.hip), 4 at the wider ones
+        max_hidden = 6 if width == MFMA_WIDTH else 4
+    if len(hidden) > max_hidden:
+        return None
     if width is None or any(w > width for w in hidden) or all(w == width for w in hidden):
         return None
     padded = [layers[0]] + [width] * len(hidden) + [1]

@@ -56,7 +56,7 @@ for H in (24, 32, 40, 48, 64):
     L = [2, H, H, H, 1]
     us, bk, v = run2d(L)
     rows.append(("config-4 grid", L, bk, us, gemm_flops(L) / gemm_flops(L20), v))
-for L in ([2, 32, 32, 1], [2, 32, 32, 32, 32, 1], [2, 20, 20, 20, 20, 1]):
+for L in ([2, 32, 32, 1], [2, 32, 32, 32, 32, 1], [2, 20, 20, 20, 20, 1], [2] + [20] * 5 + [1], [2] + [20] * 6 + [1]):
     us, bk, v = run2d(L)
     rows.append(("config-4 grid", L, bk, us, gemm_flops(L) / gemm_flops(L20), v))
 us, bk, v = run2d([2, 32, 32, 32, 1], backend="generic", n=20)

@@ -84,6 +84,35 @@ def test_one_dimensional_four_hidden_layers_reference_default_depth():
 
 def test_generic_fallback_warns_once_for_networks_beyond_every_mfma_kernel():
     with pytest.warns(UserWarning, match="generic kernels"):
-        o, m = _pair_2d("poisson2d_small", 1, layers=[2, 20, 20, 20, 20, 20, 1])     # five hidden layers: deeper than any MFMA kernel (1..4)
+        o, m = _pair_2d("poisson2d_small", 1, layers=[2] + [20] * 7 + [1])     # seven hidden layers: deeper than any MFMA kernel (1..6)
     assert m.backend() == "generic"
     _check_loss_grad(o, m)
+    with pytest.warns(UserWarning, match="generic kernels"):
+        o, m = _pair_2d("poisson2d_small", 1, layers=[2] + [32] * 5 + [1])     # five hidden layers at a width other than 20 (1..4)
+    assert m.backend() == "generic"
+
+
+@pytest.mark.parametrize("depth", [5, 6])
+def test_five_and_six_hidden_layers_on_the_mfma_kernels(depth):
+    """PINN-style deeper networks: 5 and 6 hidden layers of width <= 20 run on k_fwd_mfma / k_bwd_mfma (kernels_mfma.hip
+    instantiates L = 1..6), narrower layers zero-padded as always -- 1-D sin (P1) and 2-D tanh (P2, config-4 element shape with the
+    projection fused into the reverse kernel; a 10x10 grid on the separate launches) against the oracle."""
+    o, m = _pair_1d("poisson1d_cfg2", 1, layers=[1] + [20] * depth + [1])
+    _check_loss_grad(o, m)
+    assert m.backend() == "mfma" and f"L={depth}" in m.h.kernel_variant(), m.h.kernel_variant()
+    _check_traj(o, m, n=5)
+    o, m = _pair_2d("poisson2d_small", 1, layers=[2] + [12] * depth + [1])
+    _check_loss_grad(o, m)
+    assert m.backend() == "mfma" and f"L={depth}" in m.h.kernel_variant(), m.h.kernel_variant()
+    _check_traj(o, m, n=5)
+    from hp_vpinns_amd.vpinn import VPINN2D
+    from oracle.vpinn_oracle import OracleVPINN2D
+    L = [2] + [20] * depth + [1]
+    a = p2_args(gold("poisson2d_cfg4"), layers=L)
+    th = theta0(L, 78)
+    o, m = OracleVPINN2D(*a, init_params=th), VPINN2D(*a, init_params=th)
+    o.vectorized = True
+    l3o, go = o.loss_and_grad()
+    l3m, gm = m.loss_and_grad()
+    assert f"L={depth}" in m.h.kernel_variant() and "proj=20x20/10x10" in m.h.kernel_variant(), m.h.kernel_variant()
+    assert rel(l3m, l3o) < TOL and rel(gm, go) < TOL, (l3m, l3o, rel(gm, go))
