@@ -727,7 +727,7 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
     auto no = [&](const char* msg) -> HpvMfma* { if (why) *why = msg; return nullptr; };
     const int L = nd.nl - 1;
     const int H = nd.width[1];
-    if (L < 1 || L > 6 || (L > 4 && H != MF_H)) return no("1..6 hidden layers are covered at width <= 20, 1..4 at the other widths");
+    if (L < 1 || L > 6 || (L > 4 && H > 32)) return no("1..6 hidden layers are covered at widths <= 32, 1..4 at the wider ones");
     for (int l = 1; l <= L; ++l)
         if (nd.width[l] != H) return no("all hidden layers must have the same width (the Python classes zero-pad to one)");
     for (int u = 0; u < nd.nT1; ++u) if (nd.t1dim[u] != u) return no("tangent channels must be coordinates 0..nT1-1");

@@ -601,6 +601,9 @@ static bool pick_wide_L(HpvMfma* m, int L) {
         case 2: return pick_wide<D, NT1, NT2, ACT, 2, H>(m);
         case 3: return pick_wide<D, NT1, NT2, ACT, 3, H>(m);
         case 4: return pick_wide<D, NT1, NT2, ACT, 4, H>(m);
+        // (deeper networks at the narrower widths only: the weight fragments of five layers of 40 and more do not fit the LDS)
+        case 5: if constexpr (H <= 32) return pick_wide<D, NT1, NT2, ACT, 5, H>(m); else return false;
+        case 6: if constexpr (H <= 32) return pick_wide<D, NT1, NT2, ACT, 6, H>(m); else return false;
         default: return false;
     }
 }

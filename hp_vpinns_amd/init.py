@@ -68,8 +68,10 @@ def pad_plan(layers, extra=0, width=None, max_hidden=None):
         return None
     if width is None:
         width = device_width(hidden)
-    if max_hidden is None:          # depths the MFMA kernels are instantiated for: 6 at width 20 (kernels_mfma.hip), 4 at the wider ones
-        max_hidden = 6 if width == MFMA_WIDTH else 4
+    if width is None:
+        return None
+    if max_hidden is None:          # depths the MFMA kernels are instantiated for: 6 at the widths 20, 24, 32 (kernels_mfma.hip, kernels_wide.hip), 4 beyond
+        max_hidden = 6 if width <= 32 else 4
     if len(hidden) > max_hidden:
         return None
     if width is None or any(w > width for w in hidden) or all(w == width for w in hidden):

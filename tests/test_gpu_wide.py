@@ -88,7 +88,7 @@ def test_generic_fallback_warns_once_for_networks_beyond_every_mfma_kernel():
     assert m.backend() == "generic"
     _check_loss_grad(o, m)
     with pytest.warns(UserWarning, match="generic kernels"):
-        o, m = _pair_2d("poisson2d_small", 1, layers=[2] + [32] * 5 + [1])     # five hidden layers at a width other than 20 (1..4)
+        o, m = _pair_2d("poisson2d_small", 1, layers=[2] + [40] * 5 + [1])     # five hidden layers at a width beyond 32 (1..4 there)
     assert m.backend() == "generic"
 
 
@@ -104,6 +104,10 @@ def test_five_and_six_hidden_layers_on_the_mfma_kernels(depth):
     o, m = _pair_2d("poisson2d_small", 1, layers=[2] + [12] * depth + [1])
     _check_loss_grad(o, m)
     assert m.backend() == "mfma" and f"L={depth}" in m.h.kernel_variant(), m.h.kernel_variant()
+    _check_traj(o, m, n=5)
+    o, m = _pair_2d("poisson2d_small", 1, layers=[2] + [30] * depth + [1])          # (padded to 32: the width-generic kernels)
+    _check_loss_grad(o, m)
+    assert m.backend() == "mfma" and f"L={depth},H=32" in m.h.kernel_variant(), m.h.kernel_variant()
     _check_traj(o, m, n=5)
     from hp_vpinns_amd.vpinn import VPINN2D
     from oracle.vpinn_oracle import OracleVPINN2D

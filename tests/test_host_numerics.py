@@ -140,7 +140,8 @@ def test_zero_padding_of_a_narrow_network_is_exact():
     pad[idx] = False
     assert pad.sum() == thp.size - th.size and np.all(gp[pad] == 0.0)
     assert pad_plan([2, 20, 20, 1]) is None and pad_plan([2, 24, 1]) is None and pad_plan([2] + [5] * 7 + [1]) is None
-    assert pad_plan([2] + [5] * 6 + [1])[0] == [2] + [20] * 6 + [1] and pad_plan([2] + [30] * 5 + [1]) is None     # depth: 6 at width 20, 4 beyond
+    assert pad_plan([2] + [5] * 6 + [1])[0] == [2] + [20] * 6 + [1] and pad_plan([2] + [30] * 5 + [1])[0] == [2] + [32] * 5 + [1]
+    assert pad_plan([2] + [36] * 5 + [1]) is None     # depth: 6 up to width 32, 4 beyond
     # wider networks go to the next hidden width the width-generic MFMA kernels are instantiated for (csrc/kernels_wide.hip)
     assert pad_plan([2, 30, 30, 1])[0] == [2, 32, 32, 1] and pad_plan([2, 20, 40, 20, 1])[0] == [2, 40, 40, 40, 1]
     assert pad_plan([1, 21, 1])[0] == [1, 24, 1] and pad_plan([2, 50, 64, 1])[0] == [2, 64, 64, 1]
