@@ -1,5 +1,7 @@
-// Element-resident whole-iteration kernel for the BASELINE config-4 shape (Poisson-2D var_form 1 and every other
-// two-term "one-hot" form on 20x20-point / 10x10-test elements, [2,20,...,20,1] tanh networks):
+// Element-resident whole-iteration kernel for Poisson-2D var_form 1 and every other two-term "one-hot" form, [2,20,...,20,1] tanh
+// networks (two or three hidden layers).  Written for the BASELINE config-4 shape -- 20x20-point / 10x10-test elements, which the
+// description below uses -- and since round 4 a template over the element shape (FZ_SHAPES: also 16x16 / 8x8 and 12x12 / 6x6 points /
+// largest test-function counts; the run's own counts are run-time values):
 //
 //   ONE workgroup (4 wavefronts, one per SIMD, up to 512 registers each) owns ONE element and runs the whole
 //   iteration for it without touching HBM in between:
