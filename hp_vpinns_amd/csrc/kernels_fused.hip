@@ -808,8 +808,20 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             }
         }
     } else {
+#ifdef HPV_FZ_REV2
+        constexpr bool REV2 = FZ_TPE <= 16;       // (where the stash leaves the compiler the registers for it: a125 against a95)
+#else
+        constexpr bool REV2 = false;
+#endif
+        if constexpr (REV2) {   // experiment: two tiles per trip, the scheduler may overlap tile k + 1's recompute with tile k's tail
+            int k = 0;
 #pragma unroll 1
-        for (int k = 0; k < n_own; ++k) rev_tile(k, BA);
+            for (; k + 1 < n_own; k += 2) { rev_tile(k, BA); rev_tile(k + 1, BA); }
+            if (k < n_own) rev_tile(k, BA);
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < n_own; ++k) rev_tile(k, BA);
+        }
     }
 
     if constexpr (QT) {
