@@ -699,6 +699,12 @@ bool launch_project_wg(const ProjDesc& pd, const double* OUT, double* GBAR, doub
     HPV_WG(10, 10, 5, 5, false)
     HPV_WG(16, 16, 8, 8, false)
     HPV_WG(12, 12, 6, 6, false)
+    // larger rules (no whole-iteration kernel takes them: forward -> this -> reverse): 35 -> ~10 us of a 120 us iteration at 24x24 points
+    HPV_WG(24, 24, 12, 12, false)
+    HPV_WG(28, 28, 14, 14, false)
+    HPV_WG(32, 32, 16, 16, false)
+    HPV_WG(36, 36, 18, 18, false)
+    HPV_WG(40, 40, 20, 20, false)
 #undef HPV_WG
     return false;
 }

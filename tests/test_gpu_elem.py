@@ -311,6 +311,28 @@ def test_run_time_test_function_counts_on_every_projection_structure_hand_tuned_
     assert rel(lm, lo) < TRAJ_TOL and rel(m.get_params(), o.get_params()) < TRAJ_TOL
 
 
+@pytest.mark.parametrize("q,ntx,nty", [(24, 12, 12), (24, 7, 9), (32, 16, 5), (40, 20, 3)])
+def test_workgroup_per_element_projection_for_larger_rules(q, ntx, nty, monkeypatch):
+    """Rules no whole-iteration kernel takes (24, 32, 40 points per direction) project with k_project_wg -- instantiated for the
+    largest test-function counts, smaller ones at run time -- instead of the general k_project; against the oracle."""
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.vpinn import VPINN2D
+    from oracle.vpinn_oracle import OracleVPINN2D
+    monkeypatch.delenv("HPV_FUSE", raising=False)
+    L = [2, 20, 20, 20, 1]
+    s = poisson2d.setup(N_el_x=2, N_el_y=2, N_test_x=ntx, N_test_y=nty, N_quad=q, N_bound=17, with_test_grid=False)
+    a = (s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"], s["WXY_quad_train"], None,
+         s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"], s["X_u_train"], s["u_train"], L)
+    th = theta0(L, 126)
+    o, m = OracleVPINN2D(*a, init_params=th), VPINN2D(*a, init_params=th)
+    o.vectorized = True
+    l3o, go = o.loss_and_grad()
+    l3m, gm = m.loss_and_grad()
+    assert f"k_project_wg<{q}x{q}/{ntx}x{nty}>" in m.h.kernel_variant(), m.h.kernel_variant()
+    assert rel(l3m, l3o) < TOL and rel(gm, go) < TOL, (l3m, l3o, rel(gm, go))
+    assert rel(m.h.residuals(4 * ntx * nty), o.last["R"].reshape(-1)) < TOL
+
+
 def test_default_policy_picks_the_faster_structure_per_shape():
     """Without HPV_FUSE: the two-term forms on 16x16 / 8x8 and 12x12 / 6x6 elements run on k_iter_fused; the generic element-resident
     kernel is the default where it measured faster than the separate launches (few channel-layers: profiles/r04_element_shapes.md)
