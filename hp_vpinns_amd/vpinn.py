@@ -68,7 +68,9 @@ def _tensor_rule(X_quad, W_quad):
 # count per direction).  2-D two-term forms: csrc/kernels_fused.hip (k_iter_small, FZ_SHAPES); 1-D: csrc/kernels_tile.hip.
 _RULES_2D = ((10, 5), (12, 6), (16, 8), (20, 10))
 _RULE_1D = (80, 60)
-_RULE_PAD_MAX_ELEMS = 1536        # beyond ~6 elements per CU the kernels hand shapes other than 20 / 10 points to the separate launches
+# grids up to which the kernel of a rule runs one workgroup per element (256 CUs: csrc/kernels_fused.hip, kernels_tile.hip); beyond
+# that the separate launches take over and padding would only add points
+_RULE_PAD_MAX_ELEMS = {10: 1023, 12: 768, 16: 1536, 20: 1 << 30}
 
 
 def _pad_rule(xi, w, q_dev):
@@ -89,7 +91,7 @@ def _device_rule_2d(xi, wx, yi, wy, ntx, nty, n_elem, exact_counts=False, rules=
     for q_dev, nt_max in rules:
         counts_ok = (ntx == nt_max and nty == nt_max) if exact_counts else max(ntx, nty) <= nt_max
         if xi.size <= q_dev and counts_ok:
-            if xi.size < q_dev and (q_dev in (10, 20) or n_elem <= _RULE_PAD_MAX_ELEMS):
+            if xi.size < q_dev and n_elem <= _RULE_PAD_MAX_ELEMS[q_dev]:
                 xi, wx = _pad_rule(xi, wx, q_dev)
                 yi, wy = _pad_rule(yi, wy, q_dev)
             break
