@@ -518,6 +518,367 @@ __global__ void __launch_bounds__(256, 2) k_residual_stream(ProjDesc pd, int ch0
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same residual-only stream with LDS-DMA staging (round 4): `global_load_lds_dwordx4` moves a batch's two channel runs, its
+// right-hand side and its coefficients straight from global memory into one of THREE LDS buffers -- no register holds a load in
+// flight, so two whole batches (86 KB per CU) travel while the third is contracted; the register-staged kernel above keeps one.
+// Every load of the kernel is a DMA: an ordinary global load beside them would make the compiler drain the DMA queue at its use
+// (vmcnt(0)).  Order of a buffer's life: waves issue their shares of DMA(i) in iteration i - 2; at the top of iteration i every wave
+// waits until at most its NEWER operations are outstanding (the DMA of batch i + 1 and a few stores), then the barrier makes all
+// shares visible; the buffer is refilled in iteration i + 1, behind the barrier that ended its readers' iteration.
+// One workgroup per CU (152 KB of LDS), persistent over the batches.
+template <int QX, int QY, int NTX, int NTY, int NB>
+struct RdLds {
+    static constexpr int NQ = QX * QY, NR = NTX * NTY, LDT = QX + 2;
+    static constexpr int RUN = NB * NQ;
+    static constexpr int FO = 2 * RUN;                       // inside a buffer: [channel 0 run | channel 1 run | F of the batch | coefficients]
+    static constexpr int C0O = FO + NB * NR;                 // four arrays of 64 floats: low / high halves of c_0, of c_1 (lane e = element e of the batch)
+    static constexpr int BUF = C0O + 128;                    // doubles per buffer (16-byte multiple)
+    static constexpr int T = 3 * BUF;                        // [NB][2][NTY][LDT]
+    static constexpr int SQ = T + NB * 2 * NTY * LDT;
+    static constexpr int TOTAL = SQ + NB * NTY * 2 + 16;
+    static_assert(NB <= 8 && (2 * RUN) % 2 == 0 && (NB * NR) % 2 == 0, "16-byte units");
+};
+
+template <int QX, int QY, int NTX, int NTY, int NB>
+__global__ void __launch_bounds__(256, 1) k_residual_dma(ProjDesc pd, int ch0, int ch1, const double* __restrict__ OUT,
+                                                         double* __restrict__ R, const double* __restrict__ F,
+                                                         const double* __restrict__ coef, long coef_stride,
+                                                         const double* __restrict__ wtx, const double* __restrict__ wty,
+                                                         double* __restrict__ loss_e, long N, long n_elem) {
+    using M = RdLds<QX, QY, NTX, NTY, NB>;
+    constexpr int NQ = QX * QY, NR = NTX * NTY, LDT = M::LDT, RUN = M::RUN;
+    constexpr int RH = NTX / 2;
+    constexpr int UNITS = (2 * RUN + NB * NR) / 2;           // 16-byte units of a batch: both runs and F (contiguous in the buffer)
+    constexpr int NDI = (UNITS + 255) / 256;                 // DMA instructions per wave and batch (4 waves x 64 lanes x 16 B)
+    constexpr int NWAIT = (UNITS - 192 + 255) / 256 - 0;     // ... the FEWEST a wave issues (wave 3's last one may be empty)
+    static_assert(NQ % 2 == 0 && NB * QX <= 128 && NB * NTY <= 64 && NTX % 2 == 0 && QX % 2 == 0, "lane maps");
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const double al0 = pd.t[0].a0[ch0], al1 = pd.t[1].a0[ch1];
+    const long nbatch = (n_elem + NB - 1) / NB;
+    const double* __restrict__ C0 = OUT + (long)ch0 * N;
+    const double* __restrict__ C1 = OUT + (long)ch1 * N;
+    const double* __restrict__ Fp = F ? F : OUT;             // (no right-hand side: anything readable, the values are not used)
+    const long ntot = n_elem * NQ, nftot = n_elem * NR;
+    const int yt = wv >> 1;
+    const int yl = (wv & 1) * 64 + lane, ye = yl / QX, yi = yl % QX;
+    const bool yon = yl < NB * QX;
+    const int xh = wv & 1, xe = lane / NTY, xk = lane % NTY;
+    const bool xon = wv < 2 && lane < NB * NTY;
+    const double* __restrict__ byt = wty + (long)pd.t[yt].dy * NTY * QY;
+    const double* __restrict__ ax0 = wtx + (long)pd.t[0].dx * NTX * QX + xh * RH * QX;
+    const double* __restrict__ ax1 = wtx + (long)pd.t[1].dx * NTX * QX + xh * RH * QX;
+    // this wave's share of the DMA of batch b into buffer `buf` (b >= nbatch: nothing)
+    auto dma = [&](long b, int buf) {
+        if (b >= nbatch) return;
+        double* dst = sm + buf * M::BUF;
+#pragma unroll
+        for (int p = 0; p < NDI; ++p) {
+            const int u0 = p * 256 + wv * 64;                // wave-uniform first unit of this instruction
+            if (u0 < UNITS) {
+                const int u = u0 + lane;
+                if (u < UNITS) {
+                    const int d = 2 * u;                     // double index inside the buffer
+                    const double* src;
+                    if (d < RUN) { long o = b * RUN + d; src = C0 + (o > ntot - 2 ? ntot - 2 : o); }
+                    else if (d < 2 * RUN) { long o = b * RUN + (d - RUN); src = C1 + (o > ntot - 2 ? ntot - 2 : o); }
+                    else { long o = b * (NB * NR) + (d - 2 * RUN); src = Fp + (o > nftot - 2 ? nftot - 2 : o); }
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + 2 * u0), 16, 0, 0);
+                }
+            }
+        }
+        if (wv == 3 && lane < NB) {       // the term coefficients of the batch's elements: 8 bytes per lane
+            long e_ = b * NB + lane;
+            e_ = e_ < n_elem ? e_ : n_elem - 1;
+            float* cd = (float*)(dst + M::C0O);
+            __builtin_amdgcn_global_load_lds((gptr_t)(coef + e_), (lptr_t)cd, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)((const float*)(coef + e_) + 1), (lptr_t)(cd + 64), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(coef + coef_stride + e_), (lptr_t)(cd + 128), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)((const float*)(coef + coef_stride + e_) + 1), (lptr_t)(cd + 192), 4, 0, 0);
+        }
+    };
+    long b = blockIdx.x;
+    dma(b, 0);
+    dma(b + gridDim.x, 1);
+    int it = 0;
+    for (; b < nbatch; b += gridDim.x, ++it) {
+        const int buf = it % 3;
+        // batch `b` has landed once at most the NEWER operations of this wave are outstanding; then everybody's share is visible
+        // (no newer batch in flight: everything)
+        if (b + gridDim.x < nbatch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pj_lds_barrier();
+        dma(b + 2 * (long)gridDim.x, (it + 2) % 3);          // refills the buffer whose readers passed the barrier above
+        const double* bs = sm + buf * M::BUF;
+        const long e_x = b * NB + xe;
+        const bool xv = xon && e_x < n_elem;
+        double u[RH];
+        {
+            const double* fp = bs + M::FO + (xon ? xe : 0) * NR + (xon ? xk : 0) * NTX + xh * RH;
+#pragma unroll
+            for (int r = 0; r < RH; ++r) u[r] = F ? -fp[r] : 0.0;
+        }
+        double c0, c1;
+        {   // coefficients were DMA'd as two 4-byte halves per element: [lo halves: 64 floats][hi halves: 64 floats]
+            const float* cl = (const float*)(bs + M::C0O);
+            const int xi_ = xon ? xe : 0;
+            c0 = __hiloint2double(__float_as_int(cl[64 + xi_]), __float_as_int(cl[xi_])) * al0;
+            c1 = __hiloint2double(__float_as_int(cl[192 + xi_]), __float_as_int(cl[128 + xi_])) * al1;
+        }
+        if (yon) {
+            const double* g = bs + yt * RUN + ye * NQ + yi;
+            double gv[QY];
+#pragma unroll
+            for (int j = 0; j < QY; ++j) gv[j] = g[j * QX];
+            double* tt = sm + M::T + ((ye * 2 + yt) * NTY) * LDT + yi;
+#pragma unroll
+            for (int k = 0; k < NTY; ++k) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < QY; ++j) acc = fma(byt[k * QY + j], gv[j], acc);
+                tt[k * LDT] = acc;
+            }
+        }
+        pj_lds_barrier();
+        if (xon) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const double* tr = sm + M::T + ((xe * 2 + t) * NTY + xk) * LDT;
+                const double* __restrict__ ax = t == 0 ? ax0 : ax1;
+                double tv[QX];
+#pragma unroll
+                for (int i = 0; i < QX; i += 2) { const v2d w = *(const v2d*)(tr + i); tv[i] = w[0]; tv[i + 1] = w[1]; }
+                const double c = t == 0 ? c0 : c1;
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < QX; ++i) acc = fma(ax[r * QX + i], tv[i], acc);
+                    u[r] = fma(c, acc, u[r]);
+                }
+            }
+            double sq = 0.0;
+            if (xv) {
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    R[e_x * NR + xk * NTX + xh * RH + r] = u[r];
+                    sq = fma(u[r], u[r], sq);
+                }
+            }
+            sm[M::SQ + (xe * NTY + xk) * 2 + xh] = sq;
+        }
+        pj_lds_barrier();
+        if (tid < NB && b * NB + tid < n_elem) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NTY * 2; ++i) s += sm[M::SQ + tid * (NTY * 2) + i];
+            loss_e[b * NB + tid] = s / (double)NR;
+        }
+    }
+}
+
+template <int QX, int QY, int NTX, int NTY>
+static bool launch_residual_dma(const ProjDesc& pd, const ActiveCh& ac, const double* OUT, double* R, const double* F, const double* coef,
+                                long coef_stride, const double* wtx, const double* wty, double* loss_e, long N, long n_elem, hipStream_t s) {
+    constexpr int NB = 6;
+    using M = RdLds<QX, QY, NTX, NTY, NB>;
+    constexpr size_t lds = (size_t)M::TOTAL * sizeof(double);
+    static_assert(lds <= 160 * 1024, "three batch buffers fit the LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_residual_dma<QX, QY, NTX, NTY, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        attr_set = true;
+    }
+    const long nbatch = (n_elem + NB - 1) / NB;
+    const unsigned blocks = (unsigned)std::min<long>(nbatch, 256);          // one resident workgroup per CU, each streams its batches
+    hipLaunchKernelGGL((k_residual_dma<QX, QY, NTX, NTY, NB>), dim3(blocks), dim3(256), lds, s, pd, ac.id[0], ac.id[1], OUT, R, F, coef,
+                       coef_stride, wtx, wty, loss_e, N, n_elem);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Per-WAVE LDS-DMA stream (round 4, second structure): every wave is its own loader and consumer, no workgroup barrier anywhere.
+// A wave owns groups of 64 / QX elements exactly like k_project_tp ("a lane owns a line"), but its group's channel runs and
+// right-hand side arrive by `global_load_lds_dwordx4` in its private LDS block: at the top of a trip the wave waits for its own
+// DMA (vmcnt -- the issuing wave's count is all that orders its own reads), copies its columns / rows into registers, requests the
+// NEXT group into the same block and contracts.  The residual stores of a group are issued one trip late, right behind the next
+// request, so that the wait at the top (which also covers them: loads and stores share the counter) never meets a young store.
+// Five waves per CU keep 5 x 21.6 KB in flight; each request is a linear run of 1 KB pieces.
+template <int QX, int QY, int NTX, int NTY, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 1) k_residual_wdma(ProjDesc pd, int ch0, int ch1, const double* __restrict__ OUT,
+                                                                 double* __restrict__ R, const double* __restrict__ F,
+                                                                 const double* __restrict__ coef, long coef_stride,
+                                                                 const double* __restrict__ wtx, const double* __restrict__ wty,
+                                                                 double* __restrict__ loss_e, long N, long n_elem) {
+    constexpr int NQ = QX * QY, NR = NTX * NTY, LPE = QX, EPW = 64 / LPE, LDT = QX + 1;
+    constexpr int RUNW = EPW * NQ, FW = EPW * NR;            // doubles of a group per channel / of its right-hand side
+    constexpr int GU = RUNW / 2, FU = FW / 2;                // ... in 16-byte units
+    constexpr int NG = (GU + 63) / 64, NF = (FU + 63) / 64;  // DMA instructions per run
+    constexpr int FO = 2 * NG * 128;                         // block layout: [run 0 | run 1 | F | transpose tile | sums], runs padded to whole instructions
+    constexpr int TO = FO + NF * 128, RO = TO + EPW * NTY * LDT;
+    constexpr int WAVE_D = (RO + 64 + 1) / 2 * 2;
+    static_assert(QX == QY && RUNW % 2 == 0 && FW % 2 == 0 && NTX <= LPE && NTY <= LPE, "shape");
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* blk = sm + wv * WAVE_D;
+    const int slot = lane / LPE, li = lane % LPE;
+    const bool lane_ok = slot < EPW;
+    const double al0 = pd.t[0].a0[ch0], al1 = pd.t[1].a0[ch1];
+    const double* __restrict__ C0 = OUT + (long)ch0 * N;
+    const double* __restrict__ C1 = OUT + (long)ch1 * N;
+    const double* __restrict__ Fp = F ? F : OUT;
+    const long ntot = n_elem * NQ, nftot = n_elem * NR;
+    const long ngroups = (n_elem + EPW - 1) / EPW, gstride = (long)gridDim.x * WAVES;
+    const double* __restrict__ by0 = wty + (long)pd.t[0].dy * (NTY * QY);
+    const double* __restrict__ by1 = wty + (long)pd.t[1].dy * (NTY * QY);
+    const double* __restrict__ ax0 = wtx + (long)pd.t[0].dx * (NTX * QX);
+    const double* __restrict__ ax1 = wtx + (long)pd.t[1].dx * (NTX * QX);
+    auto request = [&](long grp) {
+        if (grp >= ngroups) return;
+#pragma unroll
+        for (int p = 0; p < 2 * NG + NF; ++p) {
+            const int run = p < NG ? 0 : (p < 2 * NG ? 1 : 2), q = run == 0 ? p : (run == 1 ? p - NG : p - 2 * NG);
+            const int u = q * 64 + lane;
+            if (u < (run == 2 ? FU : GU)) {
+                const long o = (run == 2 ? grp * FW : grp * RUNW) + 2 * u;
+                const double* src = run == 0 ? C0 + (o > ntot - 2 ? ntot - 2 : o)
+                                             : (run == 1 ? C1 + (o > ntot - 2 ? ntot - 2 : o) : Fp + (o > nftot - 2 ? nftot - 2 : o));
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(blk + p * 128), 16, 0, 0);
+            }
+        }
+    };
+    long grp = (long)blockIdx.x * WAVES + wv;
+    request(grp);
+    double up[NTX];                      // the previous group's residual row of this lane, stored one trip late
+    long ep = -1;
+    bool rowp = false;
+    double lossp = 0.0;
+#pragma unroll
+    for (int r = 0; r < NTX; ++r) up[r] = 0.0;
+    for (; grp < ngroups; grp += gstride) {
+        const long e = grp * EPW + slot;
+        const bool ev = lane_ok && e < n_elem;
+        const bool col = ev, row = ev && li < NTY;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's request has landed (and the stores of two trips ago)
+        double g0[QY], g1[QY], u[NTX];
+        {
+            const double* c0p = blk + (lane_ok ? slot : 0) * NQ + li;
+            const double* c1p = blk + NG * 128 + (lane_ok ? slot : 0) * NQ + li;
+#pragma unroll
+            for (int j = 0; j < QY; ++j) { g0[j] = c0p[j * QX]; g1[j] = c1p[j * QX]; }
+            const double* fp = blk + FO + (lane_ok ? slot : 0) * NR + (li < NTY ? li : 0) * NTX;
+#pragma unroll
+            for (int r = 0; r < NTX; ++r) u[r] = F ? -fp[r] : 0.0;
+        }
+        // (term coefficients: wave-uniform addresses -> scalar loads, the vector-memory counter never sees them)
+        double cw0[EPW], cw1[EPW];
+#pragma unroll
+        for (int s_ = 0; s_ < EPW; ++s_) {
+            long ee = grp * EPW + s_;
+            ee = ee < n_elem ? ee : n_elem - 1;
+            cw0[s_] = coef[ee]; cw1[s_] = coef[coef_stride + ee];
+        }
+        double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+        for (int s_ = 0; s_ < EPW; ++s_) { c0 = slot == s_ ? cw0[s_] : c0; c1 = slot == s_ ? cw1[s_] : c1; }
+        c0 *= al0; c1 *= al1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the block has been read: refill it
+        request(grp + gstride);
+        if (rowp) {                                            // the previous group's residual row (see the header)
+#pragma unroll
+            for (int r = 0; r < NTX; ++r) R[ep * NR + li * NTX + r] = up[r];
+        }
+        if (ep >= 0 && li == 0 && lane_ok) loss_e[ep] = lossp;
+        double* Tb = blk + TO;
+        double* Rd = blk + RO;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const double* __restrict__ byg = t == 0 ? by0 : by1;
+            const double* __restrict__ axg = t == 0 ? ax0 : ax1;
+            pj_wave_sync();
+            if (col) {
+                double acc[NTY];
+#pragma unroll
+                for (int k = 0; k < NTY; ++k) {
+                    acc[k] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < QY; ++j) acc[k] = fma(byg[k * QY + j], t == 0 ? g0[j] : g1[j], acc[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < NTY; ++k) Tb[slot * (NTY * LDT) + k * LDT + li] = acc[k];
+            }
+            pj_wave_sync();
+            if (row) {
+                double trow[QX];
+#pragma unroll
+                for (int i = 0; i < QX; ++i) trow[i] = Tb[slot * (NTY * LDT) + li * LDT + i];
+                const double c = t == 0 ? c0 : c1;
+#pragma unroll
+                for (int r = 0; r < NTX; ++r) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < QX; ++i) acc = fma(axg[r * QX + i], trow[i], acc);
+                    u[r] = fma(c, acc, u[r]);
+                }
+            }
+        }
+        double sq = 0.0;
+        if (row) {
+#pragma unroll
+            for (int r = 0; r < NTX; ++r) sq = fma(u[r], u[r], sq);
+        }
+        Rd[lane] = sq;
+        pj_wave_sync();
+        double ls = 0.0;
+        if (ev && li == 0) {
+#pragma unroll
+            for (int k = 0; k < NTY; ++k) ls += Rd[slot * LPE + k];
+        }
+#pragma unroll
+        for (int r = 0; r < NTX; ++r) up[r] = u[r];
+        ep = ev ? e : -1; rowp = row; lossp = ls / (double)NR;
+    }
+    if (rowp) {
+#pragma unroll
+        for (int r = 0; r < NTX; ++r) R[ep * NR + li * NTX + r] = up[r];
+    }
+    if (ep >= 0 && li == 0 && lane_ok) loss_e[ep] = lossp;
+}
+
+template <int QX, int QY, int NTX, int NTY>
+static bool launch_residual_wdma(const ProjDesc& pd, const ActiveCh& ac, const double* OUT, double* R, const double* F, const double* coef,
+                                 long coef_stride, const double* wtx, const double* wty, double* loss_e, long N, long n_elem, hipStream_t s) {
+    constexpr int WAVES = 5, EPW = 64 / QX, NQ = QX * QY, NR = NTX * NTY;
+    constexpr int NG = (EPW * NQ / 2 + 63) / 64, NF = (EPW * NR / 2 + 63) / 64;
+    constexpr int WAVE_D = (2 * NG * 128 + NF * 128 + EPW * NTY * (QX + 1) + 64 + 1) / 2 * 2;
+    constexpr size_t lds = (size_t)WAVES * WAVE_D * sizeof(double);
+    static_assert(lds <= 160 * 1024, "five wave blocks fit the LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_residual_wdma<QX, QY, NTX, NTY, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        attr_set = true;
+    }
+    const long ngroups = (n_elem + EPW - 1) / EPW;
+    const unsigned blocks = (unsigned)std::min<long>((ngroups + WAVES - 1) / WAVES, 256);
+    hipLaunchKernelGGL((k_residual_wdma<QX, QY, NTX, NTY, WAVES>), dim3(blocks), dim3(WAVES * 64), lds, s, pd, ac.id[0], ac.id[1], OUT, R, F,
+                       coef, coef_stride, wtx, wty, loss_e, N, n_elem);
+    return true;
+}
+
 template <int QX, int QY, int NTX, int NTY>
 static bool launch_residual_stream(const ProjDesc& pd, const ActiveCh& ac, const double* OUT, double* R, const double* F, const double* coef,
                                    long coef_stride, const double* wtx, const double* wty, double* loss_e, long N, long n_elem, hipStream_t s) {
@@ -546,9 +907,15 @@ static void launch_tp3(const ProjDesc& pd, const ActiveCh& ac, const double* OUT
     constexpr int LPE = QX > QY ? QX : QY;
     constexpr int EPW = 64 / LPE;
     constexpr int WAVE_DOUBLES = EPW * NTY * (QX + 1) + 64;
-    const size_t lds = (size_t)(2 * (3 * NTX * QX + 3 * NTY * QY) + PJ_WAVES * WAVE_DOUBLES) * sizeof(double);
+    size_t lds = (size_t)(2 * (3 * NTX * QX + 3 * NTY * QY) + PJ_WAVES * WAVE_DOUBLES) * sizeof(double);
     long blocks = (ngroups + PJ_WAVES - 1) / PJ_WAVES;
-    if (blocks > 256 * 16) blocks = 256 * 16;   // grid-stride beyond that
+    // (A/B knobs of the stand-alone bandwidth measurement: HPV_PJ_OCC_PAD = bytes of unused LDS per workgroup, i.e. fewer resident
+    //  workgroups per CU; HPV_PJ_GRID = resident-grid cap in workgroups per CU.  scripts/hbm_read_probe.hip: a plain read stream is
+    //  FASTER with fewer waves and loads in flight -- 6.3-6.6 TB/s at 2 workgroups per CU against 5.0-5.5 at 4-8)
+    static const long occ_pad = getenv("HPV_PJ_OCC_PAD") ? atol(getenv("HPV_PJ_OCC_PAD")) : 0;
+    static const long grid_cap = getenv("HPV_PJ_GRID") ? atol(getenv("HPV_PJ_GRID")) : 16;
+    lds += (size_t)occ_pad;
+    if (blocks > 256 * grid_cap) blocks = 256 * grid_cap;   // grid-stride beyond that
     if (lds > 65536) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -586,6 +953,17 @@ static bool launch_tp2(const ProjDesc& pd, const ActiveCh& ac, const double* OUT
             //  on the 2^18-element batch -- and serves the adjoint half as well)
             const bool no_stream = !(getenv("HPV_PJ_STREAM") && getenv("HPV_PJ_STREAM")[0] == '1');
             if constexpr (NA == 2 && QX == 20 && QY == 20 && NTX == 10 && NTY == 10) {
+                // large batches, residual only: the LDS-DMA stream (HPV_PJ_DMA=1: A/B switch)
+                const bool dma_on = getenv("HPV_PJ_DMA") && getenv("HPV_PJ_DMA")[0] == '1';
+                const bool wdma_on = getenv("HPV_PJ_DMA") && getenv("HPV_PJ_DMA")[0] == '2';       // per-wave loader + consumer
+                if (!do_adjoint && wdma_on && n_elem >= 4096 && N == n_elem * (long)(QX * QY) && pd.t[0].a1[ac.id[0]] == 0.0 &&
+                    pd.t[1].a1[ac.id[1]] == 0.0 && !pd.t[0].eps_mult && !pd.t[1].eps_mult &&
+                    launch_residual_wdma<QX, QY, NTX, NTY>(pd, ac, OUT, R, F, coef, coef_stride, wtx, wty, loss_e, N, n_elem, s))
+                    return true;
+                if (!do_adjoint && dma_on && n_elem >= 4096 && N == n_elem * (long)(QX * QY) && pd.t[0].a1[ac.id[0]] == 0.0 &&
+                    pd.t[1].a1[ac.id[1]] == 0.0 && !pd.t[0].eps_mult && !pd.t[1].eps_mult &&
+                    launch_residual_dma<QX, QY, NTX, NTY>(pd, ac, OUT, R, F, coef, coef_stride, wtx, wty, loss_e, N, n_elem, s))
+                    return true;
                 // large batches, residual only, unit channel weights: the streaming kernel (LDS-staged, register double-buffered)
                 if (!do_adjoint && !no_stream && n_elem >= 4096 && N == n_elem * (long)(QX * QY) && pd.t[0].a1[ac.id[0]] == 0.0 &&
                     pd.t[1].a1[ac.id[1]] == 0.0 && !pd.t[0].eps_mult && !pd.t[1].eps_mult &&

@@ -1230,7 +1230,16 @@ def test_large_batch_projection_plans_agree(monkeypatch):
     monkeypatch.setenv("HPV_PJ_STREAM", "1")        # (opt-in: equal speed to k_project_tp since that kernel's tables are SGPR operands)
     s_stream = sums(False)
     monkeypatch.delenv("HPV_PJ_STREAM")
+    monkeypatch.setenv("HPV_PJ_DMA", "1")           # the LDS-DMA stream (three batch buffers filled by global_load_lds)
+    s_dma, s_dma2 = sums(False), sums(False, n=6 * 4096 + 5)
+    monkeypatch.setenv("HPV_PJ_DMA", "2")           # every wave its own LDS-DMA loader and consumer
+    s_wd, s_wd2 = sums(False), sums(False, n=6 * 4096 + 5)
+    monkeypatch.delenv("HPV_PJ_DMA")
     s_tp = sums(False)
+    assert rel(s_wd[[0, 1, 2, 5]], s_tp[[0, 1, 2, 5]]) < 1e-12, (s_wd, s_tp)
+    assert rel(s_wd2[[0, 1, 2, 5]], s_dma2[[0, 1, 2, 5]]) < 1e-12, (s_wd2, s_dma2)
+    assert rel(s_dma[[0, 1, 2, 5]], s_tp[[0, 1, 2, 5]]) < 1e-12, (s_dma, s_tp)
+    assert rel(s_dma2[[0, 1, 2, 5]], sums(False, n=6 * 4096 + 5)[[0, 1, 2, 5]]) < 1e-12
     s_gen = sums(False, _lib.BACKEND_GENERIC)
     assert np.all(np.isfinite(s_stream)) and s_stream[1] > 0
     assert rel(s_stream[[0, 1, 2, 5]], s_tp[[0, 1, 2, 5]]) < 1e-12, (s_stream, s_tp)
