@@ -199,3 +199,27 @@ def test_advdiff_mat_export_holds_the_reference_variables(tmp_path):
     assert m["u_pred"].shape == (7, 1) and float(m["total_time_train"]) == 1.25
     advdiff.export_mat(path, s, None, [], [], 0.0)           # (a run that never reached its last tenth)
     assert scipy.io.loadmat(path)["total"].shape == (0, 4)
+
+
+def test_zero_weight_padding_of_quadrature_rules():
+    """vpinn._pad_rule / _device_rule_2d: a rule between two instantiated ones goes to the device with zero-weight points appended --
+    every quadrature sum is unchanged, the choice of the device rule follows the kernels' instantiations and grid limits."""
+    from hp_vpinns_amd.quadrature import GaussLobattoJacobiWeights
+    from hp_vpinns_amd.testfcn import tables_1d
+    from hp_vpinns_amd.vpinn import _device_rule_2d, _pad_rule
+    x, w = GaussLobattoJacobiWeights(14, 0, 0)
+    xp, wp = _pad_rule(x, w, 16)
+    assert xp.size == 16 and np.array_equal(xp[:14], x) and np.all(wp[14:] == 0.0) and np.all(xp[14:] == x[-1])
+    f = lambda t: np.cos(1.3 * t) + t ** 5
+    assert sum(a * b for a, b in zip(wp, f(xp))) == sum(a * b for a, b in zip(w, f(x)))      # the appended terms are exact zeros
+    # the tables the kernels contract with are w * phi: the padded columns vanish whatever phi is there
+    t0, tp = tables_1d(7, x), tables_1d(7, xp)
+    assert tp.shape == (3, 7, 16) and np.array_equal(tp[..., :14], t0) and np.all(np.isfinite(tp))
+    sel = lambda q, ntx, nty, ne, **k: _device_rule_2d(*(GaussLobattoJacobiWeights(q, 0, 0) * 2), ntx, nty, ne, **k)[0].size
+    assert [sel(q, q // 2, q // 2, 256) for q in (6, 10, 11, 12, 14, 16, 18, 20, 22)] == [10, 10, 12, 12, 16, 16, 20, 20, 22]
+    assert sel(14, 9, 3, 256) == 20 and sel(14, 11, 3, 256) == 14          # the test-function counts must fit the instantiation too
+    assert sel(7, 4, 4, 2048) == 7 and sel(14, 7, 7, 2048) == 14 and sel(18, 9, 9, 4096) == 20     # grids the kernel leaves to the separate launches
+    assert sel(8, 5, 5, 64, exact_counts=True, rules=((10, 5),)) == 10 and sel(8, 4, 5, 64, exact_counts=True, rules=((10, 5),)) == 8
+    xa, _ = GaussLobattoJacobiWeights(12, 0, 0)
+    xb, wb = GaussLobattoJacobiWeights(14, 0, 0)
+    assert _device_rule_2d(xa, _, xb, wb, 5, 5, 64)[0].size == 12           # different rules per direction: left alone
