@@ -1,7 +1,7 @@
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $REPO/gpurun_out/clk -o bench -- python $REPO/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-residual-roofline > $REPO/gpurun_out/clk.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $REPO/gpurun_out/clk -o bench -- python $REPO/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-residual-roofline --no-extras > $REPO/gpurun_out/clk.log 2>&1
 cd $REPO
 python - <<'PY'
 import csv, glob, collections
