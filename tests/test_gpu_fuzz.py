@@ -1,0 +1,100 @@
+"""Seeded sweep over the hyper-parameters a reference user is free to choose -- N_quad, N_test per direction, grid, depth, width,
+var_form (P1:231-240, P2:280-286, P3:43-54) -- through the DEFAULT dispatch, against the same problem on the library's generic VALU
+kernels (backend="generic": one plain code path, no shape-specific kernel, no rule padding).  The dispatch surface grew a lot in
+round 4 (element shapes x run-time counts x padded rules x plans x grid-size policies); this test walks it with combinations no other
+test names.  Loss triple, gradient and three Adam iterations must agree to round-off."""
+import numpy as np
+import pytest
+
+from cases import rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases_2d():
+    rng = np.random.RandomState(20260929)
+    out = []
+    for _ in range(64):
+        q = int(rng.choice([5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 24]))
+        ntx, nty = int(rng.randint(1, q // 2 + 1)), int(rng.randint(1, q // 2 + 1))
+        nex, ney = int(rng.randint(1, 19)), int(rng.randint(1, 19))       # 1 ... 324 elements: SPLIT shards, full grids, a second round
+        depth = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 6]))
+        width = int(rng.choice([5, 12, 20, 20, 20, 24, 30]))
+        vf = int(rng.choice([0, 1, 1, 1, 2]))
+        out.append((q, ntx, nty, nex, ney, depth, width, vf))
+    return out
+
+
+@pytest.mark.parametrize("q,ntx,nty,nex,ney,depth,width,vf", _cases_2d())
+def test_poisson2d_default_dispatch_against_the_generic_kernels(q, ntx, nty, nex, ney, depth, width, vf):
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    from hp_vpinns_amd.vpinn import VPINN2D
+    L = [2] + [width] * depth + [1]
+    s = poisson2d.setup(N_el_x=nex, N_el_y=ney, N_test_x=ntx, N_test_y=nty, N_quad=q, N_bound=9, with_test_grid=False)
+    a = (s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"], s["WXY_quad_train"], None,
+         s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"], s["X_u_train"], s["u_train"], L)
+    th = xavier_init(L, 7)
+    m, g = VPINN2D(*a, var_form=vf, init_params=th), VPINN2D(*a, var_form=vf, init_params=th, backend="generic")
+    l3m, gm = m.loss_and_grad()
+    l3g, gg = g.loss_and_grad()
+    v = m.h.kernel_variant()
+    assert g.backend() == "generic"
+    assert rel(l3m, l3g) < 1e-11 and rel(gm, gg) < 1e-9, (v, l3m, l3g, rel(gm, gg))
+    assert rel(m.h.residuals(nex * ney * ntx * nty), g.h.residuals(nex * ney * ntx * nty)) < 1e-10, v
+    m._step(3, False)
+    g._step(3, False)
+    assert rel(m.get_params(), g.get_params()) < 1e-8, v
+
+
+def _cases_1d():
+    rng = np.random.RandomState(7)
+    return [(int(rng.choice([10, 20, 40, 60, 80])), int(rng.randint(1, 31)), int(rng.randint(1, 9)), int(rng.choice([2, 3, 4, 5])),
+             int(rng.choice([8, 20, 20, 32])), int(rng.choice([1, 2, 3]))) for _ in range(20)]
+
+
+@pytest.mark.parametrize("q,nt,ne,depth,width,vf", _cases_1d())
+def test_poisson1d_default_dispatch_against_the_generic_kernels(q, nt, ne, depth, width, vf):
+    from hp_vpinns_amd.drivers import poisson1d
+    from hp_vpinns_amd.init import xavier_init
+    from hp_vpinns_amd.vpinn import VPINN1D
+    nt = min(nt, q // 2 if q > 2 else 1)
+    L = [1] + [width] * depth + [1]
+    s = poisson1d.setup(N_Element=ne, N_testfcn=nt, N_Quad=q)
+    args = (s["X_u_train"], s["u_train"], s["X_quad_train"], s["W_quad_train"], s["F_ext_total"], s["grid"], s["X_test"],
+            s["u_test"], L, s["X_f_train"], s["f_train"])
+    th = xavier_init(L, 8)
+    th[L[1]:2 * L[1]] = 0.1
+    m, g = VPINN1D(*args, var_form=vf, init_params=th), VPINN1D(*args, var_form=vf, init_params=th, backend="generic")
+    l3m, gm = m.loss_and_grad()
+    l3g, gg = g.loss_and_grad()
+    assert rel(l3m, l3g) < 1e-11 and rel(gm, gg) < 1e-9, (m.h.kernel_variant(), l3m, l3g, rel(gm, gg))
+    m._step(3, False)
+    g._step(3, False)
+    assert rel(m.get_params(), g.get_params()) < 1e-8, m.h.kernel_variant()
+
+
+def _cases_adv():
+    rng = np.random.RandomState(11)
+    return [(int(rng.choice([6, 8, 10, 12, 16, 20])), int(rng.randint(1, 6)), int(rng.randint(1, 6)), int(rng.randint(1, 9)), int(rng.randint(1, 9)),
+             int(rng.choice([2, 3, 4])), int(rng.choice([0, 1]))) for _ in range(16)]
+
+
+@pytest.mark.parametrize("q,ntx,ntt,nex,net,depth,vf", _cases_adv())
+def test_advdiff_default_dispatch_against_the_generic_kernels(q, ntx, ntt, nex, net, depth, vf):
+    from hp_vpinns_amd.drivers import advdiff
+    from hp_vpinns_amd.init import xavier_init
+    from hp_vpinns_amd.vpinn import VPINNAdvDiff
+    ntx, ntt = min(ntx, q // 2), min(ntt, q // 2)
+    L = [2] + [20] * depth + [1]
+    s = advdiff.setup(N_el_x=nex, N_el_t=net, N_test_x=ntx, N_test_t=ntt, N_quad=q, N_bound=9, with_test_grid=False)
+    a = (s["XT_u_train"], s["u_train"], s["XT_f_train"], s["XT_quad_train"], s["WXT_quad_train"], s["T_quad"], s["WT_quad"],
+         s["grid_x"], s["grid_t"], s["N_testfcn_total"], s["XT_u_train"], s["u_train"], L, None, None)
+    th = xavier_init(L, 9, extra=[0.9])
+    m, g = VPINNAdvDiff(*a, var_form=vf, init_params=th), VPINNAdvDiff(*a, var_form=vf, init_params=th, backend="generic")
+    l3m, gm = m.loss_and_grad()
+    l3g, gg = g.loss_and_grad()
+    assert rel(l3m, l3g) < 1e-11 and rel(gm, gg) < 1e-9, (m.h.kernel_variant(), l3m, l3g, rel(gm, gg))
+    m._step(3, False)
+    g._step(3, False)
+    assert rel(m.get_params(), g.get_params()) < 1e-8, m.h.kernel_variant()
