@@ -98,3 +98,48 @@ def test_advdiff_default_dispatch_against_the_generic_kernels(q, ntx, ntt, nex, 
     m._step(3, False)
     g._step(3, False)
     assert rel(m.get_params(), g.get_params()) < 1e-8, m.h.kernel_variant()
+
+
+def _cases_shards():
+    rng = np.random.RandomState(5)
+    out = []
+    for _ in range(16):
+        q = int(rng.choice([8, 10, 12, 14, 16, 20]))
+        nt = int(rng.randint(2, q // 2 + 1))
+        nex, ney = int(rng.randint(2, 17)), int(rng.randint(1, 9))
+        world = int(rng.choice([2, 3, 4, 8]))
+        out.append((q, nt, nex, ney, world, int(rng.choice([2, 3]))))
+    return out
+
+
+@pytest.mark.parametrize("q,nt,nex,ney,world,depth", _cases_shards())
+def test_element_shards_of_random_problems_add_up_to_the_whole(q, nt, nex, ney, world, depth):
+    """What the ranks of an N-GPU run own (dist.shard_range: contiguous element blocks, the boundary term on rank 0): the shards'
+    variational losses and gradients -- each on whatever kernel the default dispatch picks for ITS element count -- add up to the
+    single-GPU problem's."""
+    from hp_vpinns_amd.dist import shard_range
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    from hp_vpinns_amd.vpinn import VPINN2D
+    L = [2] + [20] * depth + [1]
+    s = poisson2d.setup(N_el_x=nex, N_el_y=ney, N_test_x=nt, N_test_y=nt, N_quad=q, N_bound=9, with_test_grid=False)
+    a = (s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"], s["WXY_quad_train"], None,
+         s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"], s["X_u_train"], s["u_train"], L)
+    th = xavier_init(L, 10)
+    full = VPINN2D(*a, init_params=th)
+    l3, g = full.h.loss_and_grad()
+    lv, gs, seen = 0.0, np.zeros_like(g), set()
+    for rank in range(world):
+        eb, ee = shard_range(nex * ney, rank, world)
+        if ee <= eb:
+            continue
+        m = VPINN2D(*a, init_params=th)
+        m.h.set_elements(s["grid_x"], s["grid_y"], eb, ee)
+        if rank != 0:
+            m.h.set_data(None, None)
+        l3r, gr = m.h.loss_and_grad()
+        seen.add(m.h.kernel_variant().split("<")[0])
+        lv += l3r[2]
+        gs += gr
+        assert (l3r[1] == 0.0) == (rank != 0)
+    assert rel(lv, l3[2]) < 1e-11 and rel(gs, g) < 1e-9, (seen, lv, l3[2], rel(gs, g))
