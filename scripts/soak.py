@@ -4,7 +4,8 @@ element meet at a device-memory barrier in every launch) next to the same shard 
 forward + split reverse kernels; HPV_FUSE=n: separate launches).  A barrier that is ever missed makes hpv_step raise (-7).  The
 three Adam trajectories agree to round-off for ~1 000 iterations and then drift apart chaotically (1e-2 relative by 50 000
 iterations) -- the SPLIT one no further from `s` than `s` is from `n` (the control), which is what a correct exchange looks like.
-soak.py [iterations per shard, default 300000]     (measured: 1.2 M launches without a timeout, profiles/README.md)"""
+soak.py [iterations per shard, default 300000] [points per direction, default 20: 20, 16 or 12]
+(measured: 1.2 M launches without a timeout, profiles/README.md)"""
 import os
 import sys
 import time
@@ -16,6 +17,7 @@ from hp_vpinns_amd.drivers import poisson2d  # noqa: E402
 from hp_vpinns_amd.init import xavier_init  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
+Q = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 L = [2, 20, 20, 20, 1]
 
 
@@ -29,7 +31,7 @@ def build(s, th, fuse):
 
 
 for ney in (8, 4, 2):
-    s = poisson2d.setup(N_el_x=16, N_el_y=ney, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
+    s = poisson2d.setup(N_el_x=16, N_el_y=ney, N_test_x=Q // 2, N_test_y=Q // 2, N_quad=Q, with_test_grid=False)
     th = xavier_init(L, 1234)
     ms = {"split": build(s, th, None), "s": build(s, th, "s"), "n": build(s, th, "n")}
     t0 = time.perf_counter()
