@@ -226,6 +226,11 @@ def main():
                           "N_test_y": 16 * [10], "N_quad": 20})
     gen_p2(out, "small", {"Net_layer": [2, 8, 8, 1], "N_el_x": 3, "N_el_y": 2, "N_test_x": 3 * [4],
                            "N_test_y": 2 * [3], "N_quad": 6, "N_bound": 10, "N_residual": 10})
+    # anchors of var_form 2 (tests/test_oracle.py): ONE element with Jx = Jy = 1, and a 2 x 2 grid (Jx = Jy = 1/2), fine rule
+    gen_p2(out, "e1", {"Net_layer": [2, 5, 1], "N_el_x": 1, "N_el_y": 1, "N_test_x": [5], "N_test_y": [5], "N_quad": 60,
+                        "N_bound": 10, "N_residual": 10})
+    gen_p2(out, "e2", {"Net_layer": [2, 5, 1], "N_el_x": 2, "N_el_y": 2, "N_test_x": 2 * [5], "N_test_y": 2 * [5], "N_quad": 60,
+                        "N_bound": 10, "N_residual": 10})
     gen_p3(out, "default", {}, m3)                                 # reference defaults (P3:31-54)
     gen_p3(out, "cfg5", {"Net_layer": L2, "N_el_x": 8, "N_test_x": 8 * [5], "N_quad": 80}, m3)
     gen_p3(out, "small", {"Net_layer": [2, 8, 8, 1], "N_el_x": 3, "N_el_t": 2, "N_test_x": 3 * [4],

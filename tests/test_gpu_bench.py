@@ -63,6 +63,12 @@ def test_bench_driver_style_single_gpu_line():
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["windows"]) == 3
     assert out["cpu_baseline_vectorized"]["omp"]["OMP_PROC_BIND"] == "close"
     assert out["roofline_residual"]["bound"] == "hbm"
+    # the N = 1 line is the base of the driver's 1 -> 8 ratio on the scaled batch: both probes are there at N = 1 too
+    assert "extras_error" not in out, out.get("extras_error")
+    sc, wk = out["scaled_strong_64x64"], out["weak_scaling_probe"]
+    assert sc["elements"] == 4096 and sc["elements_per_gpu"] == 4096 and sc["it_per_s"] > 0 and sc["exchange"] == "none"
+    assert wk["elements"] == 256 and wk["elements_per_gpu"] == 256 and wk["it_per_s"] > 0
+    assert 0.5 < wk["it_per_s"] / out["value"] < 1.5, (wk, out["value"])    # at N = 1 the weak probe IS config 4 again
 
 
 def test_bench_default_rccl_exchange_with_a_one_rank_group():

@@ -271,3 +271,120 @@ def test_oracle_1d_per_element_test_function_counts():
         want = sum(float(np.mean(R[e, :n] ** 2)) for e, n in enumerate(counts))
         got = float(orag.loss_parts()[2])
         assert abs(got - want) <= 1e-13 * max(1.0, abs(want))
+
+
+# ---- var_form 2 of the 2-D class (P2:108-115) against reference-produced F_ext_total, by Green's identity ----------------
+# P2:108-115 integrates u against the SECOND derivatives of the test functions in reference coordinates, multiplied by the
+# element jacobian alone: neither the 1/Jx^2, 1/Jy^2 of the chain rule nor the element-edge terms of the second integration by
+# parts are there (the 1-D var_form 3 has its edge term, P1:89-91).  With the exact solution in place of the network,
+#   int_e u_xx v = (J/Jx^2) A_x - (Jy/Jx) E_x,   A_x = int int u phi_r'' phi_k,   E_x = int phi_k(eta) [u phi_r']_{xi=-1}^{xi=1} d eta
+# (v = phi_r(xi) phi_k(eta), phi(+-1) = 0), so the residual the restated form leaves against the reference's own F_ext_total is
+#   R = J (1 - 1/Jx^2) A_x + J (1 - 1/Jy^2) A_y + (Jy/Jx) E_x + (Jx/Jy) E_y
+# -- the edge terms alone on ONE element with Jx = Jy = 1 (fixture e1), the (1 - 1/J^2) defect on top of them on a 2 x 2 grid
+# (fixture e2).  A restatement with the chain-rule factors, a wrong sign or a wrong table would miss this by O(1).
+def _u_exact_2d_np(x, y):
+    return (0.1 * np.sin(2 * np.pi * x) + np.tanh(10 * x)) * np.sin(2 * np.pi * y)           # P2:300-302
+
+
+@pytest.mark.parametrize("tag", ["poisson2d_e1", "poisson2d_e2"])
+def test_2d_var_form_2_defect_against_reference_rhs(tag):
+    g = gold(tag)
+    a = p2_args(g, layers=[2, 5, 1])
+    o = O.OracleVPINN2D(*a, var_form=2)
+    o.neural_net = lambda X, theta=None: _exact_2d(X)
+    o.vectorized = True
+    o.loss_parts()
+    R = o.last["R"]                                             # [ex][ey][k][r] = U - F_ext_total
+    q = int(g["N_quad"])
+    xi, w = O.GaussLobattoJacobiWeights(q, 0, 0)
+    nt = 5
+    phi = O.Test_fcn(nt, xi[:, None])[:, :, 0]                   # [r][i]
+    d1, d2 = O.dTest_fcn(nt, xi[:, None])
+    d2 = d2[:, :, 0]
+    d1e = O.dTest_fcn(nt, np.array([[-1.0], [1.0]]))[0][:, :, 0]      # [r][edge]: phi_r'(-1), phi_r'(+1)
+    gx, gy = g["grid_x"], g["grid_y"]
+    worst, scale = 0.0, 0.0
+    for ex in range(len(gx) - 1):
+        for ey in range(len(gy) - 1):
+            Jx, Jy = (gx[ex + 1] - gx[ex]) / 2, (gy[ey + 1] - gy[ey]) / 2
+            J = Jx * Jy
+            x = gx[ex] + Jx * (xi + 1)
+            y = gy[ey] + Jy * (xi + 1)
+            U = _u_exact_2d_np(x[None, :], y[:, None])           # [j][i]
+            Ax = np.einsum("j,i,ji,ri,kj->kr", w, w, U, d2, phi)
+            Ay = np.einsum("j,i,ji,ri,kj->kr", w, w, U, phi, d2)
+            ux0, ux1 = _u_exact_2d_np(gx[ex], y), _u_exact_2d_np(gx[ex + 1], y)          # u on the two x-edges, [j]
+            uy0, uy1 = _u_exact_2d_np(x, gy[ey]), _u_exact_2d_np(x, gy[ey + 1])          # u on the two y-edges, [i]
+            Ex = np.einsum("j,kj,jr->kr", w, phi, ux1[:, None] * d1e[None, :, 1] - ux0[:, None] * d1e[None, :, 0])
+            Ey = np.einsum("i,ri,ik->kr", w, phi, uy1[:, None] * d1e[None, :, 1] - uy0[:, None] * d1e[None, :, 0])
+            want = J * (1 - 1 / Jx ** 2) * Ax + J * (1 - 1 / Jy ** 2) * Ay + (Jy / Jx) * Ex + (Jx / Jy) * Ey
+            worst = max(worst, np.abs(R[ex, ey] - want).max())
+            scale = max(scale, np.abs(want).max(), np.abs(g["F_ext_total"][ex, ey]).max())
+            if tag.endswith("e1"):
+                assert Jx == 1.0 and Jy == 1.0
+                assert np.abs(want - (Ex + Ey)).max() == 0.0     # nothing but the edge terms on the unit-jacobian element
+                assert np.abs(Ex).max() > 1.0                    # ... which are O(1): u = +-tanh(10) sin(2 pi y) on x = +-1
+    # (tolerance = the quadrature error of the 60-point rule on tanh(10 x): 1.4e-6 on the element of width 2, 1e-12 on width 1)
+    assert scale > 1.0 and worst < (1e-5 if tag.endswith("e1") else 1e-10) * scale, (worst, scale)
+    print(tag, "defect identity: worst", worst, "scale", scale)
+
+
+# ---- the AdvDiff forms (P3:161-174) against the reference's exact solution: the 801-term series of P3:416-445 with
+#      epsilon = 0.1 / pi (P3:41-42) solves u_t + V u_x = epsilon u_xx, and the right-hand side is zero (P3:180): fed in place of
+#      the network, the series must make `lossv` vanish under refinement of the rule / the grid -- with the exact epsilon only ----
+def _advdiff_series(X, trunc=800):
+    x, t = X[:, 0:1], X[:, 1:2]
+    D, V = 0.1 / np.pi, 1.0
+    p = torch.arange(0, trunc + 1.0, dtype=torch.float64).reshape(1, -1)
+    c0 = 16 * np.pi ** 2 * D ** 3 * V * torch.exp(V / D / 2 * (x - V * t / 2))
+    sgn = torch.where(p % 2 == 0, 1.0, -1.0)
+    c1 = np.sinh(V / D / 2) * torch.sum(sgn * 2 * p * torch.sin(p * np.pi * x) * torch.exp(-D * p ** 2 * np.pi ** 2 * t)
+                                        / (V ** 4 + 8 * (V * np.pi * D) ** 2 * (p ** 2 + 1) + 16 * (np.pi * D) ** 4 * (p ** 2 - 1) ** 2),
+                                        dim=-1, keepdim=True)
+    c2 = np.cosh(V / D / 2) * torch.sum(sgn * (2 * p + 1) * torch.cos((p + 0.5) * np.pi * x)
+                                        * torch.exp(-D * (2 * p + 1) ** 2 * np.pi ** 2 * t / 4)
+                                        / (V ** 4 + (V * np.pi * D) ** 2 * (8 * p ** 2 + 8 * p + 10)
+                                           + (np.pi * D) ** 4 * (4 * p ** 2 + 4 * p - 3) ** 2), dim=-1, keepdim=True)
+    return c0 * (c1 + c2)
+
+
+def _advdiff_lossv(vf, nex, net, q, eps, ntest=5):
+    from hp_vpinns_amd.drivers import advdiff
+    s = advdiff.setup(N_el_x=nex, N_el_t=net, N_test_x=ntest, N_test_t=ntest, N_quad=q, with_test_grid=False)
+    L = [2, 5, 1]
+    th = theta0(L, 1, extra=[eps])
+    o = O.OracleVPINNAdvDiff(s["XT_u_train"], s["u_train"], s["XT_f_train"], s["XT_quad_train"], s["WXT_quad_train"], s["T_quad"],
+                             s["WT_quad"], s["grid_x"], s["grid_t"], s["N_testfcn_total"], s["XT_u_train"], None, L,
+                             var_form=vf, init_params=th)
+    o.neural_net = lambda X, theta=None: _advdiff_series(X)
+    o.vectorized = True
+    return float(o.loss_parts()[2].detach())
+
+
+def test_advdiff_series_is_the_fixture_solution():
+    """The torch series used below IS the reference's u_ext: compared with the grid the reference's own function produced."""
+    g = gold("advdiff_default")
+    xs, ts = g["uext_x"], g["uext_t"][1:]                        # (t = 0 is the reference's special case u_initial, P3:442-443)
+    X = torch.as_tensor(np.stack(np.meshgrid(xs, ts), -1).reshape(-1, 2))
+    assert np.abs(_advdiff_series(X).numpy().reshape(len(ts), len(xs)) - g["uext_grid"][1:]).max() < 2e-5        # (sinh(V / 2D) c1 and cosh(V / 2D) c2 cancel to 1e-7 of their size: the order of summation shows at 9e-6 in the boundary layer)
+
+
+@pytest.mark.parametrize("vf", [0, 1])
+def test_exact_solution_annihilates_the_advdiff_variational_residual(vf):
+    """Measured here: var_form 0 (the strong-form integrand, satisfied point-wise) sits at the series' own round-off floor
+    (3e-13: sinh(V/2D) c1 and cosh(V/2D) c2 cancel to 1e-7 of their size) on every rule; var_form 1 (integrated by parts: exact
+    only up to the rule's error) falls 4.0e-4 -> 6.9e-10 -> 2.4e-12 from the reference's default 1 x 1 element / 10 x 10 points
+    to 4 x 2 elements of 20 x 20 points.  The coefficient training starts from (1.0, P3:63) leaves 5.0, one 5 % off 1.35e-5."""
+    eps = 0.1 / np.pi
+    default = _advdiff_lossv(vf, 1, 1, 10, eps)                  # P3:47-52: one element, 10 x 10 points, 5 x 5 test functions
+    coarse = _advdiff_lossv(vf, 4, 2, 10, eps)
+    fine = _advdiff_lossv(vf, 4, 2, 20, eps)
+    wrong = _advdiff_lossv(vf, 4, 2, 20, 1.0)
+    off5 = _advdiff_lossv(vf, 4, 2, 20, 1.05 * eps)
+    print("advdiff vf", vf, "lossv(exact series):", default, coarse, fine, "eps = 1:", wrong, "eps 5 % off:", off5)
+    if vf == 0:
+        assert max(default, coarse, fine) < 1e-11
+    else:
+        assert coarse < 1e-4 * default and fine < 1e-1 * coarse and fine < 1e-10
+    assert fine < 1e-10 * wrong, (fine, wrong)
+    assert off5 > 1e4 * fine                                     # the variational loss identifies the coefficient
