@@ -33,8 +33,19 @@ EXPORTS = [
     "hpv_eval_channels", "hpv_bench_residual",
     "hpv_set_collocation_shard", "hpv_rccl_unique_id", "hpv_rccl_connect", "hpv_rccl_selftest", "hpv_rccl_disconnect", "hpv_exchange_in_use",
     "hpv_rccl_available", "hpv_graphs_in_use", "hpv_updates_applied", "hpv_set_shared_element_kernels", "hpv_shared_element_kernels",
-    "hpv_kernel_variant", "hpv_build_info", "hpv_rccl_abandon", "hpv_bench_residual_checksums",
+    "hpv_kernel_variant", "hpv_build_info", "hpv_rccl_abandon", "hpv_bench_residual_checksums", "hpv_rule_advice",
 ]
+
+
+def rule_advice(device, dim, q, ntx, nty, n_elem_shard, exact_counts=False):
+    """hpv_rule_advice: (q_dev, nt_dev) -- the instantiated rule a shard's rule should be zero-weight padded to (q_dev == q: leave it
+    alone) and, in 1-D, the test-function count the device tables should have.  The limits are the launch functions' own."""
+    qd, nd = C.c_int(0), C.c_int(0)
+    rc = load().hpv_rule_advice(int(device), int(dim), int(q), int(ntx), int(nty), int(n_elem_shard), 1 if exact_counts else 0,
+                                C.byref(qd), C.byref(nd))
+    if rc:
+        raise HpvError(f"hpv_rule_advice({dim}, {q}, {ntx}, {nty}, {n_elem_shard}) returned {rc}")
+    return qd.value, nd.value
 
 
 class HpvConfig(C.Structure):
@@ -156,6 +167,7 @@ def load():
     lib.hpv_bench_residual_checksums.argtypes = [h, C.c_long, C.c_int, _dp]
     lib.hpv_kernel_variant.argtypes = [h, C.c_char_p, C.c_size_t]
     lib.hpv_build_info.argtypes = []
+    lib.hpv_rule_advice.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.hpv_build_info.restype = C.c_char_p
     _libs[path] = lib
     if path == LIB_PATH:

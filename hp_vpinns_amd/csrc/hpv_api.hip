@@ -1282,6 +1282,29 @@ const char* hpv_build_info(void) {
     });
     return info.c_str();
 }
+int hpv_rule_advice(int device, int dim, int q, int ntx, int nty, long n_elem_shard, int exact_counts, int* q_dev, int* nt_dev) {
+    if (!q_dev || !nt_dev || (dim != 1 && dim != 2) || q < 1 || ntx < 1 || n_elem_shard < 0) return -1;
+    *q_dev = q; *nt_dev = ntx;
+    int n_cus = 256;
+    hipDeviceProp_t prop;
+    if (device >= 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
+    else (void)hipGetLastError();
+    if (dim == 1) {                                   // kernels_tile.hip: 80 points / 60 test functions (P1:237-238)
+        if (q > 80 || ntx > 60) return 0;
+        if (q == 80) { *nt_dev = 60; return 0; }      // fewer test functions: the first 60, per-element counts
+        if (n_elem_shard <= hpv_rule1d_pad_max(q, n_cus) && n_elem_shard <= hpv_elem_resident_max(1, 80, n_cus)) { *q_dev = 80; *nt_dev = 60; }
+        return 0;
+    }
+    static const int rules[4][2] = {{10, 5}, {12, 6}, {16, 8}, {20, 10}};     // kernels_fused.hip (k_iter_small, FZ_SHAPES)
+    for (const auto& r : rules) {
+        const bool counts_ok = exact_counts ? (ntx == r[1] && nty == r[1]) : (ntx <= r[1] && nty <= r[1]);
+        if (q <= r[0] && counts_ok) {
+            if (q < r[0] && n_elem_shard <= hpv_elem_resident_max(2, r[0], n_cus)) *q_dev = r[0];
+            break;
+        }
+    }
+    return 0;
+}
 int hpv_updates_applied(hpv_handle h, long long* n) {
     if (!h || !n) return -1;
     unsigned long long v = 0;

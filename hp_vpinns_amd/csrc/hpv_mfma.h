@@ -12,6 +12,22 @@ bool hpv_wide_pick(HpvMfma* m, int H, int key, int act, int L);
 HPV_WIDE_WIDTHS(HPV_WIDE_DECL)
 #undef HPV_WIDE_DECL
 
+// Largest shard (elements) the element-resident whole-iteration kernel of a rule takes before the separate launches amortise the
+// per-element launch-once phases better; ONE definition for the launch functions (kernels_fused.hip, kernels_tile.hip) and for
+// hpv_rule_advice (the Python classes pad a smaller rule onto an instantiated one only while the kernel would take the shard).
+// q = points per direction of the instantiated rule, dim = 1 | 2.  Measured: scripts/elem_bench.py, scripts/grid_sweep.py,
+// scripts/rule1d_sweep.py (profiles/).
+inline long hpv_elem_resident_max(int dim, int q, int n_cus) {
+    if (dim == 1) return 65536;                     // k_iter_tile 80 / 60: the grid's own limit (rows of the gradient buffer)
+    if (q == 10) return 4L * n_cus - 1;             // k_iter_small / k_iter_tile 10x10
+    if (q == 12) return 3L * n_cus;                 // k_iter_fused, fewer than 16 tiles per element
+    if (q == 16) return 6L * n_cus;
+    return 1L << 40;                                // 20x20: every size
+}
+// Up to this many elements a 1-D rule smaller than 80 points is worth padding onto the 80 / 60 instantiation (beyond it the padded
+// problem -- up to 8x the points, 12x the test functions -- costs more than the separate launches on the rule as it is)
+inline long hpv_rule1d_pad_max(int q, int n_cus) { return (q >= 40 ? 8L : 2L) * n_cus; }
+
 // Returns nullptr (and a reason) when the network shape is not covered by the fast path.
 HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_store = true);
 void hpv_mfma_destroy(HpvMfma* m);

@@ -1523,11 +1523,11 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     // shapes other than the headline one: one workgroup per element pays the launch-once phases (staging, projection, epilogue:
     // ~7 us) per element -- on grids of many small elements the separate launches amortise them better (scripts/elem_bench.py:
     // 1 024 elements of 12x12 points 106 against 99 us, of 16x16 points 158 against 163; 256 elements 30.7 / 48.9 against 49.3 / 60.5)
-    if (!q20 && !small && n_elem > (long)(TPE < 16 ? 3 : 6) * m->n_cus) return false;
+    if (!q20 && !small && n_elem > hpv_elem_resident_max(2, pd.qx, m->n_cus)) return false;
     if (small) {
         // thousands of small elements: one workgroup per element pays staging / projection / epilogue per element, the separate
         // launches stream (scripts/grid_sweep.py: 1 024 elements 80.8 against 77.5 us, 4 096 elements 292 against 273)
-        if (n_elem >= 4L * m->n_cus && !m->iter_fused_force) return false;
+        if (n_elem > hpv_elem_resident_max(2, SM_QX, m->n_cus) && !m->iter_fused_force) return false;
         // batch layout [element points | pad to 16 | data points]; at most one boundary/data tile per workgroup
         const long npad = (n_elem * SM_NQ + 15) / 16 * 16;
         const bool has_data = dt && dt->n_data > 0;

@@ -654,7 +654,7 @@ bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double
                          (key == 200 || key == 220 || key == 221 || key == 222) && m->L <= 3;
     if (!shape1d && !shape2d) { TL_WHY(2); return false; }
     // (thousands of small 2-D elements: the separate launches stream, one workgroup per element does not -- scripts/grid_sweep.py)
-    if (shape2d && n_elem >= 4L * m->n_cus && !m->iter_fused_force) { TL_WHY(5); return false; }
+    if (shape2d && n_elem > hpv_elem_resident_max(2, 10, m->n_cus) && !m->iter_fused_force) { TL_WHY(5); return false; }
     const int waves = shape1d ? 6 : 8, nq = pd.qx * pd.qy, tpe = (nq + 15) / 16;
     // batch layout [element points | pad to 16 | data points]
     const long npad = (n_elem * nq + 15) / 16 * 16;

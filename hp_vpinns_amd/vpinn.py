@@ -64,13 +64,9 @@ def _tensor_rule(X_quad, W_quad):
     return xi, wx, yi, wy
 
 
-# Quadrature rules the element-resident whole-iteration kernels are instantiated for: (points per direction, largest test-function
-# count per direction).  2-D two-term forms: csrc/kernels_fused.hip (k_iter_small, FZ_SHAPES); 1-D: csrc/kernels_tile.hip.
-_RULES_2D = ((10, 5), (12, 6), (16, 8), (20, 10))
-_RULE_1D = (80, 60)
-# grids up to which the kernel of a rule runs one workgroup per element (256 CUs: csrc/kernels_fused.hip, kernels_tile.hip); beyond
-# that the separate launches take over and padding would only add points
-_RULE_PAD_MAX_ELEMS = {10: 1023, 12: 768, 16: 1536, 20: 1 << 30}
+# Quadrature rules the element-resident whole-iteration kernels are instantiated for, and the shard sizes up to which each of
+# them runs one workgroup per element, live in the LIBRARY (csrc/hpv_mfma.h: hpv_elem_resident_max, hpv_rule1d_pad_max -- the
+# same functions gate the launches); `_lib.rule_advice` (hpv_rule_advice) answers for this rank's shard on this rank's device.
 
 
 def _pad_rule(xi, w, q_dev):
@@ -84,17 +80,15 @@ def _pad_rule(xi, w, q_dev):
     return np.concatenate([xi, np.full(n, xi[-1])]), np.concatenate([w, np.zeros(n)])
 
 
-def _device_rule_2d(xi, wx, yi, wy, ntx, nty, n_elem, exact_counts=False, rules=_RULES_2D):
-    """The (possibly padded) 2-D rule for the device; `exact_counts`: only instantiations with exactly these test-function counts."""
+def _device_rule_2d(xi, wx, yi, wy, ntx, nty, n_elem_shard, device=0, exact_counts=False, only=None):
+    """The (possibly padded) 2-D rule for the device, as the library advises for a shard of `n_elem_shard` elements on `device`;
+    `exact_counts`: only instantiations with exactly these test-function counts; `only`: accept this device rule alone."""
     if xi.size != yi.size or os.environ.get("HPV_NO_RULE_PADDING"):
         return xi, wx, yi, wy
-    for q_dev, nt_max in rules:
-        counts_ok = (ntx == nt_max and nty == nt_max) if exact_counts else max(ntx, nty) <= nt_max
-        if xi.size <= q_dev and counts_ok:
-            if xi.size < q_dev and n_elem <= _RULE_PAD_MAX_ELEMS[q_dev]:
-                xi, wx = _pad_rule(xi, wx, q_dev)
-                yi, wy = _pad_rule(yi, wy, q_dev)
-            break
+    q_dev, _ = _lib.rule_advice(device, 2, xi.size, ntx, nty, n_elem_shard, exact_counts)
+    if q_dev > xi.size and (only is None or q_dev == only):
+        xi, wx = _pad_rule(xi, wx, q_dev)
+        yi, wy = _pad_rule(yi, wy, q_dev)
     return xi, wx, yi, wy
 
 
@@ -106,12 +100,29 @@ def _caller_globals(depth=2):
         return {}
 
 
+_logged_globals = set()
+
+
+def _note_global(name, v, ns):
+    """Say ONCE per (module, name) which value came from the caller's module globals: a wrapper module or a notebook that happens to
+    hold a numeric `LR` / `var_form` / ... would otherwise change the training silently (advisor, round 4).  HPV_QUIET_GLOBALS=1
+    silences it; passing the name as a keyword argument (or `module_globals=`) avoids the lookup."""
+    mod = ns.get("__name__", "?") if ns is not None else "?"
+    if (mod, name) in _logged_globals or os.environ.get("HPV_QUIET_GLOBALS"):
+        return
+    _logged_globals.add((mod, name))
+    shown = v if not isinstance(v, list) else "<list of %d entries>" % len(v)
+    print("hp_vpinns_amd: %s = %s taken from the module globals of %r (what the reference class reads; pass %s= to override)"
+          % (name, shown, mod, name), file=sys.stderr)
+
+
 def _resolve(value, name, ns, default, kinds):
     """keyword argument > the caller's module global of that name (what the reference class reads) > reference default."""
     if value is not None:
         return value
     v = ns.get(name) if ns is not None else None
     if isinstance(v, kinds) and not isinstance(v, bool):
+        _note_global(name, v, ns)
         return v
     return default
 
@@ -188,6 +199,7 @@ class _VPINNBase:
         for ns in (self._module_globals, caller_ns):
             lst = ns.get(name) if ns is not None else None
             if isinstance(lst, list):
+                _note_global(name, lst, ns)
                 return lst
         return getattr(self, name)
 
@@ -584,11 +596,7 @@ class VPINN1D(_VPINNBase):
         self.F_ext_total = np.zeros((self.Nelement, self.N_test, 1))
         for e, f in enumerate(Fe):
             self.F_ext_total[e, :f.size, 0] = f
-        # The element-resident 1-D kernel is instantiated for the reference's own rule (80 points, 60 test functions: P1:237-238).
-        # Fewer test functions (N_testfcn is a free hyper-parameter) run on it as a p-refinement with equal counts: the device
-        # gets the first 60 test functions (phi_k does not depend on how many follow), F padded with zeros, and the count per
-        # element -- the same mechanism as the ragged lists above.
-        self._N_test_dev = 60 if (self.xquad.size == 80 and self.N_test < 60) else self.N_test
+        self._N_test_dev = self.N_test                     # (may grow to the 80 / 60 kernel's 60 below, once the backend is known)
         self.grid = np.asarray(grid, dtype=np.float64)
         self.var_form, self.LR, self.lossb_weight = var_form, LR, lossb_weight
         self._total_record_arg = total_record
@@ -597,16 +605,31 @@ class VPINN1D(_VPINNBase):
             raise ValueError("grid must have Nelement+1 entries")
         self._create(layers, var_form, LR, lossb_weight, 1.0, init_params, seed, backend, device)
 
+        # The element-resident 1-D kernel (csrc/kernels_tile.hip) is instantiated for the reference's own rule, 80 points and 60 test
+        # functions (P1:237-238), for var_forms 1 / 2 on 20-wide networks of 2-4 hidden layers.  Where THAT kernel can run:
+        #   * fewer test functions (N_testfcn is a free hyper-parameter) ride as a p-refinement with equal counts -- the device gets
+        #     the first 60 test functions (phi_k does not depend on how many follow), F padded with zeros, the count per element;
+        #   * a smaller rule is padded with zero-weight points -- only while the library says the shard is small enough for one
+        #     workgroup per element to beat the separate launches on the rule as it is (hpv_rule_advice; advisor, round 4: an
+        #     h-refined grid of 10 k elements x 10 points must NOT run 8x the points and 12x the test functions).
+        # Everywhere else (generic backend, var_form 3, wider / deeper networks) the device sees the problem as it is.
         hidden = self.layers[1:-1]
-        pad_rule = (backend != "generic" and var_form in (1, 2) and self.xquad.size < _RULE_1D[0] and self.N_test <= _RULE_1D[1]
-                    and max(hidden) <= 20 and 2 <= len(hidden) <= 4 and not os.environ.get("HPV_NO_RULE_PADDING"))
-        if pad_rule:
-            self._N_test_dev = _RULE_1D[1]
+        tile_ok = (backend != "generic" and var_form in (1, 2) and max(hidden) <= 20 and 2 <= len(hidden) <= 4
+                   and self.xquad.size <= 80 and self.N_test <= 60)
+        pad_rule = False
+        if tile_ok:
+            eb, ee = shard_range(self.Nelement, self.rank, self.world)
+            q_dev, nt_dev = _lib.rule_advice(self.device, 1, self.xquad.size, self.N_test, 1, ee - eb)
+            pad_rule = q_dev > self.xquad.size and not os.environ.get("HPV_NO_RULE_PADDING")
+            if os.environ.get("HPV_FORCE_RULE_PADDING") and self.xquad.size < 80:     # (measurement knob: scripts/rule1d_sweep.py)
+                pad_rule, nt_dev = True, 60
+            if pad_rule or self.xquad.size == 80:
+                self._N_test_dev = nt_dev
 
         def populate():
             xi, wq = self.xquad.reshape(-1), self.wquad.reshape(-1)
             if pad_rule:
-                xi, wq = _pad_rule(xi, wq, _RULE_1D[0])
+                xi, wq = _pad_rule(xi, wq, 80)
             self.h.set_quadrature(xi, wq)
             edge = None
             nt = self._N_test_dev
@@ -707,7 +730,8 @@ class VPINN2D(_VPINNBase):
                 xi, wx, yi, wy = _tensor_rule(X_quad, W_quad)
                 hidden = self.layers[1:-1]
                 if backend != "generic" and var_form == 1 and max(hidden) <= 20 and 2 <= len(hidden) <= 3:
-                    xi, wx, yi, wy = _device_rule_2d(xi, wx, yi, wy, self.Ntestx, self.Ntesty, self.Nelementx * self.Nelementy)
+                    eb, ee = shard_range(self.Nelementx * self.Nelementy, self.rank, self.world)
+                    xi, wx, yi, wy = _device_rule_2d(xi, wx, yi, wy, self.Ntestx, self.Ntesty, ee - eb, self.device)
                 self.h.set_quadrature(xi, wx, yi, wy)
                 self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntesty, yi))
                 eb, ee = shard_range(self.Nelementx * self.Nelementy, self.rank, self.world)
@@ -779,8 +803,8 @@ class VPINNAdvDiff(_VPINNBase):
             xi, wx, ti, wt = _tensor_rule(XT_quad, W_quad)
             hidden = self.layers[1:-1]
             if backend != "generic" and max(hidden) <= 20 and 2 <= len(hidden) <= 3 and xi.size < 10:     # (the 10x10 / 5x5 tile kernel)
-                xi, wx, ti, wt = _device_rule_2d(xi, wx, ti, wt, self.Ntestx, self.Ntestt, self.Nelementx * self.Nelementt, exact_counts=True,
-                                                 rules=_RULES_2D[:1])
+                eb, ee = shard_range(self.Nelementx * self.Nelementt, self.rank, self.world)
+                xi, wx, ti, wt = _device_rule_2d(xi, wx, ti, wt, self.Ntestx, self.Ntestt, ee - eb, self.device, exact_counts=True, only=10)
             self.h.set_quadrature(xi, wx, ti, wt)
             self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntestt, ti))
             eb, ee = shard_range(self.Nelementx * self.Nelementt, self.rank, self.world)

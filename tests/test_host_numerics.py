@@ -219,7 +219,15 @@ def test_zero_weight_padding_of_quadrature_rules():
     assert [sel(q, q // 2, q // 2, 256) for q in (6, 10, 11, 12, 14, 16, 18, 20, 22)] == [10, 10, 12, 12, 16, 16, 20, 20, 22]
     assert sel(14, 9, 3, 256) == 20 and sel(14, 11, 3, 256) == 14          # the test-function counts must fit the instantiation too
     assert sel(7, 4, 4, 2048) == 7 and sel(14, 7, 7, 2048) == 14 and sel(18, 9, 9, 4096) == 20     # grids the kernel leaves to the separate launches
-    assert sel(8, 5, 5, 64, exact_counts=True, rules=((10, 5),)) == 10 and sel(8, 4, 5, 64, exact_counts=True, rules=((10, 5),)) == 8
+    assert sel(8, 5, 5, 64, exact_counts=True, only=10) == 10 and sel(8, 4, 5, 64, exact_counts=True, only=10) == 8
+    assert sel(11, 6, 6, 64, exact_counts=True, only=10) == 11                # (an instantiation the caller did not ask for)
+    # 1-D: the 80 / 60 tile kernel takes a smaller rule only on shards where one workgroup per element pays (hpv_rule1d_pad_max)
+    from hp_vpinns_amd._lib import rule_advice
+    assert rule_advice(0, 1, 80, 60, 1, 16) == (80, 60) and rule_advice(0, 1, 80, 12, 1, 16) == (80, 60)
+    assert rule_advice(0, 1, 40, 20, 1, 16) == (80, 60) and rule_advice(0, 1, 10, 5, 1, 512) == (80, 60)
+    assert rule_advice(0, 1, 10, 5, 1, 10000) == (10, 5)                     # h-refinement: 10 k elements of 10 points stay as they are
+    assert rule_advice(0, 1, 40, 20, 1, 2048) == (80, 60) and rule_advice(0, 1, 40, 20, 1, 4096) == (40, 20)
+    assert rule_advice(0, 1, 90, 20, 1, 4) == (90, 20) and rule_advice(0, 1, 60, 61, 1, 4) == (60, 61)
     xa, _ = GaussLobattoJacobiWeights(12, 0, 0)
     xb, wb = GaussLobattoJacobiWeights(14, 0, 0)
     assert _device_rule_2d(xa, _, xb, wb, 5, 5, 64)[0].size == 12           # different rules per direction: left alone
