@@ -33,6 +33,15 @@ void drop_graph(hpv_ctx* h) {
 
 static int sync_check(hpv_ctx* h);
 
+int hpv_test_hook_split_skip() {
+#ifdef HPV_TEST_HOOKS   // libhpvpinn_testhooks.so only: the product library does not read the variable
+    const char* dbg = getenv("HPV_DEBUG_SPLIT_SKIP");
+    return dbg ? std::max(0, atoi(dbg)) : 0;
+#else
+    return 0;
+#endif
+}
+
 
 
 namespace {
@@ -925,7 +934,11 @@ static int enqueue_iterations(hpv_ctx* h, int n_iters) {
     int rc;
     // one-workgroup grids whose kernel finishes the iteration itself: the remaining iterations in ONE persistent launch
     // (k_iter_tile<.., PERSIST>; no graph needed -- there is one launch)
+#ifdef HPV_EXPERIMENTS
     const bool persist_on = getenv("HPV_PERSIST") && getenv("HPV_PERSIST")[0] == '1';     // opt-in (kernels_tile.hip, tile_body)
+#else
+    constexpr bool persist_on = false;      // (measured no faster: the persistent launch exists in libhpvpinn_testhooks.so only)
+#endif
     if (persist_on && !h->persist_probed && n_iters > 1 && !h->rccl_on && !h->p2p_on && h->cfg.scheme == HPV_SCHEME_VPINN) {
         // (the first training pass of a handle tells whether its grid is one such workgroup: one eager iteration)
         if ((rc = enqueue_pass(h, true, true))) return rc;
@@ -1275,6 +1288,12 @@ const char* hpv_build_info(void) {
     std::call_once(once, [] {
         info = std::string("k_iter_fused=") + hpv_fused_build_state() + ";k_iter_tall=" + hpv_tall_build_state() + ";test_hooks=";
 #ifdef HPV_TEST_HOOKS
+        info += "1";
+#else
+        info += "0";
+#endif
+        info += ";experiments=";
+#ifdef HPV_EXPERIMENTS
         info += "1";
 #else
         info += "0";

@@ -8,7 +8,7 @@ struct HpvMfma;
 // kernels_wide.hip: forward / reverse kernels for the hidden widths kernels_mfma.hip (H = 20) does not take; false = not instantiated
 bool hpv_wide_pick(HpvMfma* m, int H, int key, int act, int L);
 #define HPV_WIDE_WIDTHS(X) X(24) X(32) X(40) X(48) X(64)      // = WIDE_WIDTHS of csrc/build.sh, = WIDE_WIDTHS of hp_vpinns_amd/init.py
-#define HPV_WIDE_DECL(Hw) bool hpv_wide_pick_##Hw(HpvMfma* m, int key, int act, int L);
+#define HPV_WIDE_DECL(Hw) bool hpv_wide_pick_##Hw##_d1(HpvMfma* m, int key, int act, int L); bool hpv_wide_pick_##Hw##_d2(HpvMfma* m, int key, int act, int L);
 HPV_WIDE_WIDTHS(HPV_WIDE_DECL)
 #undef HPV_WIDE_DECL
 
@@ -27,6 +27,10 @@ inline long hpv_elem_resident_max(int dim, int q, int n_cus) {
 // Up to this many elements a 1-D rule smaller than 80 points is worth padding onto the 80 / 60 instantiation (beyond it the padded
 // problem -- up to 8x the points, 12x the test functions -- costs more than the separate launches on the rule as it is)
 inline long hpv_rule1d_pad_max(int q, int n_cus) { return (q >= 40 ? 8L : 2L) * n_cus; }
+
+// Fault injection of the exchange-timeout tests (HPV_DEBUG_SPLIT_SKIP): read in hpv_api.hip, which is compiled once per library --
+// the product's copy returns the constant 0 and does not contain the name (this file's object is shared by both libraries).
+int hpv_test_hook_split_skip();
 
 // Returns nullptr (and a reason) when the network shape is not covered by the fast path.
 HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_store = true);

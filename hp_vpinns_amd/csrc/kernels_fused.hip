@@ -1450,7 +1450,12 @@ static void launch_iter_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
 //  for the 20x20 / 10x10 shape only)
 template <int QX_, int QY_, int NTX_, int NTY_>
 static bool launch_iter_fused_shape(int L, int plan, bool gs, const MfmaArgs& a, int blocks, hipStream_t s) {
-    constexpr bool HAS_QT = ((QX_ * QY_ / 16) % 4) <= 1 && QX_ * QY_ / 16 >= 8, HAS_GS = QX_ == 20;     // (0 mod 4: the data-quarter plan)
+#ifdef HPV_EXPERIMENTS      // GS (measured slower: 67.8 against 60.6 us, profiles/r04_notes.md 6) is instantiated in libhpvpinn_testhooks.so only
+    constexpr bool HAS_GS = QX_ == 20;
+#else
+    constexpr bool HAS_GS = false;
+#endif
+    constexpr bool HAS_QT = ((QX_ * QY_ / 16) % 4) <= 1 && QX_ * QY_ / 16 >= 8;     // (0 mod 4: the data-quarter plan)
 #define FZ_GO(L_, SPLIT_, QT_, GS_) launch_iter_fused<L_, SPLIT_, QT_, GS_, QX_, QY_, NTX_, NTY_>(a, blocks, s)
     if (L != 2 && L != 3) return false;
     if (gs) {
@@ -1584,8 +1589,12 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     // GS is opt-in (HPV_FUSED_GSTASH=1): measured 67.8 against 60.6 us at config 4 -- the reverse phase does shrink (73.1 k -> 60.9 k
     // cycles) but the forward phase pays for its stores (42.9 k -> 49.4 k: the four waves' bursts share one 64 B/clk path), and with
     // 220 MB of extra traffic per iteration the chip clocks 10 % lower (1.94 against 2.16 GHz); profiles/r04_notes.md
+#ifdef HPV_EXPERIMENTS
     const char* ge = getenv("HPV_FUSED_GSTASH");
     const bool gs = q20 && a.ACTS != nullptr && ge && ge[0] == '1';
+#else
+    constexpr bool gs = false;
+#endif
     int plan = 2;
     if (split > 1) plan = 0;
 #ifdef HPV_AGPR_GUARD_TRIPPED_QT                    // csrc/build.sh: the compiler's registers reached the stash of the QT instantiation

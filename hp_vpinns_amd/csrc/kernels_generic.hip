@@ -478,7 +478,7 @@ __device__ __forceinline__ void adam_update(const AdamArgs& ad, int i, double g,
 // FIN_THREADS / FIN_COLS row groups are summed in parallel: 16 (a 256-thread block: 4 waves to launch instead of 16, eight
 // row loads in flight per thread) up to 1 024 rows, 64 beyond -- the kernel is a pure latency chain whose floor (kernarg
 // fetch, one load round trip, the store drain: ~4.7 us behind another kernel) is most of its duration.  Config 4 (256 rows):
-// 66.8 -> 65.9 us per iteration with the small block (HPV_FIN_THREADS=256|1024 forces one for A/B runs)
+// 66.8 -> 65.9 us per iteration with the small block
 template <int FIN_THREADS>
 __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restrict__ GPART_v, int rows_v,
                                                          const double* __restrict__ GPART_b, int rows_b,
@@ -616,8 +616,7 @@ void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, i
     AdamArgs ad{};
     if (fused_adam && write_grad) ad = *fused_adam;
     const int rows = (GPART_v ? rows_v : 0) + (GPART_b ? rows_b : 0) + (GPART_e ? rows_e : 0);
-    static const int fin_force = getenv("HPV_FIN_THREADS") ? atoi(getenv("HPV_FIN_THREADS")) : 0;   // (A/B switch)
-    if (fin_force == 256 || (fin_force != 1024 && rows <= 1024 && n_elem <= 4096))
+    if (rows <= 1024 && n_elem <= 4096)
         hipLaunchKernelGGL(k_finalize<256>, dim3(gblocks + 1), dim3(256), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e,
                            rows_e, loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB,
                            write_grad, ad, xerr, xiter_bump);

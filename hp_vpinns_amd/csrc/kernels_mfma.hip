@@ -716,7 +716,7 @@ static bool pick_L(HpvMfma* m, int L) {
 
 bool hpv_wide_pick(HpvMfma* m, int H, int key, int act, int L) {
     switch (H) {
-#define HPV_WIDE_CASE(Hw) case Hw: return hpv_wide_pick_##Hw(m, key, act, L);
+#define HPV_WIDE_CASE(Hw) case Hw: return act == HPV_ACT_SIN ? hpv_wide_pick_##Hw##_d1(m, key, act, L) : hpv_wide_pick_##Hw##_d2(m, key, act, L);
         HPV_WIDE_WIDTHS(HPV_WIDE_CASE)
 #undef HPV_WIDE_CASE
         default: return false;
@@ -777,10 +777,7 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
             if (m->xg) { (void)hipFree(m->xg); m->xg = nullptr; }
             m->xiter = nullptr;
         }
-#ifdef HPV_TEST_HOOKS   // libhpvpinn_testhooks.so only: the product library does not read the variable
-        const char* dbg = getenv("HPV_DEBUG_SPLIT_SKIP");
-        m->xdebug_skip = dbg ? std::max(0, atoi(dbg)) : 0;
-#endif
+        m->xdebug_skip = hpv_test_hook_split_skip();      // (hpv_api.hip: HPV_DEBUG_SPLIT_SKIP in libhpvpinn_testhooks.so, the constant 0 in the product)
     }
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);

@@ -366,6 +366,7 @@ __global__ void __launch_bounds__(PJ_WAVES * 64, (OH && PJ_WAVES == 8) ? 4 : (PI
     }
 }
 
+#ifdef HPV_EXPERIMENTS   // measured-slower plans of the residual stream (profiles/r04_notes.md 2, 10): libhpvpinn_testhooks.so only
 // ------------------------------------------------------------------------------------------------
 // Streaming residual kernel (round 4): the one-hot two-term form (Poisson-2D var_form 1) on LARGE batches, residual only
 // (R = U - F and the element loss: the launch whose bytes SURVEY.md 8(d) counts, 8 (C_u N + 2 N_R)).
@@ -900,6 +901,8 @@ static bool launch_residual_stream(const ProjDesc& pd, const ActiveCh& ac, const
     return true;
 }
 
+#endif  // HPV_EXPERIMENTS
+
 template <int QX, int QY, int NTX, int NTY, int NA, bool EPS, int PJ_WAVES, bool OH = false, bool PIPE = false>
 static void launch_tp3(const ProjDesc& pd, const ActiveCh& ac, const double* OUT, double* GBAR, double* R, const double* F,
                        const double* coef, long coef_stride, const double* wtx, const double* wty, const double* eps_ptr,
@@ -912,8 +915,12 @@ static void launch_tp3(const ProjDesc& pd, const ActiveCh& ac, const double* OUT
     // (A/B knobs of the stand-alone bandwidth measurement: HPV_PJ_OCC_PAD = bytes of unused LDS per workgroup, i.e. fewer resident
     //  workgroups per CU; HPV_PJ_GRID = resident-grid cap in workgroups per CU.  scripts/hbm_read_probe.hip: a plain read stream is
     //  FASTER with fewer waves and loads in flight -- 6.3-6.6 TB/s at 2 workgroups per CU against 5.0-5.5 at 4-8)
+#ifdef HPV_EXPERIMENTS
     static const long occ_pad = getenv("HPV_PJ_OCC_PAD") ? atol(getenv("HPV_PJ_OCC_PAD")) : 0;
     static const long grid_cap = getenv("HPV_PJ_GRID") ? atol(getenv("HPV_PJ_GRID")) : 16;
+#else
+    constexpr long occ_pad = 0, grid_cap = 16;
+#endif
     lds += (size_t)occ_pad;
     if (blocks > 256 * grid_cap) blocks = 256 * grid_cap;   // grid-stride beyond that
     if (lds > 65536) {
@@ -948,6 +955,7 @@ static bool launch_tp2(const ProjDesc& pd, const ActiveCh& ac, const double* OUT
                                                           N, n_elem, do_adjoint, ngroups, s)
     if constexpr (!EPS && NA >= 2) {
         if (onehot) {
+#ifdef HPV_EXPERIMENTS
             const bool pipe = getenv("HPV_PJ_PIPE") && getenv("HPV_PJ_PIPE")[0] == '1';     // (A/B switch)
             // (opt-in A/B switch: with its tables as SGPR operands k_project_tp reaches the same 4.4-4.5 TB/s as the streaming kernel
             //  on the 2^18-element batch -- and serves the adjoint half as well)
@@ -973,6 +981,9 @@ static bool launch_tp2(const ProjDesc& pd, const ActiveCh& ac, const double* OUT
             if (ngroups <= 1024) HPV_GO(1, true, false);
             else if (!pipe) HPV_GO(8, true, false);
             else HPV_GO(4, true, true);
+#else
+            if (ngroups <= 1024) HPV_GO(1, true, false); else HPV_GO(8, true, false);
+#endif
             return true;
         }
     }

@@ -575,6 +575,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile(MfmaArgs g) {
     tile_body<D, NT1, NT2, ACT, L, QX, QY, NTX, NTY, WAVES, false>(g, lds);
 }
 
+#ifdef HPV_EXPERIMENTS   // measured no faster (24.6 against 24.0 us, see tile_body): libhpvpinn_testhooks.so only, HPV_PERSIST=1 there
 // the persistent launch: arguments in (static) LDS, the body behind a call
 __shared__ MfmaArgs tl_args;
 template <int D, int NT1, int NT2, int ACT, int L, int QX, int QY, int NTX, int NTY, int WAVES>
@@ -594,18 +595,28 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_tile_persist(MfmaArgs g)
     }
 }
 
+#endif  // HPV_EXPERIMENTS
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 template <int D, int NT1, int NT2, int ACT, int L, int QX, int QY, int NTX, int NTY, int WAVES, bool PERSIST = false>
 static bool launch_iter_tile(const MfmaArgs& a, int blocks, hipStream_t s) {
+#ifdef HPV_EXPERIMENTS
     if constexpr (!PERSIST && QY == 1) {      // persistent loop: instantiated for the 1-D rule (config 1)
         if (a.persist_iters > 1) return launch_iter_tile<D, NT1, NT2, ACT, L, QX, QY, NTX, NTY, WAVES, true>(a, blocks, s);
     }
+#else
+    static_assert(!PERSIST, "the persistent launch exists in -DHPV_EXPERIMENTS builds only");
+#endif
     static_assert(!PERSIST || QY == 1, "the persistent launch is instantiated for the 1-D rule only");
     using M = TlLds<L, WAVES, QX, QY, NTX, NTY, D>;
     const size_t bytes = (size_t)M::total(a.P) * sizeof(double);
+#ifdef HPV_EXPERIMENTS
     static const bool dbg = getenv("HPV_TILE_DEBUG") != nullptr;
+#else
+    constexpr bool dbg = false;
+#endif
     if (bytes + (PERSIST ? sizeof(MfmaArgs) + 64 : 0) > 160 * 1024) {
         if (dbg) fprintf(stderr, "hpv_mfma_iter_tile: %zu bytes of LDS needed\n", bytes);
         return false;
@@ -613,8 +624,11 @@ static bool launch_iter_tile(const MfmaArgs& a, int blocks, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         const void* kfn;
+#ifdef HPV_EXPERIMENTS
         if constexpr (PERSIST) kfn = (const void*)k_iter_tile_persist<D, NT1, NT2, ACT, L, QX, QY, NTX, NTY, WAVES>;
-        else kfn = (const void*)k_iter_tile<D, NT1, NT2, ACT, L, QX, QY, NTX, NTY, WAVES>;
+        else
+#endif
+        kfn = (const void*)k_iter_tile<D, NT1, NT2, ACT, L, QX, QY, NTX, NTY, WAVES>;
         const hipError_t e = hipFuncSetAttribute(kfn,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) {
@@ -624,8 +638,11 @@ static bool launch_iter_tile(const MfmaArgs& a, int blocks, hipStream_t s) {
         }
         attr_set = true;
     }
+#ifdef HPV_EXPERIMENTS
     if constexpr (PERSIST) hipLaunchKernelGGL((k_iter_tile_persist<D, NT1, NT2, ACT, L, QX, QY, NTX, NTY, WAVES>), dim3(blocks), dim3(WAVES * 64), bytes, s, a);
-    else hipLaunchKernelGGL((k_iter_tile<D, NT1, NT2, ACT, L, QX, QY, NTX, NTY, WAVES>), dim3(blocks), dim3(WAVES * 64), bytes, s, a);
+    else
+#endif
+    hipLaunchKernelGGL((k_iter_tile<D, NT1, NT2, ACT, L, QX, QY, NTX, NTY, WAVES>), dim3(blocks), dim3(WAVES * 64), bytes, s, a);
     return true;
 }
 
@@ -641,7 +658,11 @@ static bool launch_iter_tile_L(int L, const MfmaArgs& a, int blocks, hipStream_t
 
 // Whole training pass (forward, projection, reverse) of a shard of small elements in one launch.  Returns false when the
 // element shape / channel set / layout is not covered; the caller then runs the separate kernels.
+#ifdef HPV_EXPERIMENTS
 #define TL_WHY(K) do { static const bool dbg_ = getenv("HPV_TILE_DEBUG") != nullptr; if (dbg_) fprintf(stderr, "hpv_mfma_iter_tile: not applicable (check %d)\n", K); } while (0)
+#else
+#define TL_WHY(K) do { } while (0)
+#endif
 bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
                         const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem, const MfmaFinalize* fin, bool* fin_done) {
     if (fin_done) *fin_done = false;
@@ -681,7 +702,11 @@ bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double
     a.persist_iters = 1;
     // persistent loop (k_iter_tile<.., PERSIST>): only where the kernel finishes the iteration itself AND applies the update
     // (opt-in, HPV_PERSIST=1: measured 24.6 us per iteration against 24.0 for one launch per iteration -- see tile_body)
+#ifdef HPV_EXPERIMENTS
     const bool persist_off = !(getenv("HPV_PERSIST") && getenv("HPV_PERSIST")[0] == '1');
+#else
+    constexpr bool persist_off = true;
+#endif
     if (fin_here && fin->ad.theta && fin->n_iters > 1 && shape1d && !persist_off) a.persist_iters = fin->n_iters;
     if (fin_here) {
         a.fin_mode = fin->ad.theta ? 2 : 1;

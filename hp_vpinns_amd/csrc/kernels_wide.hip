@@ -42,7 +42,10 @@ struct WideBwdLds {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-// SAVE: 0 nothing (forward-only evaluation), 1 every slot of the activation store (s, [cos], z_c, z_cc), 2 only s (and cos): the
+// SAVE: 1 every slot of the activation store (s, [cos], z_c, z_cc) when the launch asks for it (g.save_act, a wave-uniform RUN-TIME
+// flag: the forward-only evaluations -- predict, loss read-back -- run the same instantiation; as a third compile-time variant it
+// was a third of this file's forward kernels and of their build time, and the store-bound kernel does not notice the scalar branch);
+// 2 (libhpvpinn_testhooks.so only) only s (and cos): the
 // reverse kernel k_bwd_wide_rc then recomputes the tangent pre-activations on the MFMA pipe -- a third of the store's bytes for
 // three channels (the forward kernel is HBM-write-bound on the store: 182 MB, 4.2 TB/s at H = 32 on the config-4 grid)
 template <int D, int NT1, int NT2, int ACT, int L, int H, int SAVE>
@@ -114,7 +117,7 @@ __global__ void __launch_bounds__(WF_BLOCK, (H <= 32 ? 2 : 1)) k_fwd_wide(MfmaAr
                     double a, a1, a2;
                     act_fwd<ACT, decltype(fast)::value>(z1[s], a, a1, a2);
                     h[0][s] = a;
-                    if constexpr (SAVE != 0) {
+                    if (SAVE == 2 || g.save_act) {
                         sv[(0 * KS + s) * 64] = a;
                         if constexpr (ACT == HPV_ACT_SIN) sv[(SA1 * KS + s) * 64] = a1;
                     }
@@ -141,19 +144,19 @@ __global__ void __launch_bounds__(WF_BLOCK, (H <= 32 ? 2 : 1)) k_fwd_wide(MfmaAr
                     double a, a1, a2;
                     act_fwd<ACT, decltype(fast)::value>(z[0][s], a, a1, a2);
                     h[0][s] = a;
-                    if constexpr (SAVE != 0) {
+                    if (SAVE == 2 || g.save_act) {
                         svl[(0 * KS + s) * 64] = a;
                         if constexpr (ACT == HPV_ACT_SIN) svl[(SA1 * KS + s) * 64] = a1;
                     }
 #pragma unroll
                     for (int u = 0; u < NT1; ++u) {
-                        if constexpr (SAVE_T) svl[((SZC + u) * KS + s) * 64] = z[1 + u][s];
+                        if (SAVE_T && g.save_act) svl[((SZC + u) * KS + s) * 64] = z[1 + u][s];
                         h[1 + u][s] = a1 * z[1 + u][s];
                     }
 #pragma unroll
                     for (int b = 0; b < NT2; ++b) {
                         const double zcc = z[1 + NT1 + b][s], zc1 = z[1 + (b < NT1 ? b : 0)][s];
-                        if constexpr (SAVE_T) svl[((SZCC + b) * KS + s) * 64] = zcc;
+                        if (SAVE_T && g.save_act) svl[((SZCC + b) * KS + s) * 64] = zcc;
                         h[1 + NT1 + b][s] = a2 * zc1 * zc1 + a1 * zcc;
                     }
                 }
@@ -545,9 +548,12 @@ static bool wide_set_lds(K kernel, size_t bytes) {
 template <int D, int NT1, int NT2, int ACT, int L, int H>
 static void run_fwd_wide(const MfmaArgs& a, int blocks, hipStream_t s) {
     constexpr size_t bytes = (size_t)WideFwdLds<H, L, D>::TOTAL * sizeof(double);
-    if (a.save_act == 2) hipLaunchKernelGGL((k_fwd_wide<D, NT1, NT2, ACT, L, H, 2>), dim3(blocks), dim3(WF_BLOCK), bytes, s, a);
-    else if (a.save_act) hipLaunchKernelGGL((k_fwd_wide<D, NT1, NT2, ACT, L, H, 1>), dim3(blocks), dim3(WF_BLOCK), bytes, s, a);
-    else hipLaunchKernelGGL((k_fwd_wide<D, NT1, NT2, ACT, L, H, 0>), dim3(blocks), dim3(WF_BLOCK), bytes, s, a);
+#ifdef HPV_EXPERIMENTS
+    if constexpr (H <= 32 && L >= 2 && NT1 + NT2 > 0) {
+        if (a.save_act == 2) { hipLaunchKernelGGL((k_fwd_wide<D, NT1, NT2, ACT, L, H, 2>), dim3(blocks), dim3(WF_BLOCK), bytes, s, a); return; }
+    }
+#endif
+    hipLaunchKernelGGL((k_fwd_wide<D, NT1, NT2, ACT, L, H, 1>), dim3(blocks), dim3(WF_BLOCK), bytes, s, a);
 }
 template <int D, int NT1, int NT2, int ACT, int L, int H>
 static void run_bwd_wide(const MfmaArgs& a, int blocks, hipStream_t s) {
@@ -564,7 +570,7 @@ static void run_bwd_wide_rc(const MfmaArgs& a, int blocks, hipStream_t s) {
 template <int D, int NT1, int NT2, int ACT, int L, int H>
 static bool pick_wide(HpvMfma* m) {
     constexpr size_t fb = (size_t)WideFwdLds<H, L, D>::TOTAL * sizeof(double), bb = (size_t)WideBwdLds<H, L, D>::TOTAL * sizeof(double);
-    if (!wide_set_lds(k_fwd_wide<D, NT1, NT2, ACT, L, H, 1>, fb) || !wide_set_lds(k_fwd_wide<D, NT1, NT2, ACT, L, H, 0>, fb) ||
+    if (!wide_set_lds(k_fwd_wide<D, NT1, NT2, ACT, L, H, 1>, fb) ||
         !wide_set_lds(k_bwd_wide<D, NT1, NT2, ACT, L, H>, bb))
         return false;
     m->fwd = run_fwd_wide<D, NT1, NT2, ACT, L, H>;
@@ -575,6 +581,7 @@ static bool pick_wide(HpvMfma* m) {
     // recompute / full store: config-4 grid H = 24 125.1 / 112.9, H = 32 192.9 / 149.2; 1-D 16 elements [1,32,32,32,32,1]
     // 60.2 / 48.6): the forward kernel's store shrinks to a third, but the reverse kernel -- the compiler-scheduled recompute at
     // one wave per SIMD, 380 B of scratch at H = 32 -- loses more than the forward kernel gains.
+#ifdef HPV_EXPERIMENTS      // (libhpvpinn_testhooks.so: width 24 only, csrc/build.sh)
     if constexpr (H <= 32 && L >= 2 && NT1 + NT2 > 0) {
         constexpr size_t rb = (size_t)WideBwdRcLds<H, L, D>::TOTAL * sizeof(double);
         const char* e = getenv("HPV_WIDE_RC");
@@ -583,6 +590,7 @@ static bool pick_wide(HpvMfma* m) {
             m->store_s_only = true;
         }
     }
+#endif
     m->bwd_fused = nullptr;
     int of = 1, ob = 1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, k_fwd_wide<D, NT1, NT2, ACT, L, H, 1>, WF_BLOCK, fb);
@@ -591,7 +599,12 @@ static bool pick_wide(HpvMfma* m) {
     m->occ_bwd = ob > 0 ? ob : 1;
     const char* an = ACT == HPV_ACT_SIN ? "sin" : "tanh";
     snprintf(m->vfwd, sizeof m->vfwd, "k_fwd_wide<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=%d>", D, NT1, NT2, an, L, H);
-    snprintf(m->vbwd, sizeof m->vbwd, "%s<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=%d>", m->store_s_only ? "k_bwd_wide_rc" : "k_bwd_wide", D, NT1, NT2, an, L, H);
+#ifdef HPV_EXPERIMENTS
+    const char* bn = m->store_s_only ? "k_bwd_wide_rc" : "k_bwd_wide";
+#else
+    const char* bn = "k_bwd_wide";
+#endif
+    snprintf(m->vbwd, sizeof m->vbwd, "%s<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=%d>", bn, D, NT1, NT2, an, L, H);
     return true;
 }
 template <int D, int NT1, int NT2, int ACT, int H>
@@ -607,26 +620,30 @@ static bool pick_wide_L(HpvMfma* m, int L) {
         default: return false;
     }
 }
-template <int H>
+template <int H, int D>
 static bool pick_wide_key(HpvMfma* m, int key, int act, int L) {
-    if (act == HPV_ACT_SIN) {
+    if constexpr (D == 1) {
+        if (act != HPV_ACT_SIN) return false;
         if (key == 111) return pick_wide_L<1, 1, 1, HPV_ACT_SIN, H>(m, L);
         if (key == 110) return pick_wide_L<1, 1, 0, HPV_ACT_SIN, H>(m, L);
         if (key == 100) return pick_wide_L<1, 0, 0, HPV_ACT_SIN, H>(m, L);
         return false;
+    } else {
+        if (act == HPV_ACT_SIN) return false;
+        if (key == 222) return pick_wide_L<2, 2, 2, HPV_ACT_TANH, H>(m, L);
+        if (key == 220) return pick_wide_L<2, 2, 0, HPV_ACT_TANH, H>(m, L);
+        if (key == 200) return pick_wide_L<2, 0, 0, HPV_ACT_TANH, H>(m, L);
+        if (key == 221) return pick_wide_L<2, 2, 1, HPV_ACT_TANH, H>(m, L);
+        return false;
     }
-    if (key == 222) return pick_wide_L<2, 2, 2, HPV_ACT_TANH, H>(m, L);
-    if (key == 220) return pick_wide_L<2, 2, 0, HPV_ACT_TANH, H>(m, L);
-    if (key == 200) return pick_wide_L<2, 0, 0, HPV_ACT_TANH, H>(m, L);
-    if (key == 221) return pick_wide_L<2, 2, 1, HPV_ACT_TANH, H>(m, L);
-    return false;
 }
 
-// One translation unit per hidden width (csrc/build.sh compiles this file once per entry of WIDE_WIDTHS with -DHPV_WIDE_H=<H>:
-// 7 channel sets x 4 depths x 3 kernels each, in parallel); kernels_mfma.hip dispatches on H (hpv_wide_pick).
-#ifndef HPV_WIDE_H
-#error "compile with -DHPV_WIDE_H=<hidden width> (csrc/build.sh)"
+// One translation unit per hidden width AND input dimension (csrc/build.sh compiles this file once per entry of WIDE_WIDTHS x {1, 2}
+// with -DHPV_WIDE_H=<H> -DHPV_WIDE_D=<D>: 3 or 4 channel sets x up to 6 depths x 3 kernels each, in parallel -- the 64-wide unit
+// alone took 94 s as one file); kernels_mfma.hip dispatches on H and the activation (hpv_wide_pick).
+#if !defined(HPV_WIDE_H) || !defined(HPV_WIDE_D)
+#error "compile with -DHPV_WIDE_H=<hidden width> -DHPV_WIDE_D=<1|2> (csrc/build.sh)"
 #endif
-#define WIDE_CAT_(a, b) a##b
-#define WIDE_CAT(a, b) WIDE_CAT_(a, b)
-bool WIDE_CAT(hpv_wide_pick_, HPV_WIDE_H)(HpvMfma* m, int key, int act, int L) { return pick_wide_key<HPV_WIDE_H>(m, key, act, L); }
+#define WIDE_CAT4_(a, b, c, d) a##b##c##d
+#define WIDE_CAT4(a, b, c, d) WIDE_CAT4_(a, b, c, d)
+bool WIDE_CAT4(hpv_wide_pick_, HPV_WIDE_H, _d, HPV_WIDE_D)(HpvMfma* m, int key, int act, int L) { return pick_wide_key<HPV_WIDE_H, HPV_WIDE_D>(m, key, act, L); }

@@ -58,17 +58,29 @@ def test_missing_library_raises(tmp_path, monkeypatch):
 
 
 def test_build_info_and_test_hooks_live_in_their_own_library():
-    """The fault-injection knobs exist only in libhpvpinn_testhooks.so (-DHPV_TEST_HOOKS): the product library reports
-    test_hooks=0 and does not even contain the names of the variables (verdict round 3, weak 9)."""
+    """The fault-injection knobs AND every measured-slower kernel variant kept as evidence exist only in libhpvpinn_testhooks.so
+    (-DHPV_TEST_HOOKS -DHPV_EXPERIMENTS): the product library reports test_hooks=0 / experiments=0, does not even contain the
+    names of those variables, and reads no more than a dozen environment switches in all (verdict round 4, item 5)."""
+    import re
     from hp_vpinns_amd import _lib
     bi = _lib.build_info()
-    assert set(bi) == {"k_iter_fused", "k_iter_tall", "test_hooks"} and bi["test_hooks"] == "0"
+    assert set(bi) == {"k_iter_fused", "k_iter_tall", "test_hooks", "experiments"} and bi["test_hooks"] == "0" and bi["experiments"] == "0"
     assert bi["k_iter_fused"] in ("ok", "no-quarter-tile", "absent") and bi["k_iter_tall"] in ("ok", "no-quarter-tile", "absent")
     prod = open(_lib.LIB_PATH, "rb").read()
-    assert b"HPV_DEBUG_SPLIT_SKIP" not in prod and b"HPV_TEST_RCCL_FAIL" not in prod
+    moved = [b"HPV_DEBUG_SPLIT_SKIP", b"HPV_TEST_RCCL_FAIL", b"HPV_TEST_RCCL_CONNECT_DELAY_MS", b"HPV_PERSIST", b"HPV_PJ_PIPE",
+             b"HPV_PJ_STREAM", b"HPV_PJ_DMA", b"HPV_PJ_GRID", b"HPV_PJ_OCC_PAD", b"HPV_FUSED_GSTASH", b"HPV_WIDE_RC", b"HPV_TILE_DEBUG",
+             b"HPV_DEBUG_READ_STORE", b"HPV_DEBUG_READ_CHANNELS", b"HPV_FIN_THREADS"]
+    for name in moved:
+        assert name not in prod, name
+    for kern in (b"k_residual_stream", b"k_residual_dma", b"k_residual_wdma", b"k_iter_tile_persist", b"k_bwd_wide_rc"):
+        assert kern not in prod, kern
+    switches = sorted(set(re.findall(rb"HPV_[A-Z0-9_]{3,}", prod)))
+    assert len(switches) <= 12, switches                 # README.md, "environment switches of libhpvpinn.so"
     assert os.path.exists(_lib.TEST_HOOKS_LIB_PATH)
     hooks = open(_lib.TEST_HOOKS_LIB_PATH, "rb").read()
-    assert b"HPV_DEBUG_SPLIT_SKIP" in hooks and b"HPV_TEST_RCCL_FAIL" in hooks
+    for name in (b"HPV_DEBUG_SPLIT_SKIP", b"HPV_TEST_RCCL_FAIL", b"HPV_PERSIST", b"HPV_PJ_STREAM", b"HPV_FUSED_GSTASH", b"HPV_WIDE_RC",
+                 b"k_residual_stream", b"k_iter_tile_persist", b"k_bwd_wide_rc"):
+        assert name in hooks, name
     with _lib.library(_lib.TEST_HOOKS_LIB_PATH) as lib:
-        assert _lib.build_info(lib)["test_hooks"] == "1"
+        assert _lib.build_info(lib)["test_hooks"] == "1" and _lib.build_info(lib)["experiments"] == "1"
     assert _lib.build_info()["test_hooks"] == "0"          # (back on the product library)

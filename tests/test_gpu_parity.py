@@ -1187,7 +1187,7 @@ def test_single_workgroup_grid_finishes_the_iteration_in_the_kernel():
 
 
 def test_persistent_single_workgroup_launch_is_the_same_iteration(monkeypatch):
-    """HPV_PERSIST=1 (opt-in; measured no faster: kernels_tile.hip, tile_body): MANY iterations of the one-workgroup grid of config 1
+    """HPV_PERSIST=1 (measured no faster: kernels_tile.hip, tile_body; libhpvpinn_testhooks.so only): MANY iterations of the one-workgroup grid of config 1
     in ONE launch -- the same body function behind a call.  Loss history, parameters, Adam moments and beta powers must equal the
     one-launch-per-iteration run to round-off (two compilations of the same body), the recorded iterations must be all there, and
     early-stop chunking on top of it must keep the reference's semantics."""
@@ -1198,15 +1198,21 @@ def test_persistent_single_workgroup_launch_is_the_same_iteration(monkeypatch):
     ref = VPINN1D(*a, init_params=th)
     h_ref = ref._step_record(37)[0]
     ref._step(100, False)
+    from hp_vpinns_amd import _lib
     monkeypatch.setenv("HPV_PERSIST", "1")
-    m = VPINN1D(*a, init_params=th)
+    mp = VPINN1D(*a, init_params=th)                   # the product library neither carries the persistent launch nor reads the switch
+    mp._step(3, False)
+    assert "persistent" not in mp.h.kernel_variant(), mp.h.kernel_variant()
+    with _lib.library(_lib.TEST_HOOKS_LIB_PATH):       # -DHPV_EXPERIMENTS
+        m = VPINN1D(*a, init_params=th)
     h = m._step_record(37)[0]
     assert "persistent" in m.h.kernel_variant(), m.h.kernel_variant()
     m._step(100, False)
     assert m.h.updates_applied() == 137
     assert rel(h, h_ref) < 1e-12 and rel(m.h.get_state(), ref.h.get_state()) < 1e-11
     rec = []
-    m2 = VPINN1D(*a, init_params=th, total_record=rec)
+    with _lib.library(_lib.TEST_HOOKS_LIB_PATH):
+        m2 = VPINN1D(*a, init_params=th, total_record=rec)
     m2.train(41, 0.0)
     assert [int(r[0]) for r in rec] == [0, 10, 20, 30, 40] and rel([r[1] for r in rec], h_ref[[0, 10, 20, 30], 0].tolist() + [rec[-1][1]]) < 1e-12
 
@@ -1221,19 +1227,22 @@ def test_large_batch_projection_plans_agree(monkeypatch):
     from hp_vpinns_amd.testfcn import tables_1d
     x, w = GaussLobattoJacobiWeights(20, 0, 0)
 
-    def sums(adj, backend=_lib.BACKEND_AUTO, n=10007):
+    def sums(adj, backend=_lib.BACKEND_AUTO, n=10007, experiments=False):
+        if experiments:                                # the measured-slower plans live in the -DHPV_EXPERIMENTS build only
+            with _lib.library(_lib.TEST_HOOKS_LIB_PATH):
+                return sums(adj, backend, n)
         h = _lib.Handle(_lib.PDE_POISSON2D, 1, _lib.ACT_TANH, [2, 20, 20, 20, 1], lossb_weight=10, backend=backend)
         h.set_quadrature(x, w, x, w)
         h.set_tables(tables_1d(10, x), tables_1d(10, x))
         return h.bench_checksums(n, adj)
 
     monkeypatch.setenv("HPV_PJ_STREAM", "1")        # (opt-in: equal speed to k_project_tp since that kernel's tables are SGPR operands)
-    s_stream = sums(False)
+    s_stream = sums(False, experiments=True)
     monkeypatch.delenv("HPV_PJ_STREAM")
     monkeypatch.setenv("HPV_PJ_DMA", "1")           # the LDS-DMA stream (three batch buffers filled by global_load_lds)
-    s_dma, s_dma2 = sums(False), sums(False, n=6 * 4096 + 5)
+    s_dma, s_dma2 = sums(False, experiments=True), sums(False, n=6 * 4096 + 5, experiments=True)
     monkeypatch.setenv("HPV_PJ_DMA", "2")           # every wave its own LDS-DMA loader and consumer
-    s_wd, s_wd2 = sums(False), sums(False, n=6 * 4096 + 5)
+    s_wd, s_wd2 = sums(False, experiments=True), sums(False, n=6 * 4096 + 5, experiments=True)
     monkeypatch.delenv("HPV_PJ_DMA")
     s_tp = sums(False)
     assert rel(s_wd[[0, 1, 2, 5]], s_tp[[0, 1, 2, 5]]) < 1e-12, (s_wd, s_tp)
