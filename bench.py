@@ -107,6 +107,50 @@ def cpu_baseline_B(setup, theta, iters, windows=3, sweep=(8, 32, 64, 128)):
                       "baseline B of BASELINE.md); host has %d logical cpus" % (windows, iters, ncpu)}
 
 
+def measure_traffic(kernel_substr, timeout_s=240):
+    """HBM bytes per launch of the kernel whose name contains `kernel_substr`, measured NOW: two rocprofv3 passes (FETCH_SIZE and
+    WRITE_SIZE do not fit one pass on gfx950: MI355X_MICROARCH.md, "rocprofv3 PMC slots"; counters in their own runs with
+    --kernel-trace only) over a short child run of this script, corrected as that guide's HBM section prescribes (FETCH_SIZE
+    counts 64 B per 128-B request of a wide coalesced read: x 2; both counters are in KB).  -> (bytes, detail) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="hpv_pmc_", dir="/tmp")
+    per = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
+                   os.path.abspath(__file__), "--traffic-child", "--no-pmc", "--no-extras", "--no-cpu-baseline", "--no-residual-roofline"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (ctr, r.returncode, (r.stderr or r.stdout)[-200:])
+            tot, disp = 0.0, set()
+            for row in csv.DictReader(open(files[0])):
+                if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                    tot += float(row["Counter_Value"])
+                    disp.add(row["Dispatch_Id"])
+            if not disp:
+                return None, "no dispatch of %s in the %s pass" % (kernel_substr, ctr)
+            per[ctr] = (tot / len(disp), len(disp))
+    except Exception as e:  # noqa: BLE001 -- the measurement must never take the bench line down
+        return None, "%s: %s" % (type(e).__name__, str(e)[:200])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    by = (2.0 * per["FETCH_SIZE"][0] + per["WRITE_SIZE"][0]) * 1024.0
+    return by, {"FETCH_SIZE_KB_per_launch": per["FETCH_SIZE"][0], "WRITE_SIZE_KB_per_launch": per["WRITE_SIZE"][0],
+                "launches_profiled": per["FETCH_SIZE"][1], "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024"}
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -129,6 +173,8 @@ def main():
                     help="BASELINE.md section 3 protocol: A 5 x 20, B 5 x 200 iterations, median of the windows (minutes)")
     ap.add_argument("--l2-iters", type=int, default=40000, help="total Adam iterations before the L2 error is evaluated")
     ap.add_argument("--residual-elems", type=int, default=1 << 18)
+    ap.add_argument("--no-pmc", action="store_true", help="roofline.traffic from profiles/traffic.json instead of two rocprofv3 --pmc passes of this run")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # the short run the --pmc passes profile
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -207,6 +253,10 @@ def main():
         return [one_window(m, steps) for _ in range(windows)], n_warm
 
     model = poisson2d.build_model(s, LAYERS, var_form=1, init_params=theta, backend=args.backend, device=local_rank)
+    if args.traffic_child:      # (under rocprofv3 --pmc: 64 iterations of the same model through the same graphs, nothing else)
+        model._step(64, False)
+        model.h.sync()
+        return
     wins, n_warm = timed_windows(model, args.warmup, args.steps)
     dt = _median(wins)
     n_its_done = n_warm + len(wins) * args.steps
@@ -335,15 +385,24 @@ def main():
         kernels = {"mlp_fwd": (ktime["mlp_fwd"], C * G * N_local),
                    "mlp_bwd": (ktime["mlp_bwd"], 2 * C * G * N_local + (proj_flops if proj_in_bwd else 0))}
     dom = max(kernels, key=lambda k: kernels[k][0])
+    # roofline.traffic: measured in THIS run when rocprofv3 is there (two --pmc passes of a short child run, ~20 s each), so that the
+    # line notices a traffic regression; otherwise the committed table with its label
+    measured, mdetail = (None, "--no-pmc") if (args.no_pmc or world != 1) else measure_traffic(
+        "k_iter_fused" if whole_iter_fused else ("k_bwd" if dom == "mlp_bwd" else "k_fwd"))
 
     def roof(k):
         ms, fl = kernels[k]
         tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         key = "iter_fused" if whole_iter_fused else k
+        if k == dom and measured is not None:
+            tr, src = measured, "measured in this run"
+        else:
+            tr = traffic_tab.get(key) if world == 1 else None
+            src = ("profiles/traffic.json (rocprofv3 --pmc passes of an earlier run of this kernel, %s); not measured in this run (%s)"
+                   % (traffic_tab.get("_measured_at", "commit unknown"), mdetail if isinstance(mdetail, str) else "other kernel")) if world == 1 else None
         return {"kernel": k, "bound": "mfma", "achieved": tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / PEAK_FP64_TFLOPS, "traffic": traffic_tab.get(key) if world == 1 else None,
-                "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc passes of an earlier run of this kernel, %s); not "
-                                   "measured in this run" % traffic_tab.get("_measured_at", "commit unknown")) if world == 1 else None,
+                "frac": tf / PEAK_FP64_TFLOPS, "traffic": tr, "traffic_source": src,
+                "traffic_detail": mdetail if (k == dom and measured is not None) else None,
                 "flops_per_launch": fl, "avg_ms": ms}
     # whole-iteration algorithmic HBM bytes (fused ideal): coordinates in, F in, Adam state in/out
     ideal_bytes = 8 * (2 * N_local + n_elem_local * 100 + 7 * 921)

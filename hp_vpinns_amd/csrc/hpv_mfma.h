@@ -24,9 +24,11 @@ inline long hpv_elem_resident_max(int dim, int q, int n_cus) {
     if (q == 16) return 6L * n_cus;
     return 1L << 40;                                // 20x20: every size
 }
-// Up to this many elements a 1-D rule smaller than 80 points is worth padding onto the 80 / 60 instantiation (beyond it the padded
-// problem -- up to 8x the points, 12x the test functions -- costs more than the separate launches on the rule as it is)
-inline long hpv_rule1d_pad_max(int q, int n_cus) { return (q >= 40 ? 8L : 2L) * n_cus; }
+// Up to this many elements a 1-D rule smaller than 80 points is worth padding onto the 80 / 60 instantiation: while every element
+// has a CU to itself the padded kernel runs 27-29 us per iteration whatever the rule (against 29-42 us on the separate launches);
+// with two workgroups per CU it takes 51 us and loses to the rule as it is below 56 points (32-47 us), beyond that it scales with
+// the padded work: 1 432 us against 191 us at 16 384 elements of 10 points (profiles/r05_rule1d_sweep.md)
+inline long hpv_rule1d_pad_max(int q, int n_cus) { return (q >= 56 ? 2L : 1L) * n_cus; }
 
 // Fault injection of the exchange-timeout tests (HPV_DEBUG_SPLIT_SKIP): read in hpv_api.hip, which is compiled once per library --
 // the product's copy returns the constant 0 and does not contain the name (this file's object is shared by both libraries).

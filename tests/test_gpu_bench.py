@@ -48,7 +48,7 @@ def test_bench_two_ranks_self_launch_on_one_gpu():
 
 
 def test_bench_driver_style_single_gpu_line():
-    out = _run_bench(["--steps", "20", "--warmup", "5", "--l2-iters", "2000", "--residual-elems", "16384"])
+    out = _run_bench(["--steps", "20", "--warmup", "5", "--l2-iters", "2000", "--residual-elems", "16384", "--cpu-iters", "1"])
     assert out["n_gpus"] == 1 and out["steps"] == 20 and out["config"]["pass_structure"] == "whole-iteration"
     bi = out["config"]["build"]
     assert bi["test_hooks"] == "0" and bi["k_iter_fused"] in ("ok", "no-quarter-tile")
@@ -59,6 +59,10 @@ def test_bench_driver_style_single_gpu_line():
     assert t["max_it_per_s"] / t["min_it_per_s"] < 1.25, t         # clocks have ramped: the windows agree
     r = out["roofline"]
     assert r["bound"] == "mfma" and 0.2 < r["frac"] < 1.0 and r["traffic_source"]
+    import shutil
+    if shutil.which("rocprofv3"):      # measured in the run (two --pmc passes of a short child run), not read from the committed table
+        assert r["traffic_source"] == "measured in this run", r["traffic_source"]
+        assert 1.5e6 < r["traffic"] < 8e6 and r["traffic_detail"]["launches_profiled"] >= 64, r     # 1.9 MB algorithmic; 5.0 MB in round 4
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["windows"]) == 3
     assert out["cpu_baseline_vectorized"]["omp"]["OMP_PROC_BIND"] == "close"
@@ -79,7 +83,7 @@ def test_bench_default_rccl_exchange_with_a_one_rank_group():
     sk.bind(("127.0.0.1", 0))
     port = sk.getsockname()[1]
     sk.close()
-    out = _run_bench(["--steps", "16", "--warmup", "8", "--l2-iters", "600", "--no-cpu-baseline", "--no-residual-roofline"],
+    out = _run_bench(["--steps", "16", "--warmup", "8", "--l2-iters", "600", "--no-cpu-baseline", "--no-residual-roofline", "--no-pmc"],
                      {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "HPV_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1",
                       "MASTER_PORT": str(port)})
     cfg = out["config"]

@@ -2,7 +2,11 @@
 var_form (P1:231-240, P2:280-286, P3:43-54) -- through the DEFAULT dispatch, against the same problem on the library's generic VALU
 kernels (backend="generic": one plain code path, no shape-specific kernel, no rule padding).  The dispatch surface grew a lot in
 round 4 (element shapes x run-time counts x padded rules x plans x grid-size policies); this test walks it with combinations no other
-test names.  Loss triple, gradient and three Adam iterations must agree to round-off."""
+test names.  Loss triple, gradient and three Adam iterations must agree to round-off.
+
+Every FOURTH case of each sweep is checked against the CPU ORACLE instead (oracle/vpinn_oracle.py, vectorised: autograd double
+backward of the restated TF1 graph) -- loss triple, gradient, residuals and one TF1-Adam update -- so that the sweep does not lean
+on the generic kernels being right for shapes no fixture covers (verdict round 4, weak 1 ii)."""
 import numpy as np
 import pytest
 
@@ -21,12 +25,27 @@ def _cases_2d():
         depth = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 6]))
         width = int(rng.choice([5, 12, 20, 20, 20, 24, 30]))
         vf = int(rng.choice([0, 1, 1, 1, 2]))
-        out.append((q, ntx, nty, nex, ney, depth, width, vf))
+        out.append((q, ntx, nty, nex, ney, depth, width, vf, len(out) % 4 == 0))
     return out
 
 
-@pytest.mark.parametrize("q,ntx,nty,nex,ney,depth,width,vf", _cases_2d())
-def test_poisson2d_default_dispatch_against_the_generic_kernels(q, ntx, nty, nex, ney, depth, width, vf):
+def _against_oracle(m, o, n_res, what):
+    """The device model `m` against the oracle `o` (same inputs, same theta): loss triple, gradient, residuals, one Adam update."""
+    o.vectorized = True
+    l3m, gm = m.loss_and_grad()
+    l3o, go = o.loss_and_grad()
+    assert rel(l3m, l3o) < 1e-9 and rel(gm, go) < 1e-8, (what, l3m, l3o, rel(gm, go))
+    if n_res:
+        assert rel(m.h.residuals(n_res), o.last["R"]) < 1e-9, what
+    m._step(1, False)
+    o.adam_step()
+    # (Adam's first update is lr * sign(g) up to eps / |g|: entries whose gradient cancels to round-off are compared through the rest)
+    big = np.abs(go) > 1e-9 * np.abs(go).max()
+    assert rel(m.get_params()[big], o.get_params()[big]) < 1e-9, what
+
+
+@pytest.mark.parametrize("q,ntx,nty,nex,ney,depth,width,vf,oracle", _cases_2d())
+def test_poisson2d_default_dispatch_against_the_generic_kernels(q, ntx, nty, nex, ney, depth, width, vf, oracle):
     from hp_vpinns_amd.drivers import poisson2d
     from hp_vpinns_amd.init import xavier_init
     from hp_vpinns_amd.vpinn import VPINN2D
@@ -35,6 +54,10 @@ def test_poisson2d_default_dispatch_against_the_generic_kernels(q, ntx, nty, nex
     a = (s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"], s["WXY_quad_train"], None,
          s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"], s["X_u_train"], s["u_train"], L)
     th = xavier_init(L, 7)
+    if oracle:
+        from oracle.vpinn_oracle import OracleVPINN2D
+        m = VPINN2D(*a, var_form=vf, init_params=th)
+        return _against_oracle(m, OracleVPINN2D(*a, var_form=vf, init_params=th), nex * ney * ntx * nty, m.h.kernel_variant())
     m, g = VPINN2D(*a, var_form=vf, init_params=th), VPINN2D(*a, var_form=vf, init_params=th, backend="generic")
     l3m, gm = m.loss_and_grad()
     l3g, gg = g.loss_and_grad()
@@ -50,11 +73,11 @@ def test_poisson2d_default_dispatch_against_the_generic_kernels(q, ntx, nty, nex
 def _cases_1d():
     rng = np.random.RandomState(7)
     return [(int(rng.choice([10, 20, 40, 60, 80])), int(rng.randint(1, 31)), int(rng.randint(1, 9)), int(rng.choice([2, 3, 4, 5])),
-             int(rng.choice([8, 20, 20, 32])), int(rng.choice([1, 2, 3]))) for _ in range(20)]
+             int(rng.choice([8, 20, 20, 32])), int(rng.choice([1, 2, 3])), i % 4 == 0) for i in range(20)]
 
 
-@pytest.mark.parametrize("q,nt,ne,depth,width,vf", _cases_1d())
-def test_poisson1d_default_dispatch_against_the_generic_kernels(q, nt, ne, depth, width, vf):
+@pytest.mark.parametrize("q,nt,ne,depth,width,vf,oracle", _cases_1d())
+def test_poisson1d_default_dispatch_against_the_generic_kernels(q, nt, ne, depth, width, vf, oracle):
     from hp_vpinns_amd.drivers import poisson1d
     from hp_vpinns_amd.init import xavier_init
     from hp_vpinns_amd.vpinn import VPINN1D
@@ -65,6 +88,10 @@ def test_poisson1d_default_dispatch_against_the_generic_kernels(q, nt, ne, depth
             s["u_test"], L, s["X_f_train"], s["f_train"])
     th = xavier_init(L, 8)
     th[L[1]:2 * L[1]] = 0.1
+    if oracle:
+        from oracle.vpinn_oracle import OracleVPINN1D
+        m = VPINN1D(*args, var_form=vf, init_params=th)
+        return _against_oracle(m, OracleVPINN1D(*args, var_form=vf, init_params=th), 0, m.h.kernel_variant())
     m, g = VPINN1D(*args, var_form=vf, init_params=th), VPINN1D(*args, var_form=vf, init_params=th, backend="generic")
     l3m, gm = m.loss_and_grad()
     l3g, gg = g.loss_and_grad()
@@ -77,11 +104,11 @@ def test_poisson1d_default_dispatch_against_the_generic_kernels(q, nt, ne, depth
 def _cases_adv():
     rng = np.random.RandomState(11)
     return [(int(rng.choice([6, 8, 10, 12, 16, 20])), int(rng.randint(1, 6)), int(rng.randint(1, 6)), int(rng.randint(1, 9)), int(rng.randint(1, 9)),
-             int(rng.choice([2, 3, 4])), int(rng.choice([0, 1]))) for _ in range(16)]
+             int(rng.choice([2, 3, 4])), int(rng.choice([0, 1])), i % 4 == 0) for i in range(16)]
 
 
-@pytest.mark.parametrize("q,ntx,ntt,nex,net,depth,vf", _cases_adv())
-def test_advdiff_default_dispatch_against_the_generic_kernels(q, ntx, ntt, nex, net, depth, vf):
+@pytest.mark.parametrize("q,ntx,ntt,nex,net,depth,vf,oracle", _cases_adv())
+def test_advdiff_default_dispatch_against_the_generic_kernels(q, ntx, ntt, nex, net, depth, vf, oracle):
     from hp_vpinns_amd.drivers import advdiff
     from hp_vpinns_amd.init import xavier_init
     from hp_vpinns_amd.vpinn import VPINNAdvDiff
@@ -91,6 +118,10 @@ def test_advdiff_default_dispatch_against_the_generic_kernels(q, ntx, ntt, nex, 
     a = (s["XT_u_train"], s["u_train"], s["XT_f_train"], s["XT_quad_train"], s["WXT_quad_train"], s["T_quad"], s["WT_quad"],
          s["grid_x"], s["grid_t"], s["N_testfcn_total"], s["XT_u_train"], s["u_train"], L, None, None)
     th = xavier_init(L, 9, extra=[0.9])
+    if oracle:
+        from oracle.vpinn_oracle import OracleVPINNAdvDiff
+        m = VPINNAdvDiff(*a, var_form=vf, init_params=th)
+        return _against_oracle(m, OracleVPINNAdvDiff(*a, var_form=vf, init_params=th), nex * net * ntx * ntt, m.h.kernel_variant())
     m, g = VPINNAdvDiff(*a, var_form=vf, init_params=th), VPINNAdvDiff(*a, var_form=vf, init_params=th, backend="generic")
     l3m, gm = m.loss_and_grad()
     l3g, gg = g.loss_and_grad()

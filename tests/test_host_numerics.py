@@ -224,9 +224,9 @@ def test_zero_weight_padding_of_quadrature_rules():
     # 1-D: the 80 / 60 tile kernel takes a smaller rule only on shards where one workgroup per element pays (hpv_rule1d_pad_max)
     from hp_vpinns_amd._lib import rule_advice
     assert rule_advice(0, 1, 80, 60, 1, 16) == (80, 60) and rule_advice(0, 1, 80, 12, 1, 16) == (80, 60)
-    assert rule_advice(0, 1, 40, 20, 1, 16) == (80, 60) and rule_advice(0, 1, 10, 5, 1, 512) == (80, 60)
+    assert rule_advice(0, 1, 40, 20, 1, 16) == (80, 60) and rule_advice(0, 1, 10, 5, 1, 256) == (80, 60)
     assert rule_advice(0, 1, 10, 5, 1, 10000) == (10, 5)                     # h-refinement: 10 k elements of 10 points stay as they are
-    assert rule_advice(0, 1, 40, 20, 1, 2048) == (80, 60) and rule_advice(0, 1, 40, 20, 1, 4096) == (40, 20)
+    assert rule_advice(0, 1, 40, 20, 1, 257) == (40, 20) and rule_advice(0, 1, 60, 30, 1, 512) == (80, 60) and rule_advice(0, 1, 60, 30, 1, 513) == (60, 30)
     assert rule_advice(0, 1, 90, 20, 1, 4) == (90, 20) and rule_advice(0, 1, 60, 61, 1, 4) == (60, 61)
     xa, _ = GaussLobattoJacobiWeights(12, 0, 0)
     xb, wb = GaussLobattoJacobiWeights(14, 0, 0)
