@@ -758,8 +758,9 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
         m->ns = 1 + nd.nT1 + nd.nT2;
     }
     if (!ok) { delete m; return no("channel set / activation combination not instantiated"); }
-    if (need_store) {   // forward-only users (predict) run with save_act = 0 and need no activation store
-        size_t bytes = (size_t)m->ntiles * L * m->ns * m->ks * 64 * sizeof(double);
+    if (need_store || H != MF_H) {   // forward-only users (predict) run with save_act = 0 and need no activation store -- the width-generic
+        // forward kernel wants ONE tile's block to alias its stores onto (kernels_wide.hip, k_fwd_wide)
+        size_t bytes = (size_t)(need_store ? m->ntiles : 1) * L * m->ns * m->ks * 64 * sizeof(double);
         if (hipMalloc((void**)&m->ACTS, bytes) != hipSuccess) { delete m; return no("hipMalloc of the activation store failed"); }
         (void)hipMemset(m->ACTS, 0, bytes);
     }

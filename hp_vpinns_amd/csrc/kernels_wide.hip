@@ -42,9 +42,9 @@ struct WideBwdLds {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-// SAVE: 1 every slot of the activation store (s, [cos], z_c, z_cc) when the launch asks for it (g.save_act, a wave-uniform RUN-TIME
-// flag: the forward-only evaluations -- predict, loss read-back -- run the same instantiation; as a third compile-time variant it
-// was a third of this file's forward kernels and of their build time, and the store-bound kernel does not notice the scalar branch);
+// SAVE: 1 every slot of the activation store (s, [cos], z_c, z_cc).  The forward-only evaluations (predict, loss read-back:
+// g.save_act == 0) run the SAME instantiation with all tiles' stores aliased onto one tile's block (as a third compile-time variant
+// they were a third of this file's forward kernels and of their build time);
 // 2 (libhpvpinn_testhooks.so only) only s (and cos): the
 // reverse kernel k_bwd_wide_rc then recomputes the tangent pre-activations on the MFMA pipe -- a third of the store's bytes for
 // three channels (the forward kernel is HBM-write-bound on the store: 182 MB, 4.2 TB/s at H = 32 on the config-4 grid)
@@ -84,6 +84,7 @@ __global__ void __launch_bounds__(WF_BLOCK, (H <= 32 ? 2 : 1)) k_fwd_wide(MfmaAr
     const double bo = th[g.boff[L]];
     const double* W1 = lds + M::W1;
 
+    const long tstride = (SAVE == 2 || g.save_act) ? (long)L * (NS * KS * 64) : 0;     // doubles per tile of the activation store
     for (long tile = wave; tile < g.ntiles; tile += nwaves) {
         const long p = tile * 16 + pt;
         const bool valid = p < g.N;
@@ -99,7 +100,10 @@ __global__ void __launch_bounds__(WF_BLOCK, (H <= 32 ? 2 : 1)) k_fwd_wide(MfmaAr
         int lofs = lane;                       // opaque per tile: keeps the LDS fragment reads inside the loop
         asm volatile("" : "+v"(lofs));
         double h[C][KS];
-        double* sv = g.ACTS + (tile * L) * (long)(NS * KS * 64) + lane;
+        // forward-only launches (predict, loss read-back: g.save_act == 0) run THIS instantiation with every tile's stores aliased onto
+        // tile 0's block of the store (L2-resident, never read) instead of a third compile-time variant or a branch around each store
+        // group (tried: the branch cost the training launch 4-12 %, profiles/r05_notes.md)
+        double* sv = g.ACTS + (tile * tstride) + lane;
 
         // ---- layer 1 (VALU): z = b + x W, z_c = W[c,:], z_cc = 0 ----
         {
@@ -117,7 +121,7 @@ __global__ void __launch_bounds__(WF_BLOCK, (H <= 32 ? 2 : 1)) k_fwd_wide(MfmaAr
                     double a, a1, a2;
                     act_fwd<ACT, decltype(fast)::value>(z1[s], a, a1, a2);
                     h[0][s] = a;
-                    if (SAVE == 2 || g.save_act) {
+                    {   // (stored always: forward-only launches alias ONE tile of the store, see sv)
                         sv[(0 * KS + s) * 64] = a;
                         if constexpr (ACT == HPV_ACT_SIN) sv[(SA1 * KS + s) * 64] = a1;
                     }
@@ -144,19 +148,19 @@ __global__ void __launch_bounds__(WF_BLOCK, (H <= 32 ? 2 : 1)) k_fwd_wide(MfmaAr
                     double a, a1, a2;
                     act_fwd<ACT, decltype(fast)::value>(z[0][s], a, a1, a2);
                     h[0][s] = a;
-                    if (SAVE == 2 || g.save_act) {
+                    {   // (stored always: forward-only launches alias ONE tile of the store, see sv)
                         svl[(0 * KS + s) * 64] = a;
                         if constexpr (ACT == HPV_ACT_SIN) svl[(SA1 * KS + s) * 64] = a1;
                     }
 #pragma unroll
                     for (int u = 0; u < NT1; ++u) {
-                        if (SAVE_T && g.save_act) svl[((SZC + u) * KS + s) * 64] = z[1 + u][s];
+                        if constexpr (SAVE_T) svl[((SZC + u) * KS + s) * 64] = z[1 + u][s];
                         h[1 + u][s] = a1 * z[1 + u][s];
                     }
 #pragma unroll
                     for (int b = 0; b < NT2; ++b) {
                         const double zcc = z[1 + NT1 + b][s], zc1 = z[1 + (b < NT1 ? b : 0)][s];
-                        if (SAVE_T && g.save_act) svl[((SZCC + b) * KS + s) * 64] = zcc;
+                        if constexpr (SAVE_T) svl[((SZCC + b) * KS + s) * 64] = zcc;
                         h[1 + NT1 + b][s] = a2 * zc1 * zc1 + a1 * zcc;
                     }
                 }
