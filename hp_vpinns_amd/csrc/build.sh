@@ -60,13 +60,13 @@ guarded_compile() {   # guarded_compile <source stem> <object> <extra flags> <fi
     # (instantiations: <L, SPLIT, QT, GS = false, element shape>: the GS = true ones (test-hooks library only) hand-manage no registers; the
     #  hand-managed range starts at 256 - (tiles per wave - 2) x 10 L registers; the quarter-tile one sits closest to it and has its own fallback)
     local S=ELi20ELi20ELi10ELi10E
-    g=0; guard $asm k_iter_fusedILi3ELb0ELb0ELb0${S} 106 k_iter_fusedILi3ELb1ELb0ELb0${S} 106 k_iter_fusedILi2ELb0ELb0ELb0${S} 156 k_iter_fusedILi2ELb1ELb0ELb0${S} 156 || g=$?
+    g=0; guard $asm k_iter_fusedILi3ELb0ELb0ELb0${S}Lb0E 106 k_iter_fusedILi3ELb1ELb0ELb0${S}Lb0E 106 k_iter_fusedILi2ELb0ELb0ELb0${S}Lb0E 156 k_iter_fusedILi2ELb1ELb0ELb0${S}Lb0E 156 || g=$?
     [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check $f.hip" >&2; rm -rf $tmp; return 1; }
     if [ $g -eq 1 ]; then
       echo "build.sh: WARNING -- AGPR guard tripped in $f.hip: building without k_iter_fused (fallback = HPV_FUSE=b structure)" >&2
       add="-DHPV_AGPR_GUARD_TRIPPED"
     else
-      g=0; guard $asm k_iter_fusedILi3ELb0ELb1ELb0${S} 106 k_iter_fusedILi2ELb0ELb1ELb0${S} 156 || g=$?
+      g=0; guard $asm k_iter_fusedILi3ELb0ELb1ELb0${S}Lb0E 106 k_iter_fusedILi2ELb0ELb1ELb0${S}Lb0E 156 || g=$?
       [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check the quarter-tile instantiation of $f.hip" >&2; rm -rf $tmp; return 1; }
       if [ $g -eq 1 ]; then
         echo "build.sh: WARNING -- AGPR guard tripped in the quarter-tile instantiation of k_iter_fused: building with 7 / 6 / 6 / 6 whole tiles per wave" >&2
@@ -74,14 +74,24 @@ guarded_compile() {   # guarded_compile <source stem> <object> <extra flags> <fi
       fi
       # the other element shapes (FZ_SHAPES of kernels_fused.hip): 16x16 / 8x8 (5 tiles per wave), 12x12 / 6x6 (3)
       local S16=ELi16ELi16ELi8ELi8E S12=ELi12ELi12ELi6ELi6E
-      g=0; guard $asm k_iter_fusedILi3ELb0ELb0ELb0${S16} 166 k_iter_fusedILi3ELb1ELb0ELb0${S16} 166 k_iter_fusedILi2ELb0ELb0ELb0${S16} 196 k_iter_fusedILi2ELb1ELb0ELb0${S16} 196 \
-                       k_iter_fusedILi3ELb0ELb1ELb0${S16} 166 k_iter_fusedILi2ELb0ELb1ELb0${S16} 196 \
-                       k_iter_fusedILi3ELb0ELb0ELb0${S12} 226 k_iter_fusedILi3ELb1ELb0ELb0${S12} 226 k_iter_fusedILi3ELb0ELb1ELb0${S12} 226 \
-                       k_iter_fusedILi2ELb0ELb0ELb0${S12} 236 k_iter_fusedILi2ELb1ELb0ELb0${S12} 236 k_iter_fusedILi2ELb0ELb1ELb0${S12} 236 || g=$?
+      g=0; guard $asm k_iter_fusedILi3ELb0ELb0ELb0${S16}Lb0E 166 k_iter_fusedILi3ELb1ELb0ELb0${S16}Lb0E 166 k_iter_fusedILi2ELb0ELb0ELb0${S16}Lb0E 196 k_iter_fusedILi2ELb1ELb0ELb0${S16}Lb0E 196 \
+                       k_iter_fusedILi3ELb0ELb1ELb0${S16}Lb0E 166 k_iter_fusedILi2ELb0ELb1ELb0${S16}Lb0E 196 \
+                       k_iter_fusedILi3ELb0ELb0ELb0${S12}Lb0E 226 k_iter_fusedILi3ELb1ELb0ELb0${S12}Lb0E 226 k_iter_fusedILi3ELb0ELb1ELb0${S12}Lb0E 226 \
+                       k_iter_fusedILi2ELb0ELb0ELb0${S12}Lb0E 236 k_iter_fusedILi2ELb1ELb0ELb0${S12}Lb0E 236 k_iter_fusedILi2ELb0ELb1ELb0${S12}Lb0E 236 || g=$?
       [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check the extra element shapes of $f.hip" >&2; rm -rf $tmp; return 1; }
       if [ $g -eq 1 ]; then
         echo "build.sh: WARNING -- AGPR guard tripped in an extra element shape of k_iter_fused: those shapes run on the other structures" >&2
         add="$add -DHPV_FZ_NO_EXTRA_SHAPES"
+      fi
+      # the element loop (MULTI = last template argument true; the keys above match both values of it through their common prefix --
+      # here the MULTI instantiations alone, with their own fallback: one workgroup per element on every grid size)
+      g=0; guard $asm k_iter_fusedILi2ELb0ELb0ELb0${S}Lb1E 156 k_iter_fusedILi2ELb0ELb1ELb0${S}Lb1E 156 \
+                       k_iter_fusedILi3ELb0ELb0ELb0${S16}Lb1E 166 k_iter_fusedILi3ELb0ELb1ELb0${S16}Lb1E 166 k_iter_fusedILi2ELb0ELb0ELb0${S16}Lb1E 196 k_iter_fusedILi2ELb0ELb1ELb0${S16}Lb1E 196 \
+                       k_iter_fusedILi3ELb0ELb0ELb0${S12}Lb1E 226 k_iter_fusedILi3ELb0ELb1ELb0${S12}Lb1E 226 k_iter_fusedILi2ELb0ELb0ELb0${S12}Lb1E 236 k_iter_fusedILi2ELb0ELb1ELb0${S12}Lb1E 236 || g=$?
+      [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check the element-loop instantiations of $f.hip" >&2; rm -rf $tmp; return 1; }
+      if [ $g -eq 1 ]; then
+        echo "build.sh: WARNING -- AGPR guard tripped in an element-loop instantiation of k_iter_fused: grids larger than the chip keep one workgroup per element" >&2
+        add="$add -DHPV_FZ_NO_MULTI"
       fi
     fi
   fi

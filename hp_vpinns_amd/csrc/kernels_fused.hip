@@ -102,9 +102,19 @@ struct FzLds {
 // (and the 256 MB memory-side cache, which holds the whole 110 MB) idle; the recompute was 1 600 of a reverse tile's 7 650 datapath
 // cycles plus the AGPR shuffles around it.  Every workgroup reads back only what its own waves wrote (same CU, same L2): no fences.
 typedef double v2d __attribute__((ext_vector_type(2)));
-template <int L, bool SPLIT, bool QT, bool GS, int QX_, int QY_, int NTX_, int NTY_>
+//
+// MULTI (round 5): grids with more elements than CUs.  One workgroup per element pays the launch-once phases -- weight staging, the
+// epilogue's cross-wave reduction and gradient row, the dispatch of a fresh workgroup -- per ELEMENT (~11 k of an element's 132 k
+// cycles at 20x20 points, of 90 k at 16x16).  Here gridDim.x = CUs workgroups walk the elements b, b + gridDim.x, ..: the weight
+// fragments stay in LDS (only the projection tables, which share the transpose region, are restaged per element), and the 45
+// per-lane gradient accumulators of an element are ADDED INTO a per-wave scratch block in device memory (g.ACTS: load-add-store of
+// lane-private, coalesced 512-byte rows; L2-resident) at the end of its reverse phase instead of being reduced across lanes and
+// waves -- they are zeroed again before the next element's reverse phase, so nothing lives across a forward phase (carrying them in
+// registers took the compiler to a151 of the 106 AGPRs the stash leaves: profiles/r04_notes.md 13).  The epilogue runs once per workgroup.
+template <int L, bool SPLIT, bool QT, bool GS, int QX_, int QY_, int NTX_, int NTY_, bool MULTI = false>
 __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     static_assert(!(SPLIT && QT), "the quarter-tile scheme is for whole elements");
+    static_assert(!(MULTI && (SPLIT || GS)), "the element loop is for whole elements on the register stash");
     FZ_SHAPE_CONSTS
     using M = FzLds<L, QX_, QY_, NTX_, NTY_>;
     constexpr int LH = L > 1 ? L - 1 : 1;
@@ -118,7 +128,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     // (observed: XCC id == blockIdx % 8), so with an element count that 8 divides -- the shards of a multi-GPU run -- the partners share
     // an XCD and their exchange is served by one L2 (1.56 against 2.39 us per exchange, profiles/r04_xchg_probe.txt).  A speed choice
     // only: nothing depends on the placement.
-    const long e = SPLIT ? (long)(blockIdx.x % (unsigned)g.proj_n_elem) : (long)blockIdx.x;
+    long e = SPLIT ? (long)(blockIdx.x % (unsigned)g.proj_n_elem) : (long)blockIdx.x;      // (MULTI: advances by gridDim.x per trip)
     const int part = SPLIT ? (int)(blockIdx.x / (unsigned)g.proj_n_elem) : 0;
     const double* __restrict__ th = g.theta;
     const ProjArgs& pa = g.pa;
@@ -209,11 +219,11 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     unsigned xtag = 0;             // this launch's exchange tag (hpv_fused_dev.h, xg_*)
     if constexpr (SPLIT) { xsticky = *g.xerr; xtag = *g.xiter + 1u; }
     // the element's projection constants, requested now so that no global latency sits inside phase P
-    const double pc0 = pa.coef[e], pc1 = pa.coef[pa.coef_stride + e];
+    double pc0 = pa.coef[e], pc1 = pa.coef[pa.coef_stride + e];
     const int ro_k = tid / FZ_NTX, ro_r = tid % FZ_NTX;                 // residual (k, r) of thread tid < NR, and whether the run has it
     const bool ro_on = tid < FZ_NR && ro_k < rny && ro_r < rnx;
-    const long ro_idx = e * rnr + ro_k * rnx + ro_r;
-    const double pF = (pa.F && ro_on) ? pa.F[ro_idx] : 0.0;
+    long ro_idx = e * rnr + ro_k * rnx + ro_r;
+    double pF = (pa.F && ro_on) ? pa.F[ro_idx] : 0.0;
     // ---- tile list of this wave: element tiles wv, wv+4, .., and possibly one boundary/data tile `dtile` ----
     const int lg = SPLIT ? __builtin_ctz(split) : 0;                             // split is 2, 4 or 8
     const int tbase = SPLIT ? (part * FZ_TPE) >> lg : 0;                         // this workgroup's tile range of the element
@@ -263,6 +273,25 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     FZ_STAMP(0);
     __syncthreads();
     FZ_STAMP(1);
+    // gradient accumulators of this wave (zeroed at the head of every reverse phase; MULTI: spilled into g.ACTS between elements)
+    constexpr int LHA = L > 1 ? L - 1 : 1;
+    v4d dWacc[LHA];
+    double dS10[LHA], dS01[LHA], accC[LHA];
+    double db[L][MF_KS], dW1[2][MF_KS], dWo[MF_KS], dbo = 0.0;
+    double gdat = 0.0;           // adjoint of u at the data tile's point (boundary term, P2:122)
+    [[maybe_unused]] double gdat_q = 0.0;
+    [[maybe_unused]] bool m_first = true;      // MULTI: this is the workgroup's first element (its spill is a plain store)
+    // MULTI: the wave's spill block, [slot][64 lanes] (slot order: acc_spill below)
+    constexpr int NACC = LHA * 7 + (L + 3) * MF_KS + 1;
+    [[maybe_unused]] double* ASP = MULTI ? g.ACTS + ((long)blockIdx.x * FZ_WAVES + wv) * (NACC * 64) + lane : nullptr;
+#pragma unroll 1
+    for (;;) {       // (one trip unless MULTI)
+    // MULTI: the thread index is laundered per trip and SHADOWS the kernel-scope one inside the loop -- every per-thread LDS / global
+    // address of the phases below is then formed inside the trip.  Hoisted out of the element loop they were ~30 loop-invariant
+    // values parked in AGPRs above the hand-managed base (a136 of 106) across the stash's live range.
+    int tid_trip_ = threadIdx.x;
+    if constexpr (MULTI) asm volatile("" : "+v"(tid_trip_));
+    const int tid = tid_trip_, lane = tid & 63, q = lane >> 4, pt = lane & 15;
     const bool has_d = !QT && (wv == (tend - tbase) % FZ_WAVES) && dtile < g.ntiles;     // (QT: the data points ride in the quarter tile)
     const int n_own = n_el + (has_d ? 1 : 0);
     auto tile_of = [&](int k) -> long { return k < n_el ? e * FZ_TPE + tbase + wv + (long)k * FZ_WAVES : dtile; };
@@ -280,7 +309,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     auto gs_ptr = [&](long tile) -> v2d* { return reinterpret_cast<v2d*>(g.ACTS + tile * GS_STRIDE) + lane; };
     double* PKw = lds + M::PK + wv * (NSV * 64) + lane;
     double* PKw2 = lds + M::PK + (4 + (wv & 1)) * (NSV * 64) + lane;
-    double gdat = 0.0;           // adjoint of u at the data tile's point (boundary term, P2:122)
+    gdat = 0.0;
 
     // SPLIT: this workgroup takes no part in the exchange (an earlier launch of the handle failed -- sticky flag -- or the test
     // knob keeps partner 1 of element 0 away): it publishes nothing and leaves at the hand-off point
@@ -303,7 +332,8 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     [[maybe_unused]] const int q_ci = q * 8 + (qcs == 3 ? 4 : 0) + qj;                // ... at this index (tangent slots: their point's)
     [[maybe_unused]] double* PKZ = lds + M::PZ + wv * ((L > 1 ? L - 1 : 1) * MF_KS * 32);   // tangent pre-activations, the 32 tangent lanes only
     [[maybe_unused]] const int q_cz = q * 8 + (qcs == 2 ? 4 : 0) + qj;
-    [[maybe_unused]] double gdat_q = 0.0, qx0 = 0.0, qx1 = 0.0, qud = 0.0;
+    gdat_q = 0.0;
+    [[maybe_unused]] double qx0 = 0.0, qx1 = 0.0, qud = 0.0;
     [[maybe_unused]] const int q_xs = qcs == 3 ? FZ_NQ + 4 * wv + qj : q_lp;      // GS: the slot's point in the staged coordinates
     if constexpr (QT && GS) {
         qx0 = lds[M::XS + q_xs]; qx1 = lds[M::XS + M::XLD + q_xs];
@@ -615,11 +645,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     // =============================================================================================
     FZ_STAMP(4);
     double* TAB = lds + M::TR + wv * M::TR_WAVE;
-    v4d dWacc[LH];
-    double dS10[LH], dS01[LH], accC[LH];
 #pragma unroll
     for (int i = 0; i < LH; ++i) { dWacc[i] = v4d{0.0, 0.0, 0.0, 0.0}; dS10[i] = 0.0; dS01[i] = 0.0; accC[i] = 0.0; }
-    double db[L][MF_KS], dW1[2][MF_KS], dWo[MF_KS], dbo = 0.0;
+    dbo = 0.0;
 #pragma unroll
     for (int s = 0; s < MF_KS; ++s) {
         dWo[s] = 0.0; dW1[0][s] = 0.0; dW1[1][s] = 0.0;
@@ -932,6 +960,68 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             }
         }
     }
+    if constexpr (!MULTI) {
+        break;
+    } else {
+        // every accumulator in one fixed order = the slot order of the spill block.  MODE 0: spill (first element: store; later:
+        // load-add-store), MODE 1: add the spilled sums back into the registers.  In groups of eight behind scheduling barriers: the
+        // compiler would otherwise issue all 45 loads at once and park them in AGPRs above the hand-managed base (a211 of 106; the
+        // stash is dead here, but the build guard cannot know that)
+        auto acc_walk = [&](auto mode_, bool first) {
+            constexpr int MODE = decltype(mode_)::value;
+            int j = 0;
+            // (the block's base address is laundered here: derived from a value the optimiser cannot see through, the 45 slot addresses
+            //  are formed at the point of use -- hoisted out of the element loop they were 45 64-bit values parked in a106..a195 across
+            //  the forward and reverse phases, i.e. inside the hand-managed stash)
+            double* asp = ASP;
+            asm volatile("" : "+v"(asp));
+            auto one = [&](double v) -> double {
+                double r = v;
+                if constexpr (MODE == 0) { asp[j * 64] = first ? v : v + asp[j * 64]; }
+                else { r = v + asp[j * 64]; }
+                if ((++j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+                return r;
+            };
+#pragma unroll
+            for (int i = 0; i < LH; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dWacc[i][r] = one(dWacc[i][r]);
+                dS10[i] = one(dS10[i]); dS01[i] = one(dS01[i]); accC[i] = one(accC[i]);
+            }
+#pragma unroll
+            for (int s = 0; s < MF_KS; ++s) {
+#pragma unroll
+                for (int i = 0; i < L; ++i) db[i][s] = one(db[i][s]);
+                dW1[0][s] = one(dW1[0][s]); dW1[1][s] = one(dW1[1][s]); dWo[s] = one(dWo[s]);
+            }
+            dbo = one(dbo);
+        };
+        const long e_next = e + gridDim.x;
+        if (e_next >= g.proj_n_elem) {
+            // the last element of this workgroup: the earlier elements' sums come back into the registers, then the epilogue
+            if (!m_first) acc_walk(std::integral_constant<int, 1>{}, false);
+            break;
+        }
+        acc_walk(std::integral_constant<int, 0>{}, m_first);
+        m_first = false;
+        __syncthreads();          // every wave has left the reverse phase: the transpose region and the channel array are free
+        e = e_next;
+        pc0 = pa.coef[e]; pc1 = pa.coef[pa.coef_stride + e];
+        ro_idx = e * rnr + ro_k * rnx + ro_r;
+        pF = (pa.F && ro_on) ? pa.F[ro_idx] : 0.0;
+        dtile = g.ntiles;         // the boundary / data tiles rode with the first element
+        {   // the projection tables again (they share the transpose region); the post-forward barrier orders them before phase P
+            constexpr int NTAB = 2 * TNX * TQX;
+            const int dx0 = pa.pd.t[0].dx, dx1 = pa.pd.t[1].dx, dy0 = pa.pd.t[0].dy, dy1 = pa.pd.t[1].dy;
+            for (int f = tid; f < NTAB; f += FZ_BLOCK) {
+                const int tt_ = f / (TNX * TQX), ti_ = f % (TNX * TQX);
+                const int rr_ = ti_ / TQX, ii_ = ti_ % TQX;
+                lds[M::AX + f] = rr_ < rnx ? pa.wtx[((long)(tt_ ? dx1 : dx0) * rnx + rr_) * TQX + ii_] : 0.0;
+                lds[M::BY + f] = rr_ < rny ? pa.wty[((long)(tt_ ? dy1 : dy0) * rny + rr_) * TQY + ii_] : 0.0;
+            }
+        }
+    }
+    }   // element loop
     FZ_STAMP(5);
     // ---- epilogue: per-wave partials -> LDS -> one gradient row per workgroup ----
     __syncthreads();
@@ -1435,19 +1525,20 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int L, bool SPLIT, bool QT, bool GS, int QX_, int QY_, int NTX_, int NTY_>
+template <int L, bool SPLIT, bool QT, bool GS, int QX_, int QY_, int NTX_, int NTY_, bool MULTI = false>
 static void launch_iter_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
     const size_t bytes = (size_t)FzLds<L, QX_, QY_, NTX_, NTY_>::total(a.P) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_iter_fused<L, SPLIT, QT, GS, QX_, QY_, NTX_, NTY_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        (void)hipFuncSetAttribute((const void*)k_iter_fused<L, SPLIT, QT, GS, QX_, QY_, NTX_, NTY_, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_iter_fused<L, SPLIT, QT, GS, QX_, QY_, NTX_, NTY_>), dim3(blocks), dim3(FZ_BLOCK), bytes, s, a);
+    hipLaunchKernelGGL((k_iter_fused<L, SPLIT, QT, GS, QX_, QY_, NTX_, NTY_, MULTI>), dim3(blocks), dim3(FZ_BLOCK), bytes, s, a);
 }
 // One element shape: plan 0 = SPLIT, 1 = whole tiles, 2 = quarter tiles (shapes with 1 mod 4 tiles).  false: not instantiated.
 // (GS: the saved values travel through the activation store instead of AGPRs / LDS + recompute; HPV_FUSED_GSTASH=1 opts in; built
 //  for the 20x20 / 10x10 shape only)
+// plan 3 / 4 = plan 1 / 2 walking several elements per workgroup (MULTI: grids larger than the chip)
 template <int QX_, int QY_, int NTX_, int NTY_>
 static bool launch_iter_fused_shape(int L, int plan, bool gs, const MfmaArgs& a, int blocks, hipStream_t s) {
 #ifdef HPV_EXPERIMENTS      // GS (measured slower: 67.8 against 60.6 us, profiles/r04_notes.md 6) is instantiated in libhpvpinn_testhooks.so only
@@ -1466,12 +1557,21 @@ static bool launch_iter_fused_shape(int L, int plan, bool gs, const MfmaArgs& a,
             return true;
         } else return false;
     }
+#define FZ_GOM(L_, QT_) launch_iter_fused<L_, false, QT_, false, QX_, QY_, NTX_, NTY_, true>(a, blocks, s)
     if (plan == 0) { if (L == 2) FZ_GO(2, true, false, false); else FZ_GO(3, true, false, false); }
     else if (plan == 1) { if (L == 2) FZ_GO(2, false, false, false); else FZ_GO(3, false, false, false); }
+    // (MULTI with three hidden layers on 20x20 points is not instantiated: inside the element loop the compiler parks the reverse
+    //  loop's accumulators in a104..a117 -- inside the stash, base a106, while later tiles' values are still there; fz_multi_built)
+    else if (plan == 3) { if (L == 2) FZ_GOM(2, false); else if constexpr (QX_ != 20) FZ_GOM(3, false); else return false; }
+    else if (plan == 4) {
+        if constexpr (HAS_QT) { if (L == 2) FZ_GOM(2, true); else if constexpr (QX_ != 20) FZ_GOM(3, true); else return false; }
+        else return false;
+    }
     else {
         if constexpr (HAS_QT) { if (L == 2) FZ_GO(2, false, true, false); else FZ_GO(3, false, true, false); }
         else return false;
     }
+#undef FZ_GOM
 #undef FZ_GO
     return true;
 }
@@ -1528,7 +1628,16 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     // shapes other than the headline one: one workgroup per element pays the launch-once phases (staging, projection, epilogue:
     // ~7 us) per element -- on grids of many small elements the separate launches amortise them better (scripts/elem_bench.py:
     // 1 024 elements of 12x12 points 106 against 99 us, of 16x16 points 158 against 163; 256 elements 30.7 / 48.9 against 49.3 / 60.5)
-    if (!q20 && !small && n_elem > hpv_elem_resident_max(2, pd.qx, m->n_cus)) return false;
+    // (round 5: grids larger than the chip run the MULTI instantiation -- gridDim = CUs workgroups walk the elements, staging and
+    //  epilogue once per workgroup -- and that limit is gone for the shapes it is built for; HPV_FUSE=1 keeps one workgroup per element)
+    static const bool multi_off = []{ const char* e = getenv("HPV_FUSE"); return e && e[0] == '1'; }();
+#ifdef HPV_FZ_NO_MULTI            // csrc/build.sh: the AGPR guard tripped in an instantiation of the element loop
+    const bool multi_built = false;
+#else
+    const bool multi_built = !(q20 && m->L == 3);
+#endif
+    const bool multi = !small && !multi_off && multi_built && n_elem > m->n_cus && m->base.ACTS != nullptr;
+    if (!q20 && !small && !multi && n_elem > hpv_elem_resident_max(2, pd.qx, m->n_cus)) return false;
     if (small) {
         // thousands of small elements: one workgroup per element pays staging / projection / epilogue per element, the separate
         // launches stream (scripts/grid_sweep.py: 1 024 elements 80.8 against 77.5 us, 4 096 elements 292 against 273)
@@ -1565,7 +1674,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
         while (split < 8 && n_elem * split * 2 <= m->n_cus) split *= 2;
         if (n_elem * split > m->n_cus || n_elem > m->xsync_elems || (size_t)n_elem * 2 * NQ * 2 > m->xg_words) return false;
     }
-    const long blocks = n_elem * split;
+    const long blocks = multi ? (long)m->n_cus : n_elem * split;
     const long rest = m->ntiles - n_elem * TPE;                  // pad + boundary/data tiles: at most one per workgroup
     if (rest < 0 || rest > blocks) return false;
     if (blocks > hpv_mfma_grad_rows(m) && blocks > m->max_rows) return false;
@@ -1595,19 +1704,24 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
 #else
     constexpr bool gs = false;
 #endif
+    // MULTI spills 45 doubles per lane into the activation store: [workgroup][wave][slot][64] -- it must hold that (it is sized for
+    // the separate launches' slots of every tile: far larger on any grid that takes this branch)
+    if (multi && (size_t)blocks * FZ_WAVES * 64 * 48 > hpv_mfma_activation_store_doubles(m)) return false;
     int plan = 2;
     if (split > 1) plan = 0;
 #ifdef HPV_AGPR_GUARD_TRIPPED_QT                    // csrc/build.sh: the compiler's registers reached the stash of the QT instantiation
     else if (!gs) plan = 1;
 #endif
     else if (!has_qt || getenv("HPV_NO_QUARTER_TILE")) plan = 1;      // (A/B switch: whole tiles only, read per launch / capture)
+    if (multi) plan += 2;                                              // plans 3 / 4: several elements per workgroup
     if (!launch_iter_fused_any(pd, m->L, plan, gs, a, (int)blocks, s)) return false;
     m->last_split = split > 1;
     if (split > 1) m->split_used = true;
     char shp[40] = "";
     if (!base_shape) snprintf(shp, sizeof shp, ",%dx%d/%dx%d", pd.qx, pd.qy, pd.ntx, pd.nty);
     if (split > 1) snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=true,QT=false,GS=%s%s> split=%d", m->L, gs ? "true" : "false", shp, split);
-    else snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=false,QT=%s,GS=%s%s>", m->L, plan == 2 ? "true" : "false", gs ? "true" : "false", shp);
+    else snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=false,QT=%s,GS=%s%s>%s", m->L, (plan == 2 || plan == 4) ? "true" : "false",
+                  gs ? "true" : "false", shp, multi ? " elements-per-workgroup>1" : "");
     if (rows) *rows = (int)blocks;
     return true;
 }

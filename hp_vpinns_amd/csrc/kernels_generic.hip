@@ -634,29 +634,51 @@ int adam_state_doubles(int P) { return 2 * ((P + FIN_COLS - 1) / FIN_COLS + 1); 
 // state = {beta1^t, beta2^t} kept as running products exactly like TF's beta*_power variables.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_adam(AdamArgs ad, const double* __restrict__ g, int P, int Ptot, int ncopies) {
+    // The kernel is one latency chain behind the collective (the N > 1 iteration's tail): EVERY operand -- the failure flags, the
+    // beta powers, this thread's parameter / moments / gradient, the history slot -- is requested up front, in ONE memory round
+    // trip, instead of flag -> powers -> operands one after the other (round 5: the tail of the 1-rank-RCCL iteration, verdict item 1c).
+    const int i0 = threadIdx.x;
+    const bool own = i0 < Ptot;               // (Ptot <= 1024 on every instantiated network: one parameter per thread; more: the loop below)
+    const double flag = g[Ptot + 3];
+    const int xe = ad.xerr ? *ad.xerr : 0;
+    const double b1p = ad.state[0], b2p = ad.state[1];
+    double g0 = 0.0, m0 = 0.0, v0 = 0.0, t0 = 0.0;
+    if (own) { g0 = g[i0]; m0 = ad.m[i0]; v0 = ad.v[i0]; t0 = ad.theta[i0]; }
+    int hidx = -1;
+    double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0, sc0 = 0.0, sc1 = 0.0;
+    if (threadIdx.x == 0 && ad.hist) { hidx = *ad.hist_idx; h0 = g[Ptot]; h1 = g[Ptot + 1]; h2 = g[Ptot + 2]; h3 = Ptot > P ? ad.theta[P] : 0.0; }
+    const int c0 = (int)threadIdx.x - 512;    // the replicated copies of the beta powers: advanced by the upper half of the block
+    if (c0 >= 0 && c0 < ncopies) { sc0 = ad.state[2 * c0]; sc1 = ad.state[2 * c0 + 1]; }
     // a failed SPLIT-mode barrier on ANY rank (pad slot of the all-reduced buffer: the sum of the ranks' flags; NaN counts) or
     // on this one: no update, no history entry, beta powers untouched -- and this rank's flag set, so that every rank reports it
-    const bool failed = !(g[Ptot + 3] == 0.0) || (ad.xerr && *ad.xerr);
+    const bool failed = !(flag == 0.0) || xe;
     if (failed) {
         if (threadIdx.x == 0 && ad.xerr) *ad.xerr = 1;
         return;
     }
-    const double b1p = ad.state[0], b2p = ad.state[1];
     if (threadIdx.x == 0 && ad.n_upd) *ad.n_upd += 1;
     if (threadIdx.x == 0 && ad.hist) {   // multi-GPU iteration: g is the all-reduced packed buffer, the losses follow the gradient
-        const int i = *ad.hist_idx;
-        if (i >= 0 && i < ad.hist_cap) {   // saturating index
-            ad.hist[4 * i] = g[Ptot]; ad.hist[4 * i + 1] = g[Ptot + 1]; ad.hist[4 * i + 2] = g[Ptot + 2];
-            ad.hist[4 * i + 3] = Ptot > P ? ad.theta[P] : 0.0;   // epsilon before this update
-            *ad.hist_idx = i + 1;
+        if (hidx >= 0 && hidx < ad.hist_cap) {   // saturating index
+            ad.hist[4 * hidx] = h0; ad.hist[4 * hidx + 1] = h1; ad.hist[4 * hidx + 2] = h2;
+            ad.hist[4 * hidx + 3] = h3;          // epsilon before this update
+            *ad.hist_idx = hidx + 1;
         }
     }
+    if (own) {       // adam_update with the operands fetched above (same arithmetic, same order)
+        const double lr_t = ad.lr * sqrt(1.0 - b2p) / (1.0 - b1p);
+        const double mi = ad.b1 * m0 + (1.0 - ad.b1) * g0;
+        const double vi = ad.b2 * v0 + (1.0 - ad.b2) * g0 * g0;
+        ad.m[i0] = mi;
+        ad.v[i0] = vi;
+        ad.theta[i0] = t0 - lr_t * mi / (sqrt(vi) + ad.eps);
+    }
+    for (int i = threadIdx.x + blockDim.x; i < Ptot; i += blockDim.x) adam_update(ad, i, g[i], b1p, b2p);
+    // every replicated copy advances (each thread rewrites the copy it read above) -- behind a barrier: every wave has read copy 0
+    // (its b1p / b2p) by then
     __syncthreads();
-    for (int i = threadIdx.x; i < Ptot; i += blockDim.x) adam_update(ad, i, g[i], b1p, b2p);
-    __syncthreads();
-    for (int c = threadIdx.x; c < ncopies; c += blockDim.x) {   // advance every replicated copy
-        ad.state[2 * c] *= ad.b1;
-        ad.state[2 * c + 1] *= ad.b2;
+    if (c0 >= 0) {
+        if (c0 < ncopies) { ad.state[2 * c0] = sc0 * ad.b1; ad.state[2 * c0 + 1] = sc1 * ad.b2; }
+        for (int c = c0 + 512; c < ncopies; c += 512) { ad.state[2 * c] *= ad.b1; ad.state[2 * c + 1] *= ad.b2; }   // (> 512 copies: wide networks)
     }
 }
 

@@ -171,6 +171,46 @@ def test_hand_tuned_whole_iteration_kernel_on_other_element_shapes(q, nt, nhid, 
         assert rel(gw, gm) < 1e-11 and rel(l3w, l3m) < 1e-12
 
 
+@pytest.mark.parametrize("q,nt,nhid,nex,ney", [(16, 8, 3, 17, 17), (12, 6, 3, 17, 17), (20, 10, 2, 17, 17), (16, 8, 2, 24, 23), (12, 5, 3, 30, 27)])
+def test_hand_tuned_kernel_walks_several_elements_per_workgroup_on_grids_larger_than_the_chip(q, nt, nhid, nex, ney):
+    """k_iter_fused<.., MULTI> (round 5): on grids with more elements than CUs a workgroup walks the elements b, b + CUs, ..: weight
+    fragments staged once, the per-lane gradient accumulators added into a device-memory scratch block between elements, ONE
+    epilogue and gradient row per workgroup.  17 x 17 elements (289 = 256 + 33: most workgroups own one element, 33 own two), a
+    grid with two to three elements per workgroup and one with three to four; against the oracle (loss triple, gradient, every
+    residual, a 6-step TF1-Adam trajectory), against one workgroup per element (HPV_FUSE=1) and bit-reproducible from call to call."""
+    from hp_vpinns_amd.vpinn import VPINN2D
+    from oracle.vpinn_oracle import OracleVPINN2D
+    assert "HPV_FUSE" not in os.environ
+    L = [2] + [20] * nhid + [1]
+    a = _p2(q, nt, nex, ney, nb=40) + (L,)
+    th = theta0(L, 73)
+    o, m = OracleVPINN2D(*a, init_params=th), VPINN2D(*a, init_params=th)
+    o.vectorized = True
+    l3o, go = o.loss_and_grad()
+    l3m, gm = m.loss_and_grad()
+    v = m.h.kernel_variant()
+    assert m.h.pass_structure() == "whole-iteration" and v.startswith("k_iter_fused<L=%d," % nhid) and v.endswith("elements-per-workgroup>1"), v
+    assert rel(l3m, l3o) < TOL and rel(gm, go) < TOL, (v, l3m, l3o, rel(gm, go))
+    assert rel(m.h.residuals(nex * ney * nt * nt), o.last["R"].reshape(-1)) < TOL
+    l3b, gb = m.loss_and_grad()
+    assert np.array_equal(gb, gm) and np.array_equal(l3b, l3m)
+    os.environ["HPV_FUSE"] = "1"                    # one workgroup per element on the same grid
+    try:
+        w = VPINN2D(*a, init_params=th)
+        l3w, gw = w.loss_and_grad()
+        vw = w.h.kernel_variant()
+    finally:
+        del os.environ["HPV_FUSE"]
+    assert "elements-per-workgroup" not in vw, vw
+    assert rel(gw, gm) < 1e-11 and rel(l3w, l3m) < 1e-12, (v, vw)
+    lo, lm = [], []
+    for _ in range(6):
+        o.adam_step()
+        lo.append(float(o.loss_parts()[0]))
+        lm.append(float(m._step(1, True)[0]))
+    assert rel(lm, lo) < TRAJ_TOL and rel(m.get_params(), o.get_params()) < TRAJ_TOL
+
+
 @pytest.mark.parametrize("q,ntx,nty,nex,ney", [(20, 7, 5, 16, 16), (20, 10, 6, 5, 3), (20, 1, 1, 4, 4), (16, 5, 5, 16, 8), (16, 8, 3, 5, 3),
                                                (12, 4, 6, 16, 8), (12, 2, 5, 4, 2), (10, 3, 4, 8, 8), (10, 5, 2, 4, 4), (10, 1, 3, 3, 3)])
 def test_hand_tuned_kernels_with_fewer_test_functions_than_instantiated(q, ntx, nty, nex, ney):
