@@ -85,9 +85,10 @@ guarded_compile() {   # guarded_compile <source stem> <object> <extra flags> <fi
       fi
       # the element loop (MULTI = last template argument true; the keys above match both values of it through their common prefix --
       # here the MULTI instantiations alone, with their own fallback: one workgroup per element on every grid size)
+      # (their hand-managed range starts at min(stash base, 256 - 2 x accumulators): the spilled sums come back through the top 90 (L = 3) / 66 (L = 2) AGPRs)
       g=0; guard $asm k_iter_fusedILi2ELb0ELb0ELb0${S}Lb1E 156 k_iter_fusedILi2ELb0ELb1ELb0${S}Lb1E 156 \
-                       k_iter_fusedILi3ELb0ELb0ELb0${S16}Lb1E 166 k_iter_fusedILi3ELb0ELb1ELb0${S16}Lb1E 166 k_iter_fusedILi2ELb0ELb0ELb0${S16}Lb1E 196 k_iter_fusedILi2ELb0ELb1ELb0${S16}Lb1E 196 \
-                       k_iter_fusedILi3ELb0ELb0ELb0${S12}Lb1E 226 k_iter_fusedILi3ELb0ELb1ELb0${S12}Lb1E 226 k_iter_fusedILi2ELb0ELb0ELb0${S12}Lb1E 236 k_iter_fusedILi2ELb0ELb1ELb0${S12}Lb1E 236 || g=$?
+                       k_iter_fusedILi3ELb0ELb0ELb0${S16}Lb1E 166 k_iter_fusedILi3ELb0ELb1ELb0${S16}Lb1E 166 k_iter_fusedILi2ELb0ELb0ELb0${S16}Lb1E 190 k_iter_fusedILi2ELb0ELb1ELb0${S16}Lb1E 190 \
+                       k_iter_fusedILi3ELb0ELb0ELb0${S12}Lb1E 166 k_iter_fusedILi3ELb0ELb1ELb0${S12}Lb1E 166 k_iter_fusedILi2ELb0ELb0ELb0${S12}Lb1E 190 k_iter_fusedILi2ELb0ELb1ELb0${S12}Lb1E 190 || g=$?
       [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check the element-loop instantiations of $f.hip" >&2; rm -rf $tmp; return 1; }
       if [ $g -eq 1 ]; then
         echo "build.sh: WARNING -- AGPR guard tripped in an element-loop instantiation of k_iter_fused: grids larger than the chip keep one workgroup per element" >&2

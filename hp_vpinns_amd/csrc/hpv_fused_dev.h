@@ -33,6 +33,22 @@ __device__ __forceinline__ void acc_get_all(double (&sv)[N]) {
     if constexpr (J < N) { sv[J] = acc_get<BASE + 2 * J>(); acc_get_all<BASE, N, J + 1>(sv); }
 }
 
+// N doubles p[0], p[64], p[128], .. (one 512-byte wave row each) straight INTO the hand-managed AGPRs a[BASE + 2j : BASE + 2j + 1]:
+// all loads in flight at once without a single compiler-allocated register (k_iter_fused<.., MULTI>: the spilled gradient sums of
+// the workgroup's earlier elements come back in ONE memory round trip; through compiler registers it was either six serialized
+// round trips or 90 more registers -- inside the stash).  Groups of eight share a base address (13-bit offset field).  The caller
+// waits (acc_load_wait) before acc_get.
+template <int BASE, int N, int J = 0>
+__device__ __forceinline__ void acc_load_all(const double* p) {
+    if constexpr (J < N) {
+        asm volatile("global_load_dwordx2 a[%1:%2], %0, off offset:%3" ::"v"(p + (J / 8) * 512), "n"(BASE + 2 * J), "n"(BASE + 2 * J + 1),
+                     "n"((J % 8) * 512)
+                     : "memory");
+        acc_load_all<BASE, N, J + 1>(p);
+    }
+}
+__device__ __forceinline__ void acc_load_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // hidden -> hidden product of one channel: z^T = W^T h^T (+ bias fragment for the value channel), 16 + 4 split
 template <bool BIAS>
 __device__ __forceinline__ void fz_layer(const double* WTl, const double* WRl, const double* BHl, int lofs,

@@ -84,6 +84,7 @@ struct HpvMfma {
     void (*bwd_fused)(const MfmaArgs&, int, hipStream_t) = nullptr; // projection + reverse, element-block mode
     int occ_fwd = 1, occ_bwd = 1;   // resident 256-thread blocks per CU
     int n_cus = 256;                // compute units of the device
+    bool multi_off = false, multi_force = false;   // HPV_FUSE=1 / m at creation: k_iter_fused's element loop never / on every grid larger than the chip
     int max_rows = 0;               // gradient rows the caller allocated (>= every launch mode's row count)
     // A/B switches read at creation (HPV_FUSE): default = the element-resident whole-iteration kernel where it applies,
     // 'b' = forward + (projection fused into the reverse kernel), 'n' = forward, projection, reverse as separate launches

@@ -52,7 +52,7 @@
 #define FZ_SEG(I)
 #endif
 
-template <int L, int QX_, int QY_, int NTX_, int NTY_>
+template <int L, int QX_, int QY_, int NTX_, int NTY_, bool MULTI = false>
 struct FzLds {
     FZ_SHAPE_CONSTS
     static constexpr int LH = L > 1 ? L - 1 : 0;
@@ -69,17 +69,20 @@ struct FzLds {
     static constexpr int PZ = PK + 6 * L * MF_KS * 64;     // [4][LH*5][32] QT: the quarter tiles' tangent pre-activations of the layers >= 2 (tangent lanes, compact)
     static constexpr int TR = PZ + FZ_WAVES * LH * MF_KS * 32;   // phase P: projection scratch | phase R: per-wave transpose tiles | epilogue rows
     static constexpr int TR_WAVE = FZ_C * 2 * MF_TRB * MF_LD;
-    // projection scratch inside the TR region
-    static constexpr int AX = TR;                          // [2][NTX][QX] w_x phi^(dx_t)
+    // projection scratch inside the TR region.  MULTI (several elements per workgroup): the tables live BEHIND the region instead -- the
+    // reverse phase's transposes would overwrite them and every element would have to stage them again
+    static constexpr int TRSZ = FZ_WAVES * TR_WAVE;        // (>= FZ_WAVES * P: the epilogue rows; asserted in total())
+    static constexpr int NTABS = 2 * FZ_NTX * FZ_QX + 2 * FZ_NTY * FZ_QY;
+    static constexpr int AX = MULTI ? TR + TRSZ : TR;      // [2][NTX][QX] w_x phi^(dx_t)
     static constexpr int BY = AX + 2 * FZ_NTX * FZ_QX;     // [2][NTY][QY] w_y phi^(dy_t)
-    static constexpr int T = BY + 2 * FZ_NTY * FZ_QY;      // [2][QY][NTX]
+    static constexpr int T = MULTI ? TR : BY + 2 * FZ_NTY * FZ_QY;      // [2][QY][NTX]
     static constexpr int UP = T + 2 * FZ_QY * FZ_NTX;      // [2][NR]      per-term partial of U
     static constexpr int U = UP + 2 * FZ_NR;               // [NR]
     static constexpr int S = U + FZ_NR;                    // [2][NTY][QX]
     static constexpr int RED = S + 2 * FZ_NTY * FZ_QX;     // [16]
     static_assert(RED + 16 - TR <= FZ_WAVES * TR_WAVE, "projection scratch fits the transpose region");
     static_assert(3 * XLD <= 4 * L * MF_KS * 64, "the staged coordinates fit the parking slots the GS plan leaves free");
-    static constexpr int total(int P) { return TR + (FZ_WAVES * TR_WAVE > FZ_WAVES * P ? FZ_WAVES * TR_WAVE : FZ_WAVES * P); }
+    static constexpr int total(int P) { return TR + (TRSZ > FZ_WAVES * P ? TRSZ : FZ_WAVES * P) + (MULTI ? NTABS : 0); }
 };
 
 // SPLIT: an element is shared by g.proj_split (2, 4 or 8) workgroups -- the shards of a multi-GPU run are too small to fill the
@@ -116,7 +119,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     static_assert(!(SPLIT && QT), "the quarter-tile scheme is for whole elements");
     static_assert(!(MULTI && (SPLIT || GS)), "the element loop is for whole elements on the register stash");
     FZ_SHAPE_CONSTS
-    using M = FzLds<L, QX_, QY_, NTX_, NTY_>;
+    using M = FzLds<L, QX_, QY_, NTX_, NTY_, MULTI>;
     constexpr int LH = L > 1 ? L - 1 : 1;
     constexpr int NSV = L * MF_KS;                 // saved doubles per lane and tile
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -964,22 +967,30 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         break;
     } else {
         // every accumulator in one fixed order = the slot order of the spill block.  MODE 0: spill (first element: store; later:
-        // load-add-store), MODE 1: add the spilled sums back into the registers.  In groups of eight behind scheduling barriers: the
-        // compiler would otherwise issue all 45 loads at once and park them in AGPRs above the hand-managed base (a211 of 106; the
-        // stash is dead here, but the build guard cannot know that)
+        // load-add-store), MODE 1: add the spilled sums back into the registers.  The earlier sums travel through the TOP 2 NACC
+        // AGPRs by hand (acc_load_all: all 45 loads in flight, one round trip; the stash is dead here and the build guard keeps the
+        // compiler below min(ABASE, LBASE)) -- through compiler registers they were six serialized round trips per element
+        // (measured: 185 against 166 us on 32x32 elements of 16x16 points) or 90 registers parked inside the stash.
+        constexpr int LBASE = 256 - 2 * NACC;
         auto acc_walk = [&](auto mode_, bool first) {
             constexpr int MODE = decltype(mode_)::value;
-            int j = 0;
-            // (the block's base address is laundered here: derived from a value the optimiser cannot see through, the 45 slot addresses
-            //  are formed at the point of use -- hoisted out of the element loop they were 45 64-bit values parked in a106..a195 across
-            //  the forward and reverse phases, i.e. inside the hand-managed stash)
+            // (the block's base address is laundered here: hoisted out of the element loop the slot addresses were 45 64-bit values
+            //  parked in a106..a195 across the forward and reverse phases)
             double* asp = ASP;
             asm volatile("" : "+v"(asp));
+            double t[NACC];
+#pragma unroll
+            for (int jj = 0; jj < NACC; ++jj) t[jj] = 0.0;
+            if (!first) {
+                acc_load_all<LBASE, NACC>(asp);
+                acc_load_wait();
+                acc_get_all<LBASE, NACC>(t);
+            }
+            int j = 0;
             auto one = [&](double v) -> double {
-                double r = v;
-                if constexpr (MODE == 0) { asp[j * 64] = first ? v : v + asp[j * 64]; }
-                else { r = v + asp[j * 64]; }
-                if ((++j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+                const double r = v + t[j];
+                if constexpr (MODE == 0) asp[j * 64] = r;
+                ++j;
                 return r;
             };
 #pragma unroll
@@ -1010,16 +1021,6 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         ro_idx = e * rnr + ro_k * rnx + ro_r;
         pF = (pa.F && ro_on) ? pa.F[ro_idx] : 0.0;
         dtile = g.ntiles;         // the boundary / data tiles rode with the first element
-        {   // the projection tables again (they share the transpose region); the post-forward barrier orders them before phase P
-            constexpr int NTAB = 2 * TNX * TQX;
-            const int dx0 = pa.pd.t[0].dx, dx1 = pa.pd.t[1].dx, dy0 = pa.pd.t[0].dy, dy1 = pa.pd.t[1].dy;
-            for (int f = tid; f < NTAB; f += FZ_BLOCK) {
-                const int tt_ = f / (TNX * TQX), ti_ = f % (TNX * TQX);
-                const int rr_ = ti_ / TQX, ii_ = ti_ % TQX;
-                lds[M::AX + f] = rr_ < rnx ? pa.wtx[((long)(tt_ ? dx1 : dx0) * rnx + rr_) * TQX + ii_] : 0.0;
-                lds[M::BY + f] = rr_ < rny ? pa.wty[((long)(tt_ ? dy1 : dy0) * rny + rr_) * TQY + ii_] : 0.0;
-            }
-        }
     }
     }   // element loop
     FZ_STAMP(5);
@@ -1527,7 +1528,8 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
 // ------------------------------------------------------------------------------------------------
 template <int L, bool SPLIT, bool QT, bool GS, int QX_, int QY_, int NTX_, int NTY_, bool MULTI = false>
 static void launch_iter_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
-    const size_t bytes = (size_t)FzLds<L, QX_, QY_, NTX_, NTY_>::total(a.P) * sizeof(double);
+    const size_t bytes = (size_t)FzLds<L, QX_, QY_, NTX_, NTY_, MULTI>::total(a.P) * sizeof(double);
+    static_assert(FzLds<L, QX_, QY_, NTX_, NTY_, MULTI>::total(2 * MF_H + MF_H + (L - 1) * (MF_H * MF_H + MF_H) + MF_H + 1) * sizeof(double) <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_iter_fused<L, SPLIT, QT, GS, QX_, QY_, NTX_, NTY_, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -1628,16 +1630,29 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     // shapes other than the headline one: one workgroup per element pays the launch-once phases (staging, projection, epilogue:
     // ~7 us) per element -- on grids of many small elements the separate launches amortise them better (scripts/elem_bench.py:
     // 1 024 elements of 12x12 points 106 against 99 us, of 16x16 points 158 against 163; 256 elements 30.7 / 48.9 against 49.3 / 60.5)
-    // (round 5: grids larger than the chip run the MULTI instantiation -- gridDim = CUs workgroups walk the elements, staging and
-    //  epilogue once per workgroup -- and that limit is gone for the shapes it is built for; HPV_FUSE=1 keeps one workgroup per element)
-    static const bool multi_off = []{ const char* e = getenv("HPV_FUSE"); return e && e[0] == '1'; }();
+    // Grids larger than the chip (round 5).  One workgroup per element runs ceil(n / CUs) rounds of whole elements: a grid of 289
+    // elements costs two rounds (85 us against 64 us on the separate launches, 16x16 points), and every element pays staging, epilogue
+    // and dispatch (~10 k cycles).  The MULTI instantiation (gridDim = CUs workgroups walk the elements; staging and epilogue once
+    // per workgroup) costs a fixed ~10 us + a shorter round: measured against the separate launches it wins from 4 rounds on for
+    // 16x16 points with three hidden layers (165.9 / 168.2 us at 1 024 elements, 357.7 / 394.5 at 2 304), from ~5 rounds for the
+    // smaller shapes (12x12: 106.8 / 101.1 at 1 024, 390.8 / 412.9 at 4 096; 20x20 with two hidden layers 545 / 566 at 4 096) --
+    // profiles/r05_multi_element.md.  HPV_FUSE=1: never MULTI; HPV_FUSE=m: MULTI on every grid larger than the chip (tests).
+    const bool multi_off = m->multi_off, multi_force = m->multi_force;      // (HPV_FUSE, read when the batch was assembled)
 #ifdef HPV_FZ_NO_MULTI            // csrc/build.sh: the AGPR guard tripped in an instantiation of the element loop
     const bool multi_built = false;
 #else
     const bool multi_built = !(q20 && m->L == 3);
 #endif
-    const bool multi = !small && !multi_off && multi_built && n_elem > m->n_cus && m->base.ACTS != nullptr;
-    if (!q20 && !small && !multi && n_elem > hpv_elem_resident_max(2, pd.qx, m->n_cus)) return false;
+    const long rounds = (n_elem + m->n_cus - 1) / m->n_cus;
+    // (a static deal of elements to workgroups wastes the unfilled part of the last round: 1 600 elements = 6.25 rounds run 7 --
+    //  177 us against 151 us on the separate launches for 12x12 points, 280 against 271 for 16x16; 2 304 = 9 full rounds: 357 against 371)
+    const bool full_rounds = n_elem * 100 >= rounds * m->n_cus * 95;
+    const bool multi_pays = rounds >= ((pd.qx == 16 && m->L == 3) ? 4 : 6) && full_rounds;
+    const bool multi = !small && !multi_off && multi_built && n_elem > m->n_cus && m->base.ACTS != nullptr && (multi_pays || multi_force);
+    // one workgroup per element on a grid larger than the chip: only while the rounds are full enough (289 elements of the config-4
+    // shape: 115 us in two rounds against 88 us on the separate launches; 1 024: 228 against 280) and, for the smaller shapes, few enough
+    if (!small && !multi && !m->iter_fused_force && n_elem > m->n_cus &&
+        ((!q20 && n_elem > hpv_elem_resident_max(2, pd.qx, m->n_cus)) || n_elem * 100 < rounds * m->n_cus * 80)) return false;
     if (small) {
         // thousands of small elements: one workgroup per element pays staging / projection / epilogue per element, the separate
         // launches stream (scripts/grid_sweep.py: 1 024 elements 80.8 against 77.5 us, 4 096 elements 292 against 273)

@@ -797,6 +797,8 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
         m->iter_fused_force = e && e[0] == 'i';
         m->iter_split_ok = !(e && e[0] == 's');
         m->prefer_elem = e && e[0] == 'e';
+        m->multi_off = e && e[0] == '1';
+        m->multi_force = e && e[0] == 'm';
     }
     MfmaArgs& a = m->base;
     a = MfmaArgs{};

@@ -29,11 +29,13 @@ def run(s, L, fuse):
     return us, v
 
 
-print("| grid | points / test fcns | network | default: us / iteration | kernel | one workgroup per element (HPV_FUSE=1) | separate launches (HPV_FUSE=n) |\n|---|---|---|---|---|---|---|")
-for (ne, q, nt, nh) in ((17, 16, 8, 3), (32, 16, 8, 3), (32, 12, 6, 3), (64, 12, 6, 3), (48, 16, 8, 3), (32, 16, 8, 2), (32, 20, 10, 2), (64, 20, 10, 2), (32, 20, 10, 3), (64, 20, 10, 3)):
+print("| grid | points / test fcns | network | default: us / iteration | kernel | element loop forced (HPV_FUSE=m) | one workgroup per element (HPV_FUSE=1) | separate launches (HPV_FUSE=n) |\n|---|---|---|---|---|---|---|---|")
+for (ne, q, nt, nh) in ((17, 16, 8, 3), (32, 16, 8, 3), (40, 16, 8, 3), (48, 16, 8, 3), (32, 12, 6, 3), (40, 12, 6, 3), (64, 12, 6, 3), (32, 16, 8, 2), (48, 16, 8, 2), (32, 20, 10, 2), (40, 20, 10, 2), (64, 20, 10, 2), (17, 20, 10, 3), (64, 20, 10, 3)):
     L = [2] + [20] * nh + [1]
     s = poisson2d.setup(N_el_x=ne, N_el_y=ne, N_test_x=nt, N_test_y=nt, N_quad=q, with_test_grid=False, assemble="device")
     a, va = run(s, L, None)
+    f, vf = run(s, L, "m")
     b, vb = run(s, L, "1")
     c, vc = run(s, L, "n")
-    print("| %dx%d | %dx%d / %dx%d | %s | **%.1f** | `%s` | %.1f `%s` | %.1f |" % (ne, ne, q, q, nt, nt, L, a, va, b, vb.split("<")[0] if "k_iter" not in vb else vb, c), flush=True)
+    short = lambda v: ("k_iter_fused" + (" loop" if "elements-per" in v else "")) if "k_iter_fused" in v else v.split("<")[0]   # noqa: E731
+    print("| %dx%d | %dx%d / %dx%d | %s | **%.1f** | `%s` | %.1f `%s` | %.1f `%s` | %.1f |" % (ne, ne, q, q, nt, nt, L, a, va, f, short(vf), b, short(vb), c), flush=True)
