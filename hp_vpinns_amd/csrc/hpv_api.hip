@@ -1318,7 +1318,10 @@ int hpv_rule_advice(int device, int dim, int q, int ntx, int nty, long n_elem_sh
     for (const auto& r : rules) {
         const bool counts_ok = exact_counts ? (ntx == r[1] && nty == r[1]) : (ntx <= r[1] && nty <= r[1]);
         if (q <= r[0] && counts_ok) {
-            if (q < r[0] && n_elem_shard <= hpv_elem_resident_max(2, r[0], n_cus)) *q_dev = r[0];
+            // (pad only while the kernel of that rule would take the shard; the network depth is not known here: three hidden layers,
+            //  the reference's own depth)
+            const bool takes = r[0] == 10 ? n_elem_shard <= hpv_elem_resident_max(2, 10, n_cus) : hpv_fused_grid_plan(r[0], 3, n_elem_shard, n_cus, false) == 1;   // (not for the element loop: on many rounds the padded points cost more than the structure saves)
+            if (q < r[0] && takes) *q_dev = r[0];
             break;
         }
     }

@@ -24,6 +24,21 @@ inline long hpv_elem_resident_max(int dim, int q, int n_cus) {
     if (q == 16) return 6L * n_cus;
     return 1L << 40;                                // 20x20: every size
 }
+// How the whole-iteration kernel k_iter_fused takes a shard of n_elem elements of its 2-D rules (q = 12, 16, 20 points per direction):
+// 0 not at all (the separate launches), 1 one workgroup per element, 2 the element loop (gridDim = CUs workgroups walk the elements).
+// ONE definition for the dispatch (kernels_fused.hip) and for hpv_rule_advice (a smaller rule is padded onto an instantiated one only
+// while the kernel would take the shard).  Numbers behind it: profiles/r05_multi_element.md.
+inline int hpv_fused_grid_plan(int q, int L, long n_elem, int n_cus, bool loop_built, bool loop_off = false, bool loop_force = false, bool one_force = false) {
+    if (n_elem <= n_cus) return 1;
+    const long rounds = (n_elem + n_cus - 1) / n_cus;
+    const bool built = loop_built && !(q == 20 && L == 3);                   // (three hidden layers on 20x20 points: the loop does not fit the registers)
+    const bool pays = rounds >= ((q == 16 && L == 3) ? 4 : 6) && n_elem * 100 >= rounds * n_cus * 95;
+    if (built && !loop_off && (pays || loop_force)) return 2;
+    if (one_force) return 1;
+    if (q != 20 && n_elem > hpv_elem_resident_max(2, q, n_cus)) return 0;
+    return n_elem * 100 >= rounds * n_cus * 80 ? 1 : 0;
+}
+
 // Up to this many elements a 1-D rule smaller than 80 points is worth padding onto the 80 / 60 instantiation: while every element
 // has a CU to itself the padded kernel runs 27-29 us per iteration whatever the rule (against 29-42 us on the separate launches);
 // with two workgroups per CU it takes 51 us and loses to the rule as it is below 56 points (32-47 us), beyond that it scales with

@@ -1630,29 +1630,18 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     // shapes other than the headline one: one workgroup per element pays the launch-once phases (staging, projection, epilogue:
     // ~7 us) per element -- on grids of many small elements the separate launches amortise them better (scripts/elem_bench.py:
     // 1 024 elements of 12x12 points 106 against 99 us, of 16x16 points 158 against 163; 256 elements 30.7 / 48.9 against 49.3 / 60.5)
-    // Grids larger than the chip (round 5).  One workgroup per element runs ceil(n / CUs) rounds of whole elements: a grid of 289
-    // elements costs two rounds (85 us against 64 us on the separate launches, 16x16 points), and every element pays staging, epilogue
-    // and dispatch (~10 k cycles).  The MULTI instantiation (gridDim = CUs workgroups walk the elements; staging and epilogue once
-    // per workgroup) costs a fixed ~10 us + a shorter round: measured against the separate launches it wins from 4 rounds on for
-    // 16x16 points with three hidden layers (165.9 / 168.2 us at 1 024 elements, 357.7 / 394.5 at 2 304), from ~5 rounds for the
-    // smaller shapes (12x12: 106.8 / 101.1 at 1 024, 390.8 / 412.9 at 4 096; 20x20 with two hidden layers 545 / 566 at 4 096) --
-    // profiles/r05_multi_element.md.  HPV_FUSE=1: never MULTI; HPV_FUSE=m: MULTI on every grid larger than the chip (tests).
-    const bool multi_off = m->multi_off, multi_force = m->multi_force;      // (HPV_FUSE, read when the batch was assembled)
+    // Grids larger than the chip (round 5; hpv_fused_grid_plan, hpv_mfma.h).  One workgroup per element runs ceil(n / CUs) rounds of
+    // whole elements and pays staging, epilogue and dispatch per element; the MULTI instantiation (gridDim = CUs workgroups walk the
+    // elements) pays them once per workgroup.  Both only on full rounds -- a static deal wastes the unfilled part of the last one.
+    // HPV_FUSE=1: never the loop; HPV_FUSE=m: the loop on every grid larger than the chip (tests); HPV_FUSE=i: one workgroup per element.
 #ifdef HPV_FZ_NO_MULTI            // csrc/build.sh: the AGPR guard tripped in an instantiation of the element loop
-    const bool multi_built = false;
+    constexpr bool multi_built = false;
 #else
-    const bool multi_built = !(q20 && m->L == 3);
+    constexpr bool multi_built = true;
 #endif
-    const long rounds = (n_elem + m->n_cus - 1) / m->n_cus;
-    // (a static deal of elements to workgroups wastes the unfilled part of the last round: 1 600 elements = 6.25 rounds run 7 --
-    //  177 us against 151 us on the separate launches for 12x12 points, 280 against 271 for 16x16; 2 304 = 9 full rounds: 357 against 371)
-    const bool full_rounds = n_elem * 100 >= rounds * m->n_cus * 95;
-    const bool multi_pays = rounds >= ((pd.qx == 16 && m->L == 3) ? 4 : 6) && full_rounds;
-    const bool multi = !small && !multi_off && multi_built && n_elem > m->n_cus && m->base.ACTS != nullptr && (multi_pays || multi_force);
-    // one workgroup per element on a grid larger than the chip: only while the rounds are full enough (289 elements of the config-4
-    // shape: 115 us in two rounds against 88 us on the separate launches; 1 024: 228 against 280) and, for the smaller shapes, few enough
-    if (!small && !multi && !m->iter_fused_force && n_elem > m->n_cus &&
-        ((!q20 && n_elem > hpv_elem_resident_max(2, pd.qx, m->n_cus)) || n_elem * 100 < rounds * m->n_cus * 80)) return false;
+    const int gplan = small ? 1 : hpv_fused_grid_plan(pd.qx, m->L, n_elem, m->n_cus, multi_built && m->base.ACTS != nullptr, m->multi_off, m->multi_force, m->iter_fused_force);
+    if (gplan == 0) return false;
+    const bool multi = gplan == 2;
     if (small) {
         // thousands of small elements: one workgroup per element pays staging / projection / epilogue per element, the separate
         // launches stream (scripts/grid_sweep.py: 1 024 elements 80.8 against 77.5 us, 4 096 elements 292 against 273)
