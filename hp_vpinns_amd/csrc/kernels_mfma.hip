@@ -937,6 +937,12 @@ bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, c
     const ProjDesc& pd = pa.pd;
     if (!m->bwd_fused || !m->fuse_bwd || pd.edge || pd.nact || n_elem <= 0) return false;
     if (!(pd.qx == 20 && pd.qy == 20 && pd.ntx >= 1 && pd.ntx <= 10 && pd.nty >= 1 && pd.nty <= 10)) return false;   // (counts: run-time values)
+    // (element-block mode = whole elements in rounds of one workgroup per CU: on a ragged grid larger than the chip the three separate
+    //  launches are faster -- 289 elements: 114 against 87.5 us, profiles/r05_multi_element.md)
+    if (n_elem > m->n_cus) {
+        const long rounds = (n_elem + m->n_cus - 1) / m->n_cus;
+        if (n_elem * 100 < rounds * m->n_cus * 80) return false;
+    }
     const long tpe = (20 * 20) / 16;
     const long rest = m->ntiles - n_elem * tpe;                 // pad + data tiles: at most one per workgroup
     const int split = fused_split(m, n_elem);
