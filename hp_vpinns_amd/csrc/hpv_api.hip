@@ -231,13 +231,25 @@ AdamArgs adam_args(hpv_ctx* h) {
 int enqueue_pinn_pass(hpv_ctx* h, bool backward, bool fuse_adam);
 
 // One pass over both loss terms.  backward: also the reverse pass and the gradient reduction;
-// fuse_adam: the finalize kernel applies the TF1 Adam update itself (single-GPU training step).
-int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
+// fuse_adam: the finalize kernel applies the TF1 Adam update itself (single-GPU training step);
+// pend: RB holds the previous iteration's reduced gradient, its update not applied yet (multi-GPU sequence, see hpv_ctx::defer_adam):
+// k_iter_fused takes it into its prologue and k_finalize stores it; any other structure gets a k_adam launch in front.
+int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false, bool pend = false) {
+    if (h->cfg.scheme == HPV_SCHEME_PINN || !backward) {
+        if (pend) { launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream); pend = false; }
+    }
     if (h->cfg.scheme == HPV_SCHEME_PINN) return enqueue_pinn_pass(h, backward, fuse_adam);
     int rc = check_ready(h);
     if (rc) return rc;
     const double* eps_ptr = h->has_eps ? h->d_theta + h->P : nullptr;
     const bool use_mfma = h->mfma && h->backend == HPV_BACKEND_MFMA;
+    // the deferred update can only ride in a whole-iteration kernel that is the ONLY reader of the parameters in this pass (boundary
+    // points merged into it, no edge batch); otherwise it is applied here, before anything of this pass is launched or forked
+    if (pend && !(use_mfma && h->var.N > 0 && (h->merged || h->n_data == 0) && !h->pd.edge && !hpv_mfma_prefers_elem(h->mfma))) {
+        launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream);
+        pend = false;
+    }
+    bool pend_taken = false;
     if (!h->side_active) {  // allocations are not allowed inside a stream capture
         if ((rc = ensure_small_mfma(h, h->data, &h->mfma_data))) return rc;
         if (h->pd.edge && (rc = ensure_small_mfma(h, h->edge, &h->mfma_edge))) return rc;
@@ -262,7 +274,14 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
         bool ifused = false;
         if (backward && use_mfma) {
             tstart(h, 2);
-            if (hpv_mfma_prefers_elem(h->mfma)) {      // HPV_FUSE=e (A/B runs): the generic element-resident kernel first
+            if (pend) {      // the deferred update rides in k_iter_fused's prologue -- or is applied here, before anything else is launched
+                const MfmaPendingAdam pre{adam_args(h), h->d_RB, h->Ptot};
+                ifused = hpv_mfma_iter_fused(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem, &pre);
+                if (ifused) { pend_taken = true; h->pass_structure = hpv_mfma_sync_failed_possible(h->mfma) ? 3 : 2; }
+                else launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream);
+                pend = false;
+            }
+            if (!ifused && !pend_taken && hpv_mfma_prefers_elem(h->mfma)) {      // HPV_FUSE=e (A/B runs): the generic element-resident kernel first
                 ifused = hpv_mfma_iter_elem(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
                 if (ifused) h->pass_structure = 6;
             }
@@ -382,8 +401,8 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false) {
                     backward && h->n_data > 0 && !h->merged ? h->data.GPART : nullptr, h->data.rows,
                     backward && h->pd.edge && h->edge.N > 0 ? h->edge.GPART : nullptr, h->edge.rows, h->d_loss_e,
                     n_loss, h->d_deps_e, h->d_data_part, ndp, h->cfg.lossb_weight, h->n_data, h->P, h->has_eps, h->d_RB,
-                    backward ? 1 : 0, (backward && fuse_adam) ? &ad : nullptr, h->stream, h->d_xerr,
-                    xch_used ? hpv_mfma_xiter(h->mfma) : nullptr);
+                    backward ? 1 : 0, (backward && (fuse_adam || pend_taken)) ? &ad : nullptr, h->stream, h->d_xerr,
+                    xch_used ? hpv_mfma_xiter(h->mfma) : nullptr, pend_taken ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, -2, "kernel launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -444,11 +463,18 @@ int enqueue_pass_x(hpv_ctx* h, bool backward, bool fuse_adam) {
         // ONE collective per iteration: ncclAllReduce(sum) of [grad | d eps | lossv | w*lossb | msq | pad] over
         // xGMI, on the handle's stream (captured into the iteration graphs like the kernels), then the identical TF1 Adam
         // update on every rank
-        int rc = enqueue_pass(h, backward, false);
+        const bool pend = h->adam_pending;
+        h->adam_pending = false;                  // (taken into this pass's kernels, or applied in front of them)
+        int rc = enqueue_pass(h, backward, false, pend);
         if (rc) return rc;
         ncclResult_t r = rccl_allreduce(h, h->d_RB, (size_t)h->Ptot + 4, h->stream);
         if (r != ncclSuccess) return fail(h, -6, "ncclAllReduce failed: %s", rccl_error_string(r));
-        if (backward && fuse_adam) launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream);
+        if (backward && fuse_adam) {
+            // inside a sequence of iterations the update is deferred into the NEXT iteration's kernels (two launches + one collective
+            // per iteration); the sequence's last one -- and every stand-alone iteration -- is applied here
+            if (h->defer_adam && h->defer_ok) h->adam_pending = true;
+            else launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(h, -2, "adam launch failed: %s", hipGetErrorString(e));
         return 0;
@@ -463,6 +489,13 @@ int enqueue_pass_x(hpv_ctx* h, bool backward, bool fuse_adam) {
     return 0;
 }
 
+// end of a sequence of training iterations: the deferred update, if any, is applied (k_adam)
+void flush_adam(hpv_ctx* h) {
+    if (h->adam_pending) launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream);
+    h->adam_pending = false;
+    h->defer_adam = false;
+}
+
 #define HPV_GRAPH_ITERS 8
 
 // Capture `iters` whole training iterations (incl. the Adam updates) into an executable graph.
@@ -475,7 +508,9 @@ int build_step_graph(hpv_ctx* h, int iters, hipGraphExec_t* out) {
     hipGraph_t graph = nullptr;
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     h->side_active = true;
+    h->defer_adam = true;
     for (int k = 0; k < iters && !rc; ++k) rc = enqueue_pass_x(h, true, true);   // forward .. finalize (+ fused Adam / exchange)
+    if (!rc) flush_adam(h); else { h->adam_pending = false; h->defer_adam = false; }
     h->side_active = false;
     hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -519,6 +554,7 @@ int hpv_create(hpv_handle* out, const hpv_config* cfg) {
         delete h; return fail(nullptr, -2, "side stream / event creation failed");
     }
     { const char* ng = getenv("HPV_NO_GRAPH"); h->use_graph = !(ng && ng[0] == '1'); }
+    { const char* nd = getenv("HPV_NO_DEFERRED_ADAM"); h->defer_ok = !(nd && nd[0] == '1'); }
 
     // channel selection + integrand terms per (pde, var_form)
     int t1[2] = {0, 1}, t2[2] = {0, 1};
@@ -983,10 +1019,12 @@ static int enqueue_iterations(hpv_ctx* h, int n_iters) {
             HIPCHK(h, hipGraphLaunch(h->g_rem[rem], h->stream));
         }
     } else {
+        h->defer_adam = true;
         for (int it = 0; it < n_iters; ++it) {
-            if ((rc = enqueue_pass_x(h, true, true))) return rc;
+            if ((rc = enqueue_pass_x(h, true, true))) { h->adam_pending = false; h->defer_adam = false; return rc; }
             h->nupd_host += 1;            // (counted per enqueued iteration: an error exit leaves the count right)
         }
+        flush_adam(h);
         return 0;
     }
     h->nupd_host += n_iters;

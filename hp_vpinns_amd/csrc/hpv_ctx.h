@@ -134,6 +134,12 @@ struct hpv_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_active = false;            // true only while capturing
     bool use_graph = true;
+    // the multi-GPU iteration in two launches (in-library RCCL exchange): inside a sequence of training iterations the TF1-Adam
+    // update of iteration i is DEFERRED -- k_iter_fused of iteration i + 1 computes with the updated parameters (prologue), k_finalize
+    // behind it stores them -- and the last one of the sequence is applied by k_adam (flush_adam): nothing is pending at an API boundary
+    bool defer_ok = true;        // HPV_NO_DEFERRED_ADAM=1 turns it off (A/B, tests)
+    bool defer_adam = false;     // a sequence is being enqueued / captured
+    bool adam_pending = false;   // RB holds a reduced gradient whose update has not been applied
     hipGraphExec_t g_stepK = nullptr;    // HPV_GRAPH_ITERS iterations per replay (fewer inter-graph gaps)
     hipGraphExec_t g_rem[8] = {};        // g_rem[r]: r iterations (the remainder of a call), captured at first use
 };

@@ -72,6 +72,19 @@ struct AdamArgs {
 };
 #define HPV_HIST_CAP 4096
 
+#ifdef __HIPCC__
+// One TF1-Adam update of one parameter (P1:103-104; eps OUTSIDE the bias correction).  ONE definition for the two places of the
+// deferred update of the multi-GPU iteration (round 5): the prologue of k_iter_fused forms the updated parameter it computes with,
+// k_finalize behind it stores parameter and moments -- both must produce the same bits.
+__device__ __forceinline__ void hpv_adam_one(double lr, double b1, double b2, double eps, double b1p, double b2p, double g, double m0,
+                                             double v0, double t0, double& m1, double& v1, double& t1) {
+    const double lr_t = lr * sqrt(1.0 - b2p) / (1.0 - b1p);
+    m1 = b1 * m0 + (1.0 - b1) * g;
+    v1 = b2 * v0 + (1.0 - b2) * g * g;
+    t1 = t0 - lr_t * m1 / (sqrt(v1) + eps);
+}
+#endif
+
 // One-shot exchange of the packed buffer between the ranks of one node (multi-GPU path without a collective library
 // in the iteration): every rank owns a mailbox [2 parities][world][n] doubles + arrival counters [2][world], mapped
 // into every peer through hipIpc; see k_p2p_exchange (kernels_generic.hip).
@@ -101,7 +114,8 @@ void launch_data_loss(const double* U, const double* Ud, double* GBAR, double sc
 void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, int rows_b, const double* GPART_e,
                      int rows_e, const double* loss_e, long n_elem, const double* deps_e, const double* data_part,
                      int n_data_part, double lossb_weight, int n_data, int P, int has_eps, double* RB, int write_grad,
-                     const AdamArgs* fused_adam, hipStream_t s, const int* xerr = nullptr, unsigned int* xiter_bump = nullptr);
+                     const AdamArgs* fused_adam, hipStream_t s, const int* xerr = nullptr, unsigned int* xiter_bump = nullptr,
+                     int pending_adam = 0);
 void launch_adam(const AdamArgs& ad, const double* RB, int P, int Ptot, hipStream_t s);
 void launch_p2p_exchange(const P2PArgs& pp, double* RB, const AdamArgs* adam_or_null, int P, int Ptot, hipStream_t s);
 int adam_state_doubles(int P);

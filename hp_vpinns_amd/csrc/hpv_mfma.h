@@ -74,8 +74,11 @@ bool hpv_mfma_backward_fused(HpvMfma* m, const double* theta, const double* X, c
                              hipStream_t s, const ProjArgs& pa, long n_elem);
 // Element-resident whole-iteration kernel (kernels_fused.hip): forward, projection and reverse pass of the shard in ONE
 // launch, no activation store.  Returns false when not applicable (shape, variational form, small shard).
+// pre (optional): a deferred TF1-Adam update the kernel is to compute WITH (MfmaArgs::pre_g) -- only k_iter_fused takes it; when the
+// function returns false nothing has been launched and the caller applies the update itself (k_adam) before it goes on.
+struct MfmaPendingAdam { AdamArgs ad; const double* g; int Ptot; };
 bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
-                         const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem);
+                         const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem, const MfmaPendingAdam* pre = nullptr);
 // The same for small elements of any channel set (kernels_tile.hip): one tile per wave, the tile's saved state in registers.
 // fin (optional): everything the finalize step needs; when the grid is ONE workgroup the kernel runs it itself and *fin_done
 // is set (the caller then skips k_finalize).

@@ -58,6 +58,12 @@ struct MfmaArgs {
     double* fin_RB;       // [grad (P) | d eps | lossv | w*lossb | msq | pad]
     double fin_lossb_weight;
     int fin_n_data, fin_n_data_part, fin_has_eps, fin_ncopies;
+    // k_iter_fused, the multi-GPU iteration in two launches (round 5): the PREVIOUS iteration's all-reduced packed buffer whose TF1-Adam
+    // update (pre_ad) has not been applied yet -- the kernel computes with the updated parameters (formed in its prologue, every
+    // workgroup for itself, nothing written), k_finalize behind it stores them.  nullptr: parameters as they are.
+    const double* pre_g;
+    int pre_Ptot;
+    AdamArgs pre_ad;
 };
 
 // Fault injection for the exchange-timeout tests: compiled into libhpvpinn_testhooks.so only (csrc/build.sh); in the product
@@ -84,6 +90,7 @@ struct HpvMfma {
     void (*bwd_fused)(const MfmaArgs&, int, hipStream_t) = nullptr; // projection + reverse, element-block mode
     int occ_fwd = 1, occ_bwd = 1;   // resident 256-thread blocks per CU
     int n_cus = 256;                // compute units of the device
+    bool pre_used = false;          // the last k_iter_fused launch carried a deferred TF1-Adam update in its prologue
     bool multi_off = false, multi_force = false;   // HPV_FUSE=1 / m at creation: k_iter_fused's element loop never / on every grid larger than the chip
     int max_rows = 0;               // gradient rows the caller allocated (>= every launch mode's row count)
     // A/B switches read at creation (HPV_FUSE): default = the element-resident whole-iteration kernel where it applies,

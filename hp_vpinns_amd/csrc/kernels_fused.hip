@@ -28,6 +28,7 @@
 
 #define FZ_WAVES 4
 #define FZ_BLOCK (FZ_WAVES * 64)
+#define FZ_PRE_PER_THREAD 4     // deferred-update prologue: parameters per thread (networks of up to 1 024 parameters)
 #define FZ_C 3             // u, u_x, u_y
 // The element shape (QX x QY quadrature points, NTX x NTY test functions) is a template parameter of the kernel (round 4; it was
 // written for 20x20 / 10x10 alone); FZ_SHAPE_CONSTS names the derived constants inside a template body.  Needed of a shape: whole
@@ -144,7 +145,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     [[maybe_unused]] constexpr int TNX = FZ_NTX, TNY = FZ_NTY, TQX = FZ_QX, TQY = FZ_QY;
     const int rnx = pa.pd.ntx, rny = pa.pd.nty, rnr = rnx * rny;      // the run's test functions per direction (<= NTX, NTY)
     static_assert(FZ_NTX * FZ_QX == FZ_NTY * FZ_QY, "table staging walks both tables with one index");
-    {
+    double bo = 0.0;
+    // (`th`: the parameters -- device memory, or the LDS copy the deferred-update prologue below has formed)
+    auto stage_all = [&](auto th) {
         // layer index as a compile-time constant (kernarg offsets become scalar loads instead of a dependent vector load per
         // lane), every global read issued before the first LDS store (one memory round trip)
         constexpr int N1 = 4 * MF_KS * 64, IT1 = (N1 + FZ_BLOCK - 1) / FZ_BLOCK;
@@ -214,8 +217,46 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             const int f = it * FZ_BLOCK + tid;
             if (f < NTAB) { lds[M::AX + f] = vax[it]; lds[M::BY + f] = vby[it]; }
         }
+        bo = th[g.boff[L]];
+    };
+    if constexpr (!GS && !MULTI) {
+        if (g.pre_g) {
+            // The multi-GPU iteration in two launches (round 5): the previous iteration's update has not been applied -- its
+            // all-reduced gradient sits in g.pre_g.  Every workgroup forms the updated parameters for itself (the parking area is
+            // free until the forward phase) and stages its fragments from there; nothing is written: k_finalize, behind this launch,
+            // stores parameters, moments and beta powers with the same arithmetic (hpv_adam_one).  A failed exchange on any rank
+            // (pad slot of the reduced buffer) or here (sticky flag): no update -- and workgroup 0 latches the flag for k_finalize.
+            double* TH = lds + M::PK;
+            const AdamArgs& ad = g.pre_ad;
+            const double flag = g.pre_g[g.pre_Ptot + 3];
+            const int xe = *ad.xerr;
+            const bool failed = !(flag == 0.0) || xe;
+            const double b1p = ad.state[0], b2p = ad.state[1];
+            // every operand requested before the first is used: ONE memory round trip (the host declines networks of more than
+            // FZ_PRE_PER_THREAD * FZ_BLOCK parameters)
+            double t0[FZ_PRE_PER_THREAD], g0[FZ_PRE_PER_THREAD], m0[FZ_PRE_PER_THREAD], v0[FZ_PRE_PER_THREAD];
+#pragma unroll
+            for (int k = 0; k < FZ_PRE_PER_THREAD; ++k) {
+                const int idx = tid + k * FZ_BLOCK;
+                const bool in = idx < g.P;
+                t0[k] = in ? ad.theta[idx] : 0.0; g0[k] = in ? g.pre_g[idx] : 0.0; m0[k] = in ? ad.m[idx] : 0.0; v0[k] = in ? ad.v[idx] : 1.0;
+            }
+#pragma unroll
+            for (int k = 0; k < FZ_PRE_PER_THREAD; ++k) {
+                const int idx = tid + k * FZ_BLOCK;
+                double m1, v1, t1;
+                hpv_adam_one(ad.lr, ad.b1, ad.b2, ad.eps, b1p, b2p, g0[k], m0[k], v0[k], t0[k], m1, v1, t1);
+                if (idx < g.P) TH[idx] = failed ? t0[k] : t1;
+            }
+            if (failed && !xe && blockIdx.x == 0 && tid == 0) __hip_atomic_store(ad.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            stage_all((const double*)TH);
+        } else {
+            stage_all(th);
+        }
+    } else {
+        stage_all(th);
     }
-    const double bo = th[g.boff[L]];
     // SPLIT: has a barrier of an EARLIER launch of this handle failed?  A plain load (kernel boundaries make those stores
     // visible) requested behind the staging loads and consumed at the barrier
     int xsticky = 0;
@@ -1605,7 +1646,7 @@ static void launch_iter_small(const MfmaArgs& a, int blocks, hipStream_t s) {
 // Whole training pass (forward, projection, reverse) of a shard of 20x20 / 10x10 elements in one launch.  Returns false
 // when the shape / variational form / shard is not covered; the caller then runs the separate kernels.
 bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
-                         const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem) {
+                         const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem, const MfmaPendingAdam* pre) {
     const ProjDesc& pd = pa.pd;
     const NetDesc& nd = m->nd;
     if (!m->iter_fused_ok) return false;
@@ -1642,6 +1683,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     const int gplan = small ? 1 : hpv_fused_grid_plan(pd.qx, m->L, n_elem, m->n_cus, multi_built && m->base.ACTS != nullptr, m->multi_off, m->multi_force, m->iter_fused_force);
     if (gplan == 0) return false;
     const bool multi = gplan == 2;
+    if (pre && (small || multi || nd.P > FZ_PRE_PER_THREAD * FZ_BLOCK)) return false;       // the deferred-update prologue exists in the one-workgroup-per-element / SPLIT instantiations
     if (small) {
         // thousands of small elements: one workgroup per element pays staging / projection / epilogue per element, the separate
         // launches stream (scripts/grid_sweep.py: 1 024 elements 80.8 against 77.5 us, 4 096 elements 292 against 273)
@@ -1694,6 +1736,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     }
     a.proj_n_elem = n_elem;
     a.proj_split = split;
+    if (pre) { a.pre_g = pre->g; a.pre_Ptot = pre->Ptot; a.pre_ad = pre->ad; }
     a.xerr = m->xerr;
     a.xdebug_skip = m->xdebug_skip;
     a.xg = m->xg;
@@ -1708,6 +1751,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
 #else
     constexpr bool gs = false;
 #endif
+    if (pre && gs) return false;
     // MULTI spills 45 doubles per lane into the activation store: [workgroup][wave][slot][64] -- it must hold that (it is sized for
     // the separate launches' slots of every tile: far larger on any grid that takes this branch)
     if (multi && (size_t)blocks * FZ_WAVES * 64 * 48 > hpv_mfma_activation_store_doubles(m)) return false;
@@ -1726,6 +1770,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     if (split > 1) snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=true,QT=false,GS=%s%s> split=%d", m->L, gs ? "true" : "false", shp, split);
     else snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=false,QT=%s,GS=%s%s>%s", m->L, (plan == 2 || plan == 4) ? "true" : "false",
                   gs ? "true" : "false", shp, multi ? " elements-per-workgroup>1" : "");
+    m->pre_used = pre != nullptr;
     if (rows) *rows = (int)blocks;
     return true;
 }

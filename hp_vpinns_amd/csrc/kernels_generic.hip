@@ -487,8 +487,12 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
                                                          const double* __restrict__ deps_e,
                                                          const double* __restrict__ data_part, int n_data_part,
                                                          double lossb_weight, int n_data, int P, int has_eps,
-                                                         double* __restrict__ RB, int write_grad, AdamArgs ad,
-                                                         const int* __restrict__ xerr, unsigned int* __restrict__ xiter_bump) {
+                                                         double* RB, int write_grad, AdamArgs ad,
+                                                         const int* __restrict__ xerr, unsigned int* __restrict__ xiter_bump, int pend) {
+    // pend (the multi-GPU iteration in two launches, round 5): `ad` is the update of the PREVIOUS iteration -- its all-reduced
+    // gradient is still in RB, the iteration kernel in front of this launch has already computed with the updated parameters
+    // (k_iter_fused prologue, same arithmetic: hpv_adam_one) -- applied here, before RB takes this iteration's partial sums.  The
+    // failure flag of the reduced buffer was latched into *xerr by that prologue.
     constexpr int FIN_PARTS = FIN_THREADS / FIN_COLS;
     __shared__ double red[FIN_PARTS * FIN_COLS];
     const int Ptot = P + (has_eps ? 1 : 0);
@@ -501,11 +505,12 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
         // the Adam operands of this block's 16 parameters are requested BEFORE the row sums, so that their memory round trip
         // overlaps the rows' instead of following it (the kernel is one latency chain)
         bool upd = ad.theta && part == 0 && idx < P;
-        double m0 = 0.0, v0 = 0.0, th0 = 0.0, b1p = 0.0, b2p = 0.0;
+        double m0 = 0.0, v0 = 0.0, th0 = 0.0, b1p = 0.0, b2p = 0.0, gold = 0.0;
         int failed = 0;
         if (upd) {
             m0 = ad.m[idx]; v0 = ad.v[idx]; th0 = ad.theta[idx];
             b1p = ad.state[2 * (blockIdx.x + 1)]; b2p = ad.state[2 * (blockIdx.x + 1) + 1];
+            if (pend) gold = RB[idx];      // the previous iteration's reduced gradient (this thread overwrites the slot below)
             if (xerr) failed = *xerr;      // a SPLIT-mode barrier of this (or an earlier) iteration failed: no update
         }
         double acc = 0.0;
@@ -536,7 +541,15 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
 #pragma unroll 8
             for (int k = 0; k < FIN_PARTS; ++k) t += red[k * FIN_COLS + c];
             RB[idx] = t;
-            if (upd && !failed) {   // adam_update with the operands fetched above (same arithmetic, same order)
+            if (upd && !failed && pend) {      // the deferred update of the previous iteration
+                double mi, vi, ti;
+                hpv_adam_one(ad.lr, ad.b1, ad.b2, ad.eps, b1p, b2p, gold, m0, v0, th0, mi, vi, ti);
+                ad.m[idx] = mi; ad.v[idx] = vi; ad.theta[idx] = ti;
+                if (threadIdx.x == 0) {
+                    ad.state[2 * (blockIdx.x + 1)] = b1p * ad.b1;
+                    ad.state[2 * (blockIdx.x + 1) + 1] = b2p * ad.b2;
+                }
+            } else if (upd && !failed) {   // adam_update with the operands fetched above (same arithmetic, same order)
                 const double lr_t = ad.lr * sqrt(1.0 - b2p) / (1.0 - b1p);
                 const double mi = ad.b1 * m0 + (1.0 - ad.b1) * t;
                 const double vi = ad.b2 * v0 + (1.0 - ad.b2) * t * t;
@@ -556,12 +569,14 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
     // last block: scalars.  Everything thread 0 needs at the end is requested up front (one memory round trip, not three
     // dependent ones behind the reductions)
     double s0 = 0.0, s1 = 0.0, eps_th = 0.0, eps_m = 0.0, eps_v = 0.0;
+    double old4[4] = {0.0, 0.0, 0.0, 0.0};     // pend: the previous iteration's reduced d-epsilon and losses, read before this one's overwrite them
     int hidx = -1, failed = 0;
     if (threadIdx.x == 0 && xerr) failed = *xerr;
     if (threadIdx.x == 0 && ad.theta) {
         s0 = ad.state[0]; s1 = ad.state[1];
         if (ad.hist) hidx = *ad.hist_idx;
         if (has_eps) { eps_th = ad.theta[P]; eps_m = ad.m[P]; eps_v = ad.v[P]; }
+        if (pend) { old4[0] = has_eps ? RB[P] : 0.0; old4[1] = RB[Ptot]; old4[2] = RB[Ptot + 1]; old4[3] = RB[Ptot + 2]; }
     }
     double lv = 0.0, de = 0.0;
     for (long e = threadIdx.x; e < n_elem; e += blockDim.x) {
@@ -579,9 +594,10 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
         if (has_eps && write_grad) {
             RB[P] = de;
             if (ad.theta && !failed) {   // the trainable epsilon (P3:63): adam_update with the operands fetched above
+                const double ge = pend ? old4[0] : de;
                 const double lr_t = ad.lr * sqrt(1.0 - s1) / (1.0 - s0);
-                const double mi = ad.b1 * eps_m + (1.0 - ad.b1) * de;
-                const double vi = ad.b2 * eps_v + (1.0 - ad.b2) * de * de;
+                const double mi = ad.b1 * eps_m + (1.0 - ad.b1) * ge;
+                const double vi = ad.b2 * eps_v + (1.0 - ad.b2) * ge * ge;
                 ad.m[P] = mi;
                 ad.v[P] = vi;
                 ad.theta[P] = eps_th - lr_t * mi / (sqrt(vi) + ad.eps);
@@ -593,7 +609,9 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
             if (ad.hist) {   // single-GPU training iteration: record this forward pass's loss (see AdamArgs)
                 const int i = hidx;
                 if (i >= 0 && i < ad.hist_cap) {   // the index saturates at hist_cap (it never wraps)
-                    ad.hist[4 * i] = lv; ad.hist[4 * i + 1] = lossb_weight * msq; ad.hist[4 * i + 2] = msq; ad.hist[4 * i + 3] = eps_now;
+                    if (pend) { ad.hist[4 * i] = old4[1]; ad.hist[4 * i + 1] = old4[2]; ad.hist[4 * i + 2] = old4[3]; ad.hist[4 * i + 3] = eps_now; }
+                    else
+                    ad.hist[4 * i] = lv, ad.hist[4 * i + 1] = lossb_weight * msq, ad.hist[4 * i + 2] = msq, ad.hist[4 * i + 3] = eps_now;
                     *ad.hist_idx = i + 1;
                 }
             }
@@ -611,7 +629,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
 void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, int rows_b, const double* GPART_e,
                      int rows_e, const double* loss_e, long n_elem, const double* deps_e, const double* data_part,
                      int n_data_part, double lossb_weight, int n_data, int P, int has_eps, double* RB, int write_grad,
-                     const AdamArgs* fused_adam, hipStream_t s, const int* xerr, unsigned int* xiter_bump) {
+                     const AdamArgs* fused_adam, hipStream_t s, const int* xerr, unsigned int* xiter_bump, int pending_adam) {
     int gblocks = (P + FIN_COLS - 1) / FIN_COLS;
     AdamArgs ad{};
     if (fused_adam && write_grad) ad = *fused_adam;
@@ -619,11 +637,11 @@ void launch_finalize(const double* GPART_v, int rows_v, const double* GPART_b, i
     if (rows <= 1024 && n_elem <= 4096)
         hipLaunchKernelGGL(k_finalize<256>, dim3(gblocks + 1), dim3(256), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e,
                            rows_e, loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB,
-                           write_grad, ad, xerr, xiter_bump);
+                           write_grad, ad, xerr, xiter_bump, pending_adam);
     else
         hipLaunchKernelGGL(k_finalize<1024>, dim3(gblocks + 1), dim3(1024), 0, s, GPART_v, rows_v, GPART_b, rows_b, GPART_e,
                            rows_e, loss_e, n_elem, deps_e, data_part, n_data_part, lossb_weight, n_data, P, has_eps, RB,
-                           write_grad, ad, xerr, xiter_bump);
+                           write_grad, ad, xerr, xiter_bump, pending_adam);
 }
 int adam_state_doubles(int P) { return 2 * ((P + FIN_COLS - 1) / FIN_COLS + 1); }
 

@@ -1,0 +1,113 @@
+"""The multi-GPU iteration in two launches + one collective (round 5, verdict item 1c): inside a sequence of training iterations on
+the in-library RCCL exchange the TF1-Adam update of iteration i is DEFERRED -- k_iter_fused of iteration i + 1 forms the updated
+parameters in its prologue and computes with them, k_finalize behind it stores parameters, moments and beta powers, and only the
+sequence's last update is a k_adam launch (hpv_api.hip: enqueue_pass_x / flush_adam).  Checked on ONE GPU with the exchange connected
+to a 1-rank world (the launches an 8-GPU run makes, minus the xGMI hops): the deferred sequence against the same sequence with
+HPV_NO_DEFERRED_ADAM=1 (finalize, collective, k_adam per iteration) and against the single-GPU iteration (Adam inside k_finalize) --
+loss history, parameters, Adam moments, beta powers and the count of applied updates, through graph replays, remainder graphs, eager
+launches and iteration-by-iteration calls; on shapes where the deferred update rides in the iteration kernel and on shapes where it
+cannot (applied in front of the pass instead)."""
+import os
+
+import numpy as np
+import pytest
+
+from cases import rel
+
+pytestmark = pytest.mark.gpu
+
+L4 = [2, 20, 20, 20, 1]
+L3 = [2, 20, 20, 1]
+TOL = 1e-11          # same arithmetic on the same operands: the difference is the contraction of a*b + c the two compilations pick
+
+
+def _model(nx, ny, layers, mode, q=20, nt=10, seed=5, env=None):
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    saved = {}
+    env = dict(env or {})
+    if mode == "rccl_eager_updates":
+        env["HPV_NO_DEFERRED_ADAM"] = "1"
+    for k, v in env.items():
+        saved[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        s = poisson2d.setup(N_el_x=nx, N_el_y=ny, N_test_x=nt, N_test_y=nt, N_quad=q, N_bound=13, with_test_grid=False)
+        m = poisson2d.build_model(s, layers, init_params=xavier_init(layers, seed))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    if mode != "single":
+        m.h.rccl_connect(1, 0, m.h.rccl_unique_id())
+    return m
+
+
+def _run(m, calls):
+    hist = []
+    for kind, n in calls:
+        if kind == "record":
+            hist.append(m.h.step_record(n)[0])
+        else:
+            hist.append(np.asarray(m.h.step(n, True)).reshape(1, -1)[:, :3])
+    return np.concatenate(hist), m.h.get_params(), m.h.get_state(), m.h.updates_applied()
+
+
+CALLS = [("record", 19), ("step", 1), ("step", 1), ("step", 8), ("record", 3), ("step", 30)]      # 8 + 8 + 3 | 1 | 1 | 8 | 3 | 8 + 8 + 8 + 6
+
+
+@pytest.mark.parametrize("nx,ny,layers,env,rides", [
+    (16, 16, L4, None, True),                 # the headline shard: one workgroup per element
+    (8, 4, L4, None, True),                   # a shard of an 8-GPU run: an element shared by several workgroups (tagged exchange)
+    (6, 5, L3, None, True),                   # two hidden layers
+    (16, 16, L4, {"HPV_NO_GRAPH": "1"}, True),       # eager launches
+    (17, 17, L4, None, False),                # ragged grid larger than the chip: separate launches, the update in front of the pass
+    (4, 4, L4, {"HPV_FUSE": "s"}, False),     # separate launches by request
+], ids=["config4", "shared-element", "two-layers", "eager", "separate-ragged", "separate-forced"])
+def test_deferred_update_reproduces_the_per_iteration_update(nx, ny, layers, env, rides):
+    ref = _run(_model(nx, ny, layers, "rccl_eager_updates", env=env), CALLS)
+    m = _model(nx, ny, layers, "rccl", env=env)
+    assert m.h.exchange_in_use() == "rccl"
+    got = _run(m, CALLS)
+    one = _run(_model(nx, ny, layers, "single", env=env), CALLS)
+    n_total = sum(n for _, n in CALLS)
+    assert got[3] == ref[3] == one[3] == n_total
+    for other, what in ((ref, "k_adam per iteration"), (one, "single-GPU iteration")):
+        assert np.max(np.abs(got[0] - other[0]) / np.abs(other[0])) < TOL, what
+        assert rel(got[1], other[1]) < TOL, what
+        assert rel(got[2], other[2]) < TOL, what
+    if rides:
+        assert "k_iter_fused" in m.h.kernel_variant()
+    else:
+        assert "k_iter_fused" not in m.h.kernel_variant()
+
+
+@pytest.mark.parametrize("kind", ["one-dimensional", "strong-form"])
+def test_launch_structures_without_a_prologue_take_the_deferred_update_in_front_of_the_pass(kind):
+    """1-D models (tile / tall kernels) and the strong-form PINN branch: the deferred update is a k_adam launch in front of the next
+    pass -- same results as the per-iteration update."""
+    from hp_vpinns_amd.drivers import poisson1d, poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    from hp_vpinns_amd.vpinn import VPINN1D
+    res = []
+    for mode in ("deferred", "per-iteration"):
+        if mode == "per-iteration":
+            os.environ["HPV_NO_DEFERRED_ADAM"] = "1"
+        try:
+            if kind == "one-dimensional":
+                Ls = [1, 20, 20, 20, 20, 1]
+                s = poisson1d.setup(N_Element=3, N_testfcn=20, N_Quad=40)
+                m = VPINN1D(s["X_u_train"], s["u_train"], s["X_quad_train"], s["W_quad_train"], s["F_ext_total"], s["grid"],
+                            s["X_test"], s["u_test"], Ls, s["X_f_train"], s["f_train"], init_params=xavier_init(Ls, 3))
+            else:
+                s = poisson2d.setup(N_el_x=2, N_el_y=2, N_test_x=5, N_test_y=5, N_quad=10, N_bound=13, with_test_grid=False)
+                m = poisson2d.build_model(s, L4, init_params=xavier_init(L4, 3), scheme="PINNs")
+        finally:
+            os.environ.pop("HPV_NO_DEFERRED_ADAM", None)
+        m.h.rccl_connect(1, 0, m.h.rccl_unique_id())
+        res.append(_run(m, CALLS))
+    assert res[0][3] == res[1][3] == sum(n for _, n in CALLS)
+    assert np.max(np.abs(res[0][0] - res[1][0]) / np.abs(res[1][0])) < TOL
+    assert rel(res[0][1], res[1][1]) < TOL and rel(res[0][2], res[1][2]) < TOL
