@@ -1,7 +1,8 @@
 // fp64 device math for the activation hot loop.
 //
 // ocml's tanh(double) is a double-double evaluation (~135 f64 VALU instructions, it was 2/3 of the
-// forward kernel); this one is ~32 instructions with one v_rcp_f64 (one Newton step + a residual correction of the quotient):
+// forward kernel); the round-2 version (kept under -DHPV_TANH_R4) is ~32 instructions with one v_rcp_f64 (one Newton step + a
+// residual correction of the quotient):
 //   tanh|x| = -t / (2 + t),  t = expm1(-2|x|) = 2^k (e^r - 1) + (2^k - 1),  -2|x| = k ln2 + r, |r| <= ln2/2,
 //   e^r - 1 = r + r^2 (1/2! + r/3! + ... + r^11/13!)      (truncation < 4e-18)
 // max abs error 2.3e-16, max relative error 3.6e-16 over [-32, 32] incl. |x| -> 0 (checked against
@@ -9,6 +10,48 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef HPV_TANH_R4
+// Round 5: 27 fp64 operations instead of 32 (the forward phase of the whole-iteration kernels is fp64-VALU-bound: 15 tanh per lane
+// and tile, profiles/r05_notes.md section 5).  Same identity, same division; what changed:
+//   * k and 2^k without v_rndne / v_cvt / v_ldexp: km = fma(|x|, -2/ln2, 1.5 * 2^52) holds k in its low mantissa bits (one rounding
+//     of the exact product), kf = km - 1.5 * 2^52, and 2^k is assembled from the low dword with one integer instruction;
+//   * the reduced argument is w = |x| + k ln2/2 = -r/2 (no separate y = -2|x|), |w| <= ln2/4;
+//   * e^(-2w) - 1 = w (w Q(w) - 2) with Q a degree-9 interpolant of (e^(-2w) - 1 + 2w) / w^2 at the Chebyshev nodes of the interval
+//     (|w| |Q - exact| / 2 < 3.7e-17; the degree-11 Taylor polynomial of the round-2 version needed two more steps).
+// max relative error 3.8e-16 over [-32, 32] incl. |x| -> 0 and the reduction boundaries (host prototype in exact rational
+// arithmetic against mpmath, scripts/tanh_proto.py; on the device tests/test_gpu_parity.py).  -DHPV_TANH_R4: the round-2 version.
+__device__ __forceinline__ double hpv_tanh(double x) {
+    const double ax = fmin(fabs(x), 32.0);       // (fmin drops a NaN argument: it is put back on the result below)
+    const double km = fma(ax, -2.8853900817779268, 6755399441055744.0);
+    const double kf = km - 6755399441055744.0;   // k = rint(-2|x| / ln2), in [-93, 0]
+    double w = fma(kf, 3.46573590184561908245e-01, ax);
+    w = fma(kf, 9.54107464635293850010e-11, w);
+    double p = -5.1405589494805136e-05;
+    p = fma(p, w, 0.0002828297056809958);
+    p = fma(p, w, -0.0014109321451518497);
+    p = fma(p, w, 0.00634918945176432);
+    p = fma(p, w, -0.02539682542470863);
+    p = fma(p, w, 0.08888888907016779);
+    p = fma(p, w, -0.26666666666656197);
+    p = fma(p, w, 0.6666666666659861);
+    p = fma(p, w, -1.3333333333333335);
+    p = fma(p, w, 2.0000000000000004);
+    p = w * fma(w, p, -2.0);                     // e^r - 1, r = -2w
+    const double s = __hiloint2double((__double2loint(km) << 20) + 0x3ff00000, 0);     // 2^k
+    const double t = fma(s, p, s - 1.0);         // expm1(-2|x|) in (-1, 0]
+    const double d = 2.0 + t;                    // in (1, 2]
+    double rc = __builtin_amdgcn_rcp(d);         // ~2^-26 relative
+    double e = fma(-d, rc, 1.0);
+    rc = fma(rc, e, rc);                         // one Newton step: ~2^-52
+    double q = -t * rc;
+#ifndef HPV_TANH_NOCORR
+    const double rem = fma(-d, q, -t);           // exact residual of the quotient
+    q = fma(rem, rc, q);                         // correction: the quotient is good to ~1 ulp
+#endif
+    q = copysign(q, x);
+    return x != x ? x : q;                       // NaN in -> NaN out, like ocml / tf.tanh (one compare + select)
+}
+#else
 __device__ __forceinline__ double hpv_tanh(double x) {
     const double ax = fmin(fabs(x), 32.0);       // (fmin drops a NaN argument: it is put back on the result below)
     const double y = -2.0 * ax;
@@ -41,100 +84,10 @@ __device__ __forceinline__ double hpv_tanh(double x) {
     return x != x ? x : q;                       // NaN in -> NaN out, like ocml / tf.tanh (one compare + select)
 }
 
-// The same tanh for N independent arguments, written STAGE-MAJOR: every step of the algorithm is applied to all N values before
-// the next step.  hpv_tanh is one dependent chain of ~28 fp64 operations; with one wave per SIMD (k_iter_fused) nothing else
-// issues while a dependent v_fma_f64 waits for its predecessor, and the compiler keeps inlined copies of the scalar routine
-// one after the other.  Interleaved, the N chains cover each other's latency (same arithmetic per value: bit-identical results).
-// Left alone, instruction selection and the machine scheduler re-cluster the chains (they minimise register pressure), and a
-// scheduling fence (sched_barrier) only binds the machine scheduler, which then finds the chains already clustered.  An empty
-// `asm volatile` that takes the N values of a stage as read-write operands pins the stage-major order at every level: volatile
-// asm statements keep their program order, stage k feeds pin k, pin k feeds stage k + 1.  It emits no instruction, and MFMA /
-// LDS / memory instructions that do not touch the pinned values still move freely.
-template <int N>
-__device__ __forceinline__ void hpv_pin(double (&a)[N]) {
-    static_assert(N == 5 || N == 10, "pin lists are written out for 5 and 10 values");
-    if constexpr (N == 10)
-        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]));
-    else
-        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]));
-}
-template <int N>
-__device__ __forceinline__ void hpv_tanh_n(const double (&x)[N], double (&out)[N]) {
-    double y[N], k[N], r[N], p[N], s[N], t[N], d[N], rc[N], q[N], e[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) y[i] = fmin(fabs(x[i]), 32.0);
-    hpv_pin(y);
-#pragma unroll
-    for (int i = 0; i < N; ++i) y[i] = -2.0 * y[i];
-    hpv_pin(y);
-#pragma unroll
-    for (int i = 0; i < N; ++i) k[i] = y[i] * 1.4426950408889634;
-    hpv_pin(k);
-#pragma unroll
-    for (int i = 0; i < N; ++i) k[i] = rint(k[i]);
-    hpv_pin(k);
-#pragma unroll
-    for (int i = 0; i < N; ++i) r[i] = fma(-k[i], 6.93147180369123816490e-01, y[i]);
-    hpv_pin(r);
-#pragma unroll
-    for (int i = 0; i < N; ++i) r[i] = fma(-k[i], 1.90821492927058770002e-10, r[i]);
-    hpv_pin(r);
-#pragma unroll
-    for (int i = 0; i < N; ++i) p[i] = fma(1.6059043836821613e-10, r[i], 2.08767569878681e-09);
-    hpv_pin(p);
-#define HPV_TANH_STEP(C)                  \
-    _Pragma("unroll") for (int i = 0; i < N; ++i) p[i] = fma(p[i], r[i], C); \
-    hpv_pin(p);
-    HPV_TANH_STEP(2.505210838544172e-08)
-    HPV_TANH_STEP(2.755731922398589e-07)
-    HPV_TANH_STEP(2.7557319223985893e-06)
-    HPV_TANH_STEP(2.48015873015873e-05)
-    HPV_TANH_STEP(0.0001984126984126984)
-    HPV_TANH_STEP(0.001388888888888889)
-    HPV_TANH_STEP(0.008333333333333333)
-    HPV_TANH_STEP(0.041666666666666664)
-    HPV_TANH_STEP(0.16666666666666666)
-    HPV_TANH_STEP(0.5)
-#undef HPV_TANH_STEP
-#pragma unroll
-    for (int i = 0; i < N; ++i) e[i] = r[i] * r[i];
-    hpv_pin(e);
-#pragma unroll
-    for (int i = 0; i < N; ++i) p[i] = fma(e[i], p[i], r[i]);
-    hpv_pin(p);
-#pragma unroll
-    for (int i = 0; i < N; ++i) s[i] = __builtin_amdgcn_ldexp(1.0, (int)k[i]);
-    hpv_pin(s);
-#pragma unroll
-    for (int i = 0; i < N; ++i) e[i] = s[i] - 1.0;
-    hpv_pin(e);
-#pragma unroll
-    for (int i = 0; i < N; ++i) t[i] = fma(s[i], p[i], e[i]);
-    hpv_pin(t);
-#pragma unroll
-    for (int i = 0; i < N; ++i) d[i] = 2.0 + t[i];
-    hpv_pin(d);
-#pragma unroll
-    for (int i = 0; i < N; ++i) rc[i] = __builtin_amdgcn_rcp(d[i]);
-    hpv_pin(rc);
-#pragma unroll
-    for (int i = 0; i < N; ++i) e[i] = fma(-d[i], rc[i], 1.0);
-    hpv_pin(e);
-#pragma unroll
-    for (int i = 0; i < N; ++i) rc[i] = fma(rc[i], e[i], rc[i]);
-    hpv_pin(rc);
-#pragma unroll
-    for (int i = 0; i < N; ++i) q[i] = -t[i] * rc[i];
-    hpv_pin(q);
-#pragma unroll
-    for (int i = 0; i < N; ++i) e[i] = fma(-d[i], q[i], -t[i]);
-    hpv_pin(e);
-#pragma unroll
-    for (int i = 0; i < N; ++i) q[i] = fma(e[i], rc[i], q[i]);
-    hpv_pin(q);
-#pragma unroll
-    for (int i = 0; i < N; ++i) out[i] = x[i] != x[i] ? x[i] : copysign(q[i], x[i]);
-}
+#endif
+
+// (The stage-major evaluation of N independent tanh -- `hpv_tanh_n`, round 3: +0.4 us, the compiler's serial chains were never the
+//  problem -- is in the history: profiles/r03_fused_kernel_history.md section 2.)
 
 // sin and cos together for the 1-D drivers' activation (P1:134; the derivative channels need the cosine).  ocml's sincos is
 // two argument reductions with a Payne-Hanek branch and ~190 instructions; this one is 4 fma of Cody-Waite reduction against

@@ -1,0 +1,107 @@
+"""Host prototype of the device tanh (csrc/hpv_math.h, round 5): the same sequence of fp64 operations with every fma / product rounded
+once (exact rational arithmetic), v_rcp_f64 modelled as the reciprocal rounded to 27 bits, compared with mpmath at 60 digits.
+`device_coeffs()` reads the polynomial from the header, so that tests/test_host_numerics.py checks what is compiled.
+  python scripts/tanh_proto.py [n_samples]   prints the max relative error of the round-2 algorithm and of degree-8/9/10 interpolants"""
+import math, os, re, random, sys
+from fractions import Fraction as F
+import mpmath as mp
+mp.mp.dps = 60
+
+def fl(x): return float(x)
+def fma(a,b,c): return float(F(a)*F(b)+F(c))
+def mul(a,b): return a*b
+def rcp_approx(d):
+    # emulate ~2^-26 relative accuracy: round exact reciprocal to 27 significant bits
+    r = 1.0/d
+    m,e = math.frexp(r); m = round(m*2**27)/2**27
+    return math.ldexp(m,e)
+
+LN2 = mp.log(2)
+ln2hi = 6.93147180369123816490e-01
+ln2lo = 1.90821492927058770002e-10
+MAGIC = 6755399441055744.0
+
+def device_coeffs():
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hp_vpinns_amd", "csrc", "hpv_math.h")).read()
+    body = src[src.index("#ifndef HPV_TANH_R4"):src.index("#else")]
+    first = re.search(r"double p = (-?[0-9.e+-]+);", body).group(1)
+    rest = re.findall(r"p = fma\(p, w, (-?[0-9.e+-]+)\);", body)
+    return [float(c) for c in reversed([first] + rest)]       # ascending powers of w
+
+
+def minimax_coeffs(n):
+    # near-minimax (Chebyshev interpolation, then a few Remez-free refinements are unnecessary): Q(w) ~ (exp(-2w) - 1 + 2w) / w^2 on [-a, a], a = ln2/4 (+ margin)
+    a = LN2/4*mp.mpf('1.0001')
+    f = lambda w: (mp.expm1(-2*w) + 2*w)/(w*w) if abs(w) > mp.mpf('1e-8') else 2 - mp.mpf(4)/3*w + mp.mpf(2)/3*w*w
+    nodes = [a*mp.cos(mp.pi*(2*i+1)/(2*(n+1))) for i in range(n+1)]
+    A = mp.matrix(n+1,n+1); b = mp.matrix(n+1,1)
+    for i,x in enumerate(nodes):
+        for j in range(n+1): A[i,j] = x**j
+        b[i] = f(x)
+    c = mp.lu_solve(A,b)
+    return [float(c[j]) for j in range(n+1)]
+
+def tanh_new(x, C, corr):
+    ax = min(abs(x), 32.0)
+    km = fma(ax, -2.0/math.log(2.0) if False else -2.8853900817779268, MAGIC)
+    kf = km - MAGIC
+    k = int(kf)
+    w = fma(kf, ln2hi/2, ax)
+    w = fma(kf, ln2lo/2, w)
+    p = C[-1]
+    for c in C[-2::-1]: p = fma(p, w, c)
+    E = w * fma(w, p, -2.0)
+    s = math.ldexp(1.0, k)
+    t = fma(s, E, s - 1.0)
+    d = 2.0 + t
+    rc = rcp_approx(d)
+    e = fma(-d, rc, 1.0)
+    rc = fma(rc, e, rc)
+    q = -t * rc
+    if corr:
+        rem = fma(-d, q, -t)
+        q = fma(rem, rc, q)
+    return math.copysign(q, x)
+
+def tanh_old(x):
+    ax = min(abs(x), 32.0); y = -2.0*ax
+    k = float(round(y*1.4426950408889634))  # rint ties-even: python round is ties-even
+    r = fma(-k, ln2hi, y); r = fma(-k, ln2lo, r)
+    co = [1.6059043836821613e-10,2.08767569878681e-09,2.505210838544172e-08,2.755731922398589e-07,2.7557319223985893e-06,2.48015873015873e-05,0.0001984126984126984,0.001388888888888889,0.008333333333333333,0.041666666666666664,0.16666666666666666,0.5]
+    p = co[0]
+    for c in co[1:]: p = fma(p, r, c)
+    p = fma(r*r, p, r)
+    s = math.ldexp(1.0, int(k)); t = fma(s,p,s-1.0); d = 2.0+t
+    rc = rcp_approx(d); e = fma(-d,rc,1.0); rc = fma(rc,e,rc); q = -t*rc
+    rem = fma(-d,q,-t); q = fma(rem,rc,q)
+    return math.copysign(q,x)
+
+def samples(n):
+    random.seed(1)
+    xs = []
+    for _ in range(n):
+        u = random.random()
+        if u < 0.3: xs.append(random.uniform(-2,2))
+        elif u < 0.5: xs.append(random.uniform(-0.4,0.4))
+        elif u < 0.7: xs.append(random.uniform(-20,20))
+        elif u < 0.85: xs.append(math.copysign(10**random.uniform(-12,-1), random.random()-0.5))
+        else:  # near the reduction boundaries k ln2/2
+            k = random.randint(1,60); xs.append((k+0.5)*math.log(2)/2*(1+random.uniform(-1e-6,1e-6)))
+    return xs
+
+def maxerr(fn, xs):
+    worst = 0; wx = None
+    for x in xs:
+        ref = mp.tanh(mp.mpf(x))
+        err = abs((mp.mpf(fn(x)) - ref)/ref) if ref != 0 else 0
+        if err > worst: worst, wx = err, x
+    return float(worst), wx
+
+if __name__ == "__main__":
+    xs = samples(int(sys.argv[1]) if len(sys.argv) > 1 else 4000)
+    print("old", maxerr(tanh_old, xs))
+    print("device polynomial", maxerr(lambda x: tanh_new(x, device_coeffs(), True), xs))
+    for n in (8,9,10):
+        C = minimax_coeffs(n)
+        for corr in (False, True):
+            print("deg", n, "corr", corr, maxerr(lambda x: tanh_new(x,C,corr), xs))

@@ -231,3 +231,26 @@ def test_zero_weight_padding_of_quadrature_rules():
     xa, _ = GaussLobattoJacobiWeights(12, 0, 0)
     xb, wb = GaussLobattoJacobiWeights(14, 0, 0)
     assert _device_rule_2d(xa, _, xb, wb, 5, 5, 64)[0].size == 12           # different rules per direction: left alone
+
+
+def test_device_tanh_algorithm_in_exact_arithmetic():
+    """csrc/hpv_math.h, round 5 (27 fp64 operations: k and 2^k from the bits of one fma, degree-9 interpolant of (e^(-2w) - 1 + 2w) / w^2):
+    the same operation sequence with every operation rounded once (rational arithmetic), the polynomial READ FROM THE HEADER, against
+    mpmath at 60 digits -- relative error <= 4e-16 incl. |x| -> 0, the reduction boundaries (k + 1/2) ln2 / 2 and the clamp."""
+    import importlib.util
+    import math
+    import os
+    import random
+    spec = importlib.util.spec_from_file_location(
+        "tanh_proto", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "tanh_proto.py"))
+    tp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tp)
+    C = tp.device_coeffs()
+    assert len(C) == 10
+    xs = tp.samples(1200) + [0.5 * math.log(2.0) * (k + 0.5) for k in range(0, 90)] + [1e-300, 5e-324, 31.999, 32.0, 33.0, 1e300]
+    err, where = tp.maxerr(lambda x: tp.tanh_new(x, C, True), xs)
+    assert err < 4e-16, (err, where)
+    random.seed(7)
+    for x in [random.uniform(-3, 3) for _ in range(50)]:
+        assert tp.tanh_new(-x, C, True) == -tp.tanh_new(x, C, True)
+    assert tp.tanh_new(40.0, C, True) == 1.0 and tp.tanh_new(-1e300, C, True) == -1.0 and tp.tanh_new(0.0, C, True) == 0.0
