@@ -11,11 +11,11 @@
 #include <hip/hip_runtime.h>
 
 #ifndef HPV_TANH_R4
-// Round 5: 27 fp64 operations instead of 32 (the forward phase of the whole-iteration kernels is fp64-VALU-bound: 15 tanh per lane
+// Round 5: 25 fp64 operations instead of 32 (the forward phase of the whole-iteration kernels is fp64-VALU-bound: 15 tanh per lane
 // and tile, profiles/r05_notes.md section 5).  Same identity, same division; what changed:
 //   * k and 2^k without v_rndne / v_cvt / v_ldexp: km = fma(|x|, -2/ln2, 1.5 * 2^52) holds k in its low mantissa bits (one rounding
 //     of the exact product), kf = km - 1.5 * 2^52, and 2^k is assembled from the low dword with one integer instruction;
-//   * the reduced argument is w = |x| + k ln2/2 = -r/2 (no separate y = -2|x|), |w| <= ln2/4;
+//   * the reduced argument is w = |x| + k ln2/2 = -r/2 (no separate y = -2|x|), |w| <= ln2/4, in ONE fma (see below);
 //   * e^(-2w) - 1 = w (w Q(w) - 2) with Q a degree-9 interpolant of (e^(-2w) - 1 + 2w) / w^2 at the Chebyshev nodes of the interval
 //     (|w| |Q - exact| / 2 < 3.7e-17; the degree-11 Taylor polynomial of the round-2 version needed two more steps).
 // max relative error 3.8e-16 over [-32, 32] incl. |x| -> 0 and the reduction boundaries (host prototype in exact rational
@@ -24,8 +24,8 @@ __device__ __forceinline__ double hpv_tanh(double x) {
     const double ax = fmin(fabs(x), 32.0);       // (fmin drops a NaN argument: it is put back on the result below)
     const double km = fma(ax, -2.8853900817779268, 6755399441055744.0);
     const double kf = km - 6755399441055744.0;   // k = rint(-2|x| / ln2), in [-93, 0]
-    double w = fma(kf, 3.46573590184561908245e-01, ax);
-    w = fma(kf, 9.54107464635293850010e-11, w);
+    const double w = fma(kf, 0.34657359027997264, ax);      // ln2/2 to 53 bits: the product is exact inside the fma, the constant's own
+                                                            // rounding (2^-55 |k|) only matters where 2^k has made the exponential small
     double p = -5.1405589494805136e-05;
     p = fma(p, w, 0.0002828297056809958);
     p = fma(p, w, -0.0014109321451518497);
@@ -49,7 +49,9 @@ __device__ __forceinline__ double hpv_tanh(double x) {
     q = fma(rem, rc, q);                         // correction: the quotient is good to ~1 ulp
 #endif
     q = copysign(q, x);
-    return x != x ? x : q;                       // NaN in -> NaN out, like ocml / tf.tanh (one compare + select)
+    // NaN in -> NaN out, like ocml / tf.tanh.  The test is on the high dword (an integer compare: not an fp64-pipe instruction): every NaN
+    // that arithmetic produces is quiet, i.e. its high dword is above 0x7ff80000; a pre-activation is always the result of arithmetic
+    return (unsigned)(__double2hiint(x) & 0x7fffffff) > 0x7ff00000u ? x : q;
 }
 #else
 __device__ __forceinline__ double hpv_tanh(double x) {

@@ -46,8 +46,7 @@ def tanh_new(x, C, corr):
     km = fma(ax, -2.0/math.log(2.0) if False else -2.8853900817779268, MAGIC)
     kf = km - MAGIC
     k = int(kf)
-    w = fma(kf, ln2hi/2, ax)
-    w = fma(kf, ln2lo/2, w)
+    w = fma(kf, 0.34657359027997264, ax)
     p = C[-1]
     for c in C[-2::-1]: p = fma(p, w, c)
     E = w * fma(w, p, -2.0)

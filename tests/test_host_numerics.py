@@ -234,7 +234,7 @@ def test_zero_weight_padding_of_quadrature_rules():
 
 
 def test_device_tanh_algorithm_in_exact_arithmetic():
-    """csrc/hpv_math.h, round 5 (27 fp64 operations: k and 2^k from the bits of one fma, degree-9 interpolant of (e^(-2w) - 1 + 2w) / w^2):
+    """csrc/hpv_math.h, round 5 (25 fp64 operations: k and 2^k from the bits of one fma, degree-9 interpolant of (e^(-2w) - 1 + 2w) / w^2):
     the same operation sequence with every operation rounded once (rational arithmetic), the polynomial READ FROM THE HEADER, against
     mpmath at 60 digits -- relative error <= 4e-16 incl. |x| -> 0, the reduction boundaries (k + 1/2) ln2 / 2 and the clamp."""
     import importlib.util
