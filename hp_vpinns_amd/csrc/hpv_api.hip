@@ -606,8 +606,8 @@ int hpv_create(hpv_handle* out, const hpv_config* cfg) {
     rc |= dalloc(h, &h->d_hist, (size_t)4 * HPV_HIST_CAP);
     rc |= dalloc(h, &h->d_hist_idx, (size_t)1);
     if (!rc) (void)hipMemset(h->d_hist_idx, 0, sizeof(int));
-    rc |= dalloc(h, &h->d_xerr, (size_t)1);
-    if (!rc) (void)hipMemset(h->d_xerr, 0, sizeof(int));
+    rc |= dalloc(h, &h->d_xerr, (size_t)2);      // [0] the sticky flag; [1] "the deferred update was suppressed" (k_iter_fused prologue -> k_finalize)
+    if (!rc) (void)hipMemset(h->d_xerr, 0, 2 * sizeof(int));
     rc |= dalloc(h, &h->d_nupd, (size_t)1);
     if (!rc) (void)hipMemset(h->d_nupd, 0, sizeof(unsigned long long));
     rc |= dalloc(h, &h->d_RB, (size_t)h->Ptot + 4);

@@ -248,7 +248,12 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                 hpv_adam_one(ad.lr, ad.b1, ad.b2, ad.eps, b1p, b2p, g0[k], m0[k], v0[k], t0[k], m1, v1, t1);
                 if (idx < g.P) TH[idx] = failed ? t0[k] : t1;
             }
-            if (failed && !xe && blockIdx.x == 0 && tid == 0) __hip_atomic_store(ad.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (k_finalize decides the DEFERRED update by this launch's verdict, xerr[1], which every rank forms from the same reduced
+            //  buffer -- not by the sticky flag, which a barrier of THIS launch may set on one rank only: the replicas would part by one update)
+            if (blockIdx.x == 0 && tid == 0) {
+                ad.xerr[1] = failed ? 1 : 0;
+                if (failed && !xe) __hip_atomic_store(ad.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             __syncthreads();
             stage_all((const double*)TH);
         } else {

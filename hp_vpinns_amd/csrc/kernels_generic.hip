@@ -511,7 +511,9 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
             m0 = ad.m[idx]; v0 = ad.v[idx]; th0 = ad.theta[idx];
             b1p = ad.state[2 * (blockIdx.x + 1)]; b2p = ad.state[2 * (blockIdx.x + 1) + 1];
             if (pend) gold = RB[idx];      // the previous iteration's reduced gradient (this thread overwrites the slot below)
-            if (xerr) failed = *xerr;      // a SPLIT-mode barrier of this (or an earlier) iteration failed: no update
+            // a SPLIT-mode barrier of this (or an earlier) iteration failed: no update.  pend: the update belongs to the PREVIOUS iteration --
+            // the verdict the prologue of the iteration kernel formed from the reduced buffer (identical on every rank)
+            if (xerr) failed = pend ? xerr[1] : *xerr;
         }
         double acc = 0.0;
         if (idx < P) {
@@ -570,8 +572,8 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
     // dependent ones behind the reductions)
     double s0 = 0.0, s1 = 0.0, eps_th = 0.0, eps_m = 0.0, eps_v = 0.0;
     double old4[4] = {0.0, 0.0, 0.0, 0.0};     // pend: the previous iteration's reduced d-epsilon and losses, read before this one's overwrite them
-    int hidx = -1, failed = 0;
-    if (threadIdx.x == 0 && xerr) failed = *xerr;
+    int hidx = -1, failed = 0, failed_now = 0;        // failed: the update this launch applies; failed_now: this iteration (the pad slot)
+    if (threadIdx.x == 0 && xerr) { failed_now = *xerr; failed = pend ? xerr[1] : failed_now; }
     if (threadIdx.x == 0 && ad.theta) {
         s0 = ad.state[0]; s1 = ad.state[1];
         if (ad.hist) hidx = *ad.hist_idx;
@@ -619,7 +621,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
         RB[Ptot + 0] = lv;
         RB[Ptot + 1] = lossb_weight * msq;
         RB[Ptot + 2] = msq;
-        RB[Ptot + 3] = failed ? 1.0 : 0.0;   // pad slot: the all-reduce carries a failure on any rank to every rank (k_adam)
+        RB[Ptot + 3] = failed_now ? 1.0 : 0.0;   // pad slot: the all-reduce carries a failure on any rank to every rank (k_adam)
         // launch counter of the shared-element kernels' tagged exchange (hpv_fused_dev.h): advanced HERE, behind the launch that used
         // the tag -- every workgroup of that launch has ended, so none of them can read the advanced value
         if (xiter_bump) *xiter_bump += 1u;
