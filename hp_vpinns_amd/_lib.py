@@ -26,7 +26,7 @@ EXPORTS = [
     "hpv_set_params", "hpv_get_params", "hpv_loss_and_grad", "hpv_step", "hpv_forward_backward",
     "hpv_reduce_buffer", "hpv_apply_adam", "hpv_eval_loss", "hpv_read_loss", "hpv_sync",
     "hpv_predict", "hpv_get_residuals", "hpv_backend_in_use", "hpv_pass_structure", "hpv_set_active_tests", "hpv_enable_timing",
-    "hpv_kernel_time_ms", "hpv_bench_projection", "hpv_debug_activation", "hpv_get_state", "hpv_set_state",
+    "hpv_kernel_time_ms", "hpv_time_iteration_kernel", "hpv_bench_projection", "hpv_debug_activation", "hpv_get_state", "hpv_set_state",
     "hpv_assemble_rhs", "hpv_set_collocation", "hpv_gll_rule", "hpv_test_tables",
     "hpv_step_record", "hpv_history_reset", "hpv_history_read",
     "hpv_p2p_export", "hpv_p2p_connect", "hpv_p2p_selftest", "hpv_p2p_disconnect",
@@ -136,6 +136,7 @@ def load():
     lib.hpv_set_active_tests.argtypes = [h, C.POINTER(C.c_int), C.c_int]
     lib.hpv_enable_timing.argtypes = [h, C.c_int]
     lib.hpv_kernel_time_ms.argtypes = [h, C.c_int, _dp, C.POINTER(C.c_long)]
+    lib.hpv_time_iteration_kernel.argtypes = [h, C.c_int, _dp]
     lib.hpv_bench_projection.argtypes = [h, C.c_long, C.c_int, _dp, _dp]
     lib.hpv_debug_activation.argtypes = [h, _dp, C.c_int, _dp, _dp, _dp]
     lib.hpv_get_state.argtypes = [h, _dp, C.c_size_t]
@@ -378,6 +379,13 @@ class Handle:
         ms, n = C.c_double(), C.c_long()
         self._chk(self.lib.hpv_kernel_time_ms(self._h, int(which), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def time_iteration_kernel(self, reps):
+        """Average ms of `reps` back-to-back launches of the whole-iteration kernel between ONE hipEvent pair (HpvError -4 when the
+        handle's iteration is not one such launch)."""
+        ms = C.c_double()
+        self._chk(self.lib.hpv_time_iteration_kernel(self._h, int(reps), C.byref(ms)))
+        return ms.value
 
     def get_state(self):
         out = np.empty(3 * self.num_params() + 2)

@@ -230,6 +230,18 @@ AdamArgs adam_args(hpv_ctx* h) {
 
 int enqueue_pinn_pass(hpv_ctx* h, bool backward, bool fuse_adam);
 
+// the boundary / data term as the merged kernels see it, and the projection arguments of the quadrature batch (one definition for
+// enqueue_pass and the stand-alone timing of the iteration kernel)
+static MfmaDataTerm pass_data_term(hpv_ctx* h, bool backward) {
+    return MfmaDataTerm{h->data_off, h->merged ? h->n_data : 0, h->d_udata, h->var.GBAR, h->d_data_part,
+                        h->n_data > 0 ? -2.0 * h->cfg.lossb_weight / (double)h->n_data : 0.0, backward ? 1 : 0};
+}
+static ProjArgs pass_proj_args(hpv_ctx* h, bool backward) {
+    const double* eps_ptr = h->has_eps ? h->d_theta + h->P : nullptr;
+    return ProjArgs{h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
+                    h->d_loss_e, h->d_deps_e, h->var.N, backward ? 1 : 0, nullptr, nullptr, nullptr, nullptr};
+}
+
 // One pass over both loss terms.  backward: also the reverse pass and the gradient reduction;
 // fuse_adam: the finalize kernel applies the TF1 Adam update itself (single-GPU training step);
 // pend: RB holds the previous iteration's reduced gradient, its update not applied yet (multi-GPU sequence, see hpv_ctx::defer_adam):
@@ -265,10 +277,8 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false, bool pend = 
     bool xch_used = false;                              // a shared-element kernel (SPLIT mode, k_iter_tall) ran in this pass
     // --- variational term on this shard's quadrature batch ---
     if (h->var.N > 0) {
-        MfmaDataTerm dt{h->data_off, h->merged ? h->n_data : 0, h->d_udata, h->var.GBAR, h->d_data_part,
-                        h->n_data > 0 ? -2.0 * h->cfg.lossb_weight / (double)h->n_data : 0.0, backward ? 1 : 0};
-        ProjArgs pa{h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
-                    h->d_loss_e, h->d_deps_e, h->var.N, backward ? 1 : 0, nullptr, nullptr, nullptr, nullptr};
+        const MfmaDataTerm dt = pass_data_term(h, backward);
+        const ProjArgs pa = pass_proj_args(h, backward);
         // (1) element-resident whole-iteration kernel: forward, projection and reverse pass in one launch, no activation
         //     store (kernels_fused.hip); timed as the reverse-pass class
         bool ifused = false;
@@ -1121,6 +1131,37 @@ int hpv_history_read(hpv_handle h, int n, double* loss3_hist, double* eps_hist) 
         loss_triple(h, &raw[(size_t)4 * i], loss3_hist + 3 * i);
         if (eps_hist) eps_hist[i] = raw[(size_t)4 * i + 3];
     }
+    return 0;
+}
+
+int hpv_time_iteration_kernel(hpv_handle h, int reps, double* avg_ms) {
+    if (!h || reps < 1 || !avg_ms) return -1;
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->cfg.scheme == HPV_SCHEME_PINN || !(h->mfma && h->backend == HPV_BACKEND_MFMA) || h->var.N <= 0)
+        return fail(h, -4, "no whole-iteration kernel on this handle");
+    if ((rc = enqueue_pass(h, true))) return rc;        // everything a first pass allocates / selects
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = sync_check(h))) return rc;
+    if (h->pass_structure != 2) return fail(h, -4, "the handle's iteration is not ONE whole-iteration launch without an in-kernel exchange");
+    const MfmaDataTerm dt = pass_data_term(h, true);
+    const ProjArgs pa = pass_proj_args(h, true);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    bool ok = true;
+    (void)hipEventRecord(e0, h->stream);
+    for (int i = 0; i < reps && ok; ++i)
+        ok = hpv_mfma_iter_fused(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
+    (void)hipEventRecord(e1, h->stream);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!ok) return fail(h, -4, "the whole-iteration kernel declined the launch");
+    if (e != hipSuccess) return fail(h, -2, "timing the iteration kernel failed: %s", hipGetErrorString(e));
+    *avg_ms = (double)ms / reps;
     return 0;
 }
 

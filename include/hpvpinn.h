@@ -243,6 +243,12 @@ int hpv_debug_activation(hpv_handle h, const double* x, int n, double* a, double
  * hipEvents on the handle's stream when timing is enabled; which: 0 mlp_fwd, 1 project, 2 mlp_bwd. */
 int hpv_enable_timing(hpv_handle h, int on);
 int hpv_kernel_time_ms(hpv_handle h, int which, double* avg_ms, long* launches);
+/* Average duration (ms) of the whole-iteration kernel -- forward, projection and reverse pass of the shard in ONE launch (the work of
+ * P2:98-132 on the quadrature batch) -- over `reps` back-to-back launches bracketed by ONE hipEvent pair on the handle's stream: the
+ * per-launch timers above carry ~3.5 us of event overhead per pair, this one amortises it (it still contains the gaps between the
+ * launches).  Parameters, moments and the packed buffer of the last pass are left as they are (no finalize, no update).  -4 when the
+ * handle's iteration is not one such launch (separate launches, an in-kernel exchange between workgroups, strong-form branch). */
+int hpv_time_iteration_kernel(hpv_handle h, int reps, double* avg_ms);
 
 /* Stand-alone launch of the per-element projection (residual + adjoint) kernel on synthetic
  * integrand channels already resident on the device -- the HBM-roofline measurement of

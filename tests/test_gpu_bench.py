@@ -59,6 +59,11 @@ def test_bench_driver_style_single_gpu_line():
     assert t["max_it_per_s"] / t["min_it_per_s"] < 1.25, t         # clocks have ramped: the windows agree
     r = out["roofline"]
     assert r["bound"] == "mfma" and 0.2 < r["frac"] < 1.0 and r["traffic_source"]
+    # the dominant kernel's duration: back-to-back launches between one event pair (event overhead amortised), next to the per-launch pairs
+    assert "hpv_time_iteration_kernel" in r["timer"], r["timer"]
+    per_launch = out["kernel_ms_per_launch_events"]["mlp_bwd"]
+    assert 0.85 * per_launch < r["avg_ms"] < per_launch, (r["avg_ms"], per_launch)
+    assert r["avg_ms"] < out["ms_per_step"]
     import shutil
     if shutil.which("rocprofv3") and r["traffic_source"] == "measured in this run":
         # measured in the run (two --pmc passes of a short child run), not read from the committed table

@@ -232,3 +232,34 @@ def test_saved_values_through_device_memory_against_the_register_stash(case):
     assert ("SPLIT=true" in a[5]) == (case == "shard64")
     assert rel(a[0], b[0]) < 1e-13 and rel(a[1], b[1]) < 1e-12 and rel(a[2], b[2]) < 1e-12
     assert rel(a[3], b[3]) < 1e-9 and rel(a[4], b[4]) < 1e-9
+
+
+def test_iteration_kernel_timer_leaves_the_replica_alone_and_declines_other_structures():
+    """hpv_time_iteration_kernel (bench.py's roofline timer): back-to-back launches of the whole-iteration kernel between one event pair.
+    It must not touch parameters / moments, must agree with the per-launch timers to within their event overhead, and must decline
+    (-4) where the iteration is not one such launch."""
+    from hp_vpinns_amd import _lib
+    from hp_vpinns_amd.drivers import poisson2d
+    from hp_vpinns_amd.init import xavier_init
+    L = [2, 20, 20, 20, 1]
+    s = poisson2d.setup(N_el_x=16, N_el_y=16, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
+    m = poisson2d.build_model(s, L, init_params=xavier_init(L, 3))
+    m._step(5, False)
+    st = m.h.get_state()
+    l3 = m.loss_and_grad()
+    ms = m.h.time_iteration_kernel(50)
+    assert 0.02 < ms < 0.2, ms
+    assert np.array_equal(m.h.get_state(), st)
+    l3b = m.loss_and_grad()
+    assert np.array_equal(l3b[0], l3[0]) and np.array_equal(l3b[1], l3[1])
+    m.h.enable_timing(True)
+    m._step(20, False)
+    per_launch = m.h.kernel_time_ms(2)[0]
+    m.h.enable_timing(False)
+    assert 0.8 * per_launch < ms < 1.02 * per_launch, (ms, per_launch)
+    # a shard whose elements are shared by several workgroups (in-kernel exchange): not launchable alone
+    s2 = poisson2d.setup(N_el_x=8, N_el_y=4, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
+    m2 = poisson2d.build_model(s2, L, init_params=xavier_init(L, 3))
+    with pytest.raises(_lib.HpvError) as ei:
+        m2.h.time_iteration_kernel(5)
+    assert ei.value.code == -4
