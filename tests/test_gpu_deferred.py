@@ -63,9 +63,11 @@ CALLS = [("record", 19), ("step", 1), ("step", 1), ("step", 8), ("record", 3), (
     (8, 4, L4, None, True),                   # a shard of an 8-GPU run: an element shared by several workgroups (tagged exchange)
     (6, 5, L3, None, True),                   # two hidden layers
     (16, 16, L4, {"HPV_NO_GRAPH": "1"}, True),       # eager launches
+    (32, 16, L4, None, True),                 # two rounds of workgroups: the iteration kernel runs, but the update is applied in front of it
+                                              # (the prologue is paid per workgroup: hpv_mfma_iter_fused declines it on grids larger than the chip)
     (17, 17, L4, None, False),                # ragged grid larger than the chip: separate launches, the update in front of the pass
     (4, 4, L4, {"HPV_FUSE": "s"}, False),     # separate launches by request
-], ids=["config4", "shared-element", "two-layers", "eager", "separate-ragged", "separate-forced"])
+], ids=["config4", "shared-element", "two-layers", "eager", "two-rounds", "separate-ragged", "separate-forced"])
 def test_deferred_update_reproduces_the_per_iteration_update(nx, ny, layers, env, rides):
     ref = _run(_model(nx, ny, layers, "rccl_eager_updates", env=env), CALLS)
     m = _model(nx, ny, layers, "rccl", env=env)
