@@ -85,6 +85,7 @@ def test_poisson2d_driver_order_fills_the_list_created_after_the_constructor():
     his = ns["loss_his"]
     assert len(his) == 12 and his is ns["model"].loss_his
     o = OracleVPINN2D(*a, init_params=th, var_form=2)
+    o.vectorized = True        # (the batched restatement: same arithmetic, tests/test_oracle.py compares the two)
     assert rel(his, _oracle_trajectory(o, 12)) < 1e-7
     assert ns["u_pred"].shape == (a[11].shape[0], 1)
     # an explicit list (what hp_vpinns_amd/drivers do) still wins over the module's
@@ -103,6 +104,7 @@ def test_advdiff_driver_module_globals_reach_the_library():
     rec = ns["total_record"]
     assert [int(r[0]) for r in rec] == [0, 10, 20]
     o = OracleVPINNAdvDiff(*a, init_params=th, var_form=1, LR=0.002, V=0.5)
+    o.vectorized = True
     traj = _oracle_trajectory(o, 21)
     assert rel([r[1] for r in rec], traj[[0, 10, 20]]) < 1e-7
     assert abs(float(rec[-1][2][0]) - float(o.get_params()[-1])) < 1e-9

@@ -70,7 +70,7 @@ def test_config4_grid_with_wider_networks_against_the_oracle(H):
     assert "k_project_wg<20x20/10x10>" in m.h.kernel_variant()     # 256 elements: one workgroup per element
     assert rel(l3m, l3o) < TOL and rel(gm, go) < TOL, (l3m, l3o, rel(gm, go))
     assert rel(m.h.residuals(25600), o.last["R"].reshape(-1)) < TOL
-    _check_traj(o, m, n=10)
+    _check_traj(o, m, n=5)
 
 
 def test_one_dimensional_four_hidden_layers_reference_default_depth():
