@@ -69,6 +69,7 @@ def test_poisson2d_other_element_shapes(q, nt, vf, nhid):
     a = _p2(q, nt, 5, 3) + (L,)
     th = theta0(L, 40 + vf)
     o, m = OracleVPINN2D(*a, var_form=vf, init_params=th), VPINN2D(*a, var_form=vf, init_params=th)
+    o.vectorized = True
     _check(o, m, 15 * nt * nt, f"{q}x{q}/{nt}x{nt}")
 
 
@@ -80,6 +81,7 @@ def test_advdiff_16x16_elements_with_trainable_epsilon(vf):
     a = _p3(16, 8, 4, 2) + (L, None, None)
     th = theta0(L, 9, extra=[0.8])
     o, m = OracleVPINNAdvDiff(*a, var_form=vf, init_params=th), VPINNAdvDiff(*a, var_form=vf, init_params=th)
+    o.vectorized = True
     gm, _ = _check(o, m, 8 * 64, "16x16/8x8")
     assert abs(gm[-1] - o.loss_and_grad()[1][-1]) < 1.0        # (d/d epsilon is part of the gradient compared above)
 
@@ -93,6 +95,7 @@ def test_config4_shape_other_forms_run_element_resident_and_equal_the_separate_l
     for vf in (0, 2):
         th = theta0(L, 60 + vf)
         o, m = OracleVPINN2D(*a, var_form=vf, init_params=th), VPINN2D(*a, var_form=vf, init_params=th)
+        o.vectorized = True
         gm, l3m = _check(o, m, 16 * 100, "20x20/10x10", steps=4)
         os.environ["HPV_FUSE"] = "n"
         try:
@@ -112,6 +115,7 @@ def test_wider_network_on_the_element_resident_kernel():
     a = _p2(16, 8, 3, 3) + (L,)
     th = theta0(L, 5)
     o, m = OracleVPINN2D(*a, init_params=th), VPINN2D(*a, init_params=th)
+    o.vectorized = True
     _check(o, m, 9 * 64, "H=32,16x16/8x8", steps=4)
 
 
@@ -123,6 +127,7 @@ def test_more_boundary_tiles_than_free_slots_go_to_extra_workgroups():
     a = _p2(12, 6, 2, 1, nb=40) + (L,)
     th = theta0(L, 15)
     o, m = OracleVPINN2D(*a, init_params=th), VPINN2D(*a, init_params=th)
+    o.vectorized = True
     _check(o, m, 2 * 36, "12x12/6x6")
 
 
@@ -185,6 +190,7 @@ def test_hand_tuned_kernel_walks_several_elements_per_workgroup_on_grids_larger_
     a = _p2(q, nt, nex, ney, nb=40) + (L,)
     th = theta0(L, 73)
     o = OracleVPINN2D(*a, init_params=th)
+    o.vectorized = True
     os.environ["HPV_FUSE"] = "m"                    # (the default takes the element loop from ~5 rounds on; here: on every grid > CUs)
     try:
         m = VPINN2D(*a, init_params=th)             # (the switch is read when the device batch is assembled)
@@ -305,6 +311,7 @@ def test_hand_tuned_kernels_smaller_rules_1d_and_advdiff():
     args = (s["X_u_train"], s["u_train"], s["X_quad_train"], s["W_quad_train"], s["F_ext_total"], s["grid"], s["X_test"],
             s["u_test"], L, s["X_f_train"], s["f_train"])
     o, m = OracleVPINN1D(*args, init_params=th), VPINN1D(*args, init_params=th)
+    o.vectorized = True
     l3o, go = o.loss_and_grad()
     l3m, gm = m.loss_and_grad()
     assert m.h.pass_structure() == "whole-iteration-tile" and "80x1/60x1" in m.h.kernel_variant(), m.h.kernel_variant()

@@ -758,6 +758,7 @@ def test_fused_projection_reverse_config4_element_shape(nex, ney):
     if nex * ney <= 6:
         o = OracleVPINN2D(s["X_u_train"], s["u_train"], s["X_f_train"], s["f_train"], s["XY_quad_train"], s["WXY_quad_train"],
                           None, s["F_ext_total"], s["grid_x"], s["grid_y"], s["N_testfcn_total"], None, None, L, init_params=th)
+        o.vectorized = True
         _check_loss_grad(o, m)
         _check_traj(o, m, n=6)
         m = poisson2d.build_model(s, L, init_params=th)
