@@ -48,10 +48,16 @@ __device__ __forceinline__ double hpv_tanh(double x) {
     const double rem = fma(-d, q, -t);           // exact residual of the quotient
     q = fma(rem, rc, q);                         // correction: the quotient is good to ~1 ulp
 #endif
+    // sign and NaN on the HIGH dword only (the instructions beside the fp64 pipe count too: the forward phase issues one VALU instruction
+    // at a time): sign of x onto q (v_bfi), and the high dword of the canonical quiet NaN when x is a NaN -- any low dword makes that a
+    // NaN again, like ocml / tf.tanh (a diverged hidden state must not turn into a finite loss)
     q = copysign(q, x);
-    // NaN in -> NaN out, like ocml / tf.tanh.  The test is on the high dword (an integer compare: not an fp64-pipe instruction): every NaN
-    // that arithmetic produces is quiet, i.e. its high dword is above 0x7ff80000; a pre-activation is always the result of arithmetic
+#ifdef HPV_TANH_TAIL_A       // (A/B: the integer test + two selects of the first round-5 version)
     return (unsigned)(__double2hiint(x) & 0x7fffffff) > 0x7ff00000u ? x : q;
+#else
+    const int rh = __builtin_amdgcn_class(x, 0x3) ? 0x7ff80000 : __double2hiint(q);    // v_cmp_class_f64: signalling or quiet NaN
+    return __hiloint2double(rh, __double2loint(q));
+#endif
 }
 #else
 __device__ __forceinline__ double hpv_tanh(double x) {
