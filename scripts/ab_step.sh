@@ -1,7 +1,8 @@
 #!/bin/bash
-# A/B of library builds on the GPU box: scripts/ab_step.sh <iterations> <name>...   (name "default" = the in-tree library)
-N=$1; shift
-for v in "$@"; do
-  if [ "$v" = default ]; then unset HPV_LIBRARY; else export HPV_LIBRARY=$PWD/build_alt/$v/hp_vpinns_amd/libhpvpinn.so; fi
-  for rep in 1 2; do echo "$v: $(python scripts/quick_step.py $N 2>/dev/null | tail -1)"; done
+# A/B on ONE box: the in-tree library against build_alt/<variant> (scripts/build_variant.sh), three alternating runs of config 4 each.
+# Usage: bash scripts/ab_step.sh <variant> [iterations]
+V=$1; N=${2:-4000}
+for i in 1 2 3; do
+  echo -n "in-tree: "; timeout 300 python scripts/quick_step.py $N 2>&1 | tail -1
+  echo -n "$V: "; HPV_LIBRARY=$PWD/build_alt/$V/hp_vpinns_amd/libhpvpinn.so timeout 300 python scripts/quick_step.py $N 2>&1 | tail -1
 done
