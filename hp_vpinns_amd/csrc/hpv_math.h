@@ -107,6 +107,42 @@ __device__ __forceinline__ double hpv_tanh(double x) {
 // kernels evaluate a whole layer with it and redo the layer through hpv_sincos when any lane of the wave saw a larger
 // argument -- a branch per value would cut the five independent chains of a lane into separate basic blocks.
 #define HPV_SINCOS_MAX 1.0e6
+#ifndef HPV_SINCOS_R4
+// Round 5 (same lens as the tanh: every VALU instruction of the activation is paid per lane, tile and layer): the quadrant number from the
+// bits of km = fma(x, 2/pi, 1.5 * 2^52) (no v_rndne / v_cvt), the reduction as fma(k, -C, .) so that x = -0 stays -0 through it (k = +0:
+// (+0)(-C) + (-0) = -0) and sin = r (1 + z p) keeps that sign -- no compare-and-select for sin(-0) = -0 --, the cosine as
+// 1 - z/2 + z^2 q in three operations instead of fdlibm's six (compensated) ones.  Max error 1.9 ulp (sin) / 1.8 ulp (cos) over the
+// same sample as before (scripts/sincos_proto.py: exact-arithmetic prototype against mpmath; round-4 form 1.9 / 1.75 -- the worst cases are
+// the reduction's; away from them sin = r (1 + z p) is up to 0.4 ulp behind fma(z r, p, r)).  -DHPV_SINCOS_R4: the round-4 form.
+__device__ __forceinline__ void hpv_sincos_fast(double x, double* so, double* co) {
+    const double km = fma(x, 6.36619772367581382433e-01, 6755399441055744.0);
+    const double k = km - 6755399441055744.0;
+    double r = fma(k, -1.57079632673412561417e+00, x);
+    r = fma(k, -6.07710050630396597660e-11, r);
+    r = fma(k, -2.02226624871116645580e-21, r);
+    r = fma(k, -8.47842766036889956997e-32, r);
+    const double z = r * r;
+    double p = 1.58969099521155010221e-10;
+    p = fma(p, z, -2.50507602534068634195e-08);
+    p = fma(p, z, 2.75573137070700676789e-06);
+    p = fma(p, z, -1.98412698298579493134e-04);
+    p = fma(p, z, 8.33333333332248946124e-03);
+    p = fma(p, z, -1.66666666666666324348e-01);
+    const double s = r * fma(z, p, 1.0);
+    double q = -1.13596475577881948265e-11;
+    q = fma(q, z, 2.08757232129817482790e-09);
+    q = fma(q, z, -2.75573143513906633035e-07);
+    q = fma(q, z, 2.48015872894767294178e-05);
+    q = fma(q, z, -1.38888888888741095749e-03);
+    q = fma(q, z, 4.16666666666666019037e-02);
+    const double c = fma(z * z, q, fma(-0.5, z, 1.0));
+    const int n = __double2loint(km);            // k mod 2^32 (|x| <= 1e6: |k| < 2^20)
+    const double a = (n & 1) ? c : s, b = (n & 1) ? s : c;
+    // quadrant signs: sin flips for n = 2, 3 (mod 4), cos for n = 1, 2
+    *so = __longlong_as_double(__double_as_longlong(a) ^ ((long long)(n & 2) << 62));
+    *co = __longlong_as_double(__double_as_longlong(b) ^ ((long long)((n + 1) & 2) << 62));
+}
+#else
 __device__ __forceinline__ void hpv_sincos_fast(double x, double* so, double* co) {
     const double k = rint(x * 6.36619772367581382433e-01);
     double r = fma(-k, 1.57079632673412561417e+00, x);
@@ -136,6 +172,7 @@ __device__ __forceinline__ void hpv_sincos_fast(double x, double* so, double* co
     *so = x == 0.0 ? x : sv;                     // sin(-0) = -0 (the reduction's fma turns it into +0)
     *co = __longlong_as_double(__double_as_longlong(b) ^ ((long long)((n + 1) & 2) << 62));
 }
+#endif
 __device__ __forceinline__ void hpv_sincos(double x, double* so, double* co) {
     if (__builtin_expect(!(fabs(x) <= HPV_SINCOS_MAX), 0)) sincos(x, so, co);
     else hpv_sincos_fast(x, so, co);

@@ -254,3 +254,29 @@ def test_device_tanh_algorithm_in_exact_arithmetic():
     for x in [random.uniform(-3, 3) for _ in range(50)]:
         assert tp.tanh_new(-x, C, True) == -tp.tanh_new(x, C, True)
     assert tp.tanh_new(40.0, C, True) == 1.0 and tp.tanh_new(-1e300, C, True) == -1.0 and tp.tanh_new(0.0, C, True) == 0.0
+
+
+def test_device_sincos_algorithm_in_exact_arithmetic():
+    """csrc/hpv_math.h, round 5: the trimmed sincos (quadrant from the bits of one fma, sin = r (1 + z p), cos = 1 - z/2 + z^2 q in three
+    operations) with every operation rounded once, against mpmath -- <= 2 ulp for |x| <= 1e6 incl. the doubles nearest to multiples
+    of pi/2, and no worse than the round-4 form by more than half an ulp (scripts/sincos_proto.py; the device side: tests/test_gpu_parity.py)."""
+    import importlib.util
+    import math
+    import os
+    import random
+    import mpmath as mp
+    spec = importlib.util.spec_from_file_location(
+        "sincos_proto", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "sincos_proto.py"))
+    sp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sp)
+    random.seed(11)
+    xs = [random.uniform(-40, 40) for _ in range(600)] + [random.uniform(-1e6, 1e6) for _ in range(300)] + [k * (math.pi / 2) for k in range(0, 300)]
+    worst = {False: [0.0, 0.0], True: [0.0, 0.0]}
+    for x in xs:
+        rs, rc = mp.sin(mp.mpf(x)), mp.cos(mp.mpf(x))
+        for trimmed in (False, True):
+            a, b = sp.sincos(x, trimmed)
+            worst[trimmed][0] = max(worst[trimmed][0], sp.ulp(a, rs))
+            worst[trimmed][1] = max(worst[trimmed][1], sp.ulp(b, rc))
+    assert worst[True][0] <= 2.0 and worst[True][1] <= 2.0, worst
+    assert worst[True][0] <= worst[False][0] + 0.5 and worst[True][1] <= worst[False][1] + 0.5, worst
