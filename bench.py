@@ -212,6 +212,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    from hp_vpinns_amd.dist import shard_range
     from hp_vpinns_amd.drivers import poisson2d
     from hp_vpinns_amd.init import xavier_init
     s = poisson2d.setup(**CFG4, with_test_grid=False)
@@ -315,6 +316,15 @@ def main():
                   "note": "seeded Xavier start (1234), Adam lr 1e-3; value = the lowest-loss checkpoint of the last 10 000 iterations "
                           "(tests/test_gpu_convergence.py asserts <= 1e-2 for it)"}
     exchange = model.exchange() if world > 1 or dist is not None else "none"
+    # what the library's communicator ITSELF reports (ncclCommCount) and what its all-reduce of the packed buffer costs alone
+    # (200 eager calls between one hipEvent pair, collective): the 10-20 us DESIGN.md 7 assumes for 8 ranks becomes a measured field
+    rccl_world, collective_us = None, None
+    if exchange == "rccl":
+        try:
+            rccl_world = model.h.rccl_info()[0]
+            collective_us = model.h.rccl_time_allreduce(200)
+        except Exception as e:  # noqa: BLE001 -- evidence fields: never take the headline line down
+            collective_us = "failed: %s" % str(e)[:120]
 
     # ---- extras at EVERY N, N = 1 included (reported beside the headline number; the same kernels on larger problems): the
     #      driver's N = 1 line is the base of the 1 -> 8 ratio on the scaled batch (verdict round 4, item 1a).  They run after
@@ -368,7 +378,9 @@ def main():
             finally:
                 os.environ.pop("HPV_EXCHANGE", None)
 
-    per_rank = [{"rank": rank, "pass_structure": structure, "kernel_variant": variant, "graphs": bool(graphs), "exchange": exchange}]
+    per_rank = [{"rank": rank, "pass_structure": structure, "kernel_variant": variant, "graphs": bool(graphs), "exchange": exchange,
+                 "rccl_world": rccl_world, "collective_us": collective_us, "device": local_rank,
+                 "elements": list(shard_range(model.Nelementx * model.Nelementy, rank, world))}]
     if dist is not None:
         allr = [None] * world
         dist.all_gather_object(allr, per_rank[0])
@@ -430,6 +442,12 @@ def main():
                                          "EAGER launches (RCCL refused stream capture: no iteration graphs)"),
                                 "p2p": "in-library peer-mapped mailboxes over xGMI", "torch": "torch.distributed all_reduce (RCCL)",
                                 "none": "none"}[exchange],
+                   "rccl_world": rccl_world,
+                   "collective_us": (max(r["collective_us"] for r in per_rank)
+                                     if all(isinstance(r.get("collective_us"), float) for r in per_rank) else collective_us),
+                   "collective_note": "rccl_world = ncclCommCount of the library's own communicator; collective_us = ONE all-reduce of the "
+                                      "packed buffer (P + 4 doubles) alone, eager, 200 calls between one hipEvent pair, MAX over ranks; "
+                                      "null when the exchange is not the in-library RCCL one",
                    "pass_structure": structure, "kernel_variant": variant, "build": model.h.build_info(), "per_rank": per_rank},
         "timing": {"windows": len(wins), "window_it_per_s": [round(args.steps / w, 1) for w in wins],
                    "min_it_per_s": args.steps / max(wins), "max_it_per_s": args.steps / min(wins),

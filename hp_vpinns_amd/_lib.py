@@ -34,6 +34,7 @@ EXPORTS = [
     "hpv_set_collocation_shard", "hpv_rccl_unique_id", "hpv_rccl_connect", "hpv_rccl_selftest", "hpv_rccl_disconnect", "hpv_exchange_in_use",
     "hpv_rccl_available", "hpv_graphs_in_use", "hpv_updates_applied", "hpv_set_shared_element_kernels", "hpv_shared_element_kernels",
     "hpv_kernel_variant", "hpv_build_info", "hpv_rccl_abandon", "hpv_bench_residual_checksums", "hpv_rule_advice",
+    "hpv_rccl_info", "hpv_rccl_time_allreduce",
 ]
 
 
@@ -165,6 +166,8 @@ def load():
     lib.hpv_rccl_disconnect.argtypes = [h]
     lib.hpv_exchange_in_use.argtypes = [h]
     lib.hpv_rccl_abandon.argtypes = [h]
+    lib.hpv_rccl_info.argtypes = [h, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.hpv_rccl_time_allreduce.argtypes = [h, C.c_int, _dp]
     lib.hpv_bench_residual_checksums.argtypes = [h, C.c_long, C.c_int, _dp]
     lib.hpv_kernel_variant.argtypes = [h, C.c_char_p, C.c_size_t]
     lib.hpv_build_info.argtypes = []
@@ -442,6 +445,18 @@ class Handle:
 
     def build_info(self):
         return build_info(self.lib)
+
+    def rccl_info(self):
+        """(world, rank) as the connected communicator itself reports them (ncclCommCount / ncclCommUserRank); (0, -1): none."""
+        w, r = C.c_int(0), C.c_int(-1)
+        self._chk(self.lib.hpv_rccl_info(self._h, C.byref(w), C.byref(r)))
+        return w.value, r.value
+
+    def rccl_time_allreduce(self, reps=200):
+        """Microseconds per eager all-reduce of a packed-buffer-sized scratch buffer (the collective alone).  Collective call."""
+        us = C.c_double(0.0)
+        self._chk(self.lib.hpv_rccl_time_allreduce(self._h, int(reps), C.byref(us)))
+        return us.value
 
     def rccl_abandon(self):
         """Thread-safe: stop waiting for a blocking rccl_connect / rccl_selftest that runs on a helper thread."""

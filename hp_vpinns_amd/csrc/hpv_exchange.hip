@@ -15,6 +15,8 @@ struct RcclApi {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;          // optional (hpv_rccl_info): what the communicator itself reports
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     bool ok = false;
     std::string why;     // what went wrong, captured where it went wrong (dlerror() is one-shot and goes stale)
 };
@@ -41,6 +43,8 @@ RcclApi& rccl_api() {
         api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
         api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
+        api.CommUserRank = (decltype(api.CommUserRank))dlsym(api.lib, "ncclCommUserRank");
         api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy && api.GetErrorString;
     });
     return api;
@@ -259,6 +263,60 @@ int hpv_rccl_selftest(hpv_handle h, double* out, size_t n) {
     if (h->rccl_abandoned.load()) return -6;
     if (e2 != hipSuccess) return fail(h, -2, "rccl self-test copy failed: %s", hipGetErrorString(e2));
     return 0;
+}
+
+// What the COMMUNICATOR reports (ncclCommCount / ncclCommUserRank), not what the caller asked for: a reader of the bench line
+// can check that RCCL saw N ranks.  Local call.
+int hpv_rccl_info(hpv_handle h, int* world, int* rank) {
+    if (!h || !world || !rank) return -1;
+    *world = 0; *rank = -1;
+    if (!h->rccl_on) return 0;
+    RcclApi& api = rccl_api();
+    if (!api.CommCount || !api.CommUserRank) return fail(h, -6, "librccl has no ncclCommCount / ncclCommUserRank");
+    ncclResult_t r = api.CommCount(h->rccl_comm, world);
+    if (r == ncclSuccess) r = api.CommUserRank(h->rccl_comm, rank);
+    if (r != ncclSuccess) return fail(h, -6, "ncclCommCount failed: %s", api.GetErrorString(r));
+    return 0;
+}
+
+// The collective ALONE: `reps` eager ncclAllReduce(sum, double) calls of a buffer of the packed buffer's size (a scratch copy: the
+// handle's state is not touched) back to back on the handle's stream between one hipEvent pair, after `reps / 10 + 1` untimed
+// ones.  Collective: every rank calls it with the same `reps`.  avg_us = microseconds per all-reduce on THIS rank.
+int hpv_rccl_time_allreduce(hpv_handle h, int reps, double* avg_us) {
+    if (!h || !avg_us || reps < 1 || !h->rccl_on) return -1;
+    if (h->rccl_abandoned.load()) return -6;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t n = (size_t)h->Ptot + 4;
+    double* scratch = nullptr;
+    HIPCHK(h, hipMalloc((void**)&scratch, n * sizeof(double)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    auto done = [&](int code) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipFree(scratch);
+        return code;
+    };
+    if (hipMemsetAsync(scratch, 0, n * sizeof(double), h->stream) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+        hipEventCreate(&e1) != hipSuccess)
+        return done(fail(h, -2, "hpv_rccl_time_allreduce: set-up failed"));
+    for (int pass = 0; pass < 2 && !rc; ++pass) {
+        const int k = pass ? reps : reps / 10 + 1;
+        if (pass) (void)hipEventRecord(e0, h->stream);
+        for (int i = 0; i < k && !rc; ++i) {
+            ncclResult_t r = rccl_allreduce(h, scratch, n, h->stream);
+            if (r != ncclSuccess) rc = fail(h, -6, "ncclAllReduce failed: %s", rccl_api().GetErrorString(r));
+        }
+        if (pass) (void)hipEventRecord(e1, h->stream);
+    }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (!rc && e != hipSuccess) rc = fail(h, -2, "hpv_rccl_time_allreduce: %s", hipGetErrorString(e));
+    if (!rc) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *avg_us = 1e3 * (double)ms / (double)reps;
+    }
+    return done(rc);
 }
 
 int hpv_exchange_in_use(hpv_handle h) { return !h ? -1 : (h->rccl_on ? 1 : (h->p2p_on ? 2 : 0)); }

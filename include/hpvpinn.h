@@ -152,6 +152,13 @@ int hpv_rccl_disconnect(hpv_handle h);
  * collective that never completes -- do not use that handle again (and do not destroy it while the call is still inside). */
 int hpv_rccl_abandon(hpv_handle h);
 int hpv_exchange_in_use(hpv_handle h);
+/* Evidence for a reader of the benchmark line (the ONE collective of the path, lossv = sum_e loss_e of P2:120):
+ *   hpv_rccl_info          : world size and rank as the COMMUNICATOR reports them (ncclCommCount / ncclCommUserRank);
+ *                            0 / -1 when no communicator is connected.  Local call.
+ *   hpv_rccl_time_allreduce: the all-reduce of the packed buffer ALONE -- `reps` eager calls on a scratch buffer of the same
+ *                            size, one hipEvent pair around them, microseconds per call on this rank.  Collective. */
+int hpv_rccl_info(hpv_handle h, int* world, int* rank);
+int hpv_rccl_time_allreduce(hpv_handle h, int reps, double* avg_us);
 /* Opt-in alternative (HPV_EXCHANGE=p2p in the Python classes): in-library exchange over peer-mapped mailboxes instead of
  * a collective-library call every iteration: each rank owns a mailbox that every peer maps through hipIpc; one kernel per
  * iteration writes the buffer into all mailboxes over xGMI, waits for the peers' contributions (bounded), sums them in

