@@ -38,11 +38,11 @@ EXPORTS = [
 ]
 
 
-def rule_advice(device, dim, q, ntx, nty, n_elem_shard, exact_counts=False):
+def rule_advice(device, dim, q, ntx, nty, n_elem_shard, exact_counts=False, n_hidden=0):
     """hpv_rule_advice: (q_dev, nt_dev) -- the instantiated rule a shard's rule should be zero-weight padded to (q_dev == q: leave it
     alone) and, in 1-D, the test-function count the device tables should have.  The limits are the launch functions' own."""
     qd, nd = C.c_int(0), C.c_int(0)
-    rc = load().hpv_rule_advice(int(device), int(dim), int(q), int(ntx), int(nty), int(n_elem_shard), 1 if exact_counts else 0,
+    rc = load().hpv_rule_advice(int(device), int(dim), int(q), int(ntx), int(nty), int(n_elem_shard), 1 if exact_counts else 0, int(n_hidden),
                                 C.byref(qd), C.byref(nd))
     if rc:
         raise HpvError(f"hpv_rule_advice({dim}, {q}, {ntx}, {nty}, {n_elem_shard}) returned {rc}")
@@ -171,7 +171,7 @@ def load():
     lib.hpv_bench_residual_checksums.argtypes = [h, C.c_long, C.c_int, _dp]
     lib.hpv_kernel_variant.argtypes = [h, C.c_char_p, C.c_size_t]
     lib.hpv_build_info.argtypes = []
-    lib.hpv_rule_advice.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.hpv_rule_advice.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.hpv_build_info.restype = C.c_char_p
     _libs[path] = lib
     if path == LIB_PATH:

@@ -251,8 +251,11 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false, bool pend = 
         if (pend) { launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream); pend = false; }
     }
     if (h->cfg.scheme == HPV_SCHEME_PINN) return enqueue_pinn_pass(h, backward, fuse_adam);
+    // (an error exit BEFORE the pending update has been taken over by a launch applies it first, best effort: it was counted when
+    //  its iteration was enqueued, and dropping it would leave the device one update behind the host's count -- advisor, round 5)
+    auto apply_pend = [&] { if (pend) { launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream); pend = false; } };
     int rc = check_ready(h);
-    if (rc) return rc;
+    if (rc) { apply_pend(); return rc; }
     const double* eps_ptr = h->has_eps ? h->d_theta + h->P : nullptr;
     const bool use_mfma = h->mfma && h->backend == HPV_BACKEND_MFMA;
     // the deferred update can only ride in a whole-iteration kernel that is the ONLY reader of the parameters in this pass (boundary
@@ -263,8 +266,8 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false, bool pend = 
     }
     bool pend_taken = false;
     if (!h->side_active) {  // allocations are not allowed inside a stream capture
-        if ((rc = ensure_small_mfma(h, h->data, &h->mfma_data))) return rc;
-        if (h->pd.edge && (rc = ensure_small_mfma(h, h->edge, &h->mfma_edge))) return rc;
+        if ((rc = ensure_small_mfma(h, h->data, &h->mfma_data))) { apply_pend(); return rc; }
+        if (h->pd.edge && (rc = ensure_small_mfma(h, h->edge, &h->mfma_edge))) { apply_pend(); return rc; }
     }
     hipStream_t smain = h->stream;
     const bool fork = h->side_active && !h->merged && h->n_data > 0;
@@ -1032,7 +1035,9 @@ static int enqueue_iterations(hpv_ctx* h, int n_iters) {
         h->defer_adam = true;
         for (int it = 0; it < n_iters; ++it) {
             if ((rc = enqueue_pass_x(h, true, true))) { h->adam_pending = false; h->defer_adam = false; return rc; }
-            h->nupd_host += 1;            // (counted per enqueued iteration: an error exit leaves the count right)
+            h->nupd_host += 1;            // (counted per enqueued iteration: an error exit leaves the count right -- a pending update is
+                                          //  either stored by the failing pass's k_finalize or applied by enqueue_pass's error exit; the
+                                          //  handle is in a failed state afterwards: hpv_last_error says why)
         }
         flush_adam(h);
         return 0;
@@ -1380,7 +1385,7 @@ const char* hpv_build_info(void) {
     });
     return info.c_str();
 }
-int hpv_rule_advice(int device, int dim, int q, int ntx, int nty, long n_elem_shard, int exact_counts, int* q_dev, int* nt_dev) {
+int hpv_rule_advice(int device, int dim, int q, int ntx, int nty, long n_elem_shard, int exact_counts, int n_hidden, int* q_dev, int* nt_dev) {
     if (!q_dev || !nt_dev || (dim != 1 && dim != 2) || q < 1 || ntx < 1 || n_elem_shard < 0) return -1;
     *q_dev = q; *nt_dev = ntx;
     int n_cus = 256;
@@ -1397,9 +1402,12 @@ int hpv_rule_advice(int device, int dim, int q, int ntx, int nty, long n_elem_sh
     for (const auto& r : rules) {
         const bool counts_ok = exact_counts ? (ntx == r[1] && nty == r[1]) : (ntx <= r[1] && nty <= r[1]);
         if (q <= r[0] && counts_ok) {
-            // (pad only while the kernel of that rule would take the shard; the network depth is not known here: three hidden layers,
-            //  the reference's own depth)
-            const bool takes = r[0] == 10 ? n_elem_shard <= hpv_elem_resident_max(2, 10, n_cus) : hpv_fused_grid_plan(r[0], 3, n_elem_shard, n_cus, false) == 1;   // (not for the element loop: on many rounds the padded points cost more than the structure saves)
+            // (pad only while ONE WORKGROUP PER ELEMENT of that rule's kernel would take the shard -- the plan evaluated with the
+            //  network's depth and the element loop as built, exactly as launch_iter_fused evaluates it: where the loop (plan 2) or
+            //  the separate launches (plan 0) take the grid, the padded points cost more than the structure saves; advisor, round 5)
+            const int Lh = n_hidden > 0 ? n_hidden : 3;
+            const bool takes = r[0] == 10 ? n_elem_shard <= hpv_elem_resident_max(2, 10, n_cus)
+                                          : hpv_fused_grid_plan(r[0], Lh, n_elem_shard, n_cus, hpv_fused_loop_built()) == 1;
             if (q < r[0] && takes) *q_dev = r[0];
             break;
         }

@@ -73,15 +73,27 @@ struct AdamArgs {
 #define HPV_HIST_CAP 4096
 
 #ifdef __HIPCC__
-// One TF1-Adam update of one parameter (P1:103-104; eps OUTSIDE the bias correction).  ONE definition for the two places of the
-// deferred update of the multi-GPU iteration (round 5): the prologue of k_iter_fused forms the updated parameter it computes with,
-// k_finalize behind it stores parameter and moments -- both must produce the same bits.
+// One TF1-Adam update of one parameter (P1:103-104; eps OUTSIDE the bias correction).  ONE definition for every place an update
+// is applied (k_finalize, k_adam, k_p2p_exchange, the one-workgroup tail of k_iter_tile) or merely FORMED (the prologue of
+// k_iter_fused computes with the updated parameter of the deferred update, k_finalize behind it stores it): all of them must
+// produce the same bits, in every translation unit, under every compiler release -- so the operation sequence is pinned:
+// floating-point contraction is OFF inside (each *, +, -, /, sqrt rounds on its own; no fma is formed here or there by the
+// optimiser).  Advisor, round 5: under the default -ffp-contract the two compilations were free to fuse a*b + c differently.
+__device__ __forceinline__ double hpv_adam_lr_t(double lr, double b1p, double b2p) {
+#pragma clang fp contract(off)
+    return lr * sqrt(1.0 - b2p) / (1.0 - b1p);
+}
+__device__ __forceinline__ void hpv_adam_one_lr(double lr_t, double b1, double b2, double eps, double g, double m0, double v0,
+                                                double t0, double& m1, double& v1, double& t1) {
+#pragma clang fp contract(off)
+    const double gm = (1.0 - b1) * g, gv = (1.0 - b2) * g;
+    m1 = b1 * m0 + gm;
+    v1 = b2 * v0 + gv * g;
+    t1 = t0 - lr_t * m1 / (sqrt(v1) + eps);
+}
 __device__ __forceinline__ void hpv_adam_one(double lr, double b1, double b2, double eps, double b1p, double b2p, double g, double m0,
                                              double v0, double t0, double& m1, double& v1, double& t1) {
-    const double lr_t = lr * sqrt(1.0 - b2p) / (1.0 - b1p);
-    m1 = b1 * m0 + (1.0 - b1) * g;
-    v1 = b2 * v0 + (1.0 - b2) * g * g;
-    t1 = t0 - lr_t * m1 / (sqrt(v1) + eps);
+    hpv_adam_one_lr(hpv_adam_lr_t(lr, b1p, b2p), b1, b2, eps, g, m0, v0, t0, m1, v1, t1);
 }
 #endif
 

@@ -28,6 +28,7 @@ inline long hpv_elem_resident_max(int dim, int q, int n_cus) {
 // 0 not at all (the separate launches), 1 one workgroup per element, 2 the element loop (gridDim = CUs workgroups walk the elements).
 // ONE definition for the dispatch (kernels_fused.hip) and for hpv_rule_advice (a smaller rule is padded onto an instantiated one only
 // while the kernel would take the shard).  Numbers behind it: profiles/r05_multi_element.md.
+bool hpv_fused_loop_built();      // kernels_fused.hip: the element loop (MULTI) survived the build guard
 inline int hpv_fused_grid_plan(int q, int L, long n_elem, int n_cus, bool loop_built, bool loop_off = false, bool loop_force = false, bool one_force = false) {
     if (n_elem <= n_cus) return 1;
     const long rounds = (n_elem + n_cus - 1) / n_cus;

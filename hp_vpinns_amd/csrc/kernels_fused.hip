@@ -219,6 +219,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         }
         bo = th[g.boff[L]];
     };
+    [[maybe_unused]] int pre_failed = -1;      // the deferred-update prologue's verdict (identical in every workgroup); -1: no prologue
     if constexpr (!GS && !MULTI) {
         if (g.pre_g) {
             // The multi-GPU iteration in two launches (round 5): the previous iteration's update has not been applied -- its
@@ -231,6 +232,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             const double flag = g.pre_g[g.pre_Ptot + 3];
             const int xe = *ad.xerr;
             const bool failed = !(flag == 0.0) || xe;
+            pre_failed = failed ? 1 : 0;
             const double b1p = ad.state[0], b2p = ad.state[1];
             // every operand requested before the first is used: ONE memory round trip (the host declines networks of more than
             // FZ_PRE_PER_THREAD * FZ_BLOCK parameters)
@@ -266,7 +268,10 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     // visible) requested behind the staging loads and consumed at the barrier
     int xsticky = 0;
     unsigned xtag = 0;             // this launch's exchange tag (hpv_fused_dev.h, xg_*)
-    if constexpr (SPLIT) { xsticky = *g.xerr; xtag = *g.xiter + 1u; }
+    // (behind a deferred-update prologue the verdict formed there is used instead: workgroup 0 may be storing to *g.xerr in THIS
+    //  launch -- a partner that re-read the flag could see it while another does not, and wait for a partner that stays away
+    //  (advisor, round 5); the prologue's verdict comes from the pad slot and the pre-launch flag, the same in every workgroup)
+    if constexpr (SPLIT) { xsticky = pre_failed >= 0 ? pre_failed : *g.xerr; xtag = *g.xiter + 1u; }
     // the element's projection constants, requested now so that no global latency sits inside phase P
     double pc0 = pa.coef[e], pc1 = pa.coef[pa.coef_stride + e];
     const int ro_k = tid / FZ_NTX, ro_r = tid % FZ_NTX;                 // residual (k, r) of thread tid < NR, and whether the run has it
@@ -1798,4 +1803,14 @@ void hpv_mfma_set_split_ok(HpvMfma* m, bool on) {
     if (!m) return;
     const char* e = getenv("HPV_FUSE");
     m->iter_split_ok = on && !(e && e[0] == 's');
+}
+
+// the element loop (MULTI instantiations) is in this build (csrc/build.sh compiles them out when their AGPR guard trips); read by
+// hpv_rule_advice so that its plan is the dispatch's
+bool hpv_fused_loop_built() {
+#ifdef HPV_FZ_NO_MULTI
+    return false;
+#else
+    return true;
+#endif
 }

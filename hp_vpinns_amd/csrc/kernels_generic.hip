@@ -466,12 +466,11 @@ void launch_data_loss(const double* U, const double* Ud, double* GBAR, double sc
 // beta*_power variables; they are kept REPLICATED -- state[0..1] for the scalar block / k_adam and one copy per
 // gradient block of the fused finalize+Adam kernel -- so that no block reads a value another block updates.
 __device__ __forceinline__ void adam_update(const AdamArgs& ad, int i, double g, double b1p, double b2p) {
-    const double lr_t = ad.lr * sqrt(1.0 - b2p) / (1.0 - b1p);
-    const double mi = ad.b1 * ad.m[i] + (1.0 - ad.b1) * g;
-    const double vi = ad.b2 * ad.v[i] + (1.0 - ad.b2) * g * g;
+    double mi, vi, ti;
+    hpv_adam_one(ad.lr, ad.b1, ad.b2, ad.eps, b1p, b2p, g, ad.m[i], ad.v[i], ad.theta[i], mi, vi, ti);
     ad.m[i] = mi;
     ad.v[i] = vi;
-    ad.theta[i] -= lr_t * mi / (sqrt(vi) + ad.eps);
+    ad.theta[i] = ti;
 }
 
 #define FIN_COLS 16                          // parameters per block (one 128-B row segment per partial row)
@@ -552,12 +551,11 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
                     ad.state[2 * (blockIdx.x + 1) + 1] = b2p * ad.b2;
                 }
             } else if (upd && !failed) {   // adam_update with the operands fetched above (same arithmetic, same order)
-                const double lr_t = ad.lr * sqrt(1.0 - b2p) / (1.0 - b1p);
-                const double mi = ad.b1 * m0 + (1.0 - ad.b1) * t;
-                const double vi = ad.b2 * v0 + (1.0 - ad.b2) * t * t;
+                double mi, vi, ti;
+                hpv_adam_one(ad.lr, ad.b1, ad.b2, ad.eps, b1p, b2p, t, m0, v0, th0, mi, vi, ti);
                 ad.m[idx] = mi;
                 ad.v[idx] = vi;
-                ad.theta[idx] = th0 - lr_t * mi / (sqrt(vi) + ad.eps);
+                ad.theta[idx] = ti;
                 // this block's private copy of the running beta powers (no cross-block race); its only readers are the 16
                 // `upd` lanes of this wave, which consumed them above -- written from the prefetched values, no second round trip
                 if (threadIdx.x == 0) {
@@ -597,12 +595,11 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(const double* __restri
             RB[P] = de;
             if (ad.theta && !failed) {   // the trainable epsilon (P3:63): adam_update with the operands fetched above
                 const double ge = pend ? old4[0] : de;
-                const double lr_t = ad.lr * sqrt(1.0 - s1) / (1.0 - s0);
-                const double mi = ad.b1 * eps_m + (1.0 - ad.b1) * ge;
-                const double vi = ad.b2 * eps_v + (1.0 - ad.b2) * ge * ge;
+                double mi, vi, ti;
+                hpv_adam_one(ad.lr, ad.b1, ad.b2, ad.eps, s0, s1, ge, eps_m, eps_v, eps_th, mi, vi, ti);
                 ad.m[P] = mi;
                 ad.v[P] = vi;
-                ad.theta[P] = eps_th - lr_t * mi / (sqrt(vi) + ad.eps);
+                ad.theta[P] = ti;
             }
         }
         if (ad.theta && !failed) {
@@ -676,6 +673,10 @@ __global__ void __launch_bounds__(1024) k_adam(AdamArgs ad, const double* __rest
         if (threadIdx.x == 0 && ad.xerr) *ad.xerr = 1;
         return;
     }
+    // every up-front load above has returned in every wave before any wave stores below: thread 0's read of theta[P] (the history's
+    // "epsilon before this update") must not race the store of the thread that owns index P in another wave (advisor, round 5;
+    // `failed` is block-uniform, so the barrier is reached by all threads or by none)
+    __syncthreads();
     if (threadIdx.x == 0 && ad.n_upd) *ad.n_upd += 1;
     if (threadIdx.x == 0 && ad.hist) {   // multi-GPU iteration: g is the all-reduced packed buffer, the losses follow the gradient
         if (hidx >= 0 && hidx < ad.hist_cap) {   // saturating index
@@ -685,12 +686,11 @@ __global__ void __launch_bounds__(1024) k_adam(AdamArgs ad, const double* __rest
         }
     }
     if (own) {       // adam_update with the operands fetched above (same arithmetic, same order)
-        const double lr_t = ad.lr * sqrt(1.0 - b2p) / (1.0 - b1p);
-        const double mi = ad.b1 * m0 + (1.0 - ad.b1) * g0;
-        const double vi = ad.b2 * v0 + (1.0 - ad.b2) * g0 * g0;
+        double mi, vi, ti;
+        hpv_adam_one(ad.lr, ad.b1, ad.b2, ad.eps, b1p, b2p, g0, m0, v0, t0, mi, vi, ti);
         ad.m[i0] = mi;
         ad.v[i0] = vi;
-        ad.theta[i0] = t0 - lr_t * mi / (sqrt(vi) + ad.eps);
+        ad.theta[i0] = ti;
     }
     for (int i = threadIdx.x + blockDim.x; i < Ptot; i += blockDim.x) adam_update(ad, i, g[i], b1p, b2p);
     // every replicated copy advances (each thread rewrites the copy it read above) -- behind a barrier: every wave has read copy 0

@@ -484,7 +484,7 @@ __device__ __forceinline__ void tile_body(const MfmaArgs& g, double* lds) {
         const bool upd = g.fin_mode == 2;
         const int P = g.P, Ptot = P + (g.fin_has_eps ? 1 : 0);
         const double b1p = upd ? ad.state[0] : 0.0, b2p = upd ? ad.state[1] : 0.0;
-        const double lr_t = upd ? ad.lr * sqrt(1.0 - b2p) / (1.0 - b1p) : 0.0;
+        const double lr_t = upd ? hpv_adam_lr_t(ad.lr, b1p, b2p) : 0.0;
         // (every operand of the update is requested before the first sum: one memory round trip, not one per 384 parameters)
         constexpr int FIT = (1341 + BT - 1) / BT;      // P <= 1341 for the networks this path takes (L <= 4)
         double m0[FIT], v0[FIT], th0[FIT];
@@ -501,11 +501,11 @@ __device__ __forceinline__ void tile_body(const MfmaArgs& g, double* lds) {
                 for (int w = 0; w < n_act; ++w) t += W0[(long)w * P + idx];
                 g.fin_RB[idx] = t;
                 if (upd) {
-                    const double mi = ad.b1 * m0[it] + (1.0 - ad.b1) * t;
-                    const double vi = ad.b2 * v0[it] + (1.0 - ad.b2) * t * t;
+                    double mi, vi, ti;
+                    hpv_adam_one_lr(lr_t, ad.b1, ad.b2, ad.eps, t, m0[it], v0[it], th0[it], mi, vi, ti);
                     ad.m[idx] = mi;
                     ad.v[idx] = vi;
-                    ad.theta[idx] = th0[it] - lr_t * mi / (sqrt(vi) + ad.eps);
+                    ad.theta[idx] = ti;
                 }
             }
         }
@@ -514,11 +514,11 @@ __device__ __forceinline__ void tile_body(const MfmaArgs& g, double* lds) {
             for (int w = 0; w < n_act; ++w) t += W0[(long)w * P + idx];
             g.fin_RB[idx] = t;
             if (upd) {
-                const double mi = ad.b1 * ad.m[idx] + (1.0 - ad.b1) * t;
-                const double vi = ad.b2 * ad.v[idx] + (1.0 - ad.b2) * t * t;
+                double mi, vi, ti;
+                hpv_adam_one_lr(lr_t, ad.b1, ad.b2, ad.eps, t, ad.m[idx], ad.v[idx], ad.theta[idx], mi, vi, ti);
                 ad.m[idx] = mi;
                 ad.v[idx] = vi;
-                ad.theta[idx] = ad.theta[idx] - lr_t * mi / (sqrt(vi) + ad.eps);
+                ad.theta[idx] = ti;
             }
         }
         if (tid == 0) {      // the scalars: loss_e / deps_e of the one element were written by this thread (project_element_wg)
@@ -531,11 +531,11 @@ __device__ __forceinline__ void tile_body(const MfmaArgs& g, double* lds) {
             if (g.fin_has_eps) {
                 g.fin_RB[P] = de;
                 if (upd) {
-                    const double mi = ad.b1 * ad.m[P] + (1.0 - ad.b1) * de;
-                    const double vi = ad.b2 * ad.v[P] + (1.0 - ad.b2) * de * de;
+                    double mi, vi, ti;
+                    hpv_adam_one_lr(lr_t, ad.b1, ad.b2, ad.eps, de, ad.m[P], ad.v[P], eps_now, mi, vi, ti);
                     ad.m[P] = mi;
                     ad.v[P] = vi;
-                    ad.theta[P] = eps_now - lr_t * mi / (sqrt(vi) + ad.eps);
+                    ad.theta[P] = ti;
                 }
             }
             if (upd && ad.n_upd) *ad.n_upd += 1;

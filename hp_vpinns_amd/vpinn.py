@@ -80,12 +80,12 @@ def _pad_rule(xi, w, q_dev):
     return np.concatenate([xi, np.full(n, xi[-1])]), np.concatenate([w, np.zeros(n)])
 
 
-def _device_rule_2d(xi, wx, yi, wy, ntx, nty, n_elem_shard, device=0, exact_counts=False, only=None):
+def _device_rule_2d(xi, wx, yi, wy, ntx, nty, n_elem_shard, device=0, exact_counts=False, only=None, n_hidden=0):
     """The (possibly padded) 2-D rule for the device, as the library advises for a shard of `n_elem_shard` elements on `device`;
     `exact_counts`: only instantiations with exactly these test-function counts; `only`: accept this device rule alone."""
     if xi.size != yi.size or os.environ.get("HPV_NO_RULE_PADDING"):
         return xi, wx, yi, wy
-    q_dev, _ = _lib.rule_advice(device, 2, xi.size, ntx, nty, n_elem_shard, exact_counts)
+    q_dev, _ = _lib.rule_advice(device, 2, xi.size, ntx, nty, n_elem_shard, exact_counts, n_hidden)
     if q_dev > xi.size and (only is None or q_dev == only):
         xi, wx = _pad_rule(xi, wx, q_dev)
         yi, wy = _pad_rule(yi, wy, q_dev)
@@ -731,7 +731,7 @@ class VPINN2D(_VPINNBase):
                 hidden = self.layers[1:-1]
                 if backend != "generic" and var_form == 1 and max(hidden) <= 20 and 2 <= len(hidden) <= 3:
                     eb, ee = shard_range(self.Nelementx * self.Nelementy, self.rank, self.world)
-                    xi, wx, yi, wy = _device_rule_2d(xi, wx, yi, wy, self.Ntestx, self.Ntesty, ee - eb, self.device)
+                    xi, wx, yi, wy = _device_rule_2d(xi, wx, yi, wy, self.Ntestx, self.Ntesty, ee - eb, self.device, n_hidden=len(hidden))
                 self.h.set_quadrature(xi, wx, yi, wy)
                 self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntesty, yi))
                 eb, ee = shard_range(self.Nelementx * self.Nelementy, self.rank, self.world)

@@ -229,16 +229,19 @@ int hpv_updates_applied(hpv_handle h, long long* n);
  * the run continues instead of ending on a shared GPU (connected ranks all do so in the same call: the failure travels with
  * the all-reduced buffer).  They return -7 instead when HPV_EXCHANGE_FALLBACK=0 is set.
  * hpv_shared_element_kernels: the current setting (0 after such a fallback). */
+int hpv_shared_element_kernels(hpv_handle h);
+int hpv_set_shared_element_kernels(hpv_handle h, int on);
 /* N_quad is a free hyper-parameter (P1:237, P2:282, P3:47); the element-resident kernels are instantiated for a few rules and
  * take a SMALLER rule padded with zero-weight points (exact: the tables are w * phi).  Whether that pays depends on the shard and
  * on the device, so the library decides: for a shard of n_elem_shard elements with q points per direction and ntx x nty test
  * functions (dim = 1: nty ignored) on `device` (its CU count; 256 when no device can be queried), *q_dev = the rule to hand to
  * hpv_set_quadrature (== q: leave the rule alone) and *nt_dev = the test-function count to hand to hpv_set_tables in 1-D (the
  * 80-point kernel takes 60 functions and per-element counts; == ntx otherwise).  exact_counts != 0: only an instantiation with
- * exactly these counts (forms whose kernel has no run-time counts).  No handle needed; the same limits gate the launch functions. */
-int hpv_rule_advice(int device, int dim, int q, int ntx, int nty, long n_elem_shard, int exact_counts, int* q_dev, int* nt_dev);
-int hpv_shared_element_kernels(hpv_handle h);
-int hpv_set_shared_element_kernels(hpv_handle h, int on);
+ * exactly these counts (forms whose kernel has no run-time counts).  n_hidden = the network's hidden layers (0: unknown -> three,
+ * the reference's depth): the plan is evaluated exactly as the dispatch will evaluate it, and a rule is padded only where ONE
+ * WORKGROUP PER ELEMENT will run -- not where the element loop or the separate launches take the grid (on many rounds the padded
+ * points cost more than the structure saves).  No handle needed; the same limits gate the launch functions. */
+int hpv_rule_advice(int device, int dim, int q, int ntx, int nty, long n_elem_shard, int exact_counts, int n_hidden, int* q_dev, int* nt_dev);
 /* The network value and its input-derivative channels at the owned quadrature points, [C][n_owned*qx*qy]
  * (channel order: u, then d/dx, d/dy (d/dt), then the second derivatives the variational form integrates) --
  * what net_u / net_du / net_dxu / net_dyu / net_dtu return (P1:140-148, P2:171-185, P3:232-245).  One forward launch. */

@@ -18,7 +18,9 @@ pytestmark = pytest.mark.gpu
 
 L4 = [2, 20, 20, 20, 1]
 L3 = [2, 20, 20, 1]
-TOL = 1e-11          # same arithmetic on the same operands: the difference is the contraction of a*b + c the two compilations pick
+# Same arithmetic on the same operands, and since round 6 the same OPERATION SEQUENCE in every translation unit (hpv_adam_one pins it:
+# floating-point contraction off; advisor, round 5) -- the three structures must agree BITWISE: the prologue of k_iter_fused computes
+# with exactly the parameter k_finalize stores behind it, which is exactly what k_adam / the fused finalize would have stored.
 
 
 def _model(nx, ny, layers, mode, q=20, nt=10, seed=5, env=None):
@@ -77,9 +79,9 @@ def test_deferred_update_reproduces_the_per_iteration_update(nx, ny, layers, env
     n_total = sum(n for _, n in CALLS)
     assert got[3] == ref[3] == one[3] == n_total
     for other, what in ((ref, "k_adam per iteration"), (one, "single-GPU iteration")):
-        assert np.max(np.abs(got[0] - other[0]) / np.abs(other[0])) < TOL, what
-        assert rel(got[1], other[1]) < TOL, what
-        assert rel(got[2], other[2]) < TOL, what
+        assert np.array_equal(got[0], other[0]), (what, np.max(np.abs(got[0] - other[0]) / np.abs(other[0])))
+        assert np.array_equal(got[1], other[1]), (what, rel(got[1], other[1]))
+        assert np.array_equal(got[2], other[2]), (what, rel(got[2], other[2]))
     if rides:
         assert "k_iter_fused" in m.h.kernel_variant()
     else:
@@ -111,5 +113,4 @@ def test_launch_structures_without_a_prologue_take_the_deferred_update_in_front_
         m.h.rccl_connect(1, 0, m.h.rccl_unique_id())
         res.append(_run(m, CALLS))
     assert res[0][3] == res[1][3] == sum(n for _, n in CALLS)
-    assert np.max(np.abs(res[0][0] - res[1][0]) / np.abs(res[1][0])) < TOL
-    assert rel(res[0][1], res[1][1]) < TOL and rel(res[0][2], res[1][2]) < TOL
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])

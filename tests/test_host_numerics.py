@@ -219,6 +219,12 @@ def test_zero_weight_padding_of_quadrature_rules():
     assert [sel(q, q // 2, q // 2, 256) for q in (6, 10, 11, 12, 14, 16, 18, 20, 22)] == [10, 10, 12, 12, 16, 16, 20, 20, 22]
     assert sel(14, 9, 3, 256) == 20 and sel(14, 11, 3, 256) == 14          # the test-function counts must fit the instantiation too
     assert sel(7, 4, 4, 2048) == 7 and sel(14, 7, 7, 2048) == 14 and sel(18, 9, 9, 4096) == 20     # grids the kernel leaves to the separate launches
+    # the plan the advice evaluates is the dispatch's own (advisor, round 5): 1 024 elements of a 14-point rule under three hidden layers are
+    # four full rounds -> the element loop takes the 16x16 kernel's grid -> no padding (until round 5 the advice said 16 and the launch
+    # then ran the loop on the padded rule); 768 elements (three rounds: one workgroup per element) are padded; the loop starts at six
+    # rounds under two hidden layers, so 1 024 elements are padded there
+    assert sel(14, 7, 7, 1024, n_hidden=3) == 14 and sel(14, 7, 7, 768, n_hidden=3) == 16 and sel(14, 7, 7, 1024, n_hidden=2) == 16
+    assert sel(14, 7, 7, 1536, n_hidden=2) == 14
     assert sel(8, 5, 5, 64, exact_counts=True, only=10) == 10 and sel(8, 4, 5, 64, exact_counts=True, only=10) == 8
     assert sel(11, 6, 6, 64, exact_counts=True, only=10) == 11                # (an instantiation the caller did not ask for)
     # 1-D: the 80 / 60 tile kernel takes a smaller rule only on shards where one workgroup per element pays (hpv_rule1d_pad_max)
