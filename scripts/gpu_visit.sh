@@ -28,7 +28,7 @@ for step in "$@"; do
     bench) timeout $T python bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json; cut -c1-400 $OUT/bench.json ;;
     bench_driver) ( time timeout $T python bench.py --steps 20 --warmup 5 2> $OUT/bench_driver_style.err | tail -1 > $OUT/bench_driver_style.json ) 2> $OUT/bench_driver_style.time
                   cut -c1-300 $OUT/bench_driver_style.json; cat $OUT/bench_driver_style.time ;;
-    prof) ( cd /tmp && timeout $T rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $OLDPWD/bench.py --no-extras --no-cpu-baseline --no-residual-roofline --no-pmc > $OUT/prof_bench.json 2> $OUT/prof.err )
+    prof) ( cd /tmp && timeout $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $OLDPWD/bench.py --no-extras --no-cpu-baseline --no-residual-roofline --no-pmc > $OUT/prof_bench.json 2> $OUT/prof.err )
           f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -8 "$f" ;;
     configs) timeout $T python scripts/config_bench.py > $OUT/config_bench.md 2> $OUT/config_bench.err; cat $OUT/config_bench.md ;;
     elems) timeout $T python scripts/elem_bench.py > $OUT/elem_bench.md 2> $OUT/elem_bench.err; cat $OUT/elem_bench.md ;;
