@@ -13,7 +13,7 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $HPV_EXTRA_FLAGS"   # e.g. HPV_EXTRA_FLAGS=-DHPV_FZ_TIMING
-SRCS="kernels_mfma kernels_fused kernels_project kernels_tile kernels_tall kernels_generic hpv_api hpv_exchange hpv_bench"
+SRCS="kernels_mfma kernels_fused kernels_fused_gen kernels_project kernels_tile kernels_tall kernels_generic hpv_api hpv_exchange hpv_bench"
 ELEM_SHAPES="20,20,10,10 16,16,8,8 12,12,6,6"             # kernels_elem.hip: one object per element shape (= HPV_ELEM_SHAPES of hpv_mfma_dev.h)
 WIDE_WIDTHS="64 32 48 24 40"                            # kernels_wide.hip: one object per hidden width and dimension (= HPV_WIDE_WIDTHS of hpv_mfma.h)
 HOOKED="kernels_fused kernels_project kernels_tile kernels_tall hpv_api hpv_exchange"   # the sources that contain test hooks / experiments (built twice)
@@ -26,6 +26,7 @@ if [ "$(cat .flags 2>/dev/null)" != "$FLAGS|$HPV_FUSED_EXTRA|v2" ]; then rm -f *
 stale() {   # stale <object> <source>: the object is missing or older than its source / any header
   [ ! -f "$1" ] && return 0
   local d
+  [ "$2" = kernels_fused_gen.hip ] && [ kernels_fused.hip -nt "$1" ] && return 0      # (that unit IS kernels_fused.hip, its other instantiations)
   for d in "$2" hpv_ctx.h hpv_internal.h hpv_mfma.h hpv_mfma_dev.h hpv_wide_dev.h hpv_project_wg.h hpv_math.h hpv_fused_dev.h ../../include/hpvpinn.h; do
     [ -f "$d" ] && [ "$d" -nt "$1" ] && return 0
   done
@@ -96,6 +97,44 @@ guarded_compile() {   # guarded_compile <source stem> <object> <extra flags> <fi
       fi
     fi
   fi
+  if [ $f = kernels_fused_gen ]; then
+    # the general variational forms on k_iter_fused (template tail <.., MULTI = false, NT2, GEN = true>): same stash, same bases per shape
+    # and depth.  A trip compiles out, in this order of preference: the quarter-tile instantiations (-DHPV_FZ_GEN_NO_QT), the
+    # four-channel ones (-DHPV_FZ_GEN_NO_NT2), everything (-DHPV_FZ_GEN_TRIPPED: those forms run on the separate launches).
+    local S=ELi20ELi20ELi10ELi10E S16=ELi16ELi16ELi8ELi8E S12=ELi12ELi12ELi6ELi6E
+    local keys3="" keys3q="" keys4="" keys4q=""
+    for Lb in "3 106 166 226" "2 156 196 236"; do
+      set -- $Lb
+      keys3="$keys3 k_iter_fusedILi${1}ELb0ELb0ELb0${S}Lb0ELi0ELb1E $2 k_iter_fusedILi${1}ELb1ELb0ELb0${S}Lb0ELi0ELb1E $2"
+      keys3="$keys3 k_iter_fusedILi${1}ELb0ELb0ELb0${S16}Lb0ELi0ELb1E $3 k_iter_fusedILi${1}ELb1ELb0ELb0${S16}Lb0ELi0ELb1E $3"
+      keys3="$keys3 k_iter_fusedILi${1}ELb0ELb0ELb0${S12}Lb0ELi0ELb1E $4 k_iter_fusedILi${1}ELb1ELb0ELb0${S12}Lb0ELi0ELb1E $4"
+      keys3q="$keys3q k_iter_fusedILi${1}ELb0ELb1ELb0${S16}Lb0ELi0ELb1E $3 k_iter_fusedILi${1}ELb0ELb1ELb0${S12}Lb0ELi0ELb1E $4"
+      [ $1 = 2 ] && keys3q="$keys3q k_iter_fusedILi${1}ELb0ELb1ELb0${S}Lb0ELi0ELb1E $2"      # (L = 3 on 20x20 points: not instantiated, a111 of 106)
+      # four channels park one more tile per wave in LDS: the stash is 2 L x 5 registers shorter
+      keys4="$keys4 k_iter_fusedILi${1}ELb0ELb0ELb0${S16}Lb0ELi1ELb1E $(($3 + 10 * $1)) k_iter_fusedILi${1}ELb1ELb0ELb0${S16}Lb0ELi1ELb1E $(($3 + 10 * $1))"
+      keys4="$keys4 k_iter_fusedILi${1}ELb0ELb0ELb0${S12}Lb0ELi1ELb1E $(($4 + 10 * $1)) k_iter_fusedILi${1}ELb1ELb0ELb0${S12}Lb0ELi1ELb1E $(($4 + 10 * $1))"
+      keys4q="$keys4q k_iter_fusedILi${1}ELb0ELb1ELb0${S16}Lb0ELi1ELb1E $(($3 + 10 * $1))"
+    done
+    g=0; guard $asm $keys3 || g=$?
+    [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check $f.hip" >&2; rm -rf $tmp; return 1; }
+    if [ $g -eq 1 ]; then
+      echo "build.sh: WARNING -- AGPR guard tripped in the general forms of k_iter_fused: those forms run on the separate launches" >&2
+      add="-DHPV_FZ_GEN_TRIPPED"
+    else
+      g=0; guard $asm $keys4 || g=$?
+      [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check the four-channel instantiations of $f.hip" >&2; rm -rf $tmp; return 1; }
+      if [ $g -eq 1 ]; then
+        echo "build.sh: WARNING -- AGPR guard tripped in a four-channel instantiation of k_iter_fused: those forms run on the separate launches" >&2
+        add="-DHPV_FZ_GEN_NO_NT2"; keys4q=""
+      fi
+      g=0; guard $asm $keys3q $keys4q || g=$?
+      [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check the quarter-tile instantiations of $f.hip" >&2; rm -rf $tmp; return 1; }
+      if [ $g -eq 1 ]; then
+        echo "build.sh: WARNING -- AGPR guard tripped in a quarter-tile instantiation of the general forms: whole tiles only" >&2
+        add="$add -DHPV_FZ_GEN_NO_QT"
+      fi
+    fi
+  fi
   if [ $f = kernels_tall ]; then    # same hand-managed AGPR stash (4 tiles x L x 5 doubles at the top of the file)
     # (template tail: <.., 80, 80, 5, 5, QT>; the QT instantiations keep one stash slot less: their range starts 30 registers higher)
     local T=ELi80ELi80ELi5ELi5
@@ -121,6 +160,7 @@ guarded_compile() {   # guarded_compile <source stem> <object> <extra flags> <fi
 compile_one() {   # compile_one <source stem> <object> <extra flags>
   local f=$1 obj=$2 extra=$3
   if [ $f = kernels_fused ]; then guarded_compile $f $obj "$extra" "$HPV_FUSED_EXTRA"      # (A/B builds: flags for this file only, scripts/build_variant.sh --fused-only)
+  elif [ $f = kernels_fused_gen ]; then guarded_compile $f $obj "$extra" "$HPV_FUSED_EXTRA"
   elif [ $f = kernels_tall ]; then guarded_compile $f $obj "$extra" ""
   else $HIPCC $FLAGS $extra -c $f.hip -o $obj; fi
 }

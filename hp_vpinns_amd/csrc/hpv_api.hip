@@ -71,6 +71,7 @@ NetDesc make_netdesc(const hpv_config& c, int nT1, const int* t1dim, int nT2, co
     nd.nT1 = nT1; nd.nT2 = nT2;
     for (int i = 0; i < nT1; ++i) nd.t1dim[i] = t1dim[i];
     for (int i = 0; i < nT2; ++i) nd.t2idx[i] = t2idx[i];
+    nd.t2w[0] = 1.0; nd.t2w[1] = 0.0;
     nd.C = 1 + nT1 + nT2;
     nd.nslot = 2 + nT1 + nT2;
     long a = 0;
@@ -574,6 +575,7 @@ int hpv_create(hpv_handle* out, const hpv_config* cfg) {
     ProjDesc& pd = h->pd;
     pd = ProjDesc{};
     int nT1 = 0, nT2 = 0;
+    bool mixed = false;
     const int vf = cfg->var_form;
     auto term = [&](int dx, int dy, int eps_mult) -> TermDesc& {
         TermDesc& t = pd.t[pd.nterms++];
@@ -585,7 +587,11 @@ int hpv_create(hpv_handle* out, const hpv_config* cfg) {
         else if (vf == 3) { term(2, 0, 0).a0[0] = 1.0; pd.edge = 1; }            // P1:89-91
         else { delete h; return fail(nullptr, -1, "Poisson-1D var_form must be 1, 2 or 3"); }
     } else if (cfg->pde == HPV_PDE_POISSON2D) {
-        if (vf == 0) { nT1 = 2; nT2 = 2; TermDesc& t = term(0, 0, 0); t.a0[3] = 1.0; t.a0[4] = 1.0; }   // P2:93-96
+        if (vf == 0) {                                                           // P2:91, 93-96: integrand u_xx + u_yy
+            // ONE mixed second tangent (NetDesc::t2w = {1, 1}) instead of the two channels u_xx, u_yy: 4 channels through the
+            // forward, the tangent recompute and the reverse pass instead of 5 (second-order channels propagate linearly)
+            nT1 = 2; nT2 = 1; mixed = true; term(0, 0, 0).a0[3] = 1.0;
+        }
         else if (vf == 1) { nT1 = 2; term(1, 0, 0).a0[1] = 1.0; term(0, 1, 0).a0[2] = 1.0; }            // P2:98-105
         else if (vf == 2) { term(2, 0, 0).a0[0] = 1.0; term(0, 2, 0).a0[0] = 1.0; }                     // P2:108-115
         else { delete h; return fail(nullptr, -1, "Poisson-2D var_form must be 0, 1 or 2"); }
@@ -601,6 +607,12 @@ int hpv_create(hpv_handle* out, const hpv_config* cfg) {
         } else { delete h; return fail(nullptr, -1, "AdvDiff var_form must be 0 or 1"); }
     }
     h->nd_var = make_netdesc(*cfg, nT1, t1, nT2, t2);
+    h->nd_eval = h->nd_var;
+    if (mixed) {
+        h->nd_var.t2w[0] = 1.0; h->nd_var.t2w[1] = 1.0;
+        h->nd_eval = make_netdesc(*cfg, 2, t1, 2, t2);      // what hpv_eval_channels reports: u, u_x, u_y, u_xx, u_yy
+        h->eval_differs = true;
+    }
     h->nd_val = make_netdesc(*cfg, 0, t1, 0, t2);
     if (cfg->scheme == HPV_SCHEME_PINN) {
         if (cfg->pde != HPV_PDE_POISSON2D) { delete h; return fail(nullptr, -1, "scheme PINNs is the Poisson-2D branch (P2:128-129)"); }
@@ -644,6 +656,8 @@ void hpv_destroy(hpv_handle h) {
     if (h->mfma_data) hpv_mfma_destroy(h->mfma_data);
     if (h->mfma_edge) hpv_mfma_destroy(h->mfma_edge);
     if (h->mfma_pred) hpv_mfma_destroy(h->mfma_pred);
+    if (h->mfma_eval) hpv_mfma_destroy(h->mfma_eval);
+    if (h->d_eval_out) (void)hipFree(h->d_eval_out);
     if (h->mfma_colloc) hpv_mfma_destroy(h->mfma_colloc);
     free_batch(h->colloc);
     if (h->d_fcol) (void)hipFree(h->d_fcol);
@@ -1331,14 +1345,29 @@ int hpv_eval_channels(hpv_handle h, double* out, size_t n) {
     if (h->cfg.scheme != HPV_SCHEME_VPINN) return fail(h, -1, "hpv_eval_channels belongs to the variational scheme");
     int rc = check_ready(h);
     if (rc) return rc;
-    const int C = h->nd_var.C;
+    const int C = h->nd_eval.C;
     if (n != (size_t)C * h->Nq) return fail(h, -1, "channel buffer has %zu entries, expected %zu", n, (size_t)C * h->Nq);
     if (h->Nq == 0) return 0;
-    if (h->mfma && h->backend == HPV_BACKEND_MFMA) hpv_mfma_forward(h->mfma, h->d_theta, h->var.X, h->var.OUT, 0, h->stream);
-    else run_fwd(h, h->var, nullptr, 0);
+    const double* src = h->var.OUT;
+    if (h->eval_differs) {
+        // the training pass runs on a reduced channel set: the reference's list through a forward-only launch of its own
+        if (h->eval_N != h->var.N) {
+            if (h->mfma_eval) { hpv_mfma_destroy(h->mfma_eval); h->mfma_eval = nullptr; }
+            if ((rc = dalloc(h, &h->d_eval_out, (size_t)C * h->var.N))) return rc;
+            if (h->backend == HPV_BACKEND_MFMA) h->mfma_eval = hpv_mfma_create(h->nd_eval, h->var.N, nullptr, false);
+            h->eval_N = h->var.N;
+        }
+        if (h->mfma_eval) hpv_mfma_forward(h->mfma_eval, h->d_theta, h->var.X, h->d_eval_out, 0, h->stream);
+        else launch_mlp_fwd_generic(h->nd_eval, h->d_theta, h->var.X, nullptr, h->d_eval_out, h->var.N, 0, h->stream);
+        src = h->d_eval_out;
+    } else if (h->mfma && h->backend == HPV_BACKEND_MFMA) {
+        hpv_mfma_forward(h->mfma, h->d_theta, h->var.X, h->var.OUT, 0, h->stream);
+    } else {
+        run_fwd(h, h->var, nullptr, 0);
+    }
     HIPCHK(h, hipGetLastError());
     for (int ch = 0; ch < C; ++ch)     // the device batch may carry padding / data points behind the quadrature points
-        HIPCHK(h, hipMemcpyAsync(out + (size_t)ch * h->Nq, h->var.OUT + (size_t)ch * h->var.N, (size_t)h->Nq * sizeof(double),
+        HIPCHK(h, hipMemcpyAsync(out + (size_t)ch * h->Nq, src + (size_t)ch * h->var.N, (size_t)h->Nq * sizeof(double),
                                  hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;

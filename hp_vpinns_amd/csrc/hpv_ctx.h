@@ -92,6 +92,13 @@ struct hpv_ctx {
     HpvMfma* mfma_data = nullptr;
     HpvMfma* mfma_edge = nullptr;
     HpvMfma* mfma_pred = nullptr;
+    // hpv_eval_channels reports the REFERENCE's channel list (nd_eval); where the training pass runs on fewer channels (Poisson-2D
+    // var_form 0: u_xx + u_yy as one mixed second tangent, NetDesc::t2w) a forward-only object + output buffer are created on demand
+    NetDesc nd_eval{};
+    bool eval_differs = false;
+    HpvMfma* mfma_eval = nullptr;
+    double* d_eval_out = nullptr;
+    long eval_N = 0;
     // strong-form PINN branch (scheme == PINNs): collocation batch with the 5 Laplacian channels
     NetDesc nd_pinn{};
     Batch colloc;

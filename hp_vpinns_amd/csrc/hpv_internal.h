@@ -20,6 +20,11 @@ struct NetDesc {
     int nT1, nT2;                // number of first / second tangent channels
     int t1dim[2];                // input coordinate of each first tangent
     int t2idx[2];                // index INTO the T1 list of each second tangent
+    // MIXED second tangent (round 6; nT1 == 2 && nT2 == 1 only): the one second-order channel is  t2w[0] d2/dc0^2 + t2w[1] d2/dc1^2
+    // -- second-order Taylor channels propagate LINEARLY (z_cc -> s'' z_c^2 + s' z_cc -> W), so a weighted sum of them is itself one
+    // channel: Poisson-2D var_form 0 integrates u_xx + u_yy (P2:91) and needs 4 channels instead of 5 in the forward, the tangent
+    // recompute and the reverse pass.  {1, 0} = the plain second tangent of coordinate t2idx[0] = 0 (AdvDiff var_form 0, P3:163).
+    double t2w[2];
     int C;                       // 1 + nT1 + nT2
     int nslot;                   // saved slots per hidden layer: A, A1, ZC[nT1], ZCC[nT2]
     long actoff[HPV_MAX_LAYERS]; // hidden layer l block starts at actoff[l] * N doubles in ACT

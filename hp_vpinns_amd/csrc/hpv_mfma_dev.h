@@ -28,6 +28,7 @@ struct MfmaArgs {
     int boff[HPV_MAX_LAYERS];
     int t1dim[2];
     int t2idx[2];
+    double t2w[2];        // NT1 == 2 && NT2 == 1: weights of the mixed second tangent (NetDesc::t2w; {1, 0} = d2/dc0^2)
     int P;
     // boundary/data term folded into the forward kernel (tiles at and beyond data_off; -1: none)
     long data_off;
@@ -145,6 +146,16 @@ __device__ __forceinline__ void act_saved(double a, double a1s, double& a1, doub
         a2 = -a;
         a3 = -a1s;
     }
+}
+
+// z_c^2 as the second-tangent channel b sees it.  NT1 == 2 && NT2 == 1: the MIXED second tangent (NetDesc::t2w) rides on both first
+// tangents, w0 z_c0^2 + w1 z_c1^2; every other channel set: channel b rides on first tangent b.
+template <int NT1, int NT2>
+struct T2Mix { static constexpr bool value = NT1 == 2 && NT2 == 1; };
+template <int NT1, int NT2>
+__device__ __forceinline__ double t2_square(const double (&w)[2], int b, double zc0, double zc1) {
+    if constexpr (T2Mix<NT1, NT2>::value) return fma(w[0], zc0 * zc0, w[1] * (zc1 * zc1));
+    else { const double z = b == 0 ? zc0 : zc1; return z * z; }
 }
 
 template <int ACT, int NT1, int NT2>

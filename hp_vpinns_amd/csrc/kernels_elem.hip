@@ -125,7 +125,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_elem(MfmaArgs g) {
 #pragma unroll
             for (int b = 0; b < NT2; ++b) {
                 const double zc = W1[(b < D ? b : 0) * H + 4 * s + ql];
-                h[1 + NT1 + b][s] = a2 * zc * zc;
+                if constexpr (T2Mix<NT1, NT2>::value) h[1 + NT1 + b][s] = a2 * t2_square<NT1, NT2>(g.t2w, b, W1[4 * s + ql], W1[(D > 1 ? 1 : 0) * H + 4 * s + ql]);
+                else h[1 + NT1 + b][s] = a2 * zc * zc;
             }
         }
 #pragma unroll
@@ -144,7 +145,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_elem(MfmaArgs g) {
 #pragma unroll
                 for (int b = 0; b < NT2; ++b) {
                     const double zc1 = z[1 + (b < NT1 ? b : 0)][s];
-                    h[1 + NT1 + b][s] = a2 * zc1 * zc1 + a1 * z[1 + NT1 + b][s];
+                    if constexpr (T2Mix<NT1, NT2>::value) h[1 + NT1 + b][s] = a2 * t2_square<NT1, NT2>(g.t2w, b, z[1][s], z[NT1 > 1 ? 2 : 1][s]) + a1 * z[1 + NT1 + b][s];
+                    else h[1 + NT1 + b][s] = a2 * zc1 * zc1 + a1 * z[1 + NT1 + b][s];
                 }
             }
         }
@@ -234,7 +236,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_elem(MfmaArgs g) {
 #pragma unroll
                         for (int b = 0; b < NT2; ++b) {
                             const double z1 = zc[i][b < NT1 ? b : 0][s];
-                            hc[NT1 + b][s] = a2 * z1 * z1 + a1 * zcc[i][b][s];
+                            if constexpr (T2Mix<NT1, NT2>::value) hc[NT1 + b][s] = a2 * t2_square<NT1, NT2>(g.t2w, b, zc[i][0][s], zc[i][NT1 > 1 ? 1 : 0][s]) + a1 * zcc[i][b][s];
+                            else hc[NT1 + b][s] = a2 * z1 * z1 + a1 * zcc[i][b][s];
                         }
                     }
                     double zt[CT][KS];
@@ -269,7 +272,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_elem(MfmaArgs g) {
                 else {
                     const int b = ch - 1 - NT1;
                     const double z1 = zc[i][b < NT1 ? b : 0][s];
-                    hv[s] = a2 * z1 * z1 + a1 * zcc[i][b < NT2 ? b : 0][s];
+                    if constexpr (T2Mix<NT1, NT2>::value) hv[s] = a2 * t2_square<NT1, NT2>(g.t2w, b, zc[i][0][s], zc[i][NT1 > 1 ? 1 : 0][s]) + a1 * zcc[i][0][s];
+                    else hv[s] = a2 * z1 * z1 + a1 * zcc[i][b < NT2 ? b : 0][s];
                 }
             }
         };
@@ -304,8 +308,14 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_elem(MfmaArgs g) {
                     const int u = b < NT1 ? b : 0;
                     const double hb = hbar[1 + NT1 + b][s];
                     zbar[1 + NT1 + b][s] = hb * a1;
-                    zbar[1 + u][s] += 2.0 * hb * a2 * zc[i][u][s];
-                    zb += hb * (a3 * zc[i][u][s] * zc[i][u][s] + a2 * zcc[i][b][s]);
+                    if constexpr (T2Mix<NT1, NT2>::value) {      // the mixed second tangent rides on both first tangents
+                        zbar[1][s] += 2.0 * hb * a2 * g.t2w[0] * zc[i][0][s];
+                        zbar[2][s] += 2.0 * hb * a2 * g.t2w[1] * zc[i][NT1 > 1 ? 1 : 0][s];
+                        zb += hb * (a3 * t2_square<NT1, NT2>(g.t2w, b, zc[i][0][s], zc[i][NT1 > 1 ? 1 : 0][s]) + a2 * zcc[i][b][s]);
+                    } else {
+                        zbar[1 + u][s] += 2.0 * hb * a2 * zc[i][u][s];
+                        zb += hb * (a3 * zc[i][u][s] * zc[i][u][s] + a2 * zcc[i][b][s]);
+                    }
                 }
                 zbar[0][s] = zb;
                 db[i][s] += zb;

@@ -53,7 +53,9 @@
 #define FZ_SEG(I)
 #endif
 
-template <int L, int QX_, int QY_, int NTX_, int NTY_, bool MULTI = false>
+// C_ = network channels (3: u, u_x, u_y; 4: + the mixed second tangent, NT2 = 1); TRG_ = channels whose transposes of the weight-
+// gradient products are in LDS at a time (C_ = 3: all three, ONE pass -- the headline plan; C_ = 4: two passes of two, 22 KB less)
+template <int L, int QX_, int QY_, int NTX_, int NTY_, bool MULTI = false, int C_ = FZ_C, int TRG_ = FZ_C>
 struct FzLds {
     FZ_SHAPE_CONSTS
     static constexpr int LH = L > 1 ? L - 1 : 0;
@@ -67,9 +69,12 @@ struct FzLds {
     static constexpr int PK = CH + 2 * FZ_NQ;              // [6][L*5][64] parked s: slot w = tile 0 of wave w, slots 4, 5 = tile 1 of waves 0, 1
     static constexpr int XS = PK;                          // GS (slots 0..3 of PK are free then): [x | y | u_d][400 + 16] coordinates of the element and of the data tile
     static constexpr int XLD = FZ_NQ + 16;
-    static constexpr int PZ = PK + 6 * L * MF_KS * 64;     // [4][LH*5][32] QT: the quarter tiles' tangent pre-activations of the layers >= 2 (tangent lanes, compact)
+    // (four channels: the compiler needs ~60 registers more -- TWO tiles of every wave are parked here instead of one, slots 4..7 = tile 1
+    //  of wave w - 4, slots 8, 9 = the quarter tiles' s)
+    static constexpr int PKS = C_ > FZ_C ? 10 : 6;
+    static constexpr int PZ = PK + PKS * L * MF_KS * 64;   // [4][LH*5][32] QT: the quarter tiles' tangent pre-activations of the layers >= 2 (tangent lanes, compact)
     static constexpr int TR = PZ + FZ_WAVES * LH * MF_KS * 32;   // phase P: projection scratch | phase R: per-wave transpose tiles | epilogue rows
-    static constexpr int TR_WAVE = FZ_C * 2 * MF_TRB * MF_LD;
+    static constexpr int TR_WAVE = TRG_ * 2 * MF_TRB * MF_LD;
     // projection scratch inside the TR region.  MULTI (several elements per workgroup): the tables live BEHIND the region instead -- the
     // reverse phase's transposes would overwrite them and every element would have to stage them again
     static constexpr int TRSZ = FZ_WAVES * TR_WAVE;        // (>= FZ_WAVES * P: the epilogue rows; asserted in total())
@@ -115,12 +120,28 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // lane-private, coalesced 512-byte rows; L2-resident) at the end of its reverse phase instead of being reduced across lanes and
 // waves -- they are zeroed again before the next element's reverse phase, so nothing lives across a forward phase (carrying them in
 // registers took the compiler to a151 of the 106 AGPRs the stash leaves: profiles/r04_notes.md 13).  The epilogue runs once per workgroup.
-template <int L, bool SPLIT, bool QT, bool GS, int QX_, int QY_, int NTX_, int NTY_, bool MULTI = false>
+//
+// GEN / NT2 (round 6): every other variational form of the 2-D drivers on the same structure.  GEN: the two integrated arrays
+// in LDS are no longer the channels u_x, u_y themselves (term t <-> channel 1 + t, "one-hot") but COMBINATIONS of the channels
+// with the TermDesc weights, G_t = sum_c (a0 + eps a1)[t][c] ch_c, and the trainable epsilon (P3:163, 171) gets its gradient:
+//   two terms (AdvDiff var_form 1, P3:169-174):  slot 0 = G_0, slot 1 = G_1;  d eps from the terms that carry eps as a factor
+//   one term  (AdvDiff var_form 0, P3:161-167; Poisson-2D var_form 0, P2:91-96):  slot 0 = G_0, slot 1 = E = dG_0 / d eps
+//   (sum_c a1[c] ch_c), which meets the adjoint of G_0 at the end of the projection phase: d eps = sum_p Gbar_0[p] E[p]
+// NT2 = 1: a fourth channel, the mixed second tangent w0 u_xx + w1 u_yy (NetDesc::t2w) -- forward, tangent recompute and reverse
+// pass of kernels_tall.hip's algebra; its transposes of the weight-gradient products go through LDS in two passes of two channels.
+template <int L, bool SPLIT, bool QT, bool GS, int QX_, int QY_, int NTX_, int NTY_, bool MULTI = false, int NT2 = 0, bool GEN = false>
 __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     static_assert(!(SPLIT && QT), "the quarter-tile scheme is for whole elements");
     static_assert(!(MULTI && (SPLIT || GS)), "the element loop is for whole elements on the register stash");
+    static_assert(!((NT2 > 0 || GEN) && (GS || MULTI)), "the general forms run on the register stash, one workgroup (or a split) per element");
+    static_assert(NT2 == 0 || GEN, "a second-tangent channel is always integrated through the general term weights");
     FZ_SHAPE_CONSTS
-    using M = FzLds<L, QX_, QY_, NTX_, NTY_, MULTI>;
+    static_assert(!(NT2 > 0 && QT && FZ_TPE % FZ_WAVES != 0), "four channels leave the packed quarter tile no slot for the data points: data-quarter plan only");
+    constexpr int C = FZ_C + NT2;                  // channels of the network: u, u_x, u_y[, w0 u_xx + w1 u_yy]
+    constexpr int TRG = NT2 > 0 ? 2 : FZ_C;        // channels per transpose pass of the weight-gradient products
+    static_assert(C % TRG == 0, "whole transpose passes");
+    using M = FzLds<L, QX_, QY_, NTX_, NTY_, MULTI, C, TRG>;
+    static_assert(!GEN || M::RED + 16 <= M::TR + M::TR_WAVE, "the d-epsilon partials live in wave 0's part of the transpose region (it reads them back itself)");
     constexpr int LH = L > 1 ? L - 1 : 1;
     constexpr int NSV = L * MF_KS;                 // saved doubles per lane and tile
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -188,8 +209,10 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             // (fewer test functions than the instantiation's NTX x NTY: the tables of the missing ones are zero -- their residuals are
             //  exactly 0 and leave the sums alone; R, F and the means below use the run's own counts rnx, rny)
             const int rr_ = ti_ / TQX, ii_ = ti_ % TQX;
-            vax[it] = rr_ < rnx ? pa.wtx[((long)(tt_ ? dx1 : dx0) * rnx + rr_) * TQX + ii_] : 0.0;
-            vby[it] = rr_ < rny ? pa.wty[((long)(tt_ ? dy1 : dy0) * rny + rr_) * TQY + ii_] : 0.0;
+            // (GEN, a form of ONE term: the second term's tables are zero, like its coefficient pc1)
+            const bool ton = !GEN || tt_ == 0 || pa.pd.nterms > 1;
+            vax[it] = (rr_ < rnx && ton) ? pa.wtx[((long)(tt_ ? dx1 : dx0) * rnx + rr_) * TQX + ii_] : 0.0;
+            vby[it] = (rr_ < rny && ton) ? pa.wty[((long)(tt_ ? dy1 : dy0) * rny + rr_) * TQY + ii_] : 0.0;
         }
 #pragma unroll
         for (int i_ = 1; i_ < L; ++i_) {
@@ -273,7 +296,17 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     //  (advisor, round 5); the prologue's verdict comes from the pad slot and the pre-launch flag, the same in every workgroup)
     if constexpr (SPLIT) { xsticky = pre_failed >= 0 ? pre_failed : *g.xerr; xtag = *g.xiter + 1u; }
     // the element's projection constants, requested now so that no global latency sits inside phase P
-    double pc0 = pa.coef[e], pc1 = pa.coef[pa.coef_stride + e];
+    double pc0 = pa.coef[e], pc1 = (!GEN || pa.pd.nterms > 1) ? pa.coef[pa.coef_stride + e] : 0.0;
+    // GEN: the trainable coefficient and the term weights.  slot 0 of the LDS channel array holds G_0 = sum_c wa0(c) ch_c; slot 1
+    // holds G_1 (two terms) or E = dG_0 / d eps (one term); the channels' adjoints are gb_c = wa0(c) Gbar_0 + wb1(c) Gbar_1.
+    // (formed where they are used from kernel arguments -- scalar registers -- and eps: nothing lives across the phases)
+    [[maybe_unused]] const double geps = (GEN && pa.eps_ptr) ? pa.eps_ptr[0] : 0.0;
+    [[maybe_unused]] const bool gtwo = GEN && pa.pd.nterms > 1;
+    [[maybe_unused]] auto wa0 = [&](int c) -> double { return fma(geps, pa.pd.t[0].a1[c], pa.pd.t[0].a0[c]); };
+    [[maybe_unused]] auto wa1 = [&](int c) -> double { return gtwo ? fma(geps, pa.pd.t[1].a1[c], pa.pd.t[1].a0[c]) : pa.pd.t[0].a1[c]; };
+    [[maybe_unused]] auto wb1 = [&](int c) -> double { return gtwo ? fma(geps, pa.pd.t[1].a1[c], pa.pd.t[1].a0[c]) : 0.0; };
+    [[maybe_unused]] const double gm0 = (GEN && pa.pd.t[0].eps_mult) ? geps : 1.0, gm1 = (gtwo && pa.pd.t[1].eps_mult) ? geps : 1.0;   // the factor eps of a term (P3:171)
+    [[maybe_unused]] const double ge0 = (GEN && pa.pd.t[0].eps_mult) ? 1.0 : 0.0, ge1 = (gtwo && pa.pd.t[1].eps_mult) ? 1.0 : 0.0;
     const int ro_k = tid / FZ_NTX, ro_r = tid % FZ_NTX;                 // residual (k, r) of thread tid < NR, and whether the run has it
     const bool ro_on = tid < FZ_NR && ro_k < rny && ro_r < rnx;
     long ro_idx = e * rnr + ro_k * rnx + ro_r;
@@ -352,17 +385,17 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
 
     // s = tanh(z) of every hidden layer: tile 0's go to LDS (what is left of it), the tiles 1..6 of this wave to the top
     // AGPRs a[ABASE + (k-1) * 2 NSV ..] (see acc_put)
-    constexpr int NREG = FZ_MAXT - 2;  // tiles whose s live in AGPRs; the first one (waves 0, 1: two) of a wave is parked in LDS
+    constexpr int NREG = FZ_MAXT - 2 - (NT2 > 0 ? 1 : 0);  // tiles whose s live in AGPRs; the first one (waves 0, 1 -- NT2: every wave -- two) of a wave is parked in LDS
     constexpr int ABASE = 256 - NREG * 2 * NSV;
     if constexpr (!GS) asm volatile("" ::: "a255");       // the kernel owns all 256 AGPRs
-    const int n_lds = GS ? 0 : QT ? 1 : (wv <= 1 ? 2 : 1);       // (QT: slots 4, 5 of the parking area hold the quarter tiles' s)
+    const int n_lds = GS ? 0 : NT2 > 0 ? 2 : QT ? 1 : (wv <= 1 ? 2 : 1);       // (QT: slots 4, 5 -- NT2: 8, 9 -- of the parking area hold the quarter tiles' s)
     // GS: pairs per tile and lane -- {z_x, z_y}[layer >= 2][k-step], then s two by two; a tile's block of the activation store
     constexpr int NZP = (L > 1 ? L - 1 : 0) * MF_KS, NSP = (NSV + 1) / 2, NP = NZP + NSP;
     constexpr long GS_STRIDE = (long)L * 3 * MF_KS * 64;         // doubles per tile of the activation store (3 slots: kernels_mfma.hip)
     static_assert(NP * 128 <= GS_STRIDE, "a tile's pairs fit its block of the activation store");
     auto gs_ptr = [&](long tile) -> v2d* { return reinterpret_cast<v2d*>(g.ACTS + tile * GS_STRIDE) + lane; };
     double* PKw = lds + M::PK + wv * (NSV * 64) + lane;
-    double* PKw2 = lds + M::PK + (4 + (wv & 1)) * (NSV * 64) + lane;
+    double* PKw2 = lds + M::PK + (4 + (NT2 > 0 ? wv : (wv & 1))) * (NSV * 64) + lane;
     gdat = 0.0;
 
     // SPLIT: this workgroup takes no part in the exchange (an earlier launch of the handle failed -- sticky flag -- or the test
@@ -382,7 +415,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     [[maybe_unused]] const bool q_vdat = QT && qcs == 3 && dtile < g.ntiles && q_pdat < g.N;
     [[maybe_unused]] const long q_p = qcs == 3 ? (q_vdat ? q_pdat : 0) : (e * FZ_TPE + (FZ_TPE - 1)) * 16 + 4 * wv + qj;
     [[maybe_unused]] const int q_lp = (FZ_TPE - 1) * 16 + 4 * wv + qj;               // the element point inside the element
-    [[maybe_unused]] double* PKQ = lds + M::PK + 4 * (NSV * 64) + wv * (NSV * 32);    // compact: the 32 value / data lanes only
+    [[maybe_unused]] double* PKQ = lds + M::PK + (NT2 > 0 ? 8 : 4) * (NSV * 64) + wv * (NSV * 32);    // compact: the 32 value / data lanes only
     [[maybe_unused]] const int q_ci = q * 8 + (qcs == 3 ? 4 : 0) + qj;                // ... at this index (tangent slots: their point's)
     [[maybe_unused]] double* PKZ = lds + M::PZ + wv * ((L > 1 ? L - 1 : 1) * MF_KS * 32);   // tangent pre-activations, the 32 tangent lanes only
     [[maybe_unused]] const int q_cz = q * 8 + (qcs == 2 ? 4 : 0) + qj;
@@ -452,7 +485,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         }
         int lofs = lane;
         asm volatile("" : "+v"(lofs));       // opaque: the LDS fragment reads stay inside the loop
-        double h[NT][FZ_C][MF_KS], sv[NT][NSV];
+        double h[NT][C][MF_KS], sv[NT][NSV];
         [[maybe_unused]] double QH[MF_KS], QA[NSV];      // WQ: the packed quarter tile's layer input and its s
         // layer 1 (VALU)
 #pragma unroll
@@ -466,6 +499,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                 act_fwd<HPV_ACT_TANH>(z, a, a1, a2);
                 sv[t][s] = a;
                 h[t][0][s] = a; h[t][1][s] = a1 * w0; h[t][2][s] = a1 * w1;
+                if constexpr (NT2 > 0) h[t][3][s] = a2 * fma(g.t2w[0], w0 * w0, g.t2w[1] * (w1 * w1));      // (z_cc = 0 in front of the first layer)
             }
             if constexpr (WQ) {      // every slot evaluates its own point (the tangent slots share the element point of slot 0)
                 const double z = b1v + qx0 * w0 + qx1 * w1;
@@ -477,12 +511,14 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         }
 #pragma unroll
         for (int i = 1; i < L; ++i) {
-            double z[NT][FZ_C][MF_KS];
+            double z[NT][C][MF_KS];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 fz_layer<true>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, lds + M::BH + (i - 1) * MF_KS * 64, lofs, h[t][0], z[t][0]);
                 fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[t][1], z[t][1]);
                 fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[t][2], z[t][2]);
+                if constexpr (NT2 > 0)
+                    fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, h[t][3], z[t][3]);
             }
             if constexpr (GS) {
 #pragma unroll
@@ -504,6 +540,8 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                     act_fwd<HPV_ACT_TANH>(z[t][0][s], a, a1, a2);
                     sv[t][i * MF_KS + s] = a;
                     h[t][0][s] = a; h[t][1][s] = a1 * z[t][1][s]; h[t][2][s] = a1 * z[t][2][s];
+                    if constexpr (NT2 > 0)      // h_cc = s'' (w0 z_x^2 + w1 z_y^2) + s' z_cc
+                        h[t][3][s] = a2 * fma(g.t2w[0], z[t][1][s] * z[t][1][s], g.t2w[1] * (z[t][2][s] * z[t][2][s])) + a1 * z[t][3][s];
                 }
             if constexpr (WQ) {
 #pragma unroll
@@ -525,9 +563,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         for (int t = 0; t < NT; ++t) {
             const int k = k0 + t;
             // linear head
-            double o[FZ_C];
+            double o[C];
 #pragma unroll
-            for (int ch = 0; ch < FZ_C; ++ch) {
+            for (int ch = 0; ch < C; ++ch) {
                 double v = 0.0;
 #pragma unroll
                 for (int s = 0; s < MF_KS; ++s) v += h[t][ch][s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
@@ -539,14 +577,21 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             if (k < n_el) {
                 if (q == 0) {
                     const int lp = (tbase + wv + k * FZ_WAVES) * 16 + pt;     // point index inside the element
+                    // the two integrated arrays: the channels u_x, u_y themselves, or (GEN) the terms' combinations of the channels
+                    double g0 = o[1], g1 = o[2];
+                    if constexpr (GEN) {
+                        g0 = 0.0; g1 = 0.0;
+#pragma unroll
+                        for (int c = 1; c < C; ++c) { g0 = fma(wa0(c), o[c], g0); g1 = fma(wa1(c), o[c], g1); }
+                    }
                     if constexpr (SPLIT) {   // tagged granules, fire and forget: the partners poll the granules themselves
                         if (!xstay) {
-                            xg_publish(g.xg + (e * (2 * FZ_NQ) + lp) * 2, o[1], xtag);
-                            xg_publish(g.xg + (e * (2 * FZ_NQ) + FZ_NQ + lp) * 2, o[2], xtag);
+                            xg_publish(g.xg + (e * (2 * FZ_NQ) + lp) * 2, g0, xtag);
+                            xg_publish(g.xg + (e * (2 * FZ_NQ) + FZ_NQ + lp) * 2, g1, xtag);
                         }
                     } else {
-                        lds[M::CH + lp] = o[1];
-                        lds[M::CH + FZ_NQ + lp] = o[2];
+                        lds[M::CH + lp] = g0;
+                        lds[M::CH + FZ_NQ + lp] = g1;
                     }
                 }
             } else {
@@ -566,7 +611,15 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             for (int s = 0; s < MF_KS; ++s) v += QH[s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
             v = xrow_sum16(v);
             v = xrow_sum32(v);
-            if (!DQ && q == 0 && q_tan) lds[M::CH + (qcs - 1) * FZ_NQ + q_lp] = v;
+            if constexpr (GEN && !DQ) {
+                // slot 1 (d/dx) writes array 0, slot 2 (d/dy) array 1 -- each needs the OTHER tangent slot of its point as well
+                const double vo = dpp_move<0x104>(v), vm = dpp_move<0x114>(v);       // row_shl:4 = lane + 4, row_shr:4 = lane - 4
+                const double vx = qcs == 1 ? v : vm, vy = qcs == 1 ? vo : v;
+                const double gq = qcs == 1 ? fma(wa0(1), vx, wa0(2) * vy) : fma(wa1(1), vx, wa1(2) * vy);
+                if (q == 0 && q_tan) lds[M::CH + (qcs - 1) * FZ_NQ + q_lp] = gq;
+            } else {
+                if (!DQ && q == 0 && q_tan) lds[M::CH + (qcs - 1) * FZ_NQ + q_lp] = v;
+            }
             const double dd = q_vdat ? qud - (v + bo) : 0.0;
             gdat_q = g.data_scale * dd;
             const double sq = row_sum16(q == 0 ? dd * dd : 0.0);
@@ -658,8 +711,19 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         }
         __syncthreads();
         double sq = 0.0;
+        const double sc = 2.0 / (double)rnr;
+        [[maybe_unused]] double deps = 0.0;      // GEN: this thread's share of d loss_e / d eps
         if (tid < FZ_NR) {
-            const double u = (lds[M::UP + tid] + lds[M::UP + FZ_NR + tid]) - pF;
+            double u;
+            if constexpr (GEN) {
+                // (UP holds the terms WITHOUT their factor eps: U = m_0 UP_0 + m_1 UP_1 - F, and a term that carries eps as a factor
+                //  contributes (2/NR) U UP_t to d loss_e / d eps -- P3:171)
+                const double u0 = lds[M::UP + tid], u1 = lds[M::UP + FZ_NR + tid];
+                u = fma(gm0, u0, gm1 * u1) - pF;
+                deps = sc * u * fma(ge0, u0, ge1 * u1);
+            } else {
+                u = (lds[M::UP + tid] + lds[M::UP + FZ_NR + tid]) - pF;
+            }
             lds[M::U + tid] = u;
             if (ro_on) pa.R[ro_idx] = u;
             sq = u * u;
@@ -671,7 +735,6 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         __syncthreads();
         if (tid == 0) pa.loss_e[e] = (lds[M::RED] + lds[M::RED + 1]) / (double)rnr;
         // adjoint: S_t[k][i] = (2/NR) c_t sum_r AX_t[r][i] U[k][r];  Gbar_t[j][i] = sum_k BY_t[k][j] S_t[k][i]
-        const double sc = 2.0 / (double)rnr;
         for (int o = tid; o < 2 * FZ_NTY * FZ_QX; o += FZ_BLOCK) {
             const int t = o / (FZ_NTY * FZ_QX), kk = (o / FZ_QX) % FZ_NTY, i = o % FZ_QX;
             const double* ax = lds + M::AX + t * FZ_NTX * FZ_QX + i;
@@ -679,19 +742,33 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             double acc = 0.0;
 #pragma unroll
             for (int r = 0; r < FZ_NTX; ++r) acc = fma(ax[r * FZ_QX], ur[r], acc);
-            lds[M::S + o] = acc * sc * (t == 0 ? pc0 : pc1);
+            if constexpr (GEN) lds[M::S + o] = acc * sc * (t == 0 ? pc0 * gm0 : pc1 * gm1);
+            else lds[M::S + o] = acc * sc * (t == 0 ? pc0 : pc1);
         }
         __syncthreads();
-        for (int o = tid; o < 2 * FZ_NQ; o += FZ_BLOCK) {
+        // (GEN, one term: only array 0 gets an adjoint; array 1 holds E = dG_0 / d eps, which meets it here: d eps += Gbar_0 E)
+        const int n_adj = (GEN && !gtwo) ? FZ_NQ : 2 * FZ_NQ;
+        for (int o = tid; o < n_adj; o += FZ_BLOCK) {
             const int t = o / FZ_NQ, j = (o / FZ_QX) % FZ_QY, i = o % FZ_QX;
             const double* by = lds + M::BY + t * FZ_NTY * FZ_QY + j;
             const double* sr = lds + M::S + t * FZ_NTY * FZ_QX + i;
             double acc = 0.0;
 #pragma unroll
             for (int kk = 0; kk < FZ_NTY; ++kk) acc = fma(by[kk * FZ_QY], sr[kk * FZ_QX], acc);
+            if constexpr (GEN) { if (!gtwo) deps = fma(acc, lds[M::CH + FZ_NQ + o], deps); }
             lds[M::CH + o] = acc;
         }
+        if constexpr (GEN) {
+            if (pa.pd.has_eps) {      // (kernel-uniform)
+                deps = pj_wave_sum_dpp(deps);
+                if (lane == 0) lds[M::RED + 4 + wv] = deps;
+            }
+        }
         __syncthreads();
+        if constexpr (GEN) {
+            // (the partials sit in wave 0's own part of the transpose region -- static_assert at the top: it reads them before it writes there)
+            if (pa.pd.has_eps && tid == 0) pa.deps_e[e] = (lds[M::RED + 4] + lds[M::RED + 5]) + (lds[M::RED + 6] + lds[M::RED + 7]);
+        }
     }
 
     // =============================================================================================
@@ -748,16 +825,25 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                     for (int j = 0; j < NSV; ++j) sv[j] = 0.0;
             }
         }
-        double gb[FZ_C];
+        double gb[C];
         if (k < n_el) {
             const int lp = (tbase + wv + k * FZ_WAVES) * 16 + pt;
             gb[0] = 0.0; gb[1] = lds[M::CH + lp]; gb[2] = lds[M::CH + FZ_NQ + lp];
+            if constexpr (GEN) {      // the channels' adjoints from the integrated arrays' (one term: array 1 carries none)
+                const double g0 = gb[1], g1 = gb[2];
+#pragma unroll
+                for (int c = 1; c < C; ++c) gb[c] = fma(wa0(c), g0, wb1(c) * g1);
+            }
         } else {
             gb[0] = gdat; gb[1] = 0.0; gb[2] = 0.0;
+            if constexpr (NT2 > 0) gb[3] = 0.0;
         }
         // tangent pre-activations of every hidden layer: layer 0 has z_c = W1[c,:]; layer i: z_c = (sigma'(z_{i-1}) z_c,{i-1}) W_i
         // (GS: read back; otherwise recomputed from s on the matrix pipe)
         double zc[L][2][MF_KS];
+        [[maybe_unused]] double zq[L][MF_KS];       // NT2: second-order tangent pre-activations z_cc of the mixed channel (layer 0: zero)
+        // s'' z_c^2 as the mixed second tangent sees it
+        [[maybe_unused]] auto sq2 = [&](int i, int s) -> double { return fma(g.t2w[0], zc[i][0][s] * zc[i][0][s], g.t2w[1] * (zc[i][1][s] * zc[i][1][s])); };
 #define ZC(I, CC, SS) zc[(I)][(CC)][(SS)]
 #pragma unroll
         for (int s = 0; s < MF_KS; ++s) {
@@ -771,18 +857,26 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                 for (int s = 0; s < MF_KS; ++s) { zc[i][0][s] = B[(i - 1) * MF_KS + s][0]; zc[i][1][s] = B[(i - 1) * MF_KS + s][1]; }
             } else {
                 double hx[MF_KS], hy[MF_KS];
+                [[maybe_unused]] double hq[MF_KS];
 #pragma unroll
                 for (int s = 0; s < MF_KS; ++s) {
                     const double a = sv[(i - 1) * MF_KS + s], a1 = 1.0 - a * a;
                     hx[s] = a1 * ZC(i - 1, 0, s); hy[s] = a1 * ZC(i - 1, 1, s);
+                    if constexpr (NT2 > 0) hq[s] = (-2.0 * a * a1) * sq2(i - 1, s) + (i > 1 ? a1 * zq[i > 1 ? i - 1 : 0][s] : 0.0);
                 }
                 fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, hx, zc[i][0]);
                 fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, hy, zc[i][1]);
+                if constexpr (NT2 > 0) fz_layer<false>(lds + M::WT + (i - 1) * MF_KS * 64, lds + M::WR + (i - 1) * MF_KS * 16, nullptr, lofs, hq, zq[i]);
             }
         }
 
         FZ_SEG(0);
-        double hbar[FZ_C][MF_KS], zbar[FZ_C][MF_KS];
+        double hbar[C][MF_KS], zbar[C][MF_KS];
+        // channel 3 (NT2) of layer i's outputs: s'' (w0 z_x^2 + w1 z_y^2) + s' z_cc
+        [[maybe_unused]] auto hv3 = [&](int i, int s) -> double {
+            const double a = sv[i * MF_KS + s], a1 = 1.0 - a * a;
+            return (-2.0 * a * a1) * sq2(i, s) + (i > 0 ? a1 * zq[i][s] : 0.0);
+        };
         // ---- linear head ----
 #pragma unroll
         for (int s = 0; s < MF_KS; ++s) {
@@ -792,6 +886,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             dWo[s] = fma(a1 * zc[L - 1][0][s], gb[1], dWo[s]);
             dWo[s] = fma(a1 * zc[L - 1][1][s], gb[2], dWo[s]);
             hbar[0][s] = gb[0] * wo; hbar[1][s] = gb[1] * wo; hbar[2][s] = gb[2] * wo;
+            if constexpr (NT2 > 0) { dWo[s] = fma(hv3(L - 1, s), gb[3], dWo[s]); hbar[3][s] = gb[3] * wo; }
         }
         if (q == 0) dbo += gb[0];
         FZ_SEG(1);
@@ -805,7 +900,15 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                 const double a1 = 1.0 - a * a, a2 = -2.0 * a * a1;
                 zbar[1][s] = hbar[1][s] * a1;
                 zbar[2][s] = hbar[2][s] * a1;
-                const double zb = hbar[0][s] * a1 + a2 * (hbar[1][s] * ZC(i, 0, s) + hbar[2][s] * ZC(i, 1, s));
+                double zb = hbar[0][s] * a1 + a2 * (hbar[1][s] * ZC(i, 0, s) + hbar[2][s] * ZC(i, 1, s));
+                if constexpr (NT2 > 0) {
+                    // the mixed second tangent rides on both first tangents (hand-derived third-order reverse pass)
+                    const double hb = hbar[3][s], a3 = -2.0 * a1 * (1.0 - 3.0 * a * a);
+                    zbar[3][s] = hb * a1;
+                    zbar[1][s] = fma(2.0 * hb * a2 * g.t2w[0], ZC(i, 0, s), zbar[1][s]);
+                    zbar[2][s] = fma(2.0 * hb * a2 * g.t2w[1], ZC(i, 1, s), zbar[2][s]);
+                    zb = fma(hb, a3 * sq2(i, s) + (i > 0 ? a2 * zq[i][s] : 0.0), zb);
+                }
                 zbar[0][s] = zb;
                 db[i][s] += zb;
             }
@@ -819,21 +922,28 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                 // weight gradient dW_i[in][out] = sum_pt sum_ch h_{i-1,ch}[pt][in] zbar_ch[pt][out]: the operands are needed
                 // point-major -> per-wave LDS transpose tiles, all channels written first (one wave-level sync)
                 pj_wave_sync();
+                // (C > TRG, the four-channel forms: the transposes go through LDS in passes of TRG channels; `put` / `mul` = one pass)
+                auto tr_put = [&](int c0) {
 #pragma unroll
-                for (int ch = 0; ch < FZ_C; ++ch) {
-                    double* TA = TAB + (2 * ch) * (MF_TRB * MF_LD);
-                    double* TB = TA + MF_TRB * MF_LD;
+                    for (int cc = 0; cc < TRG; ++cc) {
+                        const int ch = c0 + cc;
+                        double* TA = TAB + (2 * cc) * (MF_TRB * MF_LD);
+                        double* TB = TA + MF_TRB * MF_LD;
 #pragma unroll
-                    for (int s = 0; s < MF_KS; ++s) {
-                        const double a = sv[(i - 1) * MF_KS + s], a1 = 1.0 - a * a;
-                        const double hv = ch == 0 ? a : a1 * ZC(i - 1, ch - 1, s);
-                        TA[(4 * s + q) * MF_LD + pt] = hv;
-                        TB[(4 * s + q) * MF_LD + pt] = zbar[ch][s];
+                        for (int s = 0; s < MF_KS; ++s) {
+                            const double a = sv[(i - 1) * MF_KS + s], a1 = 1.0 - a * a;
+                            double hv;
+                            if constexpr (NT2 > 0) hv = ch == 0 ? a : (ch == 3 ? hv3(i - 1, s) : a1 * ZC(i - 1, ch == 3 ? 0 : ch - 1, s));
+                            else hv = ch == 0 ? a : a1 * ZC(i - 1, ch - 1, s);
+                            TA[(4 * s + q) * MF_LD + pt] = hv;
+                            TB[(4 * s + q) * MF_LD + pt] = zbar[ch][s];
+                        }
                     }
-                }
+                };
+                tr_put(0);
                 // hbar_{i-1}^T = W_i zbar^T  (independent of the transposes: issued while the LDS writes above land)
 #pragma unroll
-                for (int ch = 0; ch < FZ_C; ++ch) {
+                for (int ch = 0; ch < C; ++ch) {
                     v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
                     double h4 = 0.0;
                     const double* wrl = lds + M::WRB + (i - 1) * MF_KS * 16 + q * 4 + (lane & 3);
@@ -848,26 +958,35 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                 }
                 FZ_SEG(2 + 2 * (L - 1 - i));
                 pj_wave_sync();
+                auto tr_mul = [&]() {
 #pragma unroll
-                for (int ch = 0; ch < FZ_C; ++ch) {
-                    const double* TA = TAB + (2 * ch) * (MF_TRB * MF_LD);
-                    const double* TB = TA + MF_TRB * MF_LD;
-                    double aF[4], bF[4], aS[4], bS[4];
+                    for (int ch = 0; ch < TRG; ++ch) {
+                        const double* TA = TAB + (2 * ch) * (MF_TRB * MF_LD);
+                        const double* TB = TA + MF_TRB * MF_LD;
+                        double aF[4], bF[4], aS[4], bS[4];
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        aF[kk] = TA[pt * MF_LD + 4 * kk + q];
-                        bF[kk] = TB[pt * MF_LD + 4 * kk + q];
-                        aS[kk] = TA[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
-                        bS[kk] = TB[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                        for (int kk = 0; kk < 4; ++kk) {
+                            aF[kk] = TA[pt * MF_LD + 4 * kk + q];
+                            bF[kk] = TB[pt * MF_LD + 4 * kk + q];
+                            aS[kk] = TA[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                            bS[kk] = TB[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            dWacc[i - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[kk], bF[kk], dWacc[i - 1], 0, 0, 0);
+                            dS10[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(aS[kk], bF[kk], dS10[i - 1], 0, 0, 0);
+                            dS01[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(bS[kk], aF[kk], dS01[i - 1], 0, 0, 0);
+                        }
+                        accC[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(TA[(16 + (lane & 3)) * MF_LD + (pt & 12) + q],
+                                                                       TB[(16 + (lane & 3)) * MF_LD + (pt & 12) + q], accC[i - 1], 0, 0, 0);
                     }
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        dWacc[i - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[kk], bF[kk], dWacc[i - 1], 0, 0, 0);
-                        dS10[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(aS[kk], bF[kk], dS10[i - 1], 0, 0, 0);
-                        dS01[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(bS[kk], aF[kk], dS01[i - 1], 0, 0, 0);
-                    }
-                    accC[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(TA[(16 + (lane & 3)) * MF_LD + (pt & 12) + q],
-                                                                   TB[(16 + (lane & 3)) * MF_LD + (pt & 12) + q], accC[i - 1], 0, 0, 0);
+                };
+                tr_mul();
+                if constexpr (C > TRG) {      // the second pass: channels TRG .. C - 1 through the same tiles
+                    pj_wave_sync();
+                    tr_put(TRG);
+                    pj_wave_sync();
+                    tr_mul();
                 }
                 FZ_SEG(3 + 2 * (L - 1 - i));
             }
@@ -919,7 +1038,11 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         //  expression with work in it becomes an exec-masked block of its own and cuts the schedule into pieces)
         const double mval = q_tan ? 0.0 : 1.0;                        // value-like slots (element value, data point)
         // adjoint of the slot's output: d/dx, d/dy slots from the projection, the data slot from the boundary term, value slot none
-        const double gch = lds[M::CH + (q_tan ? (qcs - 1) * FZ_NQ : 0) + q_lp];
+        double gch = lds[M::CH + (q_tan ? (qcs - 1) * FZ_NQ : 0) + q_lp];
+        if constexpr (GEN && !DQ) {      // the tangent slots' adjoints from BOTH integrated arrays' (slot 1 = d/dx, slot 2 = d/dy)
+            const double g0 = lds[M::CH + q_lp], g1 = lds[M::CH + FZ_NQ + q_lp];
+            gch = qcs == 1 ? fma(wa0(1), g0, wb1(1) * g1) : fma(wa0(2), g0, wb1(2) * g1);
+        }
         const double GB = q_tan ? (DQ ? 0.0 : gch) : (qcs == 3 ? gdat_q : 0.0);
         // packed layer inputs H_i from s and the tangent pre-activations (tangent slots; 0 elsewhere) the forward pass left in LDS
         double Hq[L][MF_KS], ZCq[L][MF_KS];
@@ -1577,17 +1700,88 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int L, bool SPLIT, bool QT, bool GS, int QX_, int QY_, int NTX_, int NTY_, bool MULTI = false>
+template <int L, bool SPLIT, bool QT, bool GS, int QX_, int QY_, int NTX_, int NTY_, bool MULTI = false, int NT2 = 0, bool GEN = false>
 static void launch_iter_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
-    const size_t bytes = (size_t)FzLds<L, QX_, QY_, NTX_, NTY_, MULTI>::total(a.P) * sizeof(double);
-    static_assert(FzLds<L, QX_, QY_, NTX_, NTY_, MULTI>::total(2 * MF_H + MF_H + (L - 1) * (MF_H * MF_H + MF_H) + MF_H + 1) * sizeof(double) <= 160 * 1024, "LDS");
+    using LDS = FzLds<L, QX_, QY_, NTX_, NTY_, MULTI, FZ_C + NT2, (NT2 > 0 ? 2 : FZ_C)>;
+    const size_t bytes = (size_t)LDS::total(a.P) * sizeof(double);
+    static_assert(LDS::total(2 * MF_H + MF_H + (L - 1) * (MF_H * MF_H + MF_H) + MF_H + 1) * sizeof(double) <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_iter_fused<L, SPLIT, QT, GS, QX_, QY_, NTX_, NTY_, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        (void)hipFuncSetAttribute((const void*)k_iter_fused<L, SPLIT, QT, GS, QX_, QY_, NTX_, NTY_, MULTI, NT2, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_iter_fused<L, SPLIT, QT, GS, QX_, QY_, NTX_, NTY_, MULTI>), dim3(blocks), dim3(FZ_BLOCK), bytes, s, a);
+    hipLaunchKernelGGL((k_iter_fused<L, SPLIT, QT, GS, QX_, QY_, NTX_, NTY_, MULTI, NT2, GEN>), dim3(blocks), dim3(FZ_BLOCK), bytes, s, a);
 }
+// The general forms (GEN: term weights, trainable epsilon; NT2 = 1: the mixed second tangent) are instantiated in a translation unit
+// of their own (kernels_fused_gen.hip = this file with HPV_FZ_GEN_TU): plan 0 = SPLIT, 1 = whole tiles, 2 = quarter tiles.
+// false: that (shape, depth, plan, channel set) is not instantiated -- or compiled out by the build guard (csrc/build.sh).
+bool hpv_fused_launch_gen(const ProjDesc& pd, int L, int plan, int nt2, const MfmaArgs& a, int blocks, hipStream_t s);
+const char* hpv_fused_gen_build_state();
+#ifdef HPV_FZ_GEN_TU
+template <int QX_, int QY_, int NTX_, int NTY_>
+static bool launch_iter_fused_gen_shape(int L, int plan, int nt2, const MfmaArgs& a, int blocks, hipStream_t s) {
+    constexpr int TPE = QX_ * QY_ / 16;
+    constexpr bool HAS_QT = (TPE % 4) <= 1 && TPE >= 8;
+    constexpr bool HAS_DQ = HAS_QT && TPE % 4 == 0;            // four channels: the data-quarter plan only
+    constexpr bool HAS_NT2 = QX_ != 20;                        // (20x20 points keep five tiles per wave in the stash: no room for a fourth channel's registers)
+    if (L != 2 && L != 3) return false;
+#define FZ_GG(L_, SPLIT_, QT_, NT2_) launch_iter_fused<L_, SPLIT_, QT_, false, QX_, QY_, NTX_, NTY_, false, NT2_, true>(a, blocks, s)
+    if (nt2 == 0) {
+        if (plan == 0) { if (L == 2) FZ_GG(2, true, false, 0); else FZ_GG(3, true, false, 0); }
+        else if (plan == 1) { if (L == 2) FZ_GG(2, false, false, 0); else FZ_GG(3, false, false, 0); }
+        else if (plan == 2) {
+#ifdef HPV_FZ_GEN_NO_QT
+            return false;
+#else
+            // (three hidden layers on 20x20 points: the general quarter tile takes the compiler to a111 of the 106 AGPRs the stash leaves)
+            if constexpr (HAS_QT) { if (L == 2) FZ_GG(2, false, true, 0); else if constexpr (QX_ != 20) FZ_GG(3, false, true, 0); else return false; } else return false;
+#endif
+        } else return false;
+        return true;
+    }
+#ifdef HPV_FZ_GEN_NO_NT2
+    return false;
+#else
+    if constexpr (HAS_NT2) {
+        if (plan == 0) { if (L == 2) FZ_GG(2, true, false, 1); else FZ_GG(3, true, false, 1); }
+        else if (plan == 1) { if (L == 2) FZ_GG(2, false, false, 1); else FZ_GG(3, false, false, 1); }
+        else if (plan == 2) {
+#ifdef HPV_FZ_GEN_NO_QT
+            return false;
+#else
+            if constexpr (HAS_DQ) { if (L == 2) FZ_GG(2, false, true, 1); else FZ_GG(3, false, true, 1); } else return false;
+#endif
+        } else return false;
+        return true;
+    } else return false;
+#endif
+#undef FZ_GG
+}
+bool hpv_fused_launch_gen(const ProjDesc& pd, int L, int plan, int nt2, const MfmaArgs& a, int blocks, hipStream_t s) {
+#ifdef HPV_FZ_GEN_TRIPPED
+    return false;
+#else
+#define FZ_TRY(A_, B_, C_, D_) \
+    if (pd.qx == A_ && pd.qy == B_ && pd.ntx <= C_ && pd.nty <= D_) return launch_iter_fused_gen_shape<A_, B_, C_, D_>(L, plan, nt2, a, blocks, s);
+    FZ_SHAPES(FZ_TRY)
+#undef FZ_TRY
+    return false;
+#endif
+}
+const char* hpv_fused_gen_build_state() {
+#if defined(HPV_FZ_GEN_TRIPPED)
+    return "absent";
+#elif defined(HPV_FZ_GEN_NO_NT2) && defined(HPV_FZ_GEN_NO_QT)
+    return "three-channel-whole-tiles-only";
+#elif defined(HPV_FZ_GEN_NO_NT2)
+    return "three-channel-only";
+#elif defined(HPV_FZ_GEN_NO_QT)
+    return "no-quarter-tile";
+#else
+    return "ok";
+#endif
+}
+#else    // ---- everything below: the main translation unit ----
 // One element shape: plan 0 = SPLIT, 1 = whole tiles, 2 = quarter tiles (shapes with 1 mod 4 tiles).  false: not instantiated.
 // (GS: the saved values travel through the activation store instead of AGPRs / LDS + recompute; HPV_FUSED_GSTASH=1 opts in; built
 //  for the 20x20 / 10x10 shape only)
@@ -1661,7 +1855,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     const NetDesc& nd = m->nd;
     if (!m->iter_fused_ok) return false;
     if (m->H != MF_H) return false;      // written for 20-wide layers (other widths: kernels_wide.hip)
-    if (!(nd.d == 2 && nd.nT1 == 2 && nd.nT2 == 0 && nd.act == HPV_ACT_TANH) || m->L < 2 || m->L > 3) return false;
+    if (!(nd.d == 2 && nd.nT1 == 2 && nd.nT2 <= 1 && nd.act == HPV_ACT_TANH) || m->L < 2 || m->L > 3) return false;
     const bool small = pd.qx == SM_QX && pd.qy == SM_QY && pd.ntx >= 1 && pd.ntx <= SM_NTX && pd.nty >= 1 && pd.nty <= SM_NTY;
     if (!fused_shape_ok(pd) && !small) return false;
     const int NQ = pd.qx * pd.qy, TPE = NQ / 16;              // points and 16-point tiles of an element
@@ -1670,10 +1864,26 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
 #ifdef HPV_FZ_NO_EXTRA_SHAPES     // csrc/build.sh: the AGPR guard tripped in an instantiation of a shape other than 20x20 / 10x10
     if (!q20 && !small) return false;
 #endif
-    if (pd.edge || pd.has_eps || pd.nterms != 2 || pd.nact) return false;
-    for (int t = 0; t < 2; ++t)          // one-hot: term t integrates exactly channel 1 + t with weight 1
+    if (pd.edge || pd.nact || pd.nterms < 1 || pd.nterms > 2) return false;
+    // one-hot (Poisson-2D var_form 1, the headline instantiations): term t integrates exactly channel 1 + t with weight 1, no epsilon.
+    // Every other form of these channel sets (round 6): the general instantiations (k_iter_fused<.., NT2, GEN>)
+    bool onehot = !pd.has_eps && pd.nterms == 2 && nd.nT2 == 0;
+    for (int t = 0; t < 2 && onehot; ++t)
         for (int ch = 0; ch < HPV_MAXC; ++ch)
-            if (pd.t[t].a0[ch] != (ch == 1 + t ? 1.0 : 0.0) || pd.t[t].a1[ch] != 0.0 || pd.t[t].eps_mult) return false;
+            if (pd.t[t].a0[ch] != (ch == 1 + t ? 1.0 : 0.0) || pd.t[t].a1[ch] != 0.0 || pd.t[t].eps_mult) onehot = false;
+    const bool gen = !onehot;
+    const int C = 3 + nd.nT2;
+    if (gen) {
+        if (small) return false;                            // (10x10 points: kernels_tile.hip)
+        for (int t = 0; t < pd.nterms; ++t) {
+            if (pd.t[t].a0[0] != 0.0 || pd.t[t].a1[0] != 0.0) return false;       // the value channel is not integrated here
+            for (int ch = C; ch < HPV_MAXC; ++ch) if (pd.t[t].a0[ch] != 0.0 || pd.t[t].a1[ch] != 0.0) return false;
+            // two terms fill both LDS arrays: none is left for dG / d eps of a term whose WEIGHTS depend on epsilon
+            if (pd.nterms == 2) for (int ch = 0; ch < HPV_MAXC; ++ch) if (pd.t[t].a1[ch] != 0.0) return false;
+        }
+        if (pd.has_eps && !pa.eps_ptr) return false;
+        if (pre && pd.has_eps) return false;                // the deferred-update prologue forms the network parameters only
+    }
     if (n_elem <= 0) return false;
 #ifdef HPV_AGPR_GUARD_TRIPPED     // csrc/build.sh: the compiler's registers reached the hand-managed AGPR range of k_iter_fused
     if (!small) return false;
@@ -1690,7 +1900,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
 #else
     constexpr bool multi_built = true;
 #endif
-    const int gplan = small ? 1 : hpv_fused_grid_plan(pd.qx, m->L, n_elem, m->n_cus, multi_built && m->base.ACTS != nullptr, m->multi_off, m->multi_force, m->iter_fused_force);
+    const int gplan = small ? 1 : hpv_fused_grid_plan(pd.qx, m->L, n_elem, m->n_cus, !gen && multi_built && m->base.ACTS != nullptr, m->multi_off, m->multi_force && !gen, m->iter_fused_force);
     if (gplan == 0) return false;
     const bool multi = gplan == 2;
     if (pre && (small || multi || nd.P > FZ_PRE_PER_THREAD * FZ_BLOCK)) return false;       // the deferred-update prologue exists in the one-workgroup-per-element / SPLIT instantiations
@@ -1773,12 +1983,20 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     else if (!gs) plan = 1;
 #endif
     else if (!has_qt || getenv("HPV_NO_QUARTER_TILE")) plan = 1;      // (A/B switch: whole tiles only, read per launch / capture)
+    if (gen && plan == 2 && nd.nT2 == 1 && TPE % 4 != 0) plan = 1;    // four channels: the packed quarter has room for the data points only
     if (multi) plan += 2;                                              // plans 3 / 4: several elements per workgroup
+    if (gen) {
+        if (gs || multi) return false;
+        if (!hpv_fused_launch_gen(pd, m->L, plan, nd.nT2, a, (int)blocks, s)) {
+            // (a quarter-tile instantiation the build guard compiled out: whole tiles)
+            if (plan != 2 || !hpv_fused_launch_gen(pd, m->L, plan = 1, nd.nT2, a, (int)blocks, s)) return false;
+        }
+    } else
     if (!launch_iter_fused_any(pd, m->L, plan, gs, a, (int)blocks, s)) return false;
     m->last_split = split > 1;
     if (split > 1) m->split_used = true;
-    char shp[40] = "";
-    if (!base_shape) snprintf(shp, sizeof shp, ",%dx%d/%dx%d", pd.qx, pd.qy, pd.ntx, pd.nty);
+    char shp[64] = "";
+    if (!base_shape || gen) snprintf(shp, sizeof shp, ",%dx%d/%dx%d%s", pd.qx, pd.qy, pd.ntx, pd.nty, gen ? (nd.nT2 ? ",NT2=1,GEN" : ",GEN") : "");
     if (split > 1) snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=true,QT=false,GS=%s%s> split=%d", m->L, gs ? "true" : "false", shp, split);
     else snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=false,QT=%s,GS=%s%s>%s", m->L, (plan == 2 || plan == 4) ? "true" : "false",
                   gs ? "true" : "false", shp, multi ? " elements-per-workgroup>1" : "");
@@ -1814,3 +2032,4 @@ bool hpv_fused_loop_built() {
     return true;
 #endif
 }
+#endif   // HPV_FZ_GEN_TU

@@ -62,6 +62,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_generic(NetDesc nd, const doubl
     long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     const int C = nd.C, nT1 = nd.nT1, nT2 = nd.nT2;
+    const bool mixed = nT1 == 2 && nT2 == 1;      // the mixed second tangent (NetDesc::t2w)
     double h[HPV_MAXC][HPV_MAXH];
     double zn[HPV_MAXC][HPV_MAXH];
     for (int j = 0; j < nd.d; ++j) {
@@ -100,7 +101,8 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_generic(NetDesc nd, const doubl
                 double zc = zn[1 + nd.t2idx[b]][k];
                 double zcc = zn[1 + nT1 + b][k];
                 if (save_act) base[((long)(2 + nT1 + b) * out + k) * N + p] = zcc;
-                h[1 + nT1 + b][k] = a2 * zc * zc + a1 * zcc;
+                if (mixed) h[1 + nT1 + b][k] = a2 * fma(nd.t2w[0], zn[1][k] * zn[1][k], nd.t2w[1] * (zn[2][k] * zn[2][k])) + a1 * zcc;
+                else h[1 + nT1 + b][k] = a2 * zc * zc + a1 * zcc;
             }
         }
     }
@@ -156,7 +158,12 @@ __device__ __forceinline__ void load_layer_outputs(const NetDesc& nd, const doub
         for (int b = 0; b < nT2; ++b) {
             double zc = valid ? base[((long)(2 + nd.t2idx[b]) * w + j) * N + p] : 0.0;
             double zcc = valid ? base[((long)(2 + nT1 + b) * w + j) * N + p] : 0.0;
-            hin[1 + nT1 + b][j] = a2 * zc * zc + a1 * zcc;
+            if (nT1 == 2 && nT2 == 1) {      // the mixed second tangent (NetDesc::t2w)
+                const double z0 = valid ? base[((long)2 * w + j) * N + p] : 0.0, z1 = valid ? base[((long)3 * w + j) * N + p] : 0.0;
+                hin[1 + nT1 + b][j] = a2 * fma(nd.t2w[0], z0 * z0, nd.t2w[1] * (z1 * z1)) + a1 * zcc;
+            } else {
+                hin[1 + nT1 + b][j] = a2 * zc * zc + a1 * zcc;
+            }
         }
     }
 }
@@ -232,8 +239,14 @@ __global__ void __launch_bounds__(BWD_BLOCK) k_mlp_bwd_generic(NetDesc nd, const
                     double zcc = valid ? base[((long)(2 + nT1 + b) * out + k) * N + p] : 0.0;
                     double hb = hbar[1 + nT1 + b][k];
                     zbar[1 + nT1 + b][k] = hb * a1;
-                    zbar[1 + t][k] += 2.0 * hb * a2 * zc[t];
-                    zb += hb * (a3 * zc[t] * zc[t] + a2 * zcc);
+                    if (nT1 == 2 && nT2 == 1) {      // the mixed second tangent (NetDesc::t2w) rides on both first tangents
+                        zbar[1][k] += 2.0 * hb * a2 * nd.t2w[0] * zc[0];
+                        zbar[2][k] += 2.0 * hb * a2 * nd.t2w[1] * zc[1];
+                        zb += hb * (a3 * fma(nd.t2w[0], zc[0] * zc[0], nd.t2w[1] * (zc[1] * zc[1])) + a2 * zcc);
+                    } else {
+                        zbar[1 + t][k] += 2.0 * hb * a2 * zc[t];
+                        zb += hb * (a3 * zc[t] * zc[t] + a2 * zcc);
+                    }
                 }
                 zbar[0][k] = valid ? zb : 0.0;
             }

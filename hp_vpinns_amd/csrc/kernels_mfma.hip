@@ -153,7 +153,8 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) k_fwd_mfma(MfmaArgs g) {
 #pragma unroll
                     for (int b = 0; b < NT2; ++b) {
                         const double zc = w1[b < D ? b : 0][s];   // T2 = coordinates 0..NT2-1
-                        h[1 + NT1 + b][s] = a2 * zc * zc;
+                        if constexpr (T2Mix<NT1, NT2>::value) h[1 + NT1 + b][s] = a2 * t2_square<NT1, NT2>(g.t2w, b, w1[0][s], w1[D > 1 ? 1 : 0][s]);
+                        else h[1 + NT1 + b][s] = a2 * zc * zc;
                     }
                 }
             };
@@ -216,7 +217,8 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) k_fwd_mfma(MfmaArgs g) {
                         const double zcc = s < 4 ? acc[1 + NT1 + b][s & 3] : z16[1 + NT1 + b];
                         const double z1 = zc[b < NT1 ? b : 0];
                         if constexpr (SAVE) svl[((SZCC + b) * MF_KS + s) * 64] = zcc;
-                        h[1 + NT1 + b][s] = a2 * z1 * z1 + a1 * zcc;
+                        if constexpr (T2Mix<NT1, NT2>::value) h[1 + NT1 + b][s] = a2 * t2_square<NT1, NT2>(g.t2w, b, zc[0], zc[NT1 > 1 ? 1 : 0]) + a1 * zcc;
+                        else h[1 + NT1 + b][s] = a2 * z1 * z1 + a1 * zcc;
                     }
                 }
             };
@@ -253,35 +255,6 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) k_fwd_mfma(MfmaArgs g) {
 // ------------------------------------------------------------------------------------------------
 // reverse
 // ------------------------------------------------------------------------------------------------
-template <int ACT, int NT1, int NT2>
-__device__ __forceinline__ void layer_outputs_from_saved(const double* svl, const int* t2idx, const double* zc1,
-                                                         bool first_layer, double hin[][MF_KS]) {
-    // (h, h_c, h_cc) of a hidden layer from its saved slots; for layer 1, z_c = W1[c,:] (zc1) and z_cc = 0
-    constexpr int SZC = 1 + (ACT == HPV_ACT_SIN ? 1 : 0);
-    constexpr int SZCC = SZC + NT1;
-#pragma unroll
-    for (int s = 0; s < MF_KS; ++s) {
-        const double a = svl[(0 * MF_KS + s) * 64];
-        double a1s = 0.0;
-        if constexpr (ACT == HPV_ACT_SIN) a1s = svl[(1 * MF_KS + s) * 64];
-        double a1, a2, a3;
-        act_saved<ACT>(a, a1s, a1, a2, a3);
-        hin[0][s] = a;
-        double zc[NT1 > 0 ? NT1 : 1];
-#pragma unroll
-        for (int u = 0; u < NT1; ++u) {
-            zc[u] = first_layer ? zc1[u * MF_KS + s] : svl[((SZC + u) * MF_KS + s) * 64];
-            hin[1 + u][s] = a1 * zc[u];
-        }
-#pragma unroll
-        for (int b = 0; b < NT2; ++b) {
-            const double zcc = first_layer ? 0.0 : svl[((SZCC + b) * MF_KS + s) * 64];
-            const double z1 = zc[b < NT1 ? b : 0];
-            hin[1 + NT1 + b][s] = a2 * z1 * z1 + a1 * zcc;
-        }
-    }
-}
-
 // PQX > 0: ELEMENT-BLOCK mode with the projection fused in.  Workgroup b owns element b: it first projects the
 // element (residual, element loss, adjoint of the integrated channels -> GBAR; project_element_wg), then runs the
 // reverse pass over the element's PQX*PQY/16 tiles (+ one of the boundary/data tiles).  The per-element
@@ -418,7 +391,8 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES == 8 || (1 + NT1 + NT2) * L
             else {
                 const int b = ch - 1 - NT1;
                 const double z1 = S.zc[b < NT1 ? b : 0][s];
-                hv[s] = a2 * z1 * z1 + a1 * S.zcc[b < NT2 ? b : 0][s];
+                if constexpr (T2Mix<NT1, NT2>::value) hv[s] = a2 * t2_square<NT1, NT2>(g.t2w, b, S.zc[0][s], S.zc[NT1 > 1 ? 1 : 0][s]) + a1 * S.zcc[0][s];
+                else hv[s] = a2 * z1 * z1 + a1 * S.zcc[b < NT2 ? b : 0][s];
             }
         }
     };
@@ -498,8 +472,14 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES == 8 || (1 + NT1 + NT2) * L
                     const int u = b < NT1 ? b : 0;
                     const double hb = hbar[1 + NT1 + b][s];
                     zbar[1 + NT1 + b][s] = hb * a1;
-                    zbar[1 + u][s] += 2.0 * hb * a2 * cur.zc[u][s];
-                    zb += hb * (a3 * cur.zc[u][s] * cur.zc[u][s] + a2 * cur.zcc[b][s]);
+                    if constexpr (T2Mix<NT1, NT2>::value) {      // the mixed second tangent rides on both first tangents
+                        zbar[1][s] += 2.0 * hb * a2 * g.t2w[0] * cur.zc[0][s];
+                        zbar[2][s] += 2.0 * hb * a2 * g.t2w[1] * cur.zc[NT1 > 1 ? 1 : 0][s];
+                        zb += hb * (a3 * t2_square<NT1, NT2>(g.t2w, b, cur.zc[0][s], cur.zc[NT1 > 1 ? 1 : 0][s]) + a2 * cur.zcc[b][s]);
+                    } else {
+                        zbar[1 + u][s] += 2.0 * hb * a2 * cur.zc[u][s];
+                        zb += hb * (a3 * cur.zc[u][s] * cur.zc[u][s] + a2 * cur.zcc[b][s]);
+                    }
                 }
                 zbar[0][s] = zb;
                 db[i][s] += zb;
@@ -804,7 +784,7 @@ HpvMfma* hpv_mfma_create(const NetDesc& nd, long N, std::string* why, bool need_
     a = MfmaArgs{};
     a.N = N; a.ntiles = m->ntiles; a.ACTS = m->ACTS; a.P = nd.P;
     for (int l = 0; l < nd.nl; ++l) { a.woff[l] = nd.woff[l]; a.boff[l] = nd.boff[l]; }
-    for (int i = 0; i < 2; ++i) { a.t1dim[i] = nd.t1dim[i]; a.t2idx[i] = nd.t2idx[i]; }
+    for (int i = 0; i < 2; ++i) { a.t1dim[i] = nd.t1dim[i]; a.t2idx[i] = nd.t2idx[i]; a.t2w[i] = nd.t2w[i]; }
     return m;
 }
 

@@ -993,6 +993,7 @@ int hpv_mfma_tall_split(HpvMfma* m, const ProjDesc& pd, long n_elem) {
     const NetDesc& nd = m->nd;
     if (!m->iter_fused_ok || !m->iter_split_ok || !m->xerr || !m->xg || !m->xiter || m->H != MF_H) return 0;
     if (!(nd.d == 2 && nd.nT1 == 2 && nd.nT2 <= 1 && nd.act == HPV_ACT_TANH) || m->L < 2 || m->L > 3) return 0;
+    if (nd.nT2 == 1 && !(nd.t2w[0] == 1.0 && nd.t2w[1] == 0.0)) return 0;      // (the mixed second tangent, NetDesc::t2w: not in this kernel)
     if (!(pd.qx == 80 && pd.qy == 80 && pd.ntx == 5 && pd.nty == 5) || pd.edge || pd.nact || pd.nterms < 1) return 0;
     if (n_elem <= 0 || n_elem > m->xsync_elems) return 0;
     const int tpe = 80 * 80 / 16;

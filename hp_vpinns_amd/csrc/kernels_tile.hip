@@ -209,7 +209,8 @@ __device__ __forceinline__ void tile_body(const MfmaArgs& g, double* lds) {
 #pragma unroll
                     for (int b = 0; b < NT2; ++b) {
                         const double zc = W1O[((b < D ? b : 0) * MF_KS + s) * 64 + lane];
-                        h[1 + NT1 + b][s] = a2 * zc * zc;
+                        if constexpr (T2Mix<NT1, NT2>::value) h[1 + NT1 + b][s] = a2 * t2_square<NT1, NT2>(g.t2w, b, W1O[s * 64 + lane], W1O[((D > 1 ? 1 : 0) * MF_KS + s) * 64 + lane]);
+                        else h[1 + NT1 + b][s] = a2 * zc * zc;
                     }
                 }
             };
@@ -264,7 +265,8 @@ __device__ __forceinline__ void tile_body(const MfmaArgs& g, double* lds) {
                         const double zcc = s < 4 ? acc[1 + NT1 + b][s & 3] : z16[1 + NT1 + b];
                         const double z1 = zc[b < NT1 ? b : 0];
                         st[i].zcc[b][s] = zcc;
-                        h[1 + NT1 + b][s] = a2 * z1 * z1 + a1 * zcc;
+                        if constexpr (T2Mix<NT1, NT2>::value) h[1 + NT1 + b][s] = a2 * t2_square<NT1, NT2>(g.t2w, b, zc[0], zc[NT1 > 1 ? 1 : 0]) + a1 * zcc;
+                        else h[1 + NT1 + b][s] = a2 * z1 * z1 + a1 * zcc;
                     }
                 }
             };
@@ -336,7 +338,8 @@ __device__ __forceinline__ void tile_body(const MfmaArgs& g, double* lds) {
                 else {
                     const int b = ch - 1 - NT1;
                     const double z1 = zc_of(i, b, s);
-                    hv[s] = a2 * z1 * z1 + (i == 0 ? 0.0 : a1 * st[i].zcc[b < NT2 ? b : 0][s]);
+                    if constexpr (T2Mix<NT1, NT2>::value) hv[s] = a2 * t2_square<NT1, NT2>(g.t2w, b, zc_of(i, 0, s), zc_of(i, NT1 > 1 ? 1 : 0, s)) + (i == 0 ? 0.0 : a1 * st[i].zcc[0][s]);
+                    else hv[s] = a2 * z1 * z1 + (i == 0 ? 0.0 : a1 * st[i].zcc[b < NT2 ? b : 0][s]);
                 }
             }
         };
@@ -382,8 +385,15 @@ __device__ __forceinline__ void tile_body(const MfmaArgs& g, double* lds) {
                     const double hb = hbar[1 + NT1 + b][s];
                     const double z1 = zc_of(i, u, s);
                     zbar[1 + NT1 + b][s] = hb * a1;
-                    zbar[1 + u][s] += 2.0 * hb * a2 * z1;
-                    zb += hb * (a3 * z1 * z1 + (i == 0 ? 0.0 : a2 * st[i].zcc[b][s]));
+                    if constexpr (T2Mix<NT1, NT2>::value) {      // the mixed second tangent rides on both first tangents
+                        const double y0 = zc_of(i, 0, s), y1 = zc_of(i, NT1 > 1 ? 1 : 0, s);
+                        zbar[1][s] += 2.0 * hb * a2 * g.t2w[0] * y0;
+                        zbar[2][s] += 2.0 * hb * a2 * g.t2w[1] * y1;
+                        zb += hb * (a3 * t2_square<NT1, NT2>(g.t2w, b, y0, y1) + (i == 0 ? 0.0 : a2 * st[i].zcc[b][s]));
+                    } else {
+                        zbar[1 + u][s] += 2.0 * hb * a2 * z1;
+                        zb += hb * (a3 * z1 * z1 + (i == 0 ? 0.0 : a2 * st[i].zcc[b][s]));
+                    }
                 }
                 zbar[0][s] = zb;
                 const double t = row_sum16(zb);

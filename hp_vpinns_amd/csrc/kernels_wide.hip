@@ -130,7 +130,8 @@ __global__ void __launch_bounds__(WF_BLOCK, (H <= 32 ? 2 : 1)) k_fwd_wide(MfmaAr
 #pragma unroll
                     for (int b = 0; b < NT2; ++b) {
                         const double zc = W1[(b < D ? b : 0) * H + 4 * s + (lofs >> 4)];                            // T2 = coordinates 0..NT2-1
-                        h[1 + NT1 + b][s] = a2 * zc * zc;
+                        if constexpr (T2Mix<NT1, NT2>::value) h[1 + NT1 + b][s] = a2 * t2_square<NT1, NT2>(g.t2w, b, W1[4 * s + (lofs >> 4)], W1[(D > 1 ? 1 : 0) * H + 4 * s + (lofs >> 4)]);
+                        else h[1 + NT1 + b][s] = a2 * zc * zc;
                     }
                 }
             };
@@ -161,7 +162,8 @@ __global__ void __launch_bounds__(WF_BLOCK, (H <= 32 ? 2 : 1)) k_fwd_wide(MfmaAr
                     for (int b = 0; b < NT2; ++b) {
                         const double zcc = z[1 + NT1 + b][s], zc1 = z[1 + (b < NT1 ? b : 0)][s];
                         if constexpr (SAVE_T) svl[((SZCC + b) * KS + s) * 64] = zcc;
-                        h[1 + NT1 + b][s] = a2 * zc1 * zc1 + a1 * zcc;
+                        if constexpr (T2Mix<NT1, NT2>::value) h[1 + NT1 + b][s] = a2 * t2_square<NT1, NT2>(g.t2w, b, z[1][s], z[NT1 > 1 ? 2 : 1][s]) + a1 * zcc;
+                        else h[1 + NT1 + b][s] = a2 * zc1 * zc1 + a1 * zcc;
                     }
                 }
             };
@@ -258,7 +260,8 @@ __global__ void __launch_bounds__(WF_BLOCK, 1) k_bwd_wide(MfmaArgs g) {
             else {
                 const int b = ch - 1 - NT1;
                 const double z1 = S.zc[b < NT1 ? b : 0][s];
-                hv[s] = a2 * z1 * z1 + a1 * S.zcc[b < NT2 ? b : 0][s];
+                if constexpr (T2Mix<NT1, NT2>::value) hv[s] = a2 * t2_square<NT1, NT2>(g.t2w, b, S.zc[0][s], S.zc[NT1 > 1 ? 1 : 0][s]) + a1 * S.zcc[0][s];
+                else hv[s] = a2 * z1 * z1 + a1 * S.zcc[b < NT2 ? b : 0][s];
             }
         }
     };
@@ -310,8 +313,14 @@ __global__ void __launch_bounds__(WF_BLOCK, 1) k_bwd_wide(MfmaArgs g) {
                     const int u = b < NT1 ? b : 0;
                     const double hb = hbar[1 + NT1 + b][s];
                     zbar[1 + NT1 + b][s] = hb * a1;
-                    zbar[1 + u][s] += 2.0 * hb * a2 * cur.zc[u][s];
-                    zb += hb * (a3 * cur.zc[u][s] * cur.zc[u][s] + a2 * cur.zcc[b][s]);
+                    if constexpr (T2Mix<NT1, NT2>::value) {      // the mixed second tangent rides on both first tangents
+                        zbar[1][s] += 2.0 * hb * a2 * g.t2w[0] * cur.zc[0][s];
+                        zbar[2][s] += 2.0 * hb * a2 * g.t2w[1] * cur.zc[NT1 > 1 ? 1 : 0][s];
+                        zb += hb * (a3 * t2_square<NT1, NT2>(g.t2w, b, cur.zc[0][s], cur.zc[NT1 > 1 ? 1 : 0][s]) + a2 * cur.zcc[b][s]);
+                    } else {
+                        zbar[1 + u][s] += 2.0 * hb * a2 * cur.zc[u][s];
+                        zb += hb * (a3 * cur.zc[u][s] * cur.zc[u][s] + a2 * cur.zcc[b][s]);
+                    }
                 }
                 zbar[0][s] = zb;
                 db[i][s] += zb;
@@ -446,7 +455,8 @@ __global__ void __launch_bounds__(WF_BLOCK, 1) k_bwd_wide_rc(MfmaArgs g) {
 #pragma unroll
                     for (int b = 0; b < NT2; ++b) {
                         const double z1 = zc[i][b < NT1 ? b : 0][s];
-                        hc[NT1 + b][s] = a2 * z1 * z1 + a1 * zcc[i][b][s];
+                        if constexpr (T2Mix<NT1, NT2>::value) hc[NT1 + b][s] = a2 * t2_square<NT1, NT2>(g.t2w, b, zc[i][0][s], zc[i][NT1 > 1 ? 1 : 0][s]) + a1 * zcc[i][b][s];
+                        else hc[NT1 + b][s] = a2 * z1 * z1 + a1 * zcc[i][b][s];
                     }
                 }
                 double zt[CT > 0 ? CT : 1][KS];
@@ -470,7 +480,8 @@ __global__ void __launch_bounds__(WF_BLOCK, 1) k_bwd_wide_rc(MfmaArgs g) {
                 else {
                     const int b = ch - 1 - NT1;
                     const double z1 = zc[i][b < NT1 ? b : 0][s];
-                    hv[s] = a2 * z1 * z1 + a1 * zcc[i][b < NT2 ? b : 0][s];
+                    if constexpr (T2Mix<NT1, NT2>::value) hv[s] = a2 * t2_square<NT1, NT2>(g.t2w, b, zc[i][0][s], zc[i][NT1 > 1 ? 1 : 0][s]) + a1 * zcc[i][0][s];
+                    else hv[s] = a2 * z1 * z1 + a1 * zcc[i][b < NT2 ? b : 0][s];
                 }
             }
         };
@@ -503,8 +514,14 @@ __global__ void __launch_bounds__(WF_BLOCK, 1) k_bwd_wide_rc(MfmaArgs g) {
                     const int u = b < NT1 ? b : 0;
                     const double hb = hbar[1 + NT1 + b][s];
                     zbar[1 + NT1 + b][s] = hb * a1;
-                    zbar[1 + u][s] += 2.0 * hb * a2 * zc[i][u][s];
-                    zb += hb * (a3 * zc[i][u][s] * zc[i][u][s] + a2 * zcc[i][b][s]);
+                    if constexpr (T2Mix<NT1, NT2>::value) {
+                        zbar[1][s] += 2.0 * hb * a2 * g.t2w[0] * zc[i][0][s];
+                        zbar[2][s] += 2.0 * hb * a2 * g.t2w[1] * zc[i][NT1 > 1 ? 1 : 0][s];
+                        zb += hb * (a3 * t2_square<NT1, NT2>(g.t2w, b, zc[i][0][s], zc[i][NT1 > 1 ? 1 : 0][s]) + a2 * zcc[i][b][s]);
+                    } else {
+                        zbar[1 + u][s] += 2.0 * hb * a2 * zc[i][u][s];
+                        zb += hb * (a3 * zc[i][u][s] * zc[i][u][s] + a2 * zcc[i][b][s]);
+                    }
                 }
                 zbar[0][s] = zb;
                 db[i][s] += zb;
