@@ -1399,7 +1399,8 @@ const char* hpv_build_info(void) {
     static std::string info;
     static std::once_flag once;
     std::call_once(once, [] {
-        info = std::string("k_iter_fused=") + hpv_fused_build_state() + ";k_iter_tall=" + hpv_tall_build_state() + ";test_hooks=";
+        info = std::string("k_iter_fused=") + hpv_fused_build_state() + ";k_iter_fused_gen=" + hpv_fused_gen_build_state() +
+               ";k_iter_tall=" + hpv_tall_build_state() + ";test_hooks=";
 #ifdef HPV_TEST_HOOKS
         info += "1";
 #else

@@ -119,6 +119,8 @@ bool hpv_mfma_prefers_elem(HpvMfma* m);             // HPV_FUSE=e: the generic e
 unsigned int* hpv_mfma_xiter(HpvMfma* m);         // launch counter of the tagged exchange (advanced by k_finalize behind a shared-element launch)
 // "ok" | "no-quarter-tile" (AGPR guard tripped in the QT instantiation) | "absent" (guard tripped: kernel compiled out)
 const char* hpv_fused_build_state();
+// the general forms of k_iter_fused (kernels_fused_gen.hip): "ok" | "no-quarter-tile" | "three-channel-only" | "three-channel-whole-tiles-only" | "absent"
+const char* hpv_fused_gen_build_state();
 const char* hpv_tall_build_state();
 bool hpv_mfma_sync_failed_possible(HpvMfma* m);   // the last whole-iteration launch ran in SPLIT mode
 int hpv_mfma_max_rows(HpvMfma* m, long n_elem, long n_data_tiles = 0);

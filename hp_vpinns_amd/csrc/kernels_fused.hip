@@ -921,6 +921,60 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             } else {
                 // weight gradient dW_i[in][out] = sum_pt sum_ch h_{i-1,ch}[pt][in] zbar_ch[pt][out]: the operands are needed
                 // point-major -> per-wave LDS transpose tiles, all channels written first (one wave-level sync)
+                if constexpr (NT2 == 0) {      // (three channels: ONE pass -- the headline instantiations' text, kept as it was)
+                pj_wave_sync();
+#pragma unroll
+                for (int ch = 0; ch < FZ_C; ++ch) {
+                    double* TA = TAB + (2 * ch) * (MF_TRB * MF_LD);
+                    double* TB = TA + MF_TRB * MF_LD;
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s) {
+                        const double a = sv[(i - 1) * MF_KS + s], a1 = 1.0 - a * a;
+                        const double hv = ch == 0 ? a : a1 * ZC(i - 1, ch - 1, s);
+                        TA[(4 * s + q) * MF_LD + pt] = hv;
+                        TB[(4 * s + q) * MF_LD + pt] = zbar[ch][s];
+                    }
+                }
+                // hbar_{i-1}^T = W_i zbar^T  (independent of the transposes: issued while the LDS writes above land)
+#pragma unroll
+                for (int ch = 0; ch < FZ_C; ++ch) {
+                    v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
+                    double h4 = 0.0;
+                    const double* wrl = lds + M::WRB + (i - 1) * MF_KS * 16 + q * 4 + (lane & 3);
+#pragma unroll
+                    for (int s = 0; s < MF_KS; ++s) {
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[M::WN + ((i - 1) * MF_KS + s) * 64 + lofs], zbar[ch][s], acc, 0, 0, 0);
+                        h4 = __builtin_amdgcn_mfma_f64_4x4x4f64(wrl[s * 16], zbar[ch][s], h4, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) hbar[ch][s] = acc[s];
+                    hbar[ch][4] = h4;
+                }
+                FZ_SEG(2 + 2 * (L - 1 - i));
+                pj_wave_sync();
+#pragma unroll
+                for (int ch = 0; ch < FZ_C; ++ch) {
+                    const double* TA = TAB + (2 * ch) * (MF_TRB * MF_LD);
+                    const double* TB = TA + MF_TRB * MF_LD;
+                    double aF[4], bF[4], aS[4], bS[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        aF[kk] = TA[pt * MF_LD + 4 * kk + q];
+                        bF[kk] = TB[pt * MF_LD + 4 * kk + q];
+                        aS[kk] = TA[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                        bS[kk] = TB[(16 + (lane & 3)) * MF_LD + 4 * kk + q];
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        dWacc[i - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[kk], bF[kk], dWacc[i - 1], 0, 0, 0);
+                        dS10[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(aS[kk], bF[kk], dS10[i - 1], 0, 0, 0);
+                        dS01[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(bS[kk], aF[kk], dS01[i - 1], 0, 0, 0);
+                    }
+                    accC[i - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(TA[(16 + (lane & 3)) * MF_LD + (pt & 12) + q],
+                                                                   TB[(16 + (lane & 3)) * MF_LD + (pt & 12) + q], accC[i - 1], 0, 0, 0);
+                }
+                FZ_SEG(3 + 2 * (L - 1 - i));
+                } else {
                 pj_wave_sync();
                 // (C > TRG, the four-channel forms: the transposes go through LDS in passes of TRG channels; `put` / `mul` = one pass)
                 auto tr_put = [&](int c0) {
@@ -989,6 +1043,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                     tr_mul();
                 }
                 FZ_SEG(3 + 2 * (L - 1 - i));
+                }
             }
         }
         FZ_SEG(1 + 2 * L);

@@ -53,15 +53,17 @@ for (q, nt, nex, ney, L, vf) in [(16, 8, 16, 16, [2, 20, 20, 20, 1], 1), (16, 8,
                                 (12, 6, 16, 16, [2, 20, 20, 20, 1], 1), (12, 6, 16, 16, [2, 20, 20, 1], 1), (12, 6, 16, 4, [2, 20, 20, 20, 1], 1),
                                 (16, 8, 32, 32, [2, 20, 20, 20, 1], 1), (12, 6, 32, 32, [2, 20, 20, 20, 1], 1),
                                 (16, 8, 16, 16, [2, 20, 20, 20, 1], 0), (20, 10, 16, 16, [2, 20, 20, 20, 1], 0), (20, 10, 16, 16, [2, 20, 20, 20, 1], 2),
+                                (12, 6, 16, 16, [2, 20, 20, 20, 1], 0), (16, 8, 16, 4, [2, 20, 20, 20, 1], 0),
                                 (16, 8, 16, 16, [2, 32, 32, 32, 1], 1)]:
     s = poisson2d.setup(N_el_x=nex, N_el_y=ney, N_test_x=nt, N_test_y=nt, N_quad=q, with_test_grid=False)
     r = both(lambda: poisson2d.build_model(s, L, var_form=vf, init_params=xavier_init(L, 1234)))
     rows.append((f"Poisson-2D var_form {vf}, {nex}x{ney} elements, {q}x{q} points, {nt}x{nt} test fcns, {L}", nex * ney * q * q) + r)
 L = [2, 20, 20, 20, 1]
-s = advdiff.setup(N_el_x=16, N_el_t=16, N_test_x=8, N_test_t=8, N_quad=16, with_test_grid=False)
-for vf in (0, 1):
-    r = both(lambda: advdiff.build_model(s, L, var_form=vf, init_params=xavier_init(L, 1234, extra=[1.0])))
-    rows.append((f"AdvDiff var_form {vf} (trainable epsilon), 16x16 elements, 16x16 points, 8x8 test fcns, {L}", 256 * 256) + r)
+for (q, nt, nex, net, vfs) in [(16, 8, 16, 16, (0, 1)), (12, 6, 16, 16, (0, 1)), (20, 10, 16, 16, (0, 1)), (16, 8, 16, 4, (0, 1))]:
+    s = advdiff.setup(N_el_x=nex, N_el_t=net, N_test_x=nt, N_test_t=nt, N_quad=q, with_test_grid=False)
+    for vf in vfs:
+        r = both(lambda: advdiff.build_model(s, L, var_form=vf, init_params=xavier_init(L, 1234, extra=[1.0])))
+        rows.append((f"AdvDiff var_form {vf} (trainable epsilon), {nex}x{net} elements, {q}x{q} points, {nt}x{nt} test fcns, {L}", nex * net * q * q) + r)
 print("| problem | points | default: us / iteration | kernel | generic element-resident kernel (HPV_FUSE=e) | separate launches (HPV_FUSE=n) |\n|---|---|---|---|---|---|")
 for name, npt, us, v, ps, use, ve, usn in rows:
     print(f"| {name} | {npt} | **{us:.1f}** ({ps}) | `{v}` | {use:.1f} `{ve}` | {usn:.1f} |")

@@ -64,7 +64,7 @@ def test_build_info_and_test_hooks_live_in_their_own_library():
     import re
     from hp_vpinns_amd import _lib
     bi = _lib.build_info()
-    assert set(bi) == {"k_iter_fused", "k_iter_tall", "test_hooks", "experiments"} and bi["test_hooks"] == "0" and bi["experiments"] == "0"
+    assert set(bi) == {"k_iter_fused", "k_iter_fused_gen", "k_iter_tall", "test_hooks", "experiments"} and bi["test_hooks"] == "0" and bi["experiments"] == "0"
     assert bi["k_iter_fused"] in ("ok", "no-quarter-tile", "absent") and bi["k_iter_tall"] in ("ok", "no-quarter-tile", "absent")
     prod = open(_lib.LIB_PATH, "rb").read()
     moved = [b"HPV_DEBUG_SPLIT_SKIP", b"HPV_TEST_RCCL_FAIL", b"HPV_TEST_RCCL_CONNECT_DELAY_MS", b"HPV_PERSIST", b"HPV_PJ_PIPE",

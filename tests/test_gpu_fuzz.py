@@ -4,9 +4,17 @@ kernels (backend="generic": one plain code path, no shape-specific kernel, no ru
 round 4 (element shapes x run-time counts x padded rules x plans x grid-size policies); this test walks it with combinations no other
 test names.  Loss triple, gradient and three Adam iterations must agree to round-off.
 
-Every FOURTH case of each sweep is checked against the CPU ORACLE instead (oracle/vpinn_oracle.py, vectorised: autograd double
-backward of the restated TF1 graph) -- loss triple, gradient, residuals and one TF1-Adam update -- so that the sweep does not lean
-on the generic kernels being right for shapes no fixture covers (verdict round 4, weak 1 ii)."""
+Every SECOND case of each sweep below 20 000 quadrature points (every fourth of the larger ones) is checked against the CPU ORACLE
+instead (oracle/vpinn_oracle.py, vectorised: autograd double backward of the restated TF1 graph) -- loss triple, gradient,
+residuals and one TF1-Adam update -- so that the sweep does not lean on the generic kernels being right for shapes no fixture
+covers (verdict round 4, weak 1 ii; round 5, weak 1: the fraction was 1/4).
+
+The sweeps have a FIXED part (the seeds below: the same combinations every run, a regression net) and a ROTATING part: the last
+eight cases of the 2-D sweep and the last four of the others are drawn from HPV_FUZZ_SEED, by default the run's clock -- the seed is
+printed in pytest's header (tests/conftest.py) and is part of every failing assertion's message; HPV_FUZZ_SEED=<n> reproduces a run."""
+import os
+import time
+
 import numpy as np
 import pytest
 
@@ -14,18 +22,26 @@ from cases import rel
 
 pytestmark = pytest.mark.gpu
 
+FUZZ_SEED = int(os.environ.get("HPV_FUZZ_SEED", str(int(time.time()) % (2 ** 31 - 1))))
+os.environ.setdefault("HPV_FUZZ_SEED_USED", str(FUZZ_SEED))      # (tests/conftest.py prints it in the header)
+
+
+def _oracle_pick(i, n_points):
+    return i % (2 if n_points < 20000 else 4) == 0
+
 
 def _cases_2d():
     rng = np.random.RandomState(20260929)
     out = []
-    for _ in range(64):
+    for i in range(64):
+        if i == 56: rng = np.random.RandomState(FUZZ_SEED)          # the rotating part
         q = int(rng.choice([5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 24]))
         ntx, nty = int(rng.randint(1, q // 2 + 1)), int(rng.randint(1, q // 2 + 1))
         nex, ney = int(rng.randint(1, 19)), int(rng.randint(1, 19))       # 1 ... 324 elements: SPLIT shards, full grids, a second round
         depth = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 6]))
         width = int(rng.choice([5, 12, 20, 20, 20, 24, 30]))
         vf = int(rng.choice([0, 1, 1, 1, 2]))
-        out.append((q, ntx, nty, nex, ney, depth, width, vf, len(out) % 4 == 0))
+        out.append((q, ntx, nty, nex, ney, depth, width, vf, _oracle_pick(len(out), q * q * nex * ney)))
     return out
 
 
@@ -34,6 +50,7 @@ def _against_oracle(m, o, n_res, what):
     o.vectorized = True
     l3m, gm = m.loss_and_grad()
     l3o, go = o.loss_and_grad()
+    what = (what, "HPV_FUZZ_SEED=%d" % FUZZ_SEED)
     assert rel(l3m, l3o) < 1e-9 and rel(gm, go) < 1e-8, (what, l3m, l3o, rel(gm, go))
     if n_res:
         assert rel(m.h.residuals(n_res), o.last["R"]) < 1e-9, what
@@ -72,8 +89,12 @@ def test_poisson2d_default_dispatch_against_the_generic_kernels(q, ntx, nty, nex
 
 def _cases_1d():
     rng = np.random.RandomState(7)
-    return [(int(rng.choice([10, 20, 40, 60, 80])), int(rng.randint(1, 31)), int(rng.randint(1, 9)), int(rng.choice([2, 3, 4, 5])),
-             int(rng.choice([8, 20, 20, 32])), int(rng.choice([1, 2, 3])), i % 4 == 0) for i in range(20)]
+    out = []
+    for i in range(20):
+        if i == 16: rng = np.random.RandomState(FUZZ_SEED + 1)      # the rotating part
+        q, nt, ne = int(rng.choice([10, 20, 40, 60, 80])), int(rng.randint(1, 31)), int(rng.randint(1, 9))
+        out.append((q, nt, ne, int(rng.choice([2, 3, 4, 5])), int(rng.choice([8, 20, 20, 32])), int(rng.choice([1, 2, 3])), _oracle_pick(i, q * ne)))
+    return out
 
 
 @pytest.mark.parametrize("q,nt,ne,depth,width,vf,oracle", _cases_1d())
@@ -103,8 +124,12 @@ def test_poisson1d_default_dispatch_against_the_generic_kernels(q, nt, ne, depth
 
 def _cases_adv():
     rng = np.random.RandomState(11)
-    return [(int(rng.choice([6, 8, 10, 12, 16, 20])), int(rng.randint(1, 6)), int(rng.randint(1, 6)), int(rng.randint(1, 9)), int(rng.randint(1, 9)),
-             int(rng.choice([2, 3, 4])), int(rng.choice([0, 1])), i % 4 == 0) for i in range(16)]
+    out = []
+    for i in range(16):
+        if i == 12: rng = np.random.RandomState(FUZZ_SEED + 2)      # the rotating part
+        q, ntx, ntt, nex, net = int(rng.choice([6, 8, 10, 12, 16, 20])), int(rng.randint(1, 6)), int(rng.randint(1, 6)), int(rng.randint(1, 9)), int(rng.randint(1, 9))
+        out.append((q, ntx, ntt, nex, net, int(rng.choice([2, 3, 4])), int(rng.choice([0, 1])), _oracle_pick(i, q * q * nex * net)))
+    return out
 
 
 @pytest.mark.parametrize("q,ntx,ntt,nex,net,depth,vf,oracle", _cases_adv())
