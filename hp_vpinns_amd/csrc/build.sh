@@ -114,6 +114,7 @@ guarded_compile() {   # guarded_compile <source stem> <object> <extra flags> <fi
       keys4="$keys4 k_iter_fusedILi${1}ELb0ELb0ELb0${S16}Lb0ELi1ELb1E $(($3 + 10 * $1)) k_iter_fusedILi${1}ELb1ELb0ELb0${S16}Lb0ELi1ELb1E $(($3 + 10 * $1))"
       keys4="$keys4 k_iter_fusedILi${1}ELb0ELb0ELb0${S12}Lb0ELi1ELb1E $(($4 + 10 * $1)) k_iter_fusedILi${1}ELb1ELb0ELb0${S12}Lb0ELi1ELb1E $(($4 + 10 * $1))"
       keys4q="$keys4q k_iter_fusedILi${1}ELb0ELb1ELb0${S16}Lb0ELi1ELb1E $(($3 + 10 * $1))"
+      [ $1 = 2 ] && keys4="$keys4 k_iter_fusedILi2ELb0ELb0ELb0${S}Lb0ELi1ELb1E $(($2 + 20)) k_iter_fusedILi2ELb1ELb0ELb0${S}Lb0ELi1ELb1E $(($2 + 20))"      # (20x20 points: two hidden layers only)
     done
     g=0; guard $asm $keys3 || g=$?
     [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check $f.hip" >&2; rm -rf $tmp; return 1; }

@@ -69,8 +69,8 @@ struct FzLds {
     static constexpr int PK = CH + 2 * FZ_NQ;              // [6][L*5][64] parked s: slot w = tile 0 of wave w, slots 4, 5 = tile 1 of waves 0, 1
     static constexpr int XS = PK;                          // GS (slots 0..3 of PK are free then): [x | y | u_d][400 + 16] coordinates of the element and of the data tile
     static constexpr int XLD = FZ_NQ + 16;
-    // (four channels: the compiler needs ~60 registers more -- TWO tiles of every wave are parked here instead of one, slots 4..7 = tile 1
-    //  of wave w - 4, slots 8, 9 = the quarter tiles' s)
+    // (four channels: the compiler needs ~60 registers more -- one more tile of every wave is parked here: slots 4..7 = tile 1 of wave
+    //  w - 4, slots 8, 9 = the quarter tiles' s (QT) or tile 2 of waves 0, 1 (whole tiles: the two waves that may own FZ_MAXT tiles))
     static constexpr int PKS = C_ > FZ_C ? 10 : 6;
     static constexpr int PZ = PK + PKS * L * MF_KS * 64;   // [4][LH*5][32] QT: the quarter tiles' tangent pre-activations of the layers >= 2 (tangent lanes, compact)
     static constexpr int TR = PZ + FZ_WAVES * LH * MF_KS * 32;   // phase P: projection scratch | phase R: per-wave transpose tiles | epilogue rows
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     constexpr int TRG = NT2 > 0 ? 2 : FZ_C;        // channels per transpose pass of the weight-gradient products
     static_assert(C % TRG == 0, "whole transpose passes");
     using M = FzLds<L, QX_, QY_, NTX_, NTY_, MULTI, C, TRG>;
-    static_assert(!GEN || M::RED + 16 <= M::TR + M::TR_WAVE, "the d-epsilon partials live in wave 0's part of the transpose region (it reads them back itself)");
+    static_assert(!GEN || (M::AX == M::TR && 4 <= M::TR_WAVE), "the d-epsilon partials live in wave 0's part of the transpose region (it reads them back itself)");
     constexpr int LH = L > 1 ? L - 1 : 1;
     constexpr int NSV = L * MF_KS;                 // saved doubles per lane and tile
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -388,7 +388,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     constexpr int NREG = FZ_MAXT - 2 - (NT2 > 0 ? 1 : 0);  // tiles whose s live in AGPRs; the first one (waves 0, 1 -- NT2: every wave -- two) of a wave is parked in LDS
     constexpr int ABASE = 256 - NREG * 2 * NSV;
     if constexpr (!GS) asm volatile("" ::: "a255");       // the kernel owns all 256 AGPRs
-    const int n_lds = GS ? 0 : NT2 > 0 ? 2 : QT ? 1 : (wv <= 1 ? 2 : 1);       // (QT: slots 4, 5 -- NT2: 8, 9 -- of the parking area hold the quarter tiles' s)
+    // (waves 0, 1 may own FZ_MAXT tiles, waves 2, 3 one less -- QT: every wave FZ_MAXT - 1 whole ones; QT: slots 4, 5 -- NT2: 8, 9 -- of the
+    //  parking area hold the quarter tiles' s)
+    const int n_lds = GS ? 0 : NT2 > 0 ? (QT ? 2 : (wv <= 1 ? 3 : 2)) : QT ? 1 : (wv <= 1 ? 2 : 1);
     // GS: pairs per tile and lane -- {z_x, z_y}[layer >= 2][k-step], then s two by two; a tile's block of the activation store
     constexpr int NZP = (L > 1 ? L - 1 : 0) * MF_KS, NSP = (NSV + 1) / 2, NP = NZP + NSP;
     constexpr long GS_STRIDE = (long)L * 3 * MF_KS * 64;         // doubles per tile of the activation store (3 slots: kernels_mfma.hip)
@@ -396,6 +398,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     auto gs_ptr = [&](long tile) -> v2d* { return reinterpret_cast<v2d*>(g.ACTS + tile * GS_STRIDE) + lane; };
     double* PKw = lds + M::PK + wv * (NSV * 64) + lane;
     double* PKw2 = lds + M::PK + (4 + (NT2 > 0 ? wv : (wv & 1))) * (NSV * 64) + lane;
+    [[maybe_unused]] double* PKw3 = lds + M::PK + (8 + (wv & 1)) * (NSV * 64) + lane;      // NT2, whole tiles: tile 2 of waves 0, 1
     gdat = 0.0;
 
     // SPLIT: this workgroup takes no part in the exchange (an earlier launch of the handle failed -- sticky flag -- or the test
@@ -444,6 +447,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             if constexpr (NSV & 1) reinterpret_cast<double*>(zs + (NSV / 2) * 64 - lane)[lane] = sv[NSV - 1];   // (odd count: the last one alone, 8-byte lanes)
         } else if (k < n_lds) {     // wave-uniform
             double* pk = k == 0 ? PKw : PKw2;
+            if constexpr (NT2 > 0) pk = k == 0 ? PKw : (k == 1 ? PKw2 : PKw3);
 #pragma unroll
             for (int j = 0; j < NSV; ++j) pk[j * 64] = sv[j];
         } else {
@@ -760,14 +764,15 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         }
         if constexpr (GEN) {
             if (pa.pd.has_eps) {      // (kernel-uniform)
+                // (into the head of the x-tables: their last reader was the S step, two barriers back; wave 0's own transpose tiles later)
                 deps = pj_wave_sum_dpp(deps);
-                if (lane == 0) lds[M::RED + 4 + wv] = deps;
+                if (lane == 0) lds[M::AX + wv] = deps;
             }
         }
         __syncthreads();
         if constexpr (GEN) {
             // (the partials sit in wave 0's own part of the transpose region -- static_assert at the top: it reads them before it writes there)
-            if (pa.pd.has_eps && tid == 0) pa.deps_e[e] = (lds[M::RED + 4] + lds[M::RED + 5]) + (lds[M::RED + 6] + lds[M::RED + 7]);
+            if (pa.pd.has_eps && tid == 0) pa.deps_e[e] = (lds[M::AX] + lds[M::AX + 1]) + (lds[M::AX + 2] + lds[M::AX + 3]);
         }
     }
 
@@ -813,6 +818,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             for (int j = 0; j < NSV; ++j) sv[j] = B[NZP + j / 2][j & 1];
         } else if (k < n_lds) {
             const double* pk = k == 0 ? PKw : PKw2;
+            if constexpr (NT2 > 0) pk = k == 0 ? PKw : (k == 1 ? PKw2 : PKw3);
 #pragma unroll
             for (int j = 0; j < NSV; ++j) sv[j] = pk[j * 64];
         } else {
@@ -1778,7 +1784,9 @@ static bool launch_iter_fused_gen_shape(int L, int plan, int nt2, const MfmaArgs
     constexpr int TPE = QX_ * QY_ / 16;
     constexpr bool HAS_QT = (TPE % 4) <= 1 && TPE >= 8;
     constexpr bool HAS_DQ = HAS_QT && TPE % 4 == 0;            // four channels: the data-quarter plan only
-    constexpr bool HAS_NT2 = QX_ != 20;                        // (20x20 points keep five tiles per wave in the stash: no room for a fourth channel's registers)
+    // (20x20 points keep four tiles per wave in the stash -- ABASE = 256 - 4 x 2 x 5 L: room for the fourth channel's registers with two
+    //  hidden layers, a77 of 176, not with three, a159 of 136)
+    const bool has_nt2 = QX_ != 20 || L == 2;
     if (L != 2 && L != 3) return false;
 #define FZ_GG(L_, SPLIT_, QT_, NT2_) launch_iter_fused<L_, SPLIT_, QT_, false, QX_, QY_, NTX_, NTY_, false, NT2_, true>(a, blocks, s)
     if (nt2 == 0) {
@@ -1797,9 +1805,9 @@ static bool launch_iter_fused_gen_shape(int L, int plan, int nt2, const MfmaArgs
 #ifdef HPV_FZ_GEN_NO_NT2
     return false;
 #else
-    if constexpr (HAS_NT2) {
-        if (plan == 0) { if (L == 2) FZ_GG(2, true, false, 1); else FZ_GG(3, true, false, 1); }
-        else if (plan == 1) { if (L == 2) FZ_GG(2, false, false, 1); else FZ_GG(3, false, false, 1); }
+    if (has_nt2) {
+        if (plan == 0) { if (L == 2) FZ_GG(2, true, false, 1); else if constexpr (QX_ != 20) FZ_GG(3, true, false, 1); }
+        else if (plan == 1) { if (L == 2) FZ_GG(2, false, false, 1); else if constexpr (QX_ != 20) FZ_GG(3, false, false, 1); }
         else if (plan == 2) {
 #ifdef HPV_FZ_GEN_NO_QT
             return false;

@@ -80,13 +80,14 @@ def _pad_rule(xi, w, q_dev):
     return np.concatenate([xi, np.full(n, xi[-1])]), np.concatenate([w, np.zeros(n)])
 
 
-def _device_rule_2d(xi, wx, yi, wy, ntx, nty, n_elem_shard, device=0, exact_counts=False, only=None, n_hidden=0):
+def _device_rule_2d(xi, wx, yi, wy, ntx, nty, n_elem_shard, device=0, exact_counts=False, only=None, n_hidden=0, reject=()):
     """The (possibly padded) 2-D rule for the device, as the library advises for a shard of `n_elem_shard` elements on `device`;
-    `exact_counts`: only instantiations with exactly these test-function counts; `only`: accept this device rule alone."""
+    `exact_counts`: only instantiations with exactly these test-function counts; `only`: accept this device rule alone;
+    `reject`: device rules whose whole-iteration kernel does not take this variational form."""
     if xi.size != yi.size or os.environ.get("HPV_NO_RULE_PADDING"):
         return xi, wx, yi, wy
     q_dev, _ = _lib.rule_advice(device, 2, xi.size, ntx, nty, n_elem_shard, exact_counts, n_hidden)
-    if q_dev > xi.size and (only is None or q_dev == only):
+    if q_dev > xi.size and (only is None or q_dev == only) and q_dev not in reject:
         xi, wx = _pad_rule(xi, wx, q_dev)
         yi, wy = _pad_rule(yi, wy, q_dev)
     return xi, wx, yi, wy
@@ -729,9 +730,12 @@ class VPINN2D(_VPINNBase):
             else:
                 xi, wx, yi, wy = _tensor_rule(X_quad, W_quad)
                 hidden = self.layers[1:-1]
-                if backend != "generic" and var_form == 1 and max(hidden) <= 20 and 2 <= len(hidden) <= 3:
+                if backend != "generic" and var_form in (0, 1) and max(hidden) <= 20 and 2 <= len(hidden) <= 3:
                     eb, ee = shard_range(self.Nelementx * self.Nelementy, self.rank, self.world)
-                    xi, wx, yi, wy = _device_rule_2d(xi, wx, yi, wy, self.Ntestx, self.Ntesty, ee - eb, self.device, n_hidden=len(hidden))
+                    # (var_form 0 runs on the FOUR-channel instantiations of the whole-iteration kernel: 12x12 and 16x16 points, 20x20 with
+                    #  two hidden layers only; the 10x10 kernel takes the two one-hot terms of var_form 1 alone)
+                    rej = () if var_form == 1 else ((10, 20) if len(hidden) == 3 else (10,))
+                    xi, wx, yi, wy = _device_rule_2d(xi, wx, yi, wy, self.Ntestx, self.Ntesty, ee - eb, self.device, n_hidden=len(hidden), reject=rej)
                 self.h.set_quadrature(xi, wx, yi, wy)
                 self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntesty, yi))
                 eb, ee = shard_range(self.Nelementx * self.Nelementy, self.rank, self.world)
@@ -805,6 +809,12 @@ class VPINNAdvDiff(_VPINNBase):
             if backend != "generic" and max(hidden) <= 20 and 2 <= len(hidden) <= 3 and xi.size < 10:     # (the 10x10 / 5x5 tile kernel)
                 eb, ee = shard_range(self.Nelementx * self.Nelementt, self.rank, self.world)
                 xi, wx, ti, wt = _device_rule_2d(xi, wx, ti, wt, self.Ntestx, self.Ntestt, ee - eb, self.device, exact_counts=True, only=10)
+            elif backend != "generic" and max(hidden) <= 20 and 2 <= len(hidden) <= 3 and 10 < xi.size < 20:
+                # rules between the instantiated ones onto the whole-iteration kernel's general forms (round 6): var_form 1 has three
+                # channels (every shape), var_form 0 four (12x12, 16x16; 20x20 with two hidden layers)
+                eb, ee = shard_range(self.Nelementx * self.Nelementt, self.rank, self.world)
+                rej = (10,) if (var_form == 1 or len(hidden) == 2) else (10, 20)
+                xi, wx, ti, wt = _device_rule_2d(xi, wx, ti, wt, self.Ntestx, self.Ntestt, ee - eb, self.device, n_hidden=len(hidden), reject=rej)
             self.h.set_quadrature(xi, wx, ti, wt)
             self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntestt, ti))
             eb, ee = shard_range(self.Nelementx * self.Nelementt, self.rank, self.world)

@@ -179,6 +179,7 @@ def test_hand_tuned_whole_iteration_kernel_on_other_element_shapes(q, nt, nhid, 
 @pytest.mark.parametrize("prob,q,nt,nhid,grid", [
     ("p2vf0", 16, 8, 3, "full"), ("p2vf0", 12, 6, 3, "full"), ("p2vf0", 16, 8, 2, "full"), ("advf0", 16, 8, 3, "full"), ("advf0", 12, 6, 2, "full"),
     ("advf1", 16, 8, 3, "full"), ("advf1", 12, 6, 2, "full"), ("advf1", 20, 10, 3, "full"), ("advf1", 20, 10, 2, "full"),
+    ("p2vf0", 20, 10, 2, "full"), ("advf0", 20, 10, 2, "shard"),
     ("p2vf0", 16, 8, 2, "shard"), ("p2vf0", 12, 6, 3, "shard"), ("advf0", 16, 8, 3, "shard"), ("advf0", 12, 6, 2, "shard"),
     ("advf1", 16, 8, 2, "shard"), ("advf1", 12, 6, 3, "shard"), ("advf1", 20, 10, 3, "shard")])
 def test_hand_tuned_whole_iteration_kernel_general_forms(prob, q, nt, nhid, grid):
@@ -246,6 +247,42 @@ def test_hand_tuned_whole_iteration_kernel_general_forms(prob, q, nt, nhid, grid
         finally:
             del os.environ["HPV_NO_QUARTER_TILE"]
         assert rel(gw, gm) < 1e-11 and rel(l3w, l3m) < 1e-12
+
+
+@pytest.mark.parametrize("prob,q,nt,nhid,want", [("p2vf0", 14, 7, 3, "16x16/7x7,NT2=1,GEN"), ("advf0", 11, 5, 3, "12x12/5x5,NT2=1,GEN"),
+                                                  ("advf1", 18, 9, 3, "20x20/9x9,GEN"), ("advf0", 18, 6, 2, "20x20/6x6,NT2=1,GEN"),
+                                                  ("p2vf0", 18, 9, 3, None)])
+def test_hand_tuned_general_forms_with_smaller_quadrature_rules_than_instantiated(prob, q, nt, nhid, want):
+    """The zero-weight padding of a rule onto an instantiated one (vpinn._pad_rule) for the general forms too: Poisson-2D var_form 0 and
+    both AdvDiff forms with N_quad between the instantiated rules run on k_iter_fused<.., GEN>; four channels with three hidden layers
+    have no 20x20 instantiation -- an 18-point rule stays as it is there (want = None).  Against the oracle on the UNPADDED problem."""
+    from hp_vpinns_amd.vpinn import VPINN2D, VPINNAdvDiff
+    from oracle.vpinn_oracle import OracleVPINN2D, OracleVPINNAdvDiff
+    assert "HPV_FUSE" not in os.environ
+    L = [2] + [20] * nhid + [1]
+    if prob == "p2vf0":
+        a = _p2(q, nt, 16, 16, nb=40) + (L,)
+        th = theta0(L, 271)
+        o, m = OracleVPINN2D(*a, var_form=0, init_params=th), VPINN2D(*a, var_form=0, init_params=th)
+    else:
+        vf = 0 if prob == "advf0" else 1
+        a = _p3(q, nt, 16, 16, nb=40) + (L, None, None)
+        th = theta0(L, 272, extra=[0.6])
+        o, m = OracleVPINNAdvDiff(*a, var_form=vf, init_params=th), VPINNAdvDiff(*a, var_form=vf, init_params=th)
+    o.vectorized = True
+    l3o, go = o.loss_and_grad()
+    l3m, gm = m.loss_and_grad()
+    v = m.h.kernel_variant()
+    gen_state = m.h.build_info().get("k_iter_fused_gen", "ok")
+    if want is None:
+        assert "k_iter_fused" not in v, v
+    elif gen_state == "ok":
+        assert want in v and m.h.pass_structure() == "whole-iteration", (v, m.h.pass_structure())
+    assert rel(l3m, l3o) < TOL and rel(gm, go) < TOL, (v, l3m, l3o, rel(gm, go))
+    assert rel(m.h.residuals(256 * nt * nt), o.last["R"].reshape(-1)) < TOL
+    o.adam_step()
+    m._step(1, False)
+    assert rel(m.get_params(), o.get_params()) < TRAJ_TOL
 
 
 @pytest.mark.parametrize("q,nt,nhid,nex,ney", [(16, 8, 3, 17, 17), (12, 6, 3, 17, 17), (20, 10, 2, 17, 17), (16, 8, 2, 24, 23), (12, 5, 3, 30, 27)])
