@@ -1437,7 +1437,7 @@ int hpv_rule_advice(int device, int dim, int q, int ntx, int nty, long n_elem_sh
             //  the separate launches (plan 0) take the grid, the padded points cost more than the structure saves; advisor, round 5)
             const int Lh = n_hidden > 0 ? n_hidden : 3;
             const bool takes = r[0] == 10 ? n_elem_shard <= hpv_elem_resident_max(2, 10, n_cus)
-                                          : hpv_fused_grid_plan(r[0], Lh, n_elem_shard, n_cus, hpv_fused_loop_built()) == 1;
+                                          : (hpv_fused_grid_plan(r[0], Lh, n_elem_shard, n_cus, hpv_fused_loop_built()) | 2) == 3;      // plans 1 and 3
             if (q < r[0] && takes) *q_dev = r[0];
             break;
         }

@@ -29,7 +29,11 @@ inline long hpv_elem_resident_max(int dim, int q, int n_cus) {
 // ONE definition for the dispatch (kernels_fused.hip) and for hpv_rule_advice (a smaller rule is padded onto an instantiated one only
 // while the kernel would take the shard).  Numbers behind it: profiles/r05_multi_element.md.
 bool hpv_fused_loop_built();      // kernels_fused.hip: the element loop (MULTI) survived the build guard
-inline int hpv_fused_grid_plan(int q, int L, long n_elem, int n_cus, bool loop_built, bool loop_off = false, bool loop_force = false, bool one_force = false) {
+// 3 (round 6): the full rounds with one workgroup per element + the ragged tail (n_elem % n_cus elements, at most half a round) in a
+// second launch in SPLIT mode, 2 - 8 workgroups per element -- 1 600 elements of the config-4 shape: 6 rounds + a 64-element tail
+// instead of 7 rounds; 289 elements: one round + 33 shared elements instead of the separate launches.
+inline int hpv_fused_grid_plan(int q, int L, long n_elem, int n_cus, bool loop_built, bool loop_off = false, bool loop_force = false, bool one_force = false,
+                               bool tail_ok = true) {
     if (n_elem <= n_cus) return 1;
     const long rounds = (n_elem + n_cus - 1) / n_cus;
     const bool built = loop_built && !(q == 20 && L == 3);                   // (three hidden layers on 20x20 points: the loop does not fit the registers)
@@ -37,6 +41,9 @@ inline int hpv_fused_grid_plan(int q, int L, long n_elem, int n_cus, bool loop_b
     if (built && !loop_off && (pays || loop_force)) return 2;
     if (one_force) return 1;
     if (q != 20 && n_elem > hpv_elem_resident_max(2, q, n_cus)) return 0;
+    const long tail = n_elem % n_cus;
+    // (smaller elements with ONE full round: the separate launches cost the same within noise -- 289 elements of 16x16 points 73 against 68 us)
+    if (tail_ok && tail > 0 && tail * 2 <= n_cus && (q == 20 || n_elem >= 2L * n_cus)) return 3;
     return n_elem * 100 >= rounds * n_cus * 80 ? 1 : 0;
 }
 

@@ -40,6 +40,8 @@ struct MfmaArgs {
     // element-block mode of the reverse kernel (projection fused in): blocks own the elements [0, proj_n_elem)
     long proj_n_elem;
     int proj_split;       // workgroups per element in the reverse kernel's element-block mode (1, 2, 4 or 8)
+    long elem0;           // k_iter_fused<SPLIT>: first element of this launch inside the shard (the ragged tail behind the full rounds; else 0)
+    long data_tile0;      // k_iter_fused<SPLIT>: first boundary / data tile of the batch (= shard elements x tiles per element)
     ProjArgs pa;
     // split whole-iteration kernels: the handle's sticky failure flag, test knob, exchange buffers
     int* xerr;            // sticky failure flag of the handle (hpv_ctx::d_xerr): set when an exchange times out; see hpv_fused_dev.h

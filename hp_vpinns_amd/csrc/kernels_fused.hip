@@ -21,6 +21,7 @@
 // Lane layout, MFMA formulation and the 16 + 4 split of a 20-wide layer are those of kernels_mfma.hip.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "hpv_mfma_dev.h"
@@ -153,7 +154,10 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     // (observed: XCC id == blockIdx % 8), so with an element count that 8 divides -- the shards of a multi-GPU run -- the partners share
     // an XCD and their exchange is served by one L2 (1.56 against 2.39 us per exchange, profiles/r04_xchg_probe.txt).  A speed choice
     // only: nothing depends on the placement.
-    long e = SPLIT ? (long)(blockIdx.x % (unsigned)g.proj_n_elem) : (long)blockIdx.x;      // (MULTI: advances by gridDim.x per trip)
+    // (SPLIT: the launch may own only the LAST g.proj_n_elem elements of the shard -- the ragged tail of a grid larger than the chip,
+    //  behind a one-workgroup-per-element launch of the full rounds: g.elem0 = its first element, el = the element inside this launch)
+    const long el = SPLIT ? (long)(blockIdx.x % (unsigned)g.proj_n_elem) : (long)blockIdx.x;
+    long e = SPLIT ? el + g.elem0 : el;      // (MULTI: advances by gridDim.x per trip)
     const int part = SPLIT ? (int)(blockIdx.x / (unsigned)g.proj_n_elem) : 0;
     const double* __restrict__ th = g.theta;
     const ProjArgs& pa = g.pa;
@@ -328,7 +332,8 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     // (25 tiles over 4 waves: wave 1).  SPLIT: only to workgroups in which that wave has a free slot compared with its
     // neighbours (tile count not a multiple of 4) -- otherwise the adopted tile is a whole extra forward + reverse that the
     // element's partners wait for -- as long as there are enough of those.
-    long dtile = g.proj_n_elem * FZ_TPE + blockIdx.x;
+    // (SPLIT: the boundary / data tiles begin behind ALL elements of the shard, g.data_tile0 -- not behind this launch's)
+    long dtile = (SPLIT ? g.data_tile0 : g.proj_n_elem * FZ_TPE) + blockIdx.x;
     if constexpr (SPLIT) {
         int n_free = 0, before = 0;
         bool mine = false;
@@ -338,8 +343,8 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             before += (fr && p < part);
             mine = mine || (fr && p == part);
         }
-        if (g.ntiles - g.proj_n_elem * FZ_TPE <= g.proj_n_elem * n_free)
-            dtile = mine ? g.proj_n_elem * FZ_TPE + e * n_free + before : g.ntiles;
+        if (g.ntiles - g.data_tile0 <= g.proj_n_elem * n_free)
+            dtile = mine ? g.data_tile0 + el * n_free + before : g.ntiles;
     }
     if constexpr (GS) {
         // the coordinates of the element's points and of the workgroup's boundary / data tile (+ its targets) to LDS: the tile loops
@@ -590,8 +595,8 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                     }
                     if constexpr (SPLIT) {   // tagged granules, fire and forget: the partners poll the granules themselves
                         if (!xstay) {
-                            xg_publish(g.xg + (e * (2 * FZ_NQ) + lp) * 2, g0, xtag);
-                            xg_publish(g.xg + (e * (2 * FZ_NQ) + FZ_NQ + lp) * 2, g1, xtag);
+                            xg_publish(g.xg + (el * (2 * FZ_NQ) + lp) * 2, g0, xtag);
+                            xg_publish(g.xg + (el * (2 * FZ_NQ) + FZ_NQ + lp) * 2, g1, xtag);
                         }
                     } else {
                         lds[M::CH + lp] = g0;
@@ -656,7 +661,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         // that chain of store-acknowledge, fetch-add, poll and reload cost 8.7 k cycles)
         constexpr int NITG = (2 * FZ_NQ * 2 + FZ_BLOCK - 1) / FZ_BLOCK;
         bool ok = true;
-        if (!xstay) ok = xg_gather<NITG, FZ_BLOCK>(g.xg + e * (2 * FZ_NQ) * 2, 2 * FZ_NQ * 2, xtag, (unsigned*)(lds + M::CH), tid);
+        if (!xstay) ok = xg_gather<NITG, FZ_BLOCK>(g.xg + el * (2 * FZ_NQ) * 2, 2 * FZ_NQ * 2, xtag, (unsigned*)(lds + M::CH), tid);
         const int timed_out = __syncthreads_or(ok ? 0 : 1);
         if (timed_out || xstay) {
             // nothing of this iteration has been written: the kernels that follow skip the update (kernels_generic.hip), the host
@@ -1912,22 +1917,28 @@ static void launch_iter_small(const MfmaArgs& a, int blocks, hipStream_t s) {
 
 // Whole training pass (forward, projection, reverse) of a shard of 20x20 / 10x10 elements in one launch.  Returns false
 // when the shape / variational form / shard is not covered; the caller then runs the separate kernels.
+// (libhpvpinn_testhooks.so: HPV_TRACE_DISPATCH=1 names the line at which the whole-iteration kernel declines a pass)
+#ifdef HPV_EXPERIMENTS
+#define fz_no(ID) (getenv("HPV_TRACE_DISPATCH") ? (fprintf(stderr, "hpv_mfma_iter_fused: declined at check %d (line %d)\n", ID, __LINE__), false) : false)
+#else
+#define fz_no(ID) false
+#endif
 bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, double* GPART, int* rows, hipStream_t s,
                          const MfmaDataTerm* dt, const ProjArgs& pa, long n_elem, const MfmaPendingAdam* pre) {
     const ProjDesc& pd = pa.pd;
     const NetDesc& nd = m->nd;
-    if (!m->iter_fused_ok) return false;
-    if (m->H != MF_H) return false;      // written for 20-wide layers (other widths: kernels_wide.hip)
-    if (!(nd.d == 2 && nd.nT1 == 2 && nd.nT2 <= 1 && nd.act == HPV_ACT_TANH) || m->L < 2 || m->L > 3) return false;
+    if (!m->iter_fused_ok) return fz_no(1);
+    if (m->H != MF_H) return fz_no(2);      // written for 20-wide layers (other widths: kernels_wide.hip)
+    if (!(nd.d == 2 && nd.nT1 == 2 && nd.nT2 <= 1 && nd.act == HPV_ACT_TANH) || m->L < 2 || m->L > 3) return fz_no(3);
     const bool small = pd.qx == SM_QX && pd.qy == SM_QY && pd.ntx >= 1 && pd.ntx <= SM_NTX && pd.nty >= 1 && pd.nty <= SM_NTY;
-    if (!fused_shape_ok(pd) && !small) return false;
+    if (!fused_shape_ok(pd) && !small) return fz_no(4);
     const int NQ = pd.qx * pd.qy, TPE = NQ / 16;              // points and 16-point tiles of an element
     const bool has_qt = TPE % 4 <= 1 && TPE >= 8, q20 = pd.qx == 20 && pd.qy == 20;
     const bool base_shape = q20 && pd.ntx == 10 && pd.nty == 10;           // BASELINE config 4 itself
 #ifdef HPV_FZ_NO_EXTRA_SHAPES     // csrc/build.sh: the AGPR guard tripped in an instantiation of a shape other than 20x20 / 10x10
-    if (!q20 && !small) return false;
+    if (!q20 && !small) return fz_no(5);
 #endif
-    if (pd.edge || pd.nact || pd.nterms < 1 || pd.nterms > 2) return false;
+    if (pd.edge || pd.nact || pd.nterms < 1 || pd.nterms > 2) return fz_no(6);
     // one-hot (Poisson-2D var_form 1, the headline instantiations): term t integrates exactly channel 1 + t with weight 1, no epsilon.
     // Every other form of these channel sets (round 6): the general instantiations (k_iter_fused<.., NT2, GEN>)
     bool onehot = !pd.has_eps && pd.nterms == 2 && nd.nT2 == 0;
@@ -1937,19 +1948,19 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     const bool gen = !onehot;
     const int C = 3 + nd.nT2;
     if (gen) {
-        if (small) return false;                            // (10x10 points: kernels_tile.hip)
+        if (small) return fz_no(7);                            // (10x10 points: kernels_tile.hip)
         for (int t = 0; t < pd.nterms; ++t) {
-            if (pd.t[t].a0[0] != 0.0 || pd.t[t].a1[0] != 0.0) return false;       // the value channel is not integrated here
-            for (int ch = C; ch < HPV_MAXC; ++ch) if (pd.t[t].a0[ch] != 0.0 || pd.t[t].a1[ch] != 0.0) return false;
+            if (pd.t[t].a0[0] != 0.0 || pd.t[t].a1[0] != 0.0) return fz_no(8);       // the value channel is not integrated here
+            for (int ch = C; ch < HPV_MAXC; ++ch) if (pd.t[t].a0[ch] != 0.0 || pd.t[t].a1[ch] != 0.0) return fz_no(9);
             // two terms fill both LDS arrays: none is left for dG / d eps of a term whose WEIGHTS depend on epsilon
-            if (pd.nterms == 2) for (int ch = 0; ch < HPV_MAXC; ++ch) if (pd.t[t].a1[ch] != 0.0) return false;
+            if (pd.nterms == 2) for (int ch = 0; ch < HPV_MAXC; ++ch) if (pd.t[t].a1[ch] != 0.0) return fz_no(10);
         }
-        if (pd.has_eps && !pa.eps_ptr) return false;
-        if (pre && pd.has_eps) return false;                // the deferred-update prologue forms the network parameters only
+        if (pd.has_eps && !pa.eps_ptr) return fz_no(11);
+        if (pre && pd.has_eps) return fz_no(12);                // the deferred-update prologue forms the network parameters only
     }
-    if (n_elem <= 0) return false;
+    if (n_elem <= 0) return fz_no(13);
 #ifdef HPV_AGPR_GUARD_TRIPPED     // csrc/build.sh: the compiler's registers reached the hand-managed AGPR range of k_iter_fused
-    if (!small) return false;
+    if (!small) return fz_no(14);
 #endif
     // shapes other than the headline one: one workgroup per element pays the launch-once phases (staging, projection, epilogue:
     // ~7 us) per element -- on grids of many small elements the separate launches amortise them better (scripts/elem_bench.py:
@@ -1963,20 +1974,37 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
 #else
     constexpr bool multi_built = true;
 #endif
-    const int gplan = small ? 1 : hpv_fused_grid_plan(pd.qx, m->L, n_elem, m->n_cus, !gen && multi_built && m->base.ACTS != nullptr, m->multi_off, m->multi_force && !gen, m->iter_fused_force);
-    if (gplan == 0) return false;
+    // (plan 3, round 6: the full rounds with one workgroup per element and, in a SECOND launch, the ragged tail's elements shared by
+    //  2 - 8 workgroups each (SPLIT) -- needs the exchange machinery of the split mode)
+    const bool tail_ok = m->xerr && m->xg && m->xiter && m->iter_split_ok && !pre;
+    int gplan = small ? 1 : hpv_fused_grid_plan(pd.qx, m->L, n_elem, m->n_cus, !gen && multi_built && m->base.ACTS != nullptr, m->multi_off, m->multi_force && !gen, m->iter_fused_force, tail_ok);
+    if (gplan == 0) return fz_no(15);
     const bool multi = gplan == 2;
-    if (pre && (small || multi || nd.P > FZ_PRE_PER_THREAD * FZ_BLOCK)) return false;       // the deferred-update prologue exists in the one-workgroup-per-element / SPLIT instantiations
+    long n_tail = 0;
+    int tsplit = 1;
+    if (gplan == 3) {
+        n_tail = n_elem % m->n_cus;
+        while (tsplit < 8 && n_tail * tsplit * 2 <= m->n_cus) tsplit *= 2;
+        const long data_tiles = m->ntiles - n_elem * TPE;
+        if (tsplit < 2 || n_tail > m->xsync_elems || (size_t)n_tail * 2 * NQ * 2 > m->xg_words || data_tiles > n_tail * tsplit) {
+            // (the tail cannot run in split mode: whole rounds as before)
+            const long rounds = (n_elem + m->n_cus - 1) / m->n_cus;
+            if (n_elem * 100 < rounds * m->n_cus * 80) return fz_no(16);
+            n_tail = 0; gplan = 1;
+        }
+    }
+    const long n_main = n_elem - n_tail;
+    if (pre && (small || multi || nd.P > FZ_PRE_PER_THREAD * FZ_BLOCK)) return fz_no(17);       // the deferred-update prologue exists in the one-workgroup-per-element / SPLIT instantiations
     if (small) {
         // thousands of small elements: one workgroup per element pays staging / projection / epilogue per element, the separate
         // launches stream (scripts/grid_sweep.py: 1 024 elements 80.8 against 77.5 us, 4 096 elements 292 against 273)
-        if (n_elem > hpv_elem_resident_max(2, SM_QX, m->n_cus) && !m->iter_fused_force) return false;
+        if (n_elem > hpv_elem_resident_max(2, SM_QX, m->n_cus) && !m->iter_fused_force) return fz_no(18);
         // batch layout [element points | pad to 16 | data points]; at most one boundary/data tile per workgroup
         const long npad = (n_elem * SM_NQ + 15) / 16 * 16;
         const bool has_data = dt && dt->n_data > 0;
-        if (has_data ? dt->data_off != npad : (m->N != npad && m->N != n_elem * SM_NQ)) return false;
-        if (has_data && m->ntiles - npad / 16 > n_elem) return false;
-        if (n_elem > hpv_mfma_grad_rows(m) && n_elem > m->max_rows) return false;
+        if (has_data ? dt->data_off != npad : (m->N != npad && m->N != n_elem * SM_NQ)) return fz_no(19);
+        if (has_data && m->ntiles - npad / 16 > n_elem) return fz_no(20);
+        if (n_elem > hpv_mfma_grad_rows(m) && n_elem > m->max_rows) return fz_no(21);
         MfmaArgs a = m->base;
         a.theta = theta; a.X = X; a.GPART = GPART;
         a.OUT = const_cast<double*>(pa.OUT);   // (only written by the -DHPV_FZ_TIMING build)
@@ -1999,14 +2027,15 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     // partners meet at a barrier in device memory, which needs all of them resident: at most one workgroup per CU
     int split = 1;
     if (n_elem * 2 <= m->n_cus && !m->iter_fused_force) {
-        if (!m->xerr || !m->xg || !m->xiter || !m->iter_split_ok) return false;
+        if (!m->xerr || !m->xg || !m->xiter || !m->iter_split_ok) return fz_no(22);
         while (split < 8 && n_elem * split * 2 <= m->n_cus) split *= 2;
-        if (n_elem * split > m->n_cus || n_elem > m->xsync_elems || (size_t)n_elem * 2 * NQ * 2 > m->xg_words) return false;
+        if (n_elem * split > m->n_cus || n_elem > m->xsync_elems || (size_t)n_elem * 2 * NQ * 2 > m->xg_words) return fz_no(23);
     }
-    const long blocks = multi ? (long)m->n_cus : n_elem * split;
+    const long blocks = multi ? (long)m->n_cus : n_main * split;
     const long rest = m->ntiles - n_elem * TPE;                  // pad + boundary/data tiles: at most one per workgroup
-    if (rest < 0 || rest > blocks) return false;
-    if (blocks > hpv_mfma_grad_rows(m) && blocks > m->max_rows) return false;
+    if (rest < 0 || (n_tail == 0 && rest > blocks)) return fz_no(24);
+    const long rows_all = blocks + n_tail * tsplit;
+    if (rows_all > hpv_mfma_grad_rows(m) && rows_all > m->max_rows) return fz_no(25);
     MfmaArgs a = m->base;
     a.theta = theta; a.X = X; a.GPART = GPART;
     a.OUT = const_cast<double*>(pa.OUT);   // SPLIT: the partners' channel exchange; otherwise only written by the -DHPV_FZ_TIMING build
@@ -2015,10 +2044,14 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
         a.data_off = dt->data_off; a.ud = dt->ud; a.gbar0 = dt->gbar0; a.data_part = dt->data_part;
         a.data_scale = dt->scale; a.data_write_gbar = dt->write_gbar;
     } else if (rest > 0) {
-        return false;    // tiles behind the elements but no data term: not a layout this kernel knows
+        return fz_no(26);    // tiles behind the elements but no data term: not a layout this kernel knows
     }
-    a.proj_n_elem = n_elem;
+    a.proj_n_elem = n_main;
     a.proj_split = split;
+    a.elem0 = 0;
+    a.data_tile0 = n_elem * TPE;
+    // (a ragged tail: the boundary / data tiles ride in the tail's launch -- this one sees a batch that ends behind its elements)
+    if (n_tail > 0) a.ntiles = n_main * TPE;
     if (pre) { a.pre_g = pre->g; a.pre_Ptot = pre->Ptot; a.pre_ad = pre->ad; }
     a.xerr = m->xerr;
     a.xdebug_skip = m->xdebug_skip;
@@ -2036,10 +2069,10 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
 #endif
     // the prologue is paid per WORKGROUP: worth it only where every workgroup is resident at once (one round); on larger grids the caller's
     // k_adam launch in front of the pass is cheaper (4 096 elements: +12.3 us against +4.5)
-    if (pre && (gs || blocks > (long)m->n_cus)) return false;
+    if (pre && (gs || blocks > (long)m->n_cus)) return fz_no(27);
     // MULTI spills 45 doubles per lane into the activation store: [workgroup][wave][slot][64] -- it must hold that (it is sized for
     // the separate launches' slots of every tile: far larger on any grid that takes this branch)
-    if (multi && (size_t)blocks * FZ_WAVES * 64 * 48 > hpv_mfma_activation_store_doubles(m)) return false;
+    if (multi && (size_t)blocks * FZ_WAVES * 64 * 48 > hpv_mfma_activation_store_doubles(m)) return fz_no(28);
     int plan = 2;
     if (split > 1) plan = 0;
 #ifdef HPV_AGPR_GUARD_TRIPPED_QT                    // csrc/build.sh: the compiler's registers reached the stash of the QT instantiation
@@ -2049,22 +2082,38 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
     if (gen && plan == 2 && nd.nT2 == 1 && TPE % 4 != 0) plan = 1;    // four channels: the packed quarter has room for the data points only
     if (multi) plan += 2;                                              // plans 3 / 4: several elements per workgroup
     if (gen) {
-        if (gs || multi) return false;
+        if (gs || multi) return fz_no(29);
         if (!hpv_fused_launch_gen(pd, m->L, plan, nd.nT2, a, (int)blocks, s)) {
             // (a quarter-tile instantiation the build guard compiled out: whole tiles)
-            if (plan != 2 || !hpv_fused_launch_gen(pd, m->L, plan = 1, nd.nT2, a, (int)blocks, s)) return false;
+            if (plan != 2 || !hpv_fused_launch_gen(pd, m->L, plan = 1, nd.nT2, a, (int)blocks, s)) return fz_no(30);
         }
     } else
-    if (!launch_iter_fused_any(pd, m->L, plan, gs, a, (int)blocks, s)) return false;
-    m->last_split = split > 1;
-    if (split > 1) m->split_used = true;
+    if (!launch_iter_fused_any(pd, m->L, plan, gs, a, (int)blocks, s)) return fz_no(31);
+    if (n_tail > 0) {
+        // the ragged tail: elements n_main .. n_elem - 1, tsplit workgroups each, gradient rows behind the first launch's
+        MfmaArgs b = a;
+        b.ntiles = m->ntiles;
+        b.proj_n_elem = n_tail;
+        b.proj_split = tsplit;
+        b.elem0 = n_main;
+        b.GPART = GPART + blocks * (long)nd.P;
+        const bool ok = gen ? hpv_fused_launch_gen(pd, m->L, 0, nd.nT2, b, (int)(n_tail * tsplit), s)
+                            : launch_iter_fused_any(pd, m->L, 0, false, b, (int)(n_tail * tsplit), s);
+        if (!ok) return fz_no(32);      // (cannot happen for an instantiated shape: plan 0 exists wherever plans 1 / 2 do)
+    }
+    m->last_split = split > 1 || n_tail > 0;
+    if (split > 1 || n_tail > 0) m->split_used = true;
     char shp[64] = "";
     if (!base_shape || gen) snprintf(shp, sizeof shp, ",%dx%d/%dx%d%s", pd.qx, pd.qy, pd.ntx, pd.nty, gen ? (nd.nT2 ? ",NT2=1,GEN" : ",GEN") : "");
     if (split > 1) snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=true,QT=false,GS=%s%s> split=%d", m->L, gs ? "true" : "false", shp, split);
     else snprintf(m->variant, sizeof m->variant, "k_iter_fused<L=%d,SPLIT=false,QT=%s,GS=%s%s>%s", m->L, (plan == 2 || plan == 4) ? "true" : "false",
                   gs ? "true" : "false", shp, multi ? " elements-per-workgroup>1" : "");
+    if (n_tail > 0) {
+        const size_t l = strlen(m->variant);
+        snprintf(m->variant + l, sizeof m->variant - l, " + SPLIT=true split=%d on the last %ld elements", tsplit, n_tail);
+    }
     m->pre_used = pre != nullptr;
-    if (rows) *rows = (int)blocks;
+    if (rows) *rows = (int)rows_all;
     return true;
 }
 

@@ -332,6 +332,55 @@ def test_hand_tuned_kernel_walks_several_elements_per_workgroup_on_grids_larger_
     assert rel(gw, gm) < 1e-11 and rel(l3w, l3m) < 1e-12, (v, vw)
 
 
+@pytest.mark.parametrize("prob,q,nt,nhid,nex,ney,tail", [("p2vf1", 20, 10, 3, 17, 17, 33), ("p2vf1", 16, 8, 3, 24, 23, 40), ("p2vf1", 20, 10, 2, 19, 15, 29),
+                                                          ("advf1", 20, 10, 3, 17, 17, 33), ("p2vf0", 16, 8, 3, 25, 22, 38)])
+def test_hand_tuned_kernel_ragged_grids_tail_in_split_mode(prob, q, nt, nhid, nex, ney, tail):
+    """Grids larger than the chip whose last round is ragged (verdict round 5, item 5; N_el_x, N_el_y are free: P2:282-283): the full
+    rounds run with one workgroup per element, the n % CUs elements of the tail in a SECOND launch of the split instantiation (2 - 8
+    workgroups per element, gradient rows behind the first launch's, boundary tiles in the tail's launch) -- 17 x 17 elements of the
+    config-4 shape are one round + 33 shared elements instead of the separate launches.  Against the oracle (loss triple, gradient,
+    every residual, a trajectory), bit-reproducible, equal to the separate launches to round-off."""
+    from hp_vpinns_amd.vpinn import VPINN2D, VPINNAdvDiff
+    from oracle.vpinn_oracle import OracleVPINN2D, OracleVPINNAdvDiff
+    assert "HPV_FUSE" not in os.environ
+    L = [2] + [20] * nhid + [1]
+    if prob.startswith("p2"):
+        vf = 1 if prob == "p2vf1" else 0
+        a = _p2(q, nt, nex, ney, nb=40) + (L,)
+        th = theta0(L, 373)
+        mk_o, mk_m = (lambda: OracleVPINN2D(*a, var_form=vf, init_params=th)), (lambda: VPINN2D(*a, var_form=vf, init_params=th))
+    else:
+        a = _p3(q, nt, nex, ney, nb=40) + (L, None, None)
+        th = theta0(L, 374, extra=[0.75])
+        mk_o, mk_m = (lambda: OracleVPINNAdvDiff(*a, var_form=1, init_params=th)), (lambda: VPINNAdvDiff(*a, var_form=1, init_params=th))
+    o, m = mk_o(), mk_m()
+    o.vectorized = True
+    l3o, go = o.loss_and_grad()
+    l3m, gm = m.loss_and_grad()
+    v = m.h.kernel_variant()
+    assert (nex * ney) % 256 == tail
+    assert m.h.pass_structure() == "whole-iteration-split" and v.startswith("k_iter_fused<L=%d,SPLIT=false" % nhid), (m.h.pass_structure(), v)
+    assert v.endswith("on the last %d elements" % tail) and "SPLIT=true split=" in v, v
+    assert rel(l3m, l3o) < TOL and rel(gm, go) < TOL, (v, l3m, l3o, rel(gm, go))
+    assert rel(m.h.residuals(nex * ney * nt * nt), o.last["R"].reshape(-1)) < TOL
+    l3b, gb = m.loss_and_grad()
+    assert np.array_equal(gb, gm) and np.array_equal(l3b, l3m)
+    lo, lm = [], []
+    for _ in range(3):
+        o.adam_step()
+        lo.append(float(o.loss_parts()[0]))
+        lm.append(float(m._step(1, True)[0]))
+    assert rel(lm, lo) < TRAJ_TOL and rel(m.get_params(), o.get_params()) < TRAJ_TOL
+    os.environ["HPV_FUSE"] = "n"
+    try:
+        w = mk_m()
+        l3s, gs = w.loss_and_grad()
+        assert w.h.pass_structure() == "separate"
+    finally:
+        del os.environ["HPV_FUSE"]
+    assert rel(gs, gm) < 1e-10 and rel(l3s, l3m) < 1e-11, (rel(gs, gm), rel(l3s, l3m))
+
+
 @pytest.mark.parametrize("q,ntx,nty,nex,ney", [(20, 7, 5, 16, 16), (20, 10, 6, 5, 3), (20, 1, 1, 4, 4), (16, 5, 5, 16, 8), (16, 8, 3, 5, 3),
                                                (12, 4, 6, 16, 8), (12, 2, 5, 4, 2), (10, 3, 4, 8, 8), (10, 5, 2, 4, 4), (10, 1, 3, 3, 3)])
 def test_hand_tuned_kernels_with_fewer_test_functions_than_instantiated(q, ntx, nty, nex, ney):
