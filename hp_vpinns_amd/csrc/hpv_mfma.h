@@ -31,7 +31,7 @@ inline long hpv_elem_resident_max(int dim, int q, int n_cus) {
 bool hpv_fused_loop_built();      // kernels_fused.hip: the element loop (MULTI) survived the build guard
 // 3 (round 6): the full rounds with one workgroup per element + the ragged tail (n_elem % n_cus elements, at most half a round) in a
 // second launch in SPLIT mode, 2 - 8 workgroups per element -- 1 600 elements of the config-4 shape: 6 rounds + a 64-element tail
-// instead of 7 rounds; 289 elements: one round + 33 shared elements instead of the separate launches.
+// instead of 7 rounds.  20x20-point elements from two full rounds on (see below).
 inline int hpv_fused_grid_plan(int q, int L, long n_elem, int n_cus, bool loop_built, bool loop_off = false, bool loop_force = false, bool one_force = false,
                                bool tail_ok = true) {
     if (n_elem <= n_cus) return 1;
@@ -42,8 +42,10 @@ inline int hpv_fused_grid_plan(int q, int L, long n_elem, int n_cus, bool loop_b
     if (one_force) return 1;
     if (q != 20 && n_elem > hpv_elem_resident_max(2, q, n_cus)) return 0;
     const long tail = n_elem % n_cus;
-    // (smaller elements with ONE full round: the separate launches cost the same within noise -- 289 elements of 16x16 points 73 against 68 us)
-    if (tail_ok && tail > 0 && tail * 2 <= n_cus && (q == 20 || n_elem >= 2L * n_cus)) return 3;
+    // (measured, scripts/ragged_bench.py: 20x20 points -- 1 600 elements 365 against 385 (7 rounds) / 415 us (separate), 1 296 elements 303 /
+    //  330 / 350; with ONE full round in front of the tail the separate launches win, 289 elements 90 against 85 us; 16x16 points: the
+    //  separate launches win on every ragged grid, 552 elements 112 against 93 us)
+    if (tail_ok && tail > 0 && tail * 2 <= n_cus && q == 20 && n_elem >= 2L * n_cus) return 3;
     return n_elem * 100 >= rounds * n_cus * 80 ? 1 : 0;
 }
 

@@ -820,6 +820,9 @@ int hpv_mfma_max_rows(HpvMfma* m, long n_elem, long n_data_tiles) {
     const long fused_rows = n_elem * fused_split(m, n_elem);
     if (m->bwd_fused && fused_rows > r && fused_rows <= 65536) r = (int)fused_rows;
     if (n_elem > r && n_elem <= 65536) r = (int)n_elem;      // the whole-iteration kernel writes one row per element
+    // SPLIT mode of the whole-iteration kernel: 2 - 8 workgroups per element while they fit the chip (three-channel sets have the fused
+    // reverse kernel's count above; the four-channel sets of the general forms do not)
+    if (n_elem * 2 <= m->n_cus) { long sp = 1; while (sp < 8 && n_elem * sp * 2 <= m->n_cus) sp *= 2; if (n_elem * sp > r) r = (int)(n_elem * sp); }
     // ... and, on a grid larger than the chip with a ragged last round, up to 8 rows per element of the tail (at most half a round of elements)
     if (n_elem > m->n_cus && n_elem + m->n_cus > r && n_elem <= 65536) r = (int)(n_elem + m->n_cus);
     if (n_elem * 64 > r && n_elem * 64 <= m->n_cus) r = (int)(n_elem * 64);   // tall-element kernel: up to 64 workgroups per element

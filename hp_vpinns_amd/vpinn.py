@@ -16,10 +16,12 @@ hyper-parameters `var_form`, `LR`, `lossb_weight`, `scheme`, `V` while the graph
 `__init__` (P1:82-102, P2:93-128, P3:161-191) and the history lists `total_record` / `loss_his`
 while `train` runs (P1:214, P2:244) -- the drivers create those lists AFTER the constructor
 (P1:333 then :335, P2:430 then :433).  The classes here keep that timing: every such name is a
-keyword argument; one that is not given is looked up in the CALLER's module globals (or the
-dict passed as `module_globals=`) -- the hyper-parameters when the constructor runs, the lists
-when `train` runs -- and only then falls back to the reference's default / a private list.  So
-`from hp_vpinns_amd.vpinn import VPINN2D as VPINN` is the whole binding.
+keyword argument; one that is not given is looked up in the dict passed as `module_globals=`
+(the documented, explicit binding: `VPINN(..., module_globals=globals())`) or, without one, in
+the CALLER's module globals (frame lookup; HPV_NO_CALLER_GLOBALS=1 switches it off) -- the
+hyper-parameters when the constructor runs, the lists when `train` runs -- and only then falls
+back to the reference's default / a private list.  So `from hp_vpinns_amd.vpinn import VPINN2D
+as VPINN` is the whole binding.
 """
 import os
 import sys
@@ -94,7 +96,12 @@ def _device_rule_2d(xi, wx, yi, wy, ntx, nty, n_elem_shard, device=0, exact_coun
 
 
 def _caller_globals(depth=2):
-    """Module globals of whoever called the public method `depth - 1` frames above this function."""
+    """Module globals of whoever called the public method `depth - 1` frames above this function -- the IMPLICIT half of the binding
+    (what makes the one-line import swap enough).  The explicit, documented half is `module_globals=globals()` in the constructor
+    call; HPV_NO_CALLER_GLOBALS=1 switches the frame lookup off altogether (keyword arguments, `module_globals=` and the reference
+    defaults remain): a wrapper module or a notebook cell then cannot change a training through a name it happens to hold."""
+    if os.environ.get("HPV_NO_CALLER_GLOBALS"):
+        return {}
     try:
         return sys._getframe(depth).f_globals
     except ValueError:      # pragma: no cover - no such frame

@@ -20,3 +20,16 @@ with _lib.library(_lib.TEST_HOOKS_LIB_PATH):
             m = advdiff.build_model(s, L, var_form=int(prob[-1]), init_params=xavier_init(L, 1, extra=[0.9]))
         l3, g = m.loss_and_grad()
         print(prob, q, nex, ney, L, "->", m.h.pass_structure(), m.h.kernel_variant(), l3, flush=True)
+
+# ---- timing probe: Poisson-2D var_form 0 on 16x16 elements of 16x16 points, per 100-iteration chunk, host- and device-assembled F ----
+import time  # noqa: E402
+for asm in ("host", "device"):
+    s = poisson2d.setup(N_el_x=16, N_el_y=16, N_test_x=8, N_test_y=8, N_quad=16, with_test_grid=False, assemble=asm)
+    L = [2, 20, 20, 20, 1]
+    m = poisson2d.build_model(s, L, var_form=0, init_params=xavier_init(L, 1234))
+    ts = []
+    for _ in range(8):
+        t0 = time.perf_counter()
+        l3 = m.h.step(100, True)
+        ts.append((time.perf_counter() - t0) / 100 * 1e6)
+    print(asm, m.h.kernel_variant(), ["%.1f" % t for t in ts], l3, flush=True)

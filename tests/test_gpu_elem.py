@@ -332,13 +332,12 @@ def test_hand_tuned_kernel_walks_several_elements_per_workgroup_on_grids_larger_
     assert rel(gw, gm) < 1e-11 and rel(l3w, l3m) < 1e-12, (v, vw)
 
 
-@pytest.mark.parametrize("prob,q,nt,nhid,nex,ney,tail", [("p2vf1", 20, 10, 3, 17, 17, 33), ("p2vf1", 16, 8, 3, 24, 23, 40), ("p2vf1", 20, 10, 2, 19, 15, 29),
-                                                          ("advf1", 20, 10, 3, 17, 17, 33), ("p2vf0", 16, 8, 3, 25, 22, 38)])
+@pytest.mark.parametrize("prob,q,nt,nhid,nex,ney,tail", [("p2vf1", 20, 10, 3, 24, 23, 40), ("advf1", 20, 9, 2, 25, 22, 38)])
 def test_hand_tuned_kernel_ragged_grids_tail_in_split_mode(prob, q, nt, nhid, nex, ney, tail):
     """Grids larger than the chip whose last round is ragged (verdict round 5, item 5; N_el_x, N_el_y are free: P2:282-283): the full
     rounds run with one workgroup per element, the n % CUs elements of the tail in a SECOND launch of the split instantiation (2 - 8
     workgroups per element, gradient rows behind the first launch's, boundary tiles in the tail's launch) -- 17 x 17 elements of the
-    config-4 shape are one round + 33 shared elements instead of the separate launches.  Against the oracle (loss triple, gradient,
+    config-4 shape from two full rounds on (24 x 23 = 2 x 256 + 40).  Against the oracle (loss triple, gradient,
     every residual, a trajectory), bit-reproducible, equal to the separate launches to round-off."""
     from hp_vpinns_amd.vpinn import VPINN2D, VPINNAdvDiff
     from oracle.vpinn_oracle import OracleVPINN2D, OracleVPINNAdvDiff
@@ -366,7 +365,7 @@ def test_hand_tuned_kernel_ragged_grids_tail_in_split_mode(prob, q, nt, nhid, ne
     l3b, gb = m.loss_and_grad()
     assert np.array_equal(gb, gm) and np.array_equal(l3b, l3m)
     lo, lm = [], []
-    for _ in range(3):
+    for _ in range(2):
         o.adam_step()
         lo.append(float(o.loss_parts()[0]))
         lm.append(float(m._step(1, True)[0]))

@@ -164,6 +164,32 @@ def test_poisson2d_reference_main_runs_on_the_replacement(tmp_path, monkeypatch)
     assert os.path.exists("Poisson2D_VPINNs_loss.pdf")
 
 
+def test_poisson2d_reference_main_with_the_explicit_binding_and_no_frame_lookup(tmp_path, monkeypatch):
+    """INTEGRATION.md 1, the explicit form: `module_globals=globals()` in the constructor call, frame lookup OFF
+    (HPV_NO_CALLER_GLOBALS=1) -- the module globals of P2:279-281 still reach the library and P2:433's list is still the one filled;
+    and with the lookup off and NO explicit binding the reference defaults apply and the history stays private."""
+    _stubs(monkeypatch)
+    monkeypatch.setenv("HPV_NO_CALLER_GLOBALS", "1")
+    src = _with_documented_edit(P2, "from hp_vpinns_amd.vpinn import VPINN2D as VPINN")
+    call = "N_testfcn_total, X_test, u_test, Net_layer)"
+    assert src.count(call) == 1                                  # P2:430-431, the constructor call
+    import matplotlib.pyplot as plt
+    monkeypatch.chdir(tmp_path)
+    for explicit in (True, False):
+        RecordingHandle.instances.clear()
+        text = src.replace(call, call[:-1] + ", module_globals=globals())") if explicit else src
+        text = text.replace("var_form  = 1", "var_form  = 2", 1) if "var_form  = 1" in text else text
+        ns = {"__name__": "__main__", "__file__": P2}
+        exec(compile(text, P2, "exec"), ns)
+        plt.close("all")
+        h, = RecordingHandle.instances
+        if explicit:
+            assert h.cfg["var_form"] == ns["var_form"] and len(ns["loss_his"]) == 10001 and ns["loss_his"] is ns["model"].loss_his
+        else:
+            assert h.cfg["var_form"] == 1                           # the reference default (P2:281), not the module's value
+            assert ns["loss_his"] == [] and len(ns["model"].loss_his) == 10001
+
+
 class _Numpy1Asarray:
     """`np` as the P3 script sees it: numpy, except that `asarray` of a ragged nest of scalars and (1,1) arrays gives the
     float array numpy < 1.24 produced through its object fallback ... by coercing the leaves (P3:451)."""
