@@ -38,6 +38,7 @@ guard() {
   local asm=$1 rc=0; shift
   while [ $# -ge 2 ]; do
     local r=0; $CHK $asm $1 $2 >&2 || r=$?
+    [ $r -eq 3 ] && { echo "build.sh: ERROR -- $1 spills registers to scratch memory (scripts/check_agpr.py): a hand-scheduled kernel must not" >&2; return 2; }
     [ $r -ge 2 ] && return 2
     [ $r -eq 1 ] && rc=1
     shift 2

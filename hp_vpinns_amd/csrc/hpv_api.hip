@@ -243,29 +243,126 @@ static ProjArgs pass_proj_args(hpv_ctx* h, bool backward) {
                     h->d_loss_e, h->d_deps_e, h->var.N, backward ? 1 : 0, nullptr, nullptr, nullptr, nullptr};
 }
 
-// One pass over both loss terms.  backward: also the reverse pass and the gradient reduction;
-// fuse_adam: the finalize kernel applies the TF1 Adam update itself (single-GPU training step);
-// pend: RB holds the previous iteration's reduced gradient, its update not applied yet (multi-GPU sequence, see hpv_ctx::defer_adam):
-// k_iter_fused takes it into its prologue and k_finalize stores it; any other structure gets a k_adam launch in front.
-int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false, bool pend = false) {
-    if (h->cfg.scheme == HPV_SCHEME_PINN || !backward) {
-        if (pend) { launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream); pend = false; }
+// ---- one pass over both loss terms ------------------------------------------------------------------------------------------
+// What a pass did (hpv_pass_structure / hpv_kernel_variant report structure and names): filled while the pass walks its plan.
+struct PassPlan {
+    long n_loss;             // loss_e / deps_e entries the pass wrote
+    bool fin_done = false;   // the whole-iteration tile kernel ran the finalize step itself
+    bool xch_used = false;   // a shared-element kernel (SPLIT mode, k_iter_tall) ran: k_finalize advances the exchange's launch counter
+    bool pend_taken = false; // the deferred TF1-Adam update rode in k_iter_fused's prologue: k_finalize stores it
+};
+
+// (1) The variational term as ONE launch -- the element-resident whole-iteration kernels, tried in the order of their speed on the
+// shapes they take (each declines what it does not cover): k_iter_fused (two-term / general forms on 12x12, 16x16, 20x20 points;
+// takes a deferred update `pend` into its prologue), k_iter_tile (one tile per wave: 1-D rules, 10x10 points; a one-workgroup grid
+// finishes the iteration itself), k_iter_elem (any instantiated shape / channel set; first with HPV_FUSE=e), k_iter_tall (80x80
+// points).  Timed as the reverse-pass class.  false: nothing was launched.
+static bool pass_whole_iteration(hpv_ctx* h, const MfmaDataTerm& dt, const ProjArgs& pa, bool fuse_adam, bool& pend, PassPlan& pl) {
+    HpvMfma* m = h->mfma;
+    Batch& v = h->var;
+    int structure = -1;
+    tstart(h, 2);
+    auto fused = [&](const MfmaPendingAdam* pre) {
+        return hpv_mfma_iter_fused(m, h->d_theta, v.X, v.GPART, &v.rows, h->stream, &dt, pa, h->n_elem, pre);
+    };
+    auto elem = [&] { return hpv_mfma_iter_elem(m, h->d_theta, v.X, v.GPART, &v.rows, h->stream, &dt, pa, h->n_elem); };
+    if (pend) {      // the deferred update rides in k_iter_fused's prologue -- or is applied here, before anything else is launched
+        const MfmaPendingAdam pre{adam_args(h), h->d_RB, h->Ptot};
+        if (fused(&pre)) { pl.pend_taken = true; structure = hpv_mfma_sync_failed_possible(m) ? 3 : 2; }
+        else launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream);
+        pend = false;
     }
-    if (h->cfg.scheme == HPV_SCHEME_PINN) return enqueue_pinn_pass(h, backward, fuse_adam);
+    if (structure < 0 && hpv_mfma_prefers_elem(m) && elem()) structure = 6;      // HPV_FUSE=e (A/B runs): the generic element-resident kernel first
+    if (structure < 0 && fused(nullptr)) structure = hpv_mfma_sync_failed_possible(m) ? 3 : 2;
+    if (structure < 0) {
+        MfmaFinalize fin{adam_args(h), h->d_RB, h->cfg.lossb_weight, h->n_data, (h->n_data + 15) / 16, h->has_eps, adam_state_doubles(h->P) / 2};
+        if (!fuse_adam) fin.ad.theta = nullptr;
+        fin.n_iters = fuse_adam ? h->persist_want : 1;
+        fin.iters_done = &h->persist_done;
+        if (hpv_mfma_iter_tile(m, h->d_theta, v.X, v.GPART, &v.rows, h->stream, &dt, pa, h->n_elem, h->merged ? &fin : nullptr, &pl.fin_done)) structure = 4;
+    }
+    if (structure < 0 && elem()) structure = 6;
+    if (structure < 0) {
+        const int ts = hpv_mfma_tall_split(m, h->pd, h->n_elem);
+        if (ts > 1 && h->n_elem * ts <= h->n_red_alloc &&
+            hpv_mfma_iter_tall(m, h->d_theta, v.X, v.GPART, &v.rows, h->stream, &dt, pa, h->n_elem)) { structure = 5; pl.n_loss = h->n_elem * ts; }
+    }
+    if (structure < 0) return false;     // (nothing was launched; the caller re-records the start event)
+    tstop(h, 2);
+    h->pass_structure = structure;
+    snprintf(h->variant, sizeof h->variant, "%s", hpv_mfma_variant(m, 0));
+    pl.xch_used = hpv_mfma_sync_failed_possible(m);
+    return true;
+}
+
+// (2) / (3) The variational term as separate launches: forward (+ edge batch) -> projection -> reverse; on the MFMA path the
+// projection rides inside the reverse kernel where that applies (element-block mode), otherwise it is the fastest projection
+// kernel that takes the shape.
+static void pass_separate(hpv_ctx* h, const MfmaDataTerm& dt, const ProjArgs& pa, bool backward, bool use_mfma) {
+    Batch& v = h->var;
+    const double* eps_ptr = pa.eps_ptr;
+    tstart(h, 0);
+    if (use_mfma) hpv_mfma_forward(h->mfma, h->d_theta, v.X, v.OUT, backward ? 1 : 0, h->stream, &dt);
+    else run_fwd(h, v, nullptr, backward ? 1 : 0);
+    tstop(h, 0);
+    if (h->pd.edge) run_fwd(h, h->edge, h->mfma_edge, backward ? 1 : 0);
+    bool bfused = false;
+    if (backward && use_mfma) {
+        tstart(h, 2);   // timed as the reverse-pass class (the projection is ~1 % of its flops)
+        bfused = hpv_mfma_backward_fused(h->mfma, h->d_theta, v.X, v.GBAR, v.GPART, &v.rows, h->stream, pa, h->n_elem);
+        if (bfused) tstop(h, 2);
+    }
+    if (backward) h->pass_structure = bfused ? 1 : 0;
+    if (bfused) { snprintf(h->variant, sizeof h->variant, "%s + %s", hpv_mfma_variant(h->mfma, 1), hpv_mfma_variant(h->mfma, 3)); }
+    else {
+        tstart(h, 1);
+        // (the specialised kernels need GBAR's unused channels pre-zeroed: true for every batch, see alloc_batch)
+        const bool special = h->cfg.backend != HPV_BACKEND_GENERIC;
+        auto wg = [&](double* upart) {
+            return launch_project_wg(h->pd, v.OUT, v.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr, h->d_loss_e, h->d_deps_e,
+                                     v.N, h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi, h->d_edge_coef, h->edge.GBAR, h->stream, upart);
+        };
+        // few elements (at most two per CU) of a 2-D shape: one workgroup per element before "a lane owns a line"
+        bool small_grid = h->dim == 2 && h->n_elem <= 512 && h->proj_split == 1 && !h->pd.nact;
+#ifdef HPV_EXPERIMENTS
+        if (getenv("HPV_PJ_WG_SMALL")) small_grid = false;      // (A/B: "a lane owns a line" on small grids too)
+#endif
+        const char* pname = "k_project";
+        if (special && small_grid && wg(nullptr)) pname = "k_project_wg";
+        else if (special && launch_project_tp(h->pd, v.OUT, v.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr, h->d_loss_e,
+                                              h->d_deps_e, v.N, h->n_elem, backward ? 1 : 0, h->stream)) pname = "k_project_tp";
+        else if (special && wg(h->d_upart)) pname = h->proj_split > 1 ? "k_project_rows" : "k_project_wg";
+        else launch_project(h->pd, v.OUT, v.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr, h->d_loss_e, h->d_deps_e, v.N,
+                            h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi, h->d_edge_coef, h->edge.GBAR, h->stream);
+        tstop(h, 1);
+        if (backward) {
+            snprintf(h->variant, sizeof h->variant, "%s + %s<%dx%d/%dx%d> + %s", use_mfma ? hpv_mfma_variant(h->mfma, 1) : "k_mlp_fwd_generic", pname,
+                     h->pd.qx, h->pd.qy, h->pd.ntx, h->pd.nty, use_mfma ? hpv_mfma_variant(h->mfma, 2) : "k_mlp_bwd_generic");
+            tstart(h, 2);
+            if (use_mfma) hpv_mfma_backward(h->mfma, h->d_theta, v.X, v.GBAR, v.GPART, &v.rows, h->stream);
+            else run_bwd(h, v, nullptr);
+            tstop(h, 2);
+        }
+    }
+    if (backward && h->pd.edge) run_bwd(h, h->edge, h->mfma_edge);
+}
+
+// backward: also the reverse pass and the gradient reduction; fuse_adam: the finalize kernel applies the TF1 Adam update itself
+// (single-GPU training step); pend: RB holds the previous iteration's reduced gradient, its update not applied yet (multi-GPU
+// sequence, see hpv_ctx::defer_adam): k_iter_fused takes it into its prologue and k_finalize stores it; any other structure gets a
+// k_adam launch in front.
+int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false, bool pend = false) {
     // (an error exit BEFORE the pending update has been taken over by a launch applies it first, best effort: it was counted when
     //  its iteration was enqueued, and dropping it would leave the device one update behind the host's count -- advisor, round 5)
     auto apply_pend = [&] { if (pend) { launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream); pend = false; } };
+    if (h->cfg.scheme == HPV_SCHEME_PINN || !backward) apply_pend();
+    if (h->cfg.scheme == HPV_SCHEME_PINN) return enqueue_pinn_pass(h, backward, fuse_adam);
     int rc = check_ready(h);
     if (rc) { apply_pend(); return rc; }
-    const double* eps_ptr = h->has_eps ? h->d_theta + h->P : nullptr;
     const bool use_mfma = h->mfma && h->backend == HPV_BACKEND_MFMA;
     // the deferred update can only ride in a whole-iteration kernel that is the ONLY reader of the parameters in this pass (boundary
     // points merged into it, no edge batch); otherwise it is applied here, before anything of this pass is launched or forked
-    if (pend && !(use_mfma && h->var.N > 0 && (h->merged || h->n_data == 0) && !h->pd.edge && !hpv_mfma_prefers_elem(h->mfma))) {
-        launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream);
-        pend = false;
-    }
-    bool pend_taken = false;
+    if (!(use_mfma && h->var.N > 0 && (h->merged || h->n_data == 0) && !h->pd.edge && !hpv_mfma_prefers_elem(h->mfma))) apply_pend();
     if (!h->side_active) {  // allocations are not allowed inside a stream capture
         if ((rc = ensure_small_mfma(h, h->data, &h->mfma_data))) { apply_pend(); return rc; }
         if (h->pd.edge && (rc = ensure_small_mfma(h, h->edge, &h->mfma_edge))) { apply_pend(); return rc; }
@@ -276,124 +373,16 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false, bool pend = 
         (void)hipEventRecord(h->ev_fork, smain);
         (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
     }
-    long n_loss = (long)h->n_elem * h->proj_split;      // loss_e / deps_e entries this pass writes
-    bool fin_done = false;                              // the whole-iteration tile kernel ran the finalize step itself
-    bool xch_used = false;                              // a shared-element kernel (SPLIT mode, k_iter_tall) ran in this pass
+    PassPlan pl{(long)h->n_elem * h->proj_split};
     // --- variational term on this shard's quadrature batch ---
     if (h->var.N > 0) {
         const MfmaDataTerm dt = pass_data_term(h, backward);
         const ProjArgs pa = pass_proj_args(h, backward);
-        // (1) element-resident whole-iteration kernel: forward, projection and reverse pass in one launch, no activation
-        //     store (kernels_fused.hip); timed as the reverse-pass class
-        bool ifused = false;
-        if (backward && use_mfma) {
-            tstart(h, 2);
-            if (pend) {      // the deferred update rides in k_iter_fused's prologue -- or is applied here, before anything else is launched
-                const MfmaPendingAdam pre{adam_args(h), h->d_RB, h->Ptot};
-                ifused = hpv_mfma_iter_fused(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem, &pre);
-                if (ifused) { pend_taken = true; h->pass_structure = hpv_mfma_sync_failed_possible(h->mfma) ? 3 : 2; }
-                else launch_adam(adam_args(h), h->d_RB, h->P, h->Ptot, h->stream);
-                pend = false;
-            }
-            if (!ifused && !pend_taken && hpv_mfma_prefers_elem(h->mfma)) {      // HPV_FUSE=e (A/B runs): the generic element-resident kernel first
-                ifused = hpv_mfma_iter_elem(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
-                if (ifused) h->pass_structure = 6;
-            }
-            if (!ifused) {
-                ifused = hpv_mfma_iter_fused(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
-                if (ifused) h->pass_structure = hpv_mfma_sync_failed_possible(h->mfma) ? 3 : 2;
-            }
-            if (!ifused) {   // small elements of the other channel sets (1-D, AdvDiff, var_form 0): kernels_tile.hip
-                // (a one-workgroup grid finishes the iteration itself: packed buffer, Adam, loss history)
-                MfmaFinalize fin{adam_args(h), h->d_RB, h->cfg.lossb_weight, h->n_data, (h->n_data + 15) / 16, h->has_eps,
-                                 adam_state_doubles(h->P) / 2};
-                if (!fuse_adam) fin.ad.theta = nullptr;
-                fin.n_iters = fuse_adam ? h->persist_want : 1;
-                fin.iters_done = &h->persist_done;
-                ifused = hpv_mfma_iter_tile(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem,
-                                            h->merged ? &fin : nullptr, &fin_done);
-                if (ifused) h->pass_structure = 4;
-            }
-            if (!ifused) {   // any other instantiated element shape / 2-D channel set: the generic element-resident kernel (kernels_elem.hip)
-                ifused = hpv_mfma_iter_elem(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem);
-                if (ifused) h->pass_structure = 6;
-            }
-            if (!ifused) {   // few tall elements (AdvDiff, 80x80 rule): many workgroups per element, partial sums exchanged (kernels_tall.hip)
-                const int ts = hpv_mfma_tall_split(h->mfma, h->pd, h->n_elem);
-                if (ts > 1 && h->n_elem * ts <= h->n_red_alloc &&
-                    hpv_mfma_iter_tall(h->mfma, h->d_theta, h->var.X, h->var.GPART, &h->var.rows, h->stream, &dt, pa, h->n_elem)) {
-                    ifused = true;
-                    h->pass_structure = 5;
-                    n_loss = h->n_elem * ts;
-                }
-            }
-            if (ifused) {
-                tstop(h, 2);   // (otherwise nothing was launched; the start event is re-recorded below)
-                snprintf(h->variant, sizeof h->variant, "%s", hpv_mfma_variant(h->mfma, 0));
-                xch_used = hpv_mfma_sync_failed_possible(h->mfma);      // this launch used the tagged exchange: k_finalize advances its counter
-            }
-        }
-        if (!ifused) {
-            tstart(h, 0);
-            if (use_mfma) hpv_mfma_forward(h->mfma, h->d_theta, h->var.X, h->var.OUT, backward ? 1 : 0, h->stream, &dt);
-            else run_fwd(h, h->var, nullptr, backward ? 1 : 0);
-            tstop(h, 0);
-            if (h->pd.edge) run_fwd(h, h->edge, h->mfma_edge, backward ? 1 : 0);
-            // (2) projection fused into the reverse kernel (element-block mode; small shards split an element over
-            //     several workgroups) when that applies, otherwise (3) its own launch
-            bool bfused = false;
-            if (backward && use_mfma) {
-                tstart(h, 2);   // timed as the reverse-pass class (the projection is ~1 % of its flops)
-                bfused = hpv_mfma_backward_fused(h->mfma, h->d_theta, h->var.X, h->var.GBAR, h->var.GPART, &h->var.rows, h->stream,
-                                                 pa, h->n_elem);
-                if (bfused) tstop(h, 2);
-            }
-            if (backward) h->pass_structure = bfused ? 1 : 0;
-            if (bfused && backward)
-                snprintf(h->variant, sizeof h->variant, "%s + %s", hpv_mfma_variant(h->mfma, 1), hpv_mfma_variant(h->mfma, 3));
-            if (!bfused) {
-                tstart(h, 1);
-                // specialised tensor-product kernel for the hot element shapes unless the generic backend is forced
-                // (needs GBAR's unused channels pre-zeroed: true for every batch, see alloc_batch)
-                const char* pname = "k_project";
-                // few elements (at most two per CU) of a 2-D shape: one workgroup per element before "a lane owns a line"
-                const bool small_grid = h->dim == 2 && h->n_elem <= 512 && h->proj_split == 1 && !h->pd.nact;
-                if (h->cfg.backend != HPV_BACKEND_GENERIC && small_grid && getenv("HPV_PJ_WG_SMALL") == nullptr &&
-                    launch_project_wg(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
-                                      eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT,
-                                      h->d_edge_dphi, h->d_edge_coef, h->edge.GBAR, h->stream, nullptr))
-                    pname = "k_project_wg";
-                else if (h->cfg.backend != HPV_BACKEND_GENERIC &&
-                    launch_project_tp(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
-                                      eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->stream))
-                    pname = "k_project_tp";
-                else if (h->cfg.backend != HPV_BACKEND_GENERIC &&
-                         launch_project_wg(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty,
-                                           eps_ptr, h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT,
-                                           h->d_edge_dphi, h->d_edge_coef, h->edge.GBAR, h->stream, h->d_upart))
-                    pname = h->proj_split > 1 ? "k_project_rows" : "k_project_wg";
-                else
-                    launch_project(h->pd, h->var.OUT, h->var.GBAR, h->d_R, h->d_F, h->d_coef, h->n_elem, h->d_wtx, h->d_wty, eps_ptr,
-                                   h->d_loss_e, h->d_deps_e, h->var.N, h->n_elem, backward ? 1 : 0, h->edge.OUT, h->d_edge_dphi,
-                                   h->d_edge_coef, h->edge.GBAR, h->stream);
-                tstop(h, 1);
-                if (backward)
-                    snprintf(h->variant, sizeof h->variant, "%s + %s<%dx%d/%dx%d> + %s", use_mfma ? hpv_mfma_variant(h->mfma, 1) : "k_mlp_fwd_generic",
-                             pname, h->pd.qx, h->pd.qy, h->pd.ntx, h->pd.nty, use_mfma ? hpv_mfma_variant(h->mfma, 2) : "k_mlp_bwd_generic");
-                if (backward) {
-                    tstart(h, 2);
-                    if (use_mfma) hpv_mfma_backward(h->mfma, h->d_theta, h->var.X, h->var.GBAR, h->var.GPART, &h->var.rows, h->stream);
-                    else run_bwd(h, h->var, nullptr);
-                    tstop(h, 2);
-                }
-            }
-            if (backward && h->pd.edge) run_bwd(h, h->edge, h->mfma_edge);
-        }
+        if (!(backward && use_mfma && pass_whole_iteration(h, dt, pa, fuse_adam, pend, pl))) pass_separate(h, dt, pa, backward, use_mfma);
     }
-    // --- boundary / data term ---
+    // --- boundary / data term: inside the quadrature batch (one partial per 16-point data tile), or its own small batch ---
     int ndp = 0;
     if (h->n_data > 0 && h->merged) {
-        // handled inside the quadrature batch by the forward kernel itself: one partial per 16-point data tile
         ndp = (h->n_data + 15) / 16;
     } else if (h->n_data > 0) {
         if (fork) h->stream = h->stream2;   // the launch helpers read h->stream
@@ -409,14 +398,14 @@ int enqueue_pass(hpv_ctx* h, bool backward, bool fuse_adam = false, bool pend = 
         (void)hipStreamWaitEvent(smain, h->ev_join, 0);
     }
     const AdamArgs ad = adam_args(h);
-    if (backward && fuse_adam) h->persist_seen = fin_done;
-    if (!fin_done)
-    launch_finalize(backward && h->var.N > 0 ? h->var.GPART : nullptr, h->var.rows,
-                    backward && h->n_data > 0 && !h->merged ? h->data.GPART : nullptr, h->data.rows,
-                    backward && h->pd.edge && h->edge.N > 0 ? h->edge.GPART : nullptr, h->edge.rows, h->d_loss_e,
-                    n_loss, h->d_deps_e, h->d_data_part, ndp, h->cfg.lossb_weight, h->n_data, h->P, h->has_eps, h->d_RB,
-                    backward ? 1 : 0, (backward && (fuse_adam || pend_taken)) ? &ad : nullptr, h->stream, h->d_xerr,
-                    xch_used ? hpv_mfma_xiter(h->mfma) : nullptr, pend_taken ? 1 : 0);
+    if (backward && fuse_adam) h->persist_seen = pl.fin_done;
+    if (!pl.fin_done)
+        launch_finalize(backward && h->var.N > 0 ? h->var.GPART : nullptr, h->var.rows,
+                        backward && h->n_data > 0 && !h->merged ? h->data.GPART : nullptr, h->data.rows,
+                        backward && h->pd.edge && h->edge.N > 0 ? h->edge.GPART : nullptr, h->edge.rows, h->d_loss_e,
+                        pl.n_loss, h->d_deps_e, h->d_data_part, ndp, h->cfg.lossb_weight, h->n_data, h->P, h->has_eps, h->d_RB,
+                        backward ? 1 : 0, (backward && (fuse_adam || pl.pend_taken)) ? &ad : nullptr, h->stream, h->d_xerr,
+                        pl.xch_used ? hpv_mfma_xiter(h->mfma) : nullptr, pl.pend_taken ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, -2, "kernel launch failed: %s", hipGetErrorString(e));
     return 0;

@@ -403,7 +403,6 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     auto gs_ptr = [&](long tile) -> v2d* { return reinterpret_cast<v2d*>(g.ACTS + tile * GS_STRIDE) + lane; };
     double* PKw = lds + M::PK + wv * (NSV * 64) + lane;
     double* PKw2 = lds + M::PK + (4 + (NT2 > 0 ? wv : (wv & 1))) * (NSV * 64) + lane;
-    [[maybe_unused]] double* PKw3 = lds + M::PK + (8 + (wv & 1)) * (NSV * 64) + lane;      // NT2, whole tiles: tile 2 of waves 0, 1
     gdat = 0.0;
 
     // SPLIT: this workgroup takes no part in the exchange (an earlier launch of the handle failed -- sticky flag -- or the test
@@ -452,7 +451,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             if constexpr (NSV & 1) reinterpret_cast<double*>(zs + (NSV / 2) * 64 - lane)[lane] = sv[NSV - 1];   // (odd count: the last one alone, 8-byte lanes)
         } else if (k < n_lds) {     // wave-uniform
             double* pk = k == 0 ? PKw : PKw2;
-            if constexpr (NT2 > 0) pk = k == 0 ? PKw : (k == 1 ? PKw2 : PKw3);
+            // (NT2: the slot is formed HERE -- a third parking pointer kept alive across the phases sent the register allocator to
+            //  scratch memory, 420 - 540 scratch accesses per instantiation and 148 instead of 58 us per iteration: profiles/r06_notes.md)
+            if constexpr (NT2 > 0) pk = lds + M::PK + (k == 0 ? wv : (k == 1 ? 4 + wv : 8 + (wv & 1))) * (NSV * 64) + lane;
 #pragma unroll
             for (int j = 0; j < NSV; ++j) pk[j * 64] = sv[j];
         } else {
@@ -823,7 +824,9 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             for (int j = 0; j < NSV; ++j) sv[j] = B[NZP + j / 2][j & 1];
         } else if (k < n_lds) {
             const double* pk = k == 0 ? PKw : PKw2;
-            if constexpr (NT2 > 0) pk = k == 0 ? PKw : (k == 1 ? PKw2 : PKw3);
+            // (NT2: the slot is formed HERE -- a third parking pointer kept alive across the phases sent the register allocator to
+            //  scratch memory, 420 - 540 scratch accesses per instantiation and 148 instead of 58 us per iteration: profiles/r06_notes.md)
+            if constexpr (NT2 > 0) pk = lds + M::PK + (k == 0 ? wv : (k == 1 ? 4 + wv : 8 + (wv & 1))) * (NSV * 64) + lane;
 #pragma unroll
             for (int j = 0; j < NSV; ++j) sv[j] = pk[j * 64];
         } else {

@@ -874,10 +874,6 @@ bool hpv_mfma_iter_elem(HpvMfma* m, const double* theta, const double* X, double
     if (!m->prefer_elem && tpe_ <= 9 && !light && n_elem > 3L * m->n_cus) return false;
     // wavefronts per workgroup (kernels_elem.hip): two per SIMD for the light channel sets, where 256 registers per wave suffice
     int waves = (m->H <= 24 && tpe_ >= 8 && light) ? 8 : 4;
-    if (const char* e = getenv("HPV_ELEM_WAVES")) {      // (A/B switch, read per launch / capture)
-        if (atoi(e) == 4) waves = 4;
-        if (atoi(e) == 8 && m->H <= 24 && tpe_ >= 8) waves = 8;
-    }
     const int nq = pd.qx * pd.qy, tpe = (nq + 15) / 16, tpw = (tpe + waves - 1) / waves, slots = waves * tpw, nfree = slots - tpe;
     // batch layout [element points | pad to 16 | data points]
     const long npad = ((long)n_elem * nq + 15) / 16 * 16;

@@ -706,7 +706,11 @@ bool hpv_mfma_iter_tile(HpvMfma* m, const double* theta, const double* X, double
     a.proj_n_elem = n_elem;
     a.proj_split = 1;
     a.pa = pa;
-    const bool fin_off = getenv("HPV_NO_INKERNEL_FINALIZE") != nullptr;            // (A/B switch, read per launch / capture)
+#ifdef HPV_EXPERIMENTS
+    const bool fin_off = getenv("HPV_NO_INKERNEL_FINALIZE") != nullptr;            // (A/B switch of libhpvpinn_testhooks.so, read per launch / capture)
+#else
+    constexpr bool fin_off = false;
+#endif
     const bool fin_here = fin && blocks == 1 && n_elem == 1 && !fin_off;
     a.fin_mode = 0;
     a.persist_iters = 1;

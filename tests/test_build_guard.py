@@ -80,3 +80,43 @@ def test_margins_of_the_built_kernels():
             assert r.returncode == 0, r.stdout + r.stderr
             hi = int(re.search(r"AGPR a(\d+),", r.stdout).group(1))
             assert base - hi >= 6, (key, hi, base)
+
+
+def test_no_whole_iteration_kernel_spills_to_scratch():
+    """Round 6: one more pointer kept alive across the phases of k_iter_fused<.., NT2 = 1> sent the register allocator to scratch
+    memory -- 420 - 540 scratch accesses per instantiation, correct results, 148 instead of 58 us per iteration, and nothing said so.
+    check_agpr.py now counts them (exit 3, build.sh fails); here: NO instantiation of the hand-scheduled whole-iteration kernels in
+    the assembly csrc/build.sh left beside the objects touches scratch memory."""
+    import re
+    import pytest
+    csrc = os.path.join(ROOT, "hp_vpinns_amd", "csrc")
+    files = ["kernels_fused.s", "kernels_fused_gen.s", "kernels_tall.s"]
+    if not all(os.path.exists(os.path.join(csrc, f)) for f in files):
+        pytest.skip("no assembly beside the objects (library built elsewhere)")
+    n_kernels, spills = 0, {}
+    for f in files:
+        lines = open(os.path.join(csrc, f)).read().split("\n")
+        name = None
+        for l in lines:
+            m = re.match(r"^(_Z\d+k_iter_(fused|tall|small)\w+):", l)
+            if m:
+                name, n_kernels = m.group(1), n_kernels + 1
+            elif l.startswith(".Lfunc_end"):
+                name = None
+            elif name and re.search(r"\bscratch_(load|store)_", l.split(";")[0]):
+                spills[name] = spills.get(name, 0) + 1
+    assert n_kernels >= 40, n_kernels
+    # (k_iter_small<3> -- eight waves of 256 registers, config 3 -- has carried seven spilled quad-words since round 3: 14 accesses
+    #  outside its tile loops; anything beyond that, or any other kernel, is a regression)
+    known = {k: v for k, v in spills.items() if "k_iter_smallILi3E" in k and v <= 16}
+    assert spills == known, {k: v for k, v in spills.items() if k not in known}
+
+
+def test_guard_reports_spills(tmp_path):
+    f = tmp_path / "k.s"
+    f.write_text(ASM.format(hi=90).replace("\ts_cbranch_scc1 .LBB0_2", "\tscratch_store_dwordx2 off, v[2:3], off offset:8\n\ts_cbranch_scc1 .LBB0_2"))
+    script = os.path.join(ROOT, "scripts", "check_agpr.py")
+    r = subprocess.run([sys.executable, script, str(f), "k_testILi3", "106"], capture_output=True, text=True)
+    assert r.returncode == 3 and "spills" in r.stderr
+    r = subprocess.run([sys.executable, script, str(f), "k_testILi3", "106", "--spills-ok"], capture_output=True, text=True)
+    assert r.returncode == 0 and "SCRATCH" in r.stdout

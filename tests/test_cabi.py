@@ -75,7 +75,8 @@ def test_build_info_and_test_hooks_live_in_their_own_library():
     for kern in (b"k_residual_stream", b"k_residual_dma", b"k_residual_wdma", b"k_iter_tile_persist", b"k_bwd_wide_rc"):
         assert kern not in prod, kern
     switches = sorted(set(re.findall(rb"HPV_[A-Z0-9_]{3,}", prod)))
-    assert len(switches) <= 12, switches                 # README.md, "environment switches of libhpvpinn.so"
+    switches = [s_ for s_ in switches if s_ != b"HPV_BACKEND_GENERIC"]     # (an enum's name in a message, not a switch)
+    assert len(switches) <= 7, switches                  # README.md, "environment switches of libhpvpinn.so" (verdict round 5, item 6)
     assert os.path.exists(_lib.TEST_HOOKS_LIB_PATH)
     hooks = open(_lib.TEST_HOOKS_LIB_PATH, "rb").read()
     for name in (b"HPV_DEBUG_SPLIT_SKIP", b"HPV_TEST_RCCL_FAIL", b"HPV_PERSIST", b"HPV_PJ_STREAM", b"HPV_FUSED_GSTASH", b"HPV_WIDE_RC",

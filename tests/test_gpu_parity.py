@@ -667,9 +667,11 @@ def test_full_size_config4_properties():
         l3w, gw = mw.loss_and_grad()
         assert "k_project_wg<20x20/10x10>" in mw.h.kernel_variant()      # 256 elements: one workgroup per element
         os.environ["HPV_PJ_WG_SMALL"] = "0"                               # ... against "a lane owns a line" on the same grid
-        mt = poisson2d.build_model(s, L, init_params=th)
-        l3t, gt = mt.loss_and_grad()
-        assert "k_project_tp<20x20/10x10>" in mt.h.kernel_variant()
+        from hp_vpinns_amd import _lib as _l
+        with _l.library(_l.TEST_HOOKS_LIB_PATH):                          # (an A/B switch of the -DHPV_EXPERIMENTS build)
+            mt = poisson2d.build_model(s, L, init_params=th)
+            l3t, gt = mt.loss_and_grad()
+            assert "k_project_tp<20x20/10x10>" in mt.h.kernel_variant()
     finally:
         del os.environ["HPV_FUSE"]
         os.environ.pop("HPV_PJ_WG_SMALL", None)
@@ -1170,10 +1172,13 @@ def test_single_workgroup_grid_finishes_the_iteration_in_the_kernel():
     st = m.h.get_state()
     os.environ["HPV_NO_INKERNEL_FINALIZE"] = "1"
     try:
-        m2 = VPINN1D(*a, init_params=th)
-        l3b, gb = m2.loss_and_grad()
-        hist2 = m2._step_record(25)[0]
-        st2 = m2.h.get_state()
+        from hp_vpinns_amd import _lib as _l
+        with _l.library(_l.TEST_HOOKS_LIB_PATH):       # (an A/B switch of the -DHPV_EXPERIMENTS build)
+            m2 = VPINN1D(*a, init_params=th)
+            l3b, gb = m2.loss_and_grad()
+            assert m2.h.pass_structure() == "whole-iteration-tile"
+            hist2 = m2._step_record(25)[0]
+            st2 = m2.h.get_state()
     finally:
         del os.environ["HPV_NO_INKERNEL_FINALIZE"]
     assert np.array_equal(l3, l3b) and np.array_equal(g, gb)
