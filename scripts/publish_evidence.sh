@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 R=gpurun_out/$1
-P=${2:-r05}
+P=${2:-r06}
 cp $R/summary.md profiles/${P}_rocprof_summary.md
 cp $R/bench.json profiles/${P}_bench.json
 cp $R/bench_driver_style.json profiles/${P}_bench_driver_style.json

@@ -39,6 +39,8 @@ stats("stats")
 stats("stats_c5")
 stats("stats_c5n")
 stats("stats_w32")
+stats("stats_advf0")
+stats("stats_advf1")
 stats("stats_b")
 stats("stats_proj1")
 stats("stats_proj0")
@@ -46,6 +48,8 @@ TITLES = (("", "bench (config 4), default path: whole-iteration kernel"),
           ("_c5", "config 5 (AdvDiff 8 x 80x80 points), default path: tall-element whole-iteration kernel"),
           ("_c5n", "config 5, HPV_FUSE=n: round 2's launches (forward -> activation store -> row-split projection -> reverse)"), ("_b", "bench (config 4), HPV_FUSE=b: forward + projection-fused reverse kernel"),
           ("_w32", "config-4 grid with [2,32,32,32,1]: the width-generic kernels k_fwd_wide / k_bwd_wide + k_project_wg"),
+          ("_advf0", "AdvDiff var_form 0, 16x16 elements of 16x16 points: k_iter_fused<.., NT2 = 1, GEN>"),
+          ("_advf1", "AdvDiff var_form 1, 16x16 elements of 16x16 points: k_iter_fused<.., GEN>"),
           ("_proj1", "projection kernel, residual + adjoint, 2^18-element batch"), ("_proj0", "projection kernel, residual only, 2^18-element batch"))
 for tagp, title in TITLES:
     fe, wr = pmc("pmc_fetch" + tagp), pmc("pmc_write" + tagp)
@@ -58,7 +62,7 @@ for tagp, title in TITLES:
             f_, w_ = fe.get(k, {}).get("FETCH_SIZE", 0.0), wr.get(k, {}).get("WRITE_SIZE", 0.0)
             if f_ + w_ > 1.0:
                 print(f"| `{k}` | {f_:.0f} | {w_:.0f} | {(2 * f_ + w_) * 1024:.3e} |")
-for tagp, title in (("", "default path"), ("_c5", "config 5, tall-element kernel"), ("_w32", "config-4 grid, 32-wide network"), ("2", "default path, second pass"), ("_b", "HPV_FUSE=b")):
+for tagp, title in (("", "default path"), ("_c5", "config 5, tall-element kernel"), ("_w32", "config-4 grid, 32-wide network"), ("_advf0", "AdvDiff var_form 0 on k_iter_fused<NT2=1,GEN>"), ("_advf1", "AdvDiff var_form 1 on k_iter_fused<GEN>"), ("2", "default path, second pass"), ("_b", "HPV_FUSE=b")):
     sq = pmc("pmc_sq" + tagp)
     if sq:
         print(f"\n### SQ counters per launch (bench, {title})\n")
@@ -84,6 +88,10 @@ for k in set(fe) | set(wr):
 fe, wr = pmc("pmc_fetch_c5"), pmc("pmc_write_c5")
 for k in set(fe) | set(wr):
     if "k_iter_tall" in k: tj["iter_tall"] = corrected(fe, wr, k)
+for gp in ("advf0", "advf1"):
+    fe, wr = pmc("pmc_fetch_" + gp), pmc("pmc_write_" + gp)
+    for k in set(fe) | set(wr):
+        if "k_iter_fused" in k: tj["iter_fused_" + gp] = corrected(fe, wr, k)
 fe, wr = pmc("pmc_fetch_c5n"), pmc("pmc_write_c5n")
 c5n = sum(corrected(fe, wr, k) for k in set(fe) | set(wr) if "rocclr" not in k)
 if c5n: tj["config5_round2_launches_total"] = c5n
