@@ -34,7 +34,7 @@ EXPORTS = [
     "hpv_set_collocation_shard", "hpv_rccl_unique_id", "hpv_rccl_connect", "hpv_rccl_selftest", "hpv_rccl_disconnect", "hpv_exchange_in_use",
     "hpv_rccl_available", "hpv_graphs_in_use", "hpv_updates_applied", "hpv_set_shared_element_kernels", "hpv_shared_element_kernels",
     "hpv_kernel_variant", "hpv_build_info", "hpv_rccl_abandon", "hpv_bench_residual_checksums", "hpv_rule_advice",
-    "hpv_rccl_info", "hpv_rccl_time_allreduce",
+    "hpv_rccl_info", "hpv_rccl_time_allreduce", "hpv_grid_plan",
 ]
 
 
@@ -47,6 +47,14 @@ def rule_advice(device, dim, q, ntx, nty, n_elem_shard, exact_counts=False, n_hi
     if rc:
         raise HpvError(f"hpv_rule_advice({dim}, {q}, {ntx}, {nty}, {n_elem_shard}) returned {rc}")
     return qd.value, nd.value
+
+
+def grid_plan(device, q, n_hidden, n_elem_shard):
+    """hpv_grid_plan: 0 separate launches | 1 one workgroup per element | 2 element loop | 3 full rounds + split tail."""
+    rc = load().hpv_grid_plan(int(device), int(q), int(n_hidden), int(n_elem_shard))
+    if rc < 0:
+        raise HpvError(f"hpv_grid_plan({q}, {n_hidden}, {n_elem_shard}) returned {rc}")
+    return rc
 
 
 class HpvConfig(C.Structure):
@@ -171,6 +179,7 @@ def load():
     lib.hpv_bench_residual_checksums.argtypes = [h, C.c_long, C.c_int, _dp]
     lib.hpv_kernel_variant.argtypes = [h, C.c_char_p, C.c_size_t]
     lib.hpv_build_info.argtypes = []
+    lib.hpv_grid_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_long]
     lib.hpv_rule_advice.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.hpv_build_info.restype = C.c_char_p
     _libs[path] = lib

@@ -1433,6 +1433,14 @@ int hpv_rule_advice(int device, int dim, int q, int ntx, int nty, long n_elem_sh
     }
     return 0;
 }
+int hpv_grid_plan(int device, int q, int n_hidden, long n_elem_shard) {
+    if ((q != 12 && q != 16 && q != 20) || n_hidden < 2 || n_hidden > 3 || n_elem_shard < 1) return -1;
+    int n_cus = 256;
+    hipDeviceProp_t prop;
+    if (device >= 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
+    else (void)hipGetLastError();
+    return hpv_fused_grid_plan(q, n_hidden, n_elem_shard, n_cus, hpv_fused_loop_built());
+}
 int hpv_updates_applied(hpv_handle h, long long* n) {
     if (!h || !n) return -1;
     unsigned long long v = 0;

@@ -242,6 +242,12 @@ int hpv_set_shared_element_kernels(hpv_handle h, int on);
  * WORKGROUP PER ELEMENT will run -- not where the element loop or the separate launches take the grid (on many rounds the padded
  * points cost more than the structure saves).  No handle needed; the same limits gate the launch functions. */
 int hpv_rule_advice(int device, int dim, int q, int ntx, int nty, long n_elem_shard, int exact_counts, int n_hidden, int* q_dev, int* nt_dev);
+/* How the whole-iteration kernel takes a shard of n_elem_shard elements of one of its 2-D rules (q = 12, 16, 20 points per
+ * direction; N_el_x, N_el_y are free: P2:282-283, P3:44-45) under a network of n_hidden hidden layers on `device`: 0 = not at all
+ * (the separate launches), 1 = one workgroup per element, 2 = the element loop (CUs workgroups walk the elements), 3 = the full
+ * rounds with one workgroup per element + the ragged tail (n mod CUs elements) shared by 2 - 8 workgroups each in a second launch.
+ * The dispatch's own function (csrc/hpv_mfma.h, hpv_fused_grid_plan) with this build's instantiations; < 0: bad arguments. */
+int hpv_grid_plan(int device, int q, int n_hidden, long n_elem_shard);
 /* The network value and its input-derivative channels at the owned quadrature points, [C][n_owned*qx*qy]
  * (channel order: u, then d/dx, d/dy (d/dt), then the second derivatives the variational form integrates) --
  * what net_u / net_du / net_dxu / net_dyu / net_dtu return (P1:140-148, P2:171-185, P3:232-245).  One forward launch. */

@@ -11,6 +11,7 @@ cp $R/bench_driver_style.json profiles/${P}_bench_driver_style.json
 cp $R/stats/bench_kernel_stats.csv profiles/${P}_bench_kernel_stats.csv
 cp $R/stats_c5/c5_kernel_stats.csv profiles/${P}_config5_kernel_stats.csv
 cp $R/stats_w32/w32_kernel_stats.csv profiles/${P}_wide32_kernel_stats.csv
+for gp in advf0 advf1; do [ -f $R/stats_$gp/${gp}_kernel_stats.csv ] && cp $R/stats_$gp/${gp}_kernel_stats.csv profiles/${P}_${gp}_kernel_stats.csv; done
 cp $R/stats_proj1/proj_kernel_stats.csv profiles/${P}_proj_kernel_stats.csv
 cp $R/stats_proj0/proj_kernel_stats.csv profiles/${P}_proj_residual_only_kernel_stats.csv
 python3 - "$R" "$P" <<'PY'

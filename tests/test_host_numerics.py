@@ -239,6 +239,27 @@ def test_zero_weight_padding_of_quadrature_rules():
     assert _device_rule_2d(xa, _, xb, wb, 5, 5, 64)[0].size == 12           # different rules per direction: left alone
 
 
+def test_grid_plan_of_the_whole_iteration_kernel():
+    """hpv_grid_plan = the dispatch's own hpv_fused_grid_plan (256 CUs when no device can be queried): one workgroup per element up to
+    the chip; the element loop on many full rounds where it is built (not for three hidden layers on 20x20 points); round 6: a ragged
+    last round of 20x20-point elements from two full rounds on = full rounds + the tail in split mode (1 600 = 6 x 256 + 64), with ONE
+    full round or smaller elements the separate launches (measured: profiles/r06_notes.md 3); tails beyond half a round keep the
+    80 %-full rule."""
+    from hp_vpinns_amd._lib import HpvError, grid_plan
+    assert grid_plan(-1, 20, 3, 256) == 1 and grid_plan(-1, 20, 3, 100) == 1 and grid_plan(-1, 12, 2, 1) == 1
+    assert grid_plan(-1, 20, 3, 1600) == 3 and grid_plan(-1, 20, 3, 1296) == 3 and grid_plan(-1, 20, 3, 552) == 3
+    assert grid_plan(-1, 20, 3, 289) == 0                        # one full round + 33: the separate launches (90 against 85 us)
+    assert grid_plan(-1, 20, 3, 4096) == 1 and grid_plan(-1, 20, 3, 512) == 1          # whole rounds
+    assert grid_plan(-1, 20, 3, 400) == 0 and grid_plan(-1, 20, 3, 480) == 1            # 1.56 / 1.88 rounds: below / above 80 % full
+    assert grid_plan(-1, 16, 3, 552) == 0 and grid_plan(-1, 16, 3, 289) == 0            # 16x16 points: ragged grids on the separate launches
+    assert grid_plan(-1, 16, 3, 1024) == 2 and grid_plan(-1, 16, 3, 768) == 1           # the element loop from four full rounds on
+    assert grid_plan(-1, 20, 2, 1536) == 2 and grid_plan(-1, 20, 2, 1600) == 3          # two hidden layers: the loop exists on 20x20 points
+    assert grid_plan(-1, 12, 3, 1024) == 0                                              # many small elements: beyond hpv_elem_resident_max
+    for bad in ((14, 3, 10), (20, 4, 10), (20, 3, 0)):
+        with pytest.raises(HpvError):
+            grid_plan(-1, *bad)
+
+
 def test_device_tanh_algorithm_in_exact_arithmetic():
     """csrc/hpv_math.h, round 5 (25 fp64 operations: k and 2^k from the bits of one fma, degree-9 interpolant of (e^(-2w) - 1 + 2w) / w^2):
     the same operation sequence with every operation rounded once (rational arithmetic), the polynomial READ FROM THE HEADER, against
