@@ -202,15 +202,16 @@ def main():
         os.environ.setdefault("HPV_EXCHANGE", "p2p")
     torch.cuda.set_device(local_rank)
     dist = None
-    red_dev = "cpu" if one_gpu else "cuda"
+    # The bench's own control plane -- barriers, MAX over ranks, the object collectives of the communicator set-up -- runs on CPU tensors
+    # over gloo at every N: the library's communicator (hpv_rccl_*) is then the ONLY RCCL communicator of a rank (verdict round 5, weak 5 ii:
+    # torch's NCCL communicator beside it would have been a first-ever co-existence at N > 1); "cuda:nccl" stays registered for the
+    # `torch` exchange fallback, which creates its communicator lazily, only if it is ever used.
+    red_dev = "cpu"
     if world > 1 or ("RANK" in os.environ and os.environ.get("HPV_FORCE_DIST") == "1"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("cpu:gloo,cuda:nccl")      # (the one-GPU test hook takes the same group: its exchange is the mailbox one)
 
     from hp_vpinns_amd.dist import shard_range
     from hp_vpinns_amd.drivers import poisson2d
@@ -219,10 +220,10 @@ def main():
     theta = xavier_init(LAYERS, 1234)
 
     def barrier(m):
-        if dist is not None:
-            dist.barrier()
         m.h.sync()
         torch.cuda.synchronize()
+        if dist is not None:
+            dist.all_reduce(torch.zeros(1, dtype=torch.float64))      # (a barrier over gloo, CPU tensor: every rank's device work is done)
 
     def max_over_ranks(v):
         if dist is None:
