@@ -646,7 +646,9 @@ static void run_fwd(const MfmaArgs& a, int blocks, hipStream_t s) {
 static size_t bwd_lds_bytes(int P, int L, int C, int waves);
 template <int D, int NT1, int NT2, int ACT, int L, int QX, int QY, int NTX, int NTY>
 static void run_bwd_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
-    constexpr int FW = L <= 3 ? 8 : 4;   // wavefronts per element block (a 4-hidden-layer net needs > 256 registers per wave)
+    // wavefronts per element block (a 4-hidden-layer net needs > 256 registers per wave; four channels: their transpose tiles for eight
+    // waves are 174 KB of LDS)
+    constexpr int FW = (L <= 3 && NT2 == 0) ? 8 : 4;
     size_t lds = bwd_lds_bytes(a.P, L, 1 + NT1 + NT2, FW);
     static bool attr_set = false;
     if (!attr_set) {
@@ -667,12 +669,14 @@ template <int D, int NT1, int NT2, int ACT, int L>
 static bool pick(HpvMfma* m) {
     m->fwd = run_fwd<D, NT1, NT2, ACT, L>;
     m->bwd = run_bwd<D, NT1, NT2, ACT, L>;
-    if constexpr (D == 2 && NT1 == 2 && NT2 == 0 && ACT == HPV_ACT_TANH)   // BASELINE config 4 (Poisson-2D var_form 1)
+    // BASELINE config 4 (Poisson-2D var_form 1); round 6: the four-channel forms on that element shape too (Poisson-2D var_form 0, AdvDiff
+    // var_form 0 -- with three hidden layers they have no whole-iteration instantiation there: the projection rides in the reverse kernel)
+    if constexpr (D == 2 && NT1 == 2 && NT2 <= 1 && ACT == HPV_ACT_TANH)
         m->bwd_fused = run_bwd_fused<D, NT1, NT2, ACT, L, 20, 20, 10, 10>;
     const char* an = ACT == HPV_ACT_SIN ? "sin" : "tanh";
     snprintf(m->vfwd, sizeof m->vfwd, "k_fwd_mfma<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=20>", D, NT1, NT2, an, L);
     snprintf(m->vbwd, sizeof m->vbwd, "k_bwd_mfma<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=20>", D, NT1, NT2, an, L);
-    if (m->bwd_fused) snprintf(m->vbwd_fused, sizeof m->vbwd_fused, "k_bwd_mfma<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=20,proj=20x20/10x10,waves=%d>", D, NT1, NT2, an, L, L <= 3 ? 8 : 4);
+    if (m->bwd_fused) snprintf(m->vbwd_fused, sizeof m->vbwd_fused, "k_bwd_mfma<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=20,proj=20x20/10x10,waves=%d>", D, NT1, NT2, an, L, (L <= 3 && NT2 == 0) ? 8 : 4);
     size_t lds = bwd_lds_bytes(m->nd.P, L, 1 + NT1 + NT2);
     int of = 1, ob = 1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, k_fwd_mfma<D, NT1, NT2, ACT, L>, MF_BLOCK, fwd_lds_bytes(L));
