@@ -109,8 +109,7 @@ guarded_compile() {   # guarded_compile <source stem> <object> <extra flags> <fi
       keys3="$keys3 k_iter_fusedILi${1}ELb0ELb0ELb0${S}Lb0ELi0ELb1E $2 k_iter_fusedILi${1}ELb1ELb0ELb0${S}Lb0ELi0ELb1E $2"
       keys3="$keys3 k_iter_fusedILi${1}ELb0ELb0ELb0${S16}Lb0ELi0ELb1E $3 k_iter_fusedILi${1}ELb1ELb0ELb0${S16}Lb0ELi0ELb1E $3"
       keys3="$keys3 k_iter_fusedILi${1}ELb0ELb0ELb0${S12}Lb0ELi0ELb1E $4 k_iter_fusedILi${1}ELb1ELb0ELb0${S12}Lb0ELi0ELb1E $4"
-      keys3q="$keys3q k_iter_fusedILi${1}ELb0ELb1ELb0${S16}Lb0ELi0ELb1E $3 k_iter_fusedILi${1}ELb0ELb1ELb0${S12}Lb0ELi0ELb1E $4"
-      [ $1 = 2 ] && keys3q="$keys3q k_iter_fusedILi${1}ELb0ELb1ELb0${S}Lb0ELi0ELb1E $2"      # (L = 3 on 20x20 points: not instantiated, a111 of 106)
+      keys3q="$keys3q k_iter_fusedILi${1}ELb0ELb1ELb0${S}Lb0ELi0ELb1E $2 k_iter_fusedILi${1}ELb0ELb1ELb0${S16}Lb0ELi0ELb1E $3 k_iter_fusedILi${1}ELb0ELb1ELb0${S12}Lb0ELi0ELb1E $4"
       # four channels park one more tile per wave in LDS: the stash is 2 L x 5 registers shorter
       keys4="$keys4 k_iter_fusedILi${1}ELb0ELb0ELb0${S16}Lb0ELi1ELb1E $(($3 + 10 * $1)) k_iter_fusedILi${1}ELb1ELb0ELb0${S16}Lb0ELi1ELb1E $(($3 + 10 * $1))"
       keys4="$keys4 k_iter_fusedILi${1}ELb0ELb0ELb0${S12}Lb0ELi1ELb1E $(($4 + 10 * $1)) k_iter_fusedILi${1}ELb1ELb0ELb0${S12}Lb0ELi1ELb1E $(($4 + 10 * $1))"

@@ -304,12 +304,28 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     // GEN: the trainable coefficient and the term weights.  slot 0 of the LDS channel array holds G_0 = sum_c wa0(c) ch_c; slot 1
     // holds G_1 (two terms) or E = dG_0 / d eps (one term); the channels' adjoints are gb_c = wa0(c) Gbar_0 + wb1(c) Gbar_1.
     // (formed where they are used from kernel arguments -- scalar registers -- and eps: nothing lives across the phases)
-    [[maybe_unused]] const double geps = (GEN && pa.eps_ptr) ? pa.eps_ptr[0] : 0.0;
+    // (wave-uniform values made so explicitly -- v_readfirstlane of both halves -- and formed ONCE: they live in scalar registers.  Formed at
+    //  their uses they were hoisted as VECTOR values parked in a102..a111 across the phases: the general quarter tile on 20x20 points did
+    //  not fit its stash (a111 of 106); now a99, the other general instantiations a91 / a147 instead of a99 / a159)
+    [[maybe_unused]] auto uni = [](double x) -> double {
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+    };
+    [[maybe_unused]] const double geps = (GEN && pa.eps_ptr) ? uni(pa.eps_ptr[0]) : 0.0;
     [[maybe_unused]] const bool gtwo = GEN && pa.pd.nterms > 1;
-    [[maybe_unused]] auto wa0 = [&](int c) -> double { return fma(geps, pa.pd.t[0].a1[c], pa.pd.t[0].a0[c]); };
-    [[maybe_unused]] auto wa1 = [&](int c) -> double { return gtwo ? fma(geps, pa.pd.t[1].a1[c], pa.pd.t[1].a0[c]) : pa.pd.t[0].a1[c]; };
-    [[maybe_unused]] auto wb1 = [&](int c) -> double { return gtwo ? fma(geps, pa.pd.t[1].a1[c], pa.pd.t[1].a0[c]) : 0.0; };
-    [[maybe_unused]] const double gm0 = (GEN && pa.pd.t[0].eps_mult) ? geps : 1.0, gm1 = (gtwo && pa.pd.t[1].eps_mult) ? geps : 1.0;   // the factor eps of a term (P3:171)
+    [[maybe_unused]] double WA0[C], WA1[C], WB1[C];
+    if constexpr (GEN) {
+#pragma unroll
+        for (int c = 1; c < C; ++c) {
+            const double t1 = uni(fma(geps, pa.pd.t[1].a1[c], pa.pd.t[1].a0[c]));
+            WA0[c] = uni(fma(geps, pa.pd.t[0].a1[c], pa.pd.t[0].a0[c]));
+            WA1[c] = uni(gtwo ? t1 : pa.pd.t[0].a1[c]);
+            WB1[c] = uni(gtwo ? t1 : 0.0);
+        }
+    }
+    [[maybe_unused]] auto wa0 = [&](int c) -> double { return WA0[c]; };
+    [[maybe_unused]] auto wa1 = [&](int c) -> double { return WA1[c]; };
+    [[maybe_unused]] auto wb1 = [&](int c) -> double { return WB1[c]; };
+    [[maybe_unused]] const double gm0 = uni((GEN && pa.pd.t[0].eps_mult) ? geps : 1.0), gm1 = uni((gtwo && pa.pd.t[1].eps_mult) ? geps : 1.0);   // the factor eps of a term (P3:171)
     [[maybe_unused]] const double ge0 = (GEN && pa.pd.t[0].eps_mult) ? 1.0 : 0.0, ge1 = (gtwo && pa.pd.t[1].eps_mult) ? 1.0 : 0.0;
     const int ro_k = tid / FZ_NTX, ro_r = tid % FZ_NTX;                 // residual (k, r) of thread tid < NR, and whether the run has it
     const bool ro_on = tid < FZ_NR && ro_k < rny && ro_r < rnx;
@@ -1804,8 +1820,7 @@ static bool launch_iter_fused_gen_shape(int L, int plan, int nt2, const MfmaArgs
 #ifdef HPV_FZ_GEN_NO_QT
             return false;
 #else
-            // (three hidden layers on 20x20 points: the general quarter tile takes the compiler to a111 of the 106 AGPRs the stash leaves)
-            if constexpr (HAS_QT) { if (L == 2) FZ_GG(2, false, true, 0); else if constexpr (QX_ != 20) FZ_GG(3, false, true, 0); else return false; } else return false;
+            if constexpr (HAS_QT) { if (L == 2) FZ_GG(2, false, true, 0); else FZ_GG(3, false, true, 0); } else return false;
 #endif
         } else return false;
         return true;

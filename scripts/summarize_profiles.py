@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 outputs of scripts/gpu_round.sh into a markdown summary."""
+"""Condense the rocprofv3 outputs of scripts/gpu_round_r0N.sh into a markdown summary."""
 import collections
 import csv
 import glob
