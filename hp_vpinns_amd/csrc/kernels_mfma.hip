@@ -669,9 +669,10 @@ template <int D, int NT1, int NT2, int ACT, int L>
 static bool pick(HpvMfma* m) {
     m->fwd = run_fwd<D, NT1, NT2, ACT, L>;
     m->bwd = run_bwd<D, NT1, NT2, ACT, L>;
-    // BASELINE config 4 (Poisson-2D var_form 1); round 6: the four-channel forms on that element shape too (Poisson-2D var_form 0, AdvDiff
-    // var_form 0 -- with three hidden layers they have no whole-iteration instantiation there: the projection rides in the reverse kernel)
-    if constexpr (D == 2 && NT1 == 2 && NT2 <= 1 && ACT == HPV_ACT_TANH)
+    // BASELINE config 4 (Poisson-2D var_form 1).  (Round 6 measured it for the four-channel forms on that element shape, which have no
+    // whole-iteration instantiation with three hidden layers there: 95.3 against 95.5 us on the separate launches -- four waves per block
+    // instead of eight, their transpose tiles would be 174 KB: not instantiated)
+    if constexpr (D == 2 && NT1 == 2 && NT2 == 0 && ACT == HPV_ACT_TANH)
         m->bwd_fused = run_bwd_fused<D, NT1, NT2, ACT, L, 20, 20, 10, 10>;
     const char* an = ACT == HPV_ACT_SIN ? "sin" : "tanh";
     snprintf(m->vfwd, sizeof m->vfwd, "k_fwd_mfma<D=%d,NT1=%d,NT2=%d,%s,L=%d,H=20>", D, NT1, NT2, an, L);

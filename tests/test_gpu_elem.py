@@ -555,7 +555,7 @@ def test_default_policy_picks_the_faster_structure_per_shape():
                                         (12, 6, [2, 20, 20, 20, 1], 2, "whole-iteration-element", 8),
                                         (20, 10, [2, 20, 20, 20, 1], 2, "whole-iteration-element", 8),
                                         (16, 8, [2, 20, 20, 20, 1], 0, "whole-iteration-split", None),      # (round 6: the general forms of k_iter_fused)
-                                        (20, 10, [2, 20, 20, 20, 1], 0, "fused-reverse", None),             # (four channels, three layers on 20x20 points: the projection rides in the reverse kernel)
+                                        (20, 10, [2, 20, 20, 20, 1], 0, "separate", None),                  # (four channels, three layers on 20x20 points: no instantiation)
                                         (16, 8, [2, 32, 32, 32, 1], 1, "separate", None)]:
         a = _p2(q, nt, 3, 3) + (L,)
         m = VPINN2D(*a, var_form=vf, init_params=theta0(L, 3))
