@@ -605,7 +605,9 @@ int hpv_create(hpv_handle* out, const hpv_config* cfg) {
     h->nd_val = make_netdesc(*cfg, 0, t1, 0, t2);
     if (cfg->scheme == HPV_SCHEME_PINN) {
         if (cfg->pde != HPV_PDE_POISSON2D) { delete h; return fail(nullptr, -1, "scheme PINNs is the Poisson-2D branch (P2:128-129)"); }
-        h->nd_pinn = make_netdesc(*cfg, 2, t1, 2, t2);
+        // (u_xx + u_yy as ONE mixed second tangent, NetDesc::t2w: four channels instead of five through forward and reverse -- P2:187-194)
+        h->nd_pinn = make_netdesc(*cfg, 2, t1, 1, t2);
+        h->nd_pinn.t2w[0] = 1.0; h->nd_pinn.t2w[1] = 1.0;
     } else if (cfg->scheme != HPV_SCHEME_VPINN) { delete h; return fail(nullptr, -1, "unknown scheme %d", cfg->scheme); }
     pd.C = h->nd_var.C;
     pd.has_eps = h->has_eps;

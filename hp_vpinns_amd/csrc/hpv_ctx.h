@@ -99,7 +99,7 @@ struct hpv_ctx {
     HpvMfma* mfma_eval = nullptr;
     double* d_eval_out = nullptr;
     long eval_N = 0;
-    // strong-form PINN branch (scheme == PINNs): collocation batch with the 5 Laplacian channels
+    // strong-form PINN branch (scheme == PINNs): collocation batch: u, u_x, u_y and the Laplacian as one mixed second tangent (four channels)
     NetDesc nd_pinn{};
     Batch colloc;
     HpvMfma* mfma_colloc = nullptr;

@@ -825,7 +825,7 @@ void launch_debug_act(int act, const double* x, int n, double* a, double* a1, do
 
 // ------------------------------------------------------------------------------------------------
 // Strong-form PINN residual of the 2-D Poisson problem (P2:187-194): r = u_xx + u_yy - f at the
-// collocation points; lossp = mean(r^2) (P2:124).  Channels: [u, u_x, u_y, u_xx, u_yy].
+// collocation points; lossp = mean(r^2) (P2:124).  Channels: [u, u_x, u_y, u_xx + u_yy] (the Laplacian as one mixed second tangent).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_pinn_residual(const double* __restrict__ OUT, const double* __restrict__ f,
                                                       double* __restrict__ GBAR, double* __restrict__ part, long N,
@@ -835,9 +835,9 @@ __global__ void __launch_bounds__(256) k_pinn_residual(const double* __restrict_
     double sq = 0.0;
     const double sc = 2.0 / (double)n_total;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
-        const double r = OUT[3 * N + p] + OUT[4 * N + p] - f[p];
+        const double r = OUT[3 * N + p] - f[p];
         sq += r * r;
-        if (write_gbar) { GBAR[3 * N + p] = sc * r; GBAR[4 * N + p] = sc * r; }
+        if (write_gbar) GBAR[3 * N + p] = sc * r;
     }
     sq = block_sum(sq, red);
     if (threadIdx.x == 0) part[blockIdx.x] = sq / (double)n_total;
