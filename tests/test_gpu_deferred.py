@@ -23,7 +23,7 @@ L3 = [2, 20, 20, 1]
 # with exactly the parameter k_finalize stores behind it, which is exactly what k_adam / the fused finalize would have stored.
 
 
-def _model(nx, ny, layers, mode, q=20, nt=10, seed=5, env=None):
+def _model(nx, ny, layers, mode, q=20, nt=10, seed=5, env=None, var_form=1):
     from hp_vpinns_amd.drivers import poisson2d
     from hp_vpinns_amd.init import xavier_init
     saved = {}
@@ -35,7 +35,7 @@ def _model(nx, ny, layers, mode, q=20, nt=10, seed=5, env=None):
         os.environ[k] = v
     try:
         s = poisson2d.setup(N_el_x=nx, N_el_y=ny, N_test_x=nt, N_test_y=nt, N_quad=q, N_bound=13, with_test_grid=False)
-        m = poisson2d.build_model(s, layers, init_params=xavier_init(layers, seed))
+        m = poisson2d.build_model(s, layers, var_form=var_form, init_params=xavier_init(layers, seed))
     finally:
         for k, v in saved.items():
             if v is None:
@@ -69,13 +69,23 @@ CALLS = [("record", 19), ("step", 1), ("step", 1), ("step", 8), ("record", 3), (
                                               # (the prologue is paid per workgroup: hpv_mfma_iter_fused declines it on grids larger than the chip)
     (17, 17, L4, None, False),                # ragged grid larger than the chip: separate launches, the update in front of the pass
     (4, 4, L4, {"HPV_FUSE": "s"}, False),     # separate launches by request
-], ids=["config4", "shared-element", "two-layers", "eager", "two-rounds", "separate-ragged", "separate-forced"])
+    (16, 16, L4, {"Q": "16", "VF": "0"}, True),      # round 6: the general forms -- Poisson-2D var_form 0 (four channels) on 16x16 points, one workgroup per element
+    (8, 4, L3, {"Q": "12", "VF": "0"}, True),        # ... and a shared-element shard of it
+    (24, 23, L4, None, True),                 # round 6: two full rounds + a 40-element tail in split mode: two launches, the update applied in front
+], ids=["config4", "shared-element", "two-layers", "eager", "two-rounds", "separate-ragged", "separate-forced", "general-form", "general-form-shard",
+        "ragged-tail"])
 def test_deferred_update_reproduces_the_per_iteration_update(nx, ny, layers, env, rides):
-    ref = _run(_model(nx, ny, layers, "rccl_eager_updates", env=env), CALLS)
-    m = _model(nx, ny, layers, "rccl", env=env)
+    env = dict(env or {})
+    kw = {}
+    if "Q" in env:      # (not environment variables: the element shape / variational form of the general-form cases)
+        kw = dict(q=int(env.pop("Q")), var_form=int(env.pop("VF")))
+        kw["nt"] = kw["q"] // 2
+    env = env or None
+    ref = _run(_model(nx, ny, layers, "rccl_eager_updates", env=env, **kw), CALLS)
+    m = _model(nx, ny, layers, "rccl", env=env, **kw)
     assert m.h.exchange_in_use() == "rccl"
     got = _run(m, CALLS)
-    one = _run(_model(nx, ny, layers, "single", env=env), CALLS)
+    one = _run(_model(nx, ny, layers, "single", env=env, **kw), CALLS)
     n_total = sum(n for _, n in CALLS)
     assert got[3] == ref[3] == one[3] == n_total
     for other, what in ((ref, "k_adam per iteration"), (one, "single-GPU iteration")):
