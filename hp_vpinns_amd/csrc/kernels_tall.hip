@@ -213,110 +213,79 @@ __global__ void __launch_bounds__(TA_BLOCK, 1) k_iter_tall(MfmaArgs g) {
     // =============================================================================================
     // phase F: forward
     // =============================================================================================
-    // Two tiles per trip (round 6; kernels_fused.hip's forward does the same): their instruction streams are independent, so the
-    // scheduler fills the MFMA -> tanh -> MFMA dependency bubbles of one tile with the other's work -- a single wave per SIMD has
-    // nothing else to issue.  (-DHPV_TALL_FWD1: one tile per trip, A/B)
-    auto fwd_trip = [&](int k0, auto NT_) {
-        constexpr int NT = decltype(NT_)::value;
-        double x0[NT], x1[NT];
-        bool valid[NT];
-        long pp[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const long tile = tile_of(k0 + t);
-            pp[t] = tile * 16 + pt;
-            valid[t] = pp[t] < g.N;
-            const long pc = valid[t] ? pp[t] : g.N - 1;
-            x0[t] = valid[t] ? g.X[pc] : 0.0; x1[t] = valid[t] ? g.X[g.N + pc] : 0.0;
-        }
+#pragma unroll 1
+    for (int k = 0; k < n_own; ++k) {
+        const long tile = tile_of(k);
+        const long p = tile * 16 + pt;
+        const bool valid = p < g.N;
+        const long pc = valid ? p : g.N - 1;
+        const double x0 = valid ? g.X[pc] : 0.0, x1 = valid ? g.X[g.N + pc] : 0.0;
         int lofs = lane;
         asm volatile("" : "+v"(lofs));       // opaque: the LDS fragment reads stay inside the loop
-        double h[NT][C][MF_KS], sv[NT][NSV];
+        double h[C][MF_KS], sv[NSV];
         // layer 1 (VALU)
 #pragma unroll
         for (int s = 0; s < MF_KS; ++s) {
             const double w0 = lds[M::W1O + (0 * MF_KS + s) * 64 + lofs], w1 = lds[M::W1O + (1 * MF_KS + s) * 64 + lofs];
-            const double b1v = lds[M::W1O + (3 * MF_KS + s) * 64 + lofs];
+            const double z = lds[M::W1O + (3 * MF_KS + s) * 64 + lofs] + x0 * w0 + x1 * w1;
+            double a, a1, a2;
+            act_fwd<HPV_ACT_TANH>(z, a, a1, a2);
+            sv[s] = a;
+            h[0][s] = a;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const double z = b1v + x0[t] * w0 + x1[t] * w1;
-                double a, a1, a2;
-                act_fwd<HPV_ACT_TANH>(z, a, a1, a2);
-                sv[t][s] = a;
-                h[t][0][s] = a;
+            for (int u = 0; u < NT1; ++u) h[1 + u][s] = a1 * (u == 0 ? w0 : w1);
 #pragma unroll
-                for (int u = 0; u < NT1; ++u) h[t][1 + u][s] = a1 * (u == 0 ? w0 : w1);
-#pragma unroll
-                for (int b = 0; b < NT2; ++b) { const double wb = b == 0 ? w0 : w1; h[t][1 + NT1 + b][s] = a2 * wb * wb; }
-            }
+            for (int b = 0; b < NT2; ++b) { const double wb = b == 0 ? w0 : w1; h[1 + NT1 + b][s] = a2 * wb * wb; }
         }
 #pragma unroll
         for (int i = 1; i < L; ++i) {
-            double z[NT][C][MF_KS];
+            double z[C][MF_KS];
+            fz_layer<true>(WTl + (i - 1) * MF_KS * 64, WRl + (i - 1) * MF_KS * 16, BHl + (i - 1) * MF_KS * 64, lofs, h[0], z[0]);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                fz_layer<true>(WTl + (i - 1) * MF_KS * 64, WRl + (i - 1) * MF_KS * 16, BHl + (i - 1) * MF_KS * 64, lofs, h[t][0], z[t][0]);
+            for (int ch = 1; ch < C; ++ch)
+                fz_layer<false>(WTl + (i - 1) * MF_KS * 64, WRl + (i - 1) * MF_KS * 16, nullptr, lofs, h[ch], z[ch]);
 #pragma unroll
-                for (int ch = 1; ch < C; ++ch)
-                    fz_layer<false>(WTl + (i - 1) * MF_KS * 64, WRl + (i - 1) * MF_KS * 16, nullptr, lofs, h[t][ch], z[t][ch]);
+            for (int s = 0; s < MF_KS; ++s) {
+                double a, a1, a2;
+                act_fwd<HPV_ACT_TANH>(z[0][s], a, a1, a2);
+                sv[i * MF_KS + s] = a;
+                h[0][s] = a;
+#pragma unroll
+                for (int u = 0; u < NT1; ++u) h[1 + u][s] = a1 * z[1 + u][s];
+#pragma unroll
+                for (int b = 0; b < NT2; ++b) h[1 + NT1 + b][s] = a2 * z[1 + b][s] * z[1 + b][s] + a1 * z[1 + NT1 + b][s];
             }
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int s = 0; s < MF_KS; ++s) {
-                    double a, a1, a2;
-                    act_fwd<HPV_ACT_TANH>(z[t][0][s], a, a1, a2);
-                    sv[t][i * MF_KS + s] = a;
-                    h[t][0][s] = a;
-#pragma unroll
-                    for (int u = 0; u < NT1; ++u) h[t][1 + u][s] = a1 * z[t][1 + u][s];
-#pragma unroll
-                    for (int b = 0; b < NT2; ++b) h[t][1 + NT1 + b][s] = a2 * z[t][1 + b][s] * z[t][1 + b][s] + a1 * z[t][1 + NT1 + b][s];
-                }
         }
+        // linear head
+        double o[C];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int k = k0 + t;
-            // linear head
-            double o[C];
+        for (int ch = 0; ch < C; ++ch) {
+            double v = 0.0;
 #pragma unroll
-            for (int ch = 0; ch < C; ++ch) {
-                double v = 0.0;
+            for (int s = 0; s < MF_KS; ++s) v += h[ch][s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
+            v = xrow_sum16(v);
+            v = xrow_sum32(v);
+            o[ch] = v;
+        }
+        o[0] += bo;
+        if (k < n_el) {
+            if (q == 0) {
+                const int lp = lp_of(k);
 #pragma unroll
-                for (int s = 0; s < MF_KS; ++s) v += h[t][ch][s] * lds[M::W1O + (2 * MF_KS + s) * 64 + lofs];
-                v = xrow_sum16(v);
-                v = xrow_sum32(v);
-                o[ch] = v;
+                for (int ch = 0; ch < C; ++ch) lds[M::CH + ch * MAXP + lp] = o[ch];
             }
-            o[0] += bo;
-            if (k < n_el) {
-                if (q == 0) {
-                    const int lp = lp_of(k);
-#pragma unroll
-                    for (int ch = 0; ch < C; ++ch) lds[M::CH + ch * MAXP + lp] = o[ch];
-                }
-            } else {
-                // lossb = w mean((u_d - u)^2) (P3:184): adjoint of u kept in a register, per-tile partial sum to memory
-                const double dd = valid[t] ? g.ud[pp[t] - g.data_off] - o[0] : 0.0;
-                gdat = g.data_scale * dd;
-                const double sq = row_sum16(dd * dd);
-                if (lane == 0) g.data_part[pp[t] / 16 - g.data_off / 16] = sq;
-            }
-            switch (k) {     // wave-uniform; the stash slot must be a compile-time register index
-#define TA_STASH(K) case K: if constexpr (K < NSLOT) acc_put_all<ABASE + K * 2 * NSV, NSV>(sv[t]); break;
-                TA_STASH(0) TA_STASH(1) TA_STASH(2) TA_STASH(3)
+        } else {
+            // lossb = w mean((u_d - u)^2) (P3:184): adjoint of u kept in a register, per-tile partial sum to memory
+            const double dd = valid ? g.ud[p - g.data_off] - o[0] : 0.0;
+            gdat = g.data_scale * dd;
+            const double sq = row_sum16(dd * dd);
+            if (lane == 0) g.data_part[p / 16 - g.data_off / 16] = sq;
+        }
+        switch (k) {     // wave-uniform; the stash slot must be a compile-time register index
+#define TA_STASH(K) case K: if constexpr (K < NSLOT) acc_put_all<ABASE + K * 2 * NSV, NSV>(sv); break;
+            TA_STASH(0) TA_STASH(1) TA_STASH(2) TA_STASH(3)
 #undef TA_STASH
-            }
         }
-    };
-    {
-        int k0 = 0;
-#ifndef HPV_TALL_FWD1
-#pragma unroll 1
-        for (; k0 + 1 < n_own; k0 += 2) fwd_trip(k0, std::integral_constant<int, 2>{});
-#endif
-#pragma unroll 1
-        for (; k0 < n_own; ++k0) fwd_trip(k0, std::integral_constant<int, 1>{});
     }
     // ---- QT: this wave's packed quarter of the workgroup's extra tile (slot c = pt >> 2 = channel, j = pt & 3 = point) ----
     const int qcs = pt >> 2, qj = pt & 3;
