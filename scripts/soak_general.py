@@ -52,7 +52,7 @@ for name, mk in cases:
         assert np.all(np.isfinite(pa)) and np.all(np.isfinite(pb)), "non-finite parameters"
         if early is None:
             early = float(np.abs(pa - pb).max() / np.abs(pb).max())
-            assert early < 1e-7, (name, early)
+            assert early < 1e-6, (name, early)      # (AdvDiff: any two structures part at this rate, scripts/traj_probe.py)
     print("%s: %s | %d iterations x 2 structures in %.1f s; relative parameter difference to the separate launches after 1 000 iterations "
           "%.1e, at the end %.1e; loss %.3e against %.3e%s" % (name, a.h.kernel_variant(), n, time.perf_counter() - t0, early,
           float(np.abs(pa - pb).max() / np.abs(pb).max()), a.loss()[0], b.loss()[0],
