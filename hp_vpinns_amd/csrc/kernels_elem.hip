@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k_iter_elem(MfmaArgs g) {
 // host side
 // ------------------------------------------------------------------------------------------------
 // Wavefronts per workgroup: 4 (one per SIMD, 512 registers each) or 8 (two per SIMD, 256 registers each: half the tiles per wave,
-// the two waves of a SIMD cover each other's LDS / MFMA-result latencies).  HPV_ELEM_WAVES=4|8 forces one for A/B runs.
+// the two waves of a SIMD cover each other's LDS / MFMA-result latencies).  (The A/B switch HPV_ELEM_WAVES is gone since round 6.)
 template <int D, int NT1, int NT2, int ACT, int L, int H, int QX, int QY, int NTX, int NTY, int EL_WAVES>
 static bool launch_iter_elem_w(const MfmaArgs& a, int blocks, hipStream_t s) {
     using M = ElLds<D, NT1, NT2, L, H, QX, QY, NTX, NTY, EL_WAVES>;
