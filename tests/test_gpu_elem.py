@@ -225,7 +225,7 @@ def test_hand_tuned_whole_iteration_kernel_general_forms(prob, q, nt, nhid, grid
     l3b, gb = m.loss_and_grad()
     assert np.array_equal(gb, gm) and np.array_equal(l3b, l3m)
     lo, lm = [], []
-    for _ in range(2 if grid == "full" else 30):        # (the small shard: a longer trajectory -- epsilon moves through 30 updates)
+    for _ in range(2 if grid == "full" else 10):        # (the small shard: a longer trajectory -- epsilon moves through 10 updates)
         o.adam_step()
         lo.append(float(o.loss_parts()[0]))
         lm.append(float(m._step(1, True)[0]))

@@ -4,7 +4,7 @@ kernels (backend="generic": one plain code path, no shape-specific kernel, no ru
 round 4 (element shapes x run-time counts x padded rules x plans x grid-size policies); this test walks it with combinations no other
 test names.  Loss triple, gradient and three Adam iterations must agree to round-off.
 
-Every SECOND case of each sweep below 20 000 quadrature points (every fourth of the larger ones) is checked against the CPU ORACLE
+Every case of each sweep below 8 000 quadrature points, every SECOND one below 20 000 and every fourth of the larger ones is checked against the CPU ORACLE
 instead (oracle/vpinn_oracle.py, vectorised: autograd double backward of the restated TF1 graph) -- loss triple, gradient,
 residuals and one TF1-Adam update -- so that the sweep does not lean on the generic kernels being right for shapes no fixture
 covers (verdict round 4, weak 1 ii; round 5, weak 1: the fraction was 1/4).
@@ -27,7 +27,8 @@ os.environ.setdefault("HPV_FUZZ_SEED_USED", str(FUZZ_SEED))      # (tests/confte
 
 
 def _oracle_pick(i, n_points):
-    return i % (2 if n_points < 20000 else 4) == 0
+    """against the CPU oracle: every case below 8 000 quadrature points, every second one below 20 000, every fourth of the larger ones"""
+    return n_points < 8000 or i % (2 if n_points < 20000 else 4) == 0
 
 
 def _cases_2d():
