@@ -69,6 +69,12 @@ def test_margins_of_the_built_kernels():
     guarded = {"kernels_fused.s": [("k_iter_fusedILi3ELb0ELb1ELb0" + S20, 106), ("k_iter_fusedILi3ELb0ELb0ELb0" + S20, 106),
                                    ("k_iter_fusedILi3ELb1ELb0ELb0" + S20, 106), ("k_iter_fusedILi2ELb0ELb1ELb0" + S20, 156),
                                    ("k_iter_fusedILi3ELb0ELb1ELb0" + S16, 166), ("k_iter_fusedILi3ELb0ELb1ELb0" + S12, 226)],
+               # round 6, the general forms (template tail <.., MULTI = false, NT2, GEN = true>): three channels on the one-hot kernels' stash,
+               # four channels with one more tile per wave in LDS (the stash starts 2 L x 5 registers higher)
+               "kernels_fused_gen.s": [("k_iter_fusedILi3ELb0ELb1ELb0" + S20 + "Lb0ELi0ELb1E", 106), ("k_iter_fusedILi3ELb0ELb0ELb0" + S20 + "Lb0ELi0ELb1E", 106),
+                                       ("k_iter_fusedILi3ELb1ELb0ELb0" + S20 + "Lb0ELi0ELb1E", 106), ("k_iter_fusedILi3ELb0ELb1ELb0" + S16 + "Lb0ELi0ELb1E", 166),
+                                       ("k_iter_fusedILi3ELb0ELb1ELb0" + S16 + "Lb0ELi1ELb1E", 196), ("k_iter_fusedILi3ELb1ELb0ELb0" + S16 + "Lb0ELi1ELb1E", 196),
+                                       ("k_iter_fusedILi2ELb0ELb0ELb0" + S20 + "Lb0ELi1ELb1E", 176)],
                "kernels_tall.s": [("k_iter_tallILi2ELi1ELi3" + T + "ELb0", 136), ("k_iter_tallILi2ELi1ELi3" + T + "ELb1", 166),
                                   ("k_iter_tallILi2ELi0ELi3" + T + "ELb1", 166)]}
     if not all(os.path.exists(os.path.join(csrc, f)) for f in guarded):
