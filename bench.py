@@ -211,6 +211,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # (one node, rendezvous on the loopback address: gloo binds the loopback interface too instead of resolving the container's
+        #  hostname, which may not resolve)
+        if os.environ.get("MASTER_ADDR") in ("127.0.0.1", "localhost") and os.path.isdir("/sys/class/net/lo"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("cpu:gloo,cuda:nccl")      # (the one-GPU test hook takes the same group: its exchange is the mailbox one)
 
     from hp_vpinns_amd.dist import shard_range
