@@ -26,8 +26,8 @@ def dist_info():
 
     * a torch.distributed process group exists: its rank / world size;
     * none exists but the process was started by `torchrun` / `python -m torch.distributed.run` (WORLD_SIZE > 1 in the
-      environment): the group is created HERE from the launcher's environment (env:// rendezvous; "nccl" = RCCL bound to
-      device LOCAL_RANK when a GPU is visible, "gloo" otherwise; HPV_DIST_BACKEND overrides), so that a reference driver with
+      environment): the group is created HERE from the launcher's environment (env:// rendezvous; "cpu:gloo,cuda:nccl" with
+      the device set to LOCAL_RANK when a GPU is visible, "gloo" otherwise; HPV_DIST_BACKEND overrides), so that a reference driver with
       nothing but the one-line import swap (P2:430-434 unchanged) shards its elements over the N processes.  Until round 5 this
       case fell through to (0, 1, 0): N processes each trained the WHOLE problem on device 0, silently;
     * WORLD_SIZE > 1 but the launcher's variables are incomplete, or the group cannot be created: RuntimeError naming the line to
@@ -54,10 +54,14 @@ def dist_info():
         raise RuntimeError("hp_vpinns_amd: WORLD_SIZE=%d but %s not set (start the driver with torchrun, or %s)"
                            % (world_env, ", ".join(missing), hint))
     import torch
-    backend = os.environ.get("HPV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    # (a GPU is visible: the control plane -- object collectives of the communicator set-up, barriers -- on gloo, "cuda:nccl" registered
+    #  for the `torch` exchange fallback and created lazily, only if that fallback is ever used: the library's own communicator
+    #  (hpv_rccl_*) is then the only RCCL communicator of the rank, as in bench.py)
+    backend = os.environ.get("HPV_DIST_BACKEND") or ("cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo")
     try:
-        if backend == "nccl":
+        if "nccl" in backend:
             torch.cuda.set_device(local)
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
