@@ -164,6 +164,8 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
 #ifdef HPV_FZ_TIMING
     long long fz_t[8];
     const long long fz_start = clock64(), fz_wall = wall_clock64();
+    long long fz_seg[2 + 2 * L], fz_last = clock64();      // (kernel scope: the epilogue behind the element loop reads them)
+    int fz_n_own = 0;
 #endif
 
     // ---- stage every weight fragment and the projection tables ----
@@ -814,7 +816,8 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     }
 
 #ifdef HPV_FZ_TIMING
-    long long fz_seg[2 + 2 * L], fz_last = clock64();
+    fz_last = clock64();
+    fz_n_own = n_own;
     for (int i = 0; i < 2 + 2 * L; ++i) fz_seg[i] = 0;
 #endif
     // one reverse tile; GS: `B` = the tile's pairs, requested a tile ahead
@@ -1343,7 +1346,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         if (!SPLIT && g.OUT) {     // reverse-body segments of this wave (sums over its tiles) + its tile count, into the channel buffer
             double* os = g.OUT + ((long)blockIdx.x * 4 + wv) * 12;
             for (int i = 0; i < 2 + 2 * L; ++i) os[i] = (double)fz_seg[i];
-            os[2 + 2 * L] = (double)n_own;
+            os[2 + 2 * L] = (double)fz_n_own;
         }
     }
 #endif
