@@ -134,6 +134,17 @@ guarded_compile() {   # guarded_compile <source stem> <object> <extra flags> <fi
         echo "build.sh: WARNING -- AGPR guard tripped in a quarter-tile instantiation of the general forms: whole tiles only" >&2
         add="$add -DHPV_FZ_GEN_NO_QT"
       fi
+      # the tight plan (FzPlan: four channels, three hidden layers, 20x20 points): twelve of the first stash place's fifteen doubles live in LDS
+      if [ "$add" = "${add#*NO_NT2}" ]; then
+        g=0; guard $asm k_iter_fusedILi3ELb0ELb0ELb0${S}Lb0ELi1ELb1E $((106 + 30 + 24)) || g=$?
+        [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check the tight-plan instantiation of $f.hip" >&2; rm -rf $tmp; return 1; }
+        if [ $g -eq 1 ]; then
+          echo "build.sh: WARNING -- AGPR guard tripped in the tight-plan instantiation of k_iter_fused: four channels on 20x20 points with three hidden layers run on the separate launches" >&2
+          add="$add -DHPV_FZ_GEN_NO_TIGHT"
+        fi
+      else
+        add="$add -DHPV_FZ_GEN_NO_TIGHT"
+      fi
     fi
   fi
   if [ $f = kernels_tall ]; then    # same hand-managed AGPR stash (4 tiles x L x 5 doubles at the top of the file)

@@ -32,6 +32,15 @@ template <int BASE, int N, int J = 0>
 __device__ __forceinline__ void acc_get_all(double (&sv)[N]) {
     if constexpr (J < N) { sv[J] = acc_get<BASE + 2 * J>(); acc_get_all<BASE, N, J + 1>(sv); }
 }
+// (the doubles J0 .. N - 1 only, at BASE: a stash place whose first J0 doubles live elsewhere)
+template <int BASE, int N, int J0, int J = J0>
+__device__ __forceinline__ void acc_put_from(const double (&sv)[N]) {
+    if constexpr (J < N) { acc_put<BASE + 2 * (J - J0)>(sv[J]); acc_put_from<BASE, N, J0, J + 1>(sv); }
+}
+template <int BASE, int N, int J0, int J = J0>
+__device__ __forceinline__ void acc_get_from(double (&sv)[N]) {
+    if constexpr (J < N) { sv[J] = acc_get<BASE + 2 * (J - J0)>(); acc_get_from<BASE, N, J0, J + 1>(sv); }
+}
 
 // N doubles p[0], p[64], p[128], .. (one 512-byte wave row each) straight INTO the hand-managed AGPRs a[BASE + 2j : BASE + 2j + 1]:
 // all loads in flight at once without a single compiler-allocated register (k_iter_fused<.., MULTI>: the spilled gradient sums of

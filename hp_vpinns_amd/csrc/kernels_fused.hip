@@ -56,7 +56,10 @@
 
 // C_ = network channels (3: u, u_x, u_y; 4: + the mixed second tangent, NT2 = 1); TRG_ = channels whose transposes of the weight-
 // gradient products are in LDS at a time (C_ = 3: all three, ONE pass -- the headline plan; C_ = 4: two passes of two, 22 KB less)
-template <int L, int QX_, int QY_, int NTX_, int NTY_, bool MULTI = false, int C_ = FZ_C, int TRG_ = FZ_C>
+// NPART_ (the tight plan, FzPlan below): the first NPART_ saved doubles of one MORE tile of every wave live here instead of in the stash
+// (the stash is 2 NPART_ registers shorter), and the epilogue's gradient rows overlay the parking area (dead by then) instead of the
+// transpose region, which then only has to hold ONE channel's tiles.
+template <int L, int QX_, int QY_, int NTX_, int NTY_, bool MULTI = false, int C_ = FZ_C, int TRG_ = FZ_C, int NPART_ = 0>
 struct FzLds {
     FZ_SHAPE_CONSTS
     static constexpr int LH = L > 1 ? L - 1 : 0;
@@ -73,8 +76,9 @@ struct FzLds {
     // (four channels: the compiler needs ~60 registers more -- one more tile of every wave is parked here: slots 4..7 = tile 1 of wave
     //  w - 4, slots 8, 9 = the quarter tiles' s (QT) or tile 2 of waves 0, 1 (whole tiles: the two waves that may own FZ_MAXT tiles))
     static constexpr int PKS = C_ > FZ_C ? 10 : 6;
-    static constexpr int PZ = PK + PKS * L * MF_KS * 64;   // [4][LH*5][32] QT: the quarter tiles' tangent pre-activations of the layers >= 2 (tangent lanes, compact)
-    static constexpr int TR = PZ + FZ_WAVES * LH * MF_KS * 32;   // phase P: projection scratch | phase R: per-wave transpose tiles | epilogue rows
+    static constexpr int PP = PK + PKS * L * MF_KS * 64;   // [4][NPART_][64] the tight plan's part of a stash tile
+    static constexpr int PZ = PP + FZ_WAVES * NPART_ * 64; // [4][LH*5][32] QT: the quarter tiles' tangent pre-activations of the layers >= 2 (tangent lanes, compact)
+    static constexpr int TR = PZ + (NPART_ > 0 ? 0 : FZ_WAVES * LH * MF_KS * 32);   // (the tight plan runs whole tiles: no quarter tiles' array)   // phase P: projection scratch | phase R: per-wave transpose tiles | epilogue rows
     static constexpr int TR_WAVE = TRG_ * 2 * MF_TRB * MF_LD;
     // projection scratch inside the TR region.  MULTI (several elements per workgroup): the tables live BEHIND the region instead -- the
     // reverse phase's transposes would overwrite them and every element would have to stage them again
@@ -89,7 +93,19 @@ struct FzLds {
     static constexpr int RED = S + 2 * FZ_NTY * FZ_QX;     // [16]
     static_assert(RED + 16 - TR <= FZ_WAVES * TR_WAVE, "projection scratch fits the transpose region");
     static_assert(3 * XLD <= 4 * L * MF_KS * 64, "the staged coordinates fit the parking slots the GS plan leaves free");
-    static constexpr int total(int P) { return TR + (TRSZ > FZ_WAVES * P ? TRSZ : FZ_WAVES * P) + (MULTI ? NTABS : 0); }
+    static constexpr int EPI = NPART_ > 0 ? PK : TR;       // the epilogue's rows [4][P]
+    static constexpr int total(int P) { return NPART_ > 0 ? TR + TRSZ : TR + (TRSZ > FZ_WAVES * P ? TRSZ : FZ_WAVES * P) + (MULTI ? NTABS : 0); }
+};
+// The tight plan (round 6): four channels with three hidden layers on 20x20 points.  Seven tiles on a wave, four of them in the
+// stash, leave the compiler 136 registers where it needs ~150; a third parked tile per wave is 14 LDS slots, 179 KB.  So: the
+// weight-gradient transposes go through LDS one channel at a time (TRG = 1: 21 KB instead of 43), the epilogue's rows overlay the
+// parking area, the quarter tiles' array is not needed (whole tiles), and the room that frees holds NPART of the 15 saved doubles of
+// one stash tile: the stash begins at a160 (the compiler's high-water mark in that instantiation: a149).
+template <int L, int QX_, int QY_, int NT2>
+struct FzPlan {
+    static constexpr bool TIGHT = NT2 > 0 && L == 3 && QX_ * QY_ / 16 > 16;
+    static constexpr int TRG = TIGHT ? 1 : (NT2 > 0 ? 2 : FZ_C);
+    static constexpr int NPART = TIGHT ? 12 : 0;
 };
 
 // SPLIT: an element is shared by g.proj_split (2, 4 or 8) workgroups -- the shards of a multi-GPU run are too small to fill the
@@ -139,9 +155,12 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     FZ_SHAPE_CONSTS
     static_assert(!(NT2 > 0 && QT && FZ_TPE % FZ_WAVES != 0), "four channels leave the packed quarter tile no slot for the data points: data-quarter plan only");
     constexpr int C = FZ_C + NT2;                  // channels of the network: u, u_x, u_y[, w0 u_xx + w1 u_yy]
-    constexpr int TRG = NT2 > 0 ? 2 : FZ_C;        // channels per transpose pass of the weight-gradient products
+    using PLAN = FzPlan<L, QX_, QY_, NT2>;
+    constexpr int TRG = PLAN::TRG;                 // channels per transpose pass of the weight-gradient products
+    constexpr int NPART = PLAN::NPART;             // saved doubles of the stash's last tile that live in LDS (the tight plan)
     static_assert(C % TRG == 0, "whole transpose passes");
-    using M = FzLds<L, QX_, QY_, NTX_, NTY_, MULTI, C, TRG>;
+    static_assert(NPART == 0 || (!QT && !SPLIT), "the tight plan: whole tiles, one workgroup per element");
+    using M = FzLds<L, QX_, QY_, NTX_, NTY_, MULTI, C, TRG, NPART>;
     static_assert(!GEN || (M::AX == M::TR && 4 <= M::TR_WAVE), "the d-epsilon partials live in wave 0's part of the transpose region (it reads them back itself)");
     constexpr int LH = L > 1 ? L - 1 : 1;
     constexpr int NSV = L * MF_KS;                 // saved doubles per lane and tile
@@ -409,7 +428,8 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     // s = tanh(z) of every hidden layer: tile 0's go to LDS (what is left of it), the tiles 1..6 of this wave to the top
     // AGPRs a[ABASE + (k-1) * 2 NSV ..] (see acc_put)
     constexpr int NREG = FZ_MAXT - 2 - (NT2 > 0 ? 1 : 0);  // tiles whose s live in AGPRs; the first one (waves 0, 1 -- NT2: every wave -- two) of a wave is parked in LDS
-    constexpr int ABASE = 256 - NREG * 2 * NSV;
+    constexpr int ABASE = 256 - NREG * 2 * NSV + 2 * NPART;    // (tight plan: the stash's FIRST place is NPART doubles short -- they are in LDS)
+    constexpr int AFULL = ABASE - 2 * NPART;                   // place K of the stash begins at AFULL + K * 2 NSV (place 0: its doubles NPART.. only)
     if constexpr (!GS) asm volatile("" ::: "a255");       // the kernel owns all 256 AGPRs
     // (waves 0, 1 may own FZ_MAXT tiles, waves 2, 3 one less -- QT: every wave FZ_MAXT - 1 whole ones; QT: slots 4, 5 -- NT2: 8, 9 -- of the
     //  parking area hold the quarter tiles' s)
@@ -476,8 +496,19 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             for (int j = 0; j < NSV; ++j) pk[j * 64] = sv[j];
         } else {
             switch (k - n_lds) {
-#define FZ_STASH(K) case K: if constexpr (K < NREG) acc_put_all<ABASE + K * 2 * NSV, NSV>(sv); break;
-                FZ_STASH(0) FZ_STASH(1) FZ_STASH(2) FZ_STASH(3) FZ_STASH(4)
+#define FZ_STASH(K) case K: if constexpr (K < NREG) acc_put_all<AFULL + K * 2 * NSV, NSV>(sv); break;
+                case 0:
+                    if constexpr (NREG < 1) {
+                    } else if constexpr (NPART > 0) {
+                        double* pp = lds + M::PP + wv * (NPART * 64) + lane;
+#pragma unroll
+                        for (int j = 0; j < NPART; ++j) pp[j * 64] = sv[j];
+                        acc_put_from<ABASE, NSV, NPART>(sv);
+                    } else {
+                        acc_put_all<ABASE, NSV>(sv);
+                    }
+                    break;
+                FZ_STASH(1) FZ_STASH(2) FZ_STASH(3) FZ_STASH(4)
 #undef FZ_STASH
             }
         }
@@ -850,8 +881,19 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
             for (int j = 0; j < NSV; ++j) sv[j] = pk[j * 64];
         } else {
             switch (k - n_lds) {
-#define FZ_FETCH(K) case K: if constexpr (K < NREG) acc_get_all<ABASE + K * 2 * NSV, NSV>(sv); break;
-                FZ_FETCH(0) FZ_FETCH(1) FZ_FETCH(2) FZ_FETCH(3) FZ_FETCH(4)
+#define FZ_FETCH(K) case K: if constexpr (K < NREG) acc_get_all<AFULL + K * 2 * NSV, NSV>(sv); break;
+                case 0:
+                    if constexpr (NREG < 1) {
+                    } else if constexpr (NPART > 0) {
+                        const double* pp = lds + M::PP + wv * (NPART * 64) + lane;
+#pragma unroll
+                        for (int j = 0; j < NPART; ++j) sv[j] = pp[j * 64];
+                        acc_get_from<ABASE, NSV, NPART>(sv);
+                    } else {
+                        acc_get_all<ABASE, NSV>(sv);
+                    }
+                    break;
+                FZ_FETCH(1) FZ_FETCH(2) FZ_FETCH(3) FZ_FETCH(4)
 #undef FZ_FETCH
                 default:
 #pragma unroll
@@ -1069,9 +1111,10 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
                     }
                 };
                 tr_mul();
-                if constexpr (C > TRG) {      // the second pass: channels TRG .. C - 1 through the same tiles
+#pragma unroll
+                for (int c0 = TRG; c0 < C; c0 += TRG) {      // the further passes: channels c0 .. c0 + TRG - 1 through the same tiles
                     pj_wave_sync();
-                    tr_put(TRG);
+                    tr_put(c0);
                     pj_wave_sync();
                     tr_mul();
                 }
@@ -1289,7 +1332,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     // ---- epilogue: per-wave partials -> LDS -> one gradient row per workgroup ----
     __syncthreads();
     FZ_STAMP(6);
-    double* WP = lds + M::TR + (long)wv * g.P;     // every one of the P entries is written below
+    double* WP = lds + M::EPI + (long)wv * g.P;     // every one of the P entries is written below
 #pragma unroll
     for (int i = 1; i < L; ++i) {
 #pragma unroll
@@ -1325,7 +1368,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         if (lane == 0) WP[g.boff[L]] = t;
     }
     __syncthreads();
-    const double* W0 = lds + M::TR;
+    const double* W0 = lds + M::EPI;
     double* row = g.GPART + (long)blockIdx.x * g.P;
     for (int idx = tid; idx < g.P; idx += FZ_BLOCK) {
         double acc = 0.0;
@@ -1790,7 +1833,8 @@ __global__ void __launch_bounds__(SM_BLOCK, 1) k_iter_small(MfmaArgs g) {
 // ------------------------------------------------------------------------------------------------
 template <int L, bool SPLIT, bool QT, bool GS, int QX_, int QY_, int NTX_, int NTY_, bool MULTI = false, int NT2 = 0, bool GEN = false>
 static void launch_iter_fused(const MfmaArgs& a, int blocks, hipStream_t s) {
-    using LDS = FzLds<L, QX_, QY_, NTX_, NTY_, MULTI, FZ_C + NT2, (NT2 > 0 ? 2 : FZ_C)>;
+    using LDS = FzLds<L, QX_, QY_, NTX_, NTY_, MULTI, FZ_C + NT2, FzPlan<L, QX_, QY_, NT2>::TRG, FzPlan<L, QX_, QY_, NT2>::NPART>;
+    static_assert(LDS::EPI == LDS::TR || FZ_WAVES * (2 * MF_H + MF_H + (L - 1) * (MF_H * MF_H + MF_H) + MF_H + 1) <= LDS::PP - LDS::PK, "the epilogue's rows fit the parking area");
     const size_t bytes = (size_t)LDS::total(a.P) * sizeof(double);
     static_assert(LDS::total(2 * MF_H + MF_H + (L - 1) * (MF_H * MF_H + MF_H) + MF_H + 1) * sizeof(double) <= 160 * 1024, "LDS");
     static bool attr_set = false;
@@ -1812,8 +1856,13 @@ static bool launch_iter_fused_gen_shape(int L, int plan, int nt2, const MfmaArgs
     constexpr bool HAS_QT = (TPE % 4) <= 1 && TPE >= 8;
     constexpr bool HAS_DQ = HAS_QT && TPE % 4 == 0;            // four channels: the data-quarter plan only
     // (20x20 points keep four tiles per wave in the stash -- ABASE = 256 - 4 x 2 x 5 L: room for the fourth channel's registers with two
-    //  hidden layers, a77 of 176, not with three, a159 of 136)
-    const bool has_nt2 = QX_ != 20 || L == 2;
+    //  hidden layers, a77 of 176, not with three, a159 of 136: three layers run the tight plan (FzPlan), whole tiles on whole elements only)
+#ifdef HPV_FZ_GEN_NO_TIGHT
+    constexpr bool HAS_TIGHT = false;
+#else
+    constexpr bool HAS_TIGHT = true;
+#endif
+    const bool has_nt2 = QX_ != 20 || L == 2 || (HAS_TIGHT && plan == 1);
     if (L != 2 && L != 3) return false;
 #define FZ_GG(L_, SPLIT_, QT_, NT2_) launch_iter_fused<L_, SPLIT_, QT_, false, QX_, QY_, NTX_, NTY_, false, NT2_, true>(a, blocks, s)
     if (nt2 == 0) {
@@ -1833,7 +1882,7 @@ static bool launch_iter_fused_gen_shape(int L, int plan, int nt2, const MfmaArgs
 #else
     if (has_nt2) {
         if (plan == 0) { if (L == 2) FZ_GG(2, true, false, 1); else if constexpr (QX_ != 20) FZ_GG(3, true, false, 1); }
-        else if (plan == 1) { if (L == 2) FZ_GG(2, false, false, 1); else if constexpr (QX_ != 20) FZ_GG(3, false, false, 1); }
+        else if (plan == 1) { if (L == 2) FZ_GG(2, false, false, 1); else if constexpr (QX_ != 20 || HAS_TIGHT) FZ_GG(3, false, false, 1); }
         else if (plan == 2) {
 #ifdef HPV_FZ_GEN_NO_QT
             return false;
@@ -1997,7 +2046,8 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
 #endif
     // (plan 3, round 6: the full rounds with one workgroup per element and, in a SECOND launch, the ragged tail's elements shared by
     //  2 - 8 workgroups each (SPLIT) -- needs the exchange machinery of the split mode)
-    const bool tail_ok = m->xerr && m->xg && m->xiter && m->iter_split_ok && !pre;
+    // (four channels with three hidden layers on 20x20 points, the tight plan: no SPLIT instantiation to run a tail on)
+    const bool tail_ok = m->xerr && m->xg && m->xiter && m->iter_split_ok && !pre && !(gen && nd.nT2 == 1 && q20 && m->L == 3);
     int gplan = small ? 1 : hpv_fused_grid_plan(pd.qx, m->L, n_elem, m->n_cus, !gen && multi_built && m->base.ACTS != nullptr, m->multi_off, m->multi_force && !gen, m->iter_fused_force, tail_ok);
     if (gplan == 0) return fz_no(15);
     const bool multi = gplan == 2;

@@ -180,6 +180,7 @@ def test_hand_tuned_whole_iteration_kernel_on_other_element_shapes(q, nt, nhid, 
     ("p2vf0", 16, 8, 3, "full"), ("p2vf0", 12, 6, 3, "full"), ("p2vf0", 16, 8, 2, "full"), ("advf0", 16, 8, 3, "full"), ("advf0", 12, 6, 2, "full"),
     ("advf1", 16, 8, 3, "full"), ("advf1", 12, 6, 2, "full"), ("advf1", 20, 10, 3, "full"), ("advf1", 20, 10, 2, "full"),
     ("p2vf0", 20, 10, 2, "full"), ("advf0", 20, 10, 2, "shard"),
+    ("p2vf0", 20, 10, 3, "full"), ("advf0", 20, 10, 3, "full"),       # (the tight plan: FzPlan of kernels_fused.hip)
     ("p2vf0", 16, 8, 2, "shard"), ("p2vf0", 12, 6, 3, "shard"), ("advf0", 16, 8, 3, "shard"), ("advf0", 12, 6, 2, "shard"),
     ("advf1", 16, 8, 2, "shard"), ("advf1", 12, 6, 3, "shard"), ("advf1", 20, 10, 3, "shard")])
 def test_hand_tuned_whole_iteration_kernel_general_forms(prob, q, nt, nhid, grid):
@@ -555,7 +556,7 @@ def test_default_policy_picks_the_faster_structure_per_shape():
                                         (12, 6, [2, 20, 20, 20, 1], 2, "whole-iteration-element", 8),
                                         (20, 10, [2, 20, 20, 20, 1], 2, "whole-iteration-element", 8),
                                         (16, 8, [2, 20, 20, 20, 1], 0, "whole-iteration-split", None),      # (round 6: the general forms of k_iter_fused)
-                                        (20, 10, [2, 20, 20, 20, 1], 0, "separate", None),                  # (four channels, three layers on 20x20 points: no instantiation)
+                                        (20, 10, [2, 20, 20, 20, 1], 0, "separate", None),                  # (four channels, three layers on 20x20 points: the tight plan runs whole elements only -- a small shard stays on the separate launches)
                                         (16, 8, [2, 32, 32, 32, 1], 1, "separate", None)]:
         a = _p2(q, nt, 3, 3) + (L,)
         m = VPINN2D(*a, var_form=vf, init_params=theta0(L, 3))
