@@ -136,7 +136,7 @@ guarded_compile() {   # guarded_compile <source stem> <object> <extra flags> <fi
       fi
       # the tight plan (FzPlan: four channels, three hidden layers, 20x20 points): twelve of the first stash place's fifteen doubles live in LDS
       if [ "$add" = "${add#*NO_NT2}" ]; then
-        g=0; guard $asm k_iter_fusedILi3ELb0ELb0ELb0${S}Lb0ELi1ELb1E $((106 + 30 + 24)) || g=$?
+        g=0; guard $asm k_iter_fusedILi3ELb0ELb0ELb0${S}Lb0ELi1ELb1E $((106 + 30 + 24)) k_iter_fusedILi3ELb1ELb0ELb0${S}Lb0ELi1ELb1E $((106 + 30 + 24)) || g=$?
         [ $g -eq 2 ] && { echo "build.sh: ERROR -- the AGPR guard could not check the tight-plan instantiation of $f.hip" >&2; rm -rf $tmp; return 1; }
         if [ $g -eq 1 ]; then
           echo "build.sh: WARNING -- AGPR guard tripped in the tight-plan instantiation of k_iter_fused: four channels on 20x20 points with three hidden layers run on the separate launches" >&2

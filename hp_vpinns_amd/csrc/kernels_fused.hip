@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
     constexpr int TRG = PLAN::TRG;                 // channels per transpose pass of the weight-gradient products
     constexpr int NPART = PLAN::NPART;             // saved doubles of the stash's last tile that live in LDS (the tight plan)
     static_assert(C % TRG == 0, "whole transpose passes");
-    static_assert(NPART == 0 || (!QT && !SPLIT), "the tight plan: whole tiles, one workgroup per element");
+    static_assert(NPART == 0 || !QT, "the tight plan: whole tiles");
     using M = FzLds<L, QX_, QY_, NTX_, NTY_, MULTI, C, TRG, NPART>;
     static_assert(!GEN || (M::AX == M::TR && 4 <= M::TR_WAVE), "the d-epsilon partials live in wave 0's part of the transpose region (it reads them back itself)");
     constexpr int LH = L > 1 ? L - 1 : 1;
@@ -1862,7 +1862,7 @@ static bool launch_iter_fused_gen_shape(int L, int plan, int nt2, const MfmaArgs
 #else
     constexpr bool HAS_TIGHT = true;
 #endif
-    const bool has_nt2 = QX_ != 20 || L == 2 || (HAS_TIGHT && plan == 1);
+    const bool has_nt2 = QX_ != 20 || L == 2 || (HAS_TIGHT && plan <= 1);
     if (L != 2 && L != 3) return false;
 #define FZ_GG(L_, SPLIT_, QT_, NT2_) launch_iter_fused<L_, SPLIT_, QT_, false, QX_, QY_, NTX_, NTY_, false, NT2_, true>(a, blocks, s)
     if (nt2 == 0) {
@@ -1881,7 +1881,7 @@ static bool launch_iter_fused_gen_shape(int L, int plan, int nt2, const MfmaArgs
     return false;
 #else
     if (has_nt2) {
-        if (plan == 0) { if (L == 2) FZ_GG(2, true, false, 1); else if constexpr (QX_ != 20) FZ_GG(3, true, false, 1); }
+        if (plan == 0) { if (L == 2) FZ_GG(2, true, false, 1); else if constexpr (QX_ != 20 || HAS_TIGHT) FZ_GG(3, true, false, 1); }
         else if (plan == 1) { if (L == 2) FZ_GG(2, false, false, 1); else if constexpr (QX_ != 20 || HAS_TIGHT) FZ_GG(3, false, false, 1); }
         else if (plan == 2) {
 #ifdef HPV_FZ_GEN_NO_QT
@@ -2029,6 +2029,10 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
         if (pre && pd.has_eps) return fz_no(12);                // the deferred-update prologue forms the network parameters only
     }
     if (n_elem <= 0) return fz_no(13);
+    // the tight plan (four channels, three hidden layers, 20x20 points: whole tiles 7 + 7 + 6 + 6) gains 12 % on one round of elements, 5 % on
+    // two (552 elements: 196.3 against 207.1 us) and nothing from six on (1 600: 516.0 against 513.8 -- the separate launches amortise
+    // to 82 us per 256 elements there): profiles/r06_tight_plan.txt
+    if (gen && nd.nT2 == 1 && q20 && m->L == 3 && n_elem > 5L * m->n_cus && !m->iter_fused_force) return fz_no(33);
 #ifdef HPV_AGPR_GUARD_TRIPPED     // csrc/build.sh: the compiler's registers reached the hand-managed AGPR range of k_iter_fused
     if (!small) return fz_no(14);
 #endif
@@ -2046,8 +2050,7 @@ bool hpv_mfma_iter_fused(HpvMfma* m, const double* theta, const double* X, doubl
 #endif
     // (plan 3, round 6: the full rounds with one workgroup per element and, in a SECOND launch, the ragged tail's elements shared by
     //  2 - 8 workgroups each (SPLIT) -- needs the exchange machinery of the split mode)
-    // (four channels with three hidden layers on 20x20 points, the tight plan: no SPLIT instantiation to run a tail on)
-    const bool tail_ok = m->xerr && m->xg && m->xiter && m->iter_split_ok && !pre && !(gen && nd.nT2 == 1 && q20 && m->L == 3);
+    const bool tail_ok = m->xerr && m->xg && m->xiter && m->iter_split_ok && !pre;
     int gplan = small ? 1 : hpv_fused_grid_plan(pd.qx, m->L, n_elem, m->n_cus, !gen && multi_built && m->base.ACTS != nullptr, m->multi_off, m->multi_force && !gen, m->iter_fused_force, tail_ok);
     if (gplan == 0) return fz_no(15);
     const bool multi = gplan == 2;

@@ -180,7 +180,7 @@ def test_hand_tuned_whole_iteration_kernel_on_other_element_shapes(q, nt, nhid, 
     ("p2vf0", 16, 8, 3, "full"), ("p2vf0", 12, 6, 3, "full"), ("p2vf0", 16, 8, 2, "full"), ("advf0", 16, 8, 3, "full"), ("advf0", 12, 6, 2, "full"),
     ("advf1", 16, 8, 3, "full"), ("advf1", 12, 6, 2, "full"), ("advf1", 20, 10, 3, "full"), ("advf1", 20, 10, 2, "full"),
     ("p2vf0", 20, 10, 2, "full"), ("advf0", 20, 10, 2, "shard"),
-    ("p2vf0", 20, 10, 3, "full"), ("advf0", 20, 10, 3, "full"),       # (the tight plan: FzPlan of kernels_fused.hip)
+    ("p2vf0", 20, 10, 3, "full"), ("advf0", 20, 10, 3, "full"), ("p2vf0", 20, 10, 3, "shard"), ("advf0", 20, 10, 3, "shard"),       # (the tight plan: FzPlan of kernels_fused.hip)
     ("p2vf0", 16, 8, 2, "shard"), ("p2vf0", 12, 6, 3, "shard"), ("advf0", 16, 8, 3, "shard"), ("advf0", 12, 6, 2, "shard"),
     ("advf1", 16, 8, 2, "shard"), ("advf1", 12, 6, 3, "shard"), ("advf1", 20, 10, 3, "shard")])
 def test_hand_tuned_whole_iteration_kernel_general_forms(prob, q, nt, nhid, grid):
@@ -333,7 +333,8 @@ def test_hand_tuned_kernel_walks_several_elements_per_workgroup_on_grids_larger_
     assert rel(gw, gm) < 1e-11 and rel(l3w, l3m) < 1e-12, (v, vw)
 
 
-@pytest.mark.parametrize("prob,q,nt,nhid,nex,ney,tail", [("p2vf1", 20, 10, 3, 24, 23, 40), ("advf1", 20, 9, 2, 25, 22, 38)])
+@pytest.mark.parametrize("prob,q,nt,nhid,nex,ney,tail", [("p2vf1", 20, 10, 3, 24, 23, 40), ("advf1", 20, 9, 2, 25, 22, 38),
+                                                             ("p2vf0", 20, 10, 3, 23, 24, 40)])      # (four channels, three layers: the tight plan, both launches)
 def test_hand_tuned_kernel_ragged_grids_tail_in_split_mode(prob, q, nt, nhid, nex, ney, tail):
     """Grids larger than the chip whose last round is ragged (verdict round 5, item 5; N_el_x, N_el_y are free: P2:282-283): the full
     rounds run with one workgroup per element, the n % CUs elements of the tail in a SECOND launch of the split instantiation (2 - 8
@@ -556,7 +557,7 @@ def test_default_policy_picks_the_faster_structure_per_shape():
                                         (12, 6, [2, 20, 20, 20, 1], 2, "whole-iteration-element", 8),
                                         (20, 10, [2, 20, 20, 20, 1], 2, "whole-iteration-element", 8),
                                         (16, 8, [2, 20, 20, 20, 1], 0, "whole-iteration-split", None),      # (round 6: the general forms of k_iter_fused)
-                                        (20, 10, [2, 20, 20, 20, 1], 0, "separate", None),                  # (four channels, three layers on 20x20 points: the tight plan runs whole elements only -- a small shard stays on the separate launches)
+                                        (20, 10, [2, 20, 20, 20, 1], 0, "whole-iteration-split", None),      # (four channels, three layers on 20x20 points: the tight plan, FzPlan of kernels_fused.hip)
                                         (16, 8, [2, 32, 32, 32, 1], 1, "separate", None)]:
         a = _p2(q, nt, 3, 3) + (L,)
         m = VPINN2D(*a, var_form=vf, init_params=theta0(L, 3))
