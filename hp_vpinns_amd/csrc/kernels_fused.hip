@@ -1913,8 +1913,12 @@ const char* hpv_fused_gen_build_state() {
     return "three-channel-whole-tiles-only";
 #elif defined(HPV_FZ_GEN_NO_NT2)
     return "three-channel-only";
+#elif defined(HPV_FZ_GEN_NO_QT) && defined(HPV_FZ_GEN_NO_TIGHT)
+    return "no-quarter-tile,no-tight-plan";
 #elif defined(HPV_FZ_GEN_NO_QT)
     return "no-quarter-tile";
+#elif defined(HPV_FZ_GEN_NO_TIGHT)
+    return "no-tight-plan";
 #else
     return "ok";
 #endif
