@@ -3,7 +3,7 @@
 whole-iteration kernel (AdvDiff var_form 0 / 1 with the trainable epsilon, Poisson-2D var_form 0) on a full grid and on SPLIT shards, and
 a ragged grid (full rounds + the tail in split mode).  A missed exchange makes hpv_step raise (-7); the Adam trajectories agree to
 round-off for ~1 000 iterations (checked: 1e-7) and then drift apart chaotically like any two summation orders do.
-soak_general.py [iterations per case, default 100000]"""
+soak_general.py [iterations per case, default 100000]   (SOAK_TIGHT_ONLY=1: only the tight-plan cases at the end of the list)"""
 import os
 import sys
 import time
@@ -39,6 +39,16 @@ for (nex, ney) in ((16, 16), (16, 4), (5, 3)):
 s = poisson2d.setup(N_el_x=24, N_el_y=23, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False, assemble="device")
 cases.append(("Poisson-2D var_form 1, 24x23 elements of 20x20 points (two rounds + a 40-element tail)",
               (lambda s=s: poisson2d.build_model(s, L, var_form=1, init_params=xavier_init(L, 1234)))))
+# the tight plan (four channels, three hidden layers, 20x20 points: FzPlan of kernels_fused.hip): full grid, SPLIT shard, ragged grid
+tight = []
+for (nex, ney) in ((16, 16), (16, 4), (24, 23)):
+    s = poisson2d.setup(N_el_x=nex, N_el_y=ney, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False, assemble="device")
+    tight.append(("Poisson-2D var_form 0, %dx%d elements of 20x20 points" % (nex, ney),
+                  (lambda s=s: poisson2d.build_model(s, L, var_form=0, init_params=xavier_init(L, 1234)))))
+s = advdiff.setup(N_el_x=16, N_el_t=16, N_test_x=10, N_test_t=10, N_quad=20, with_test_grid=False)
+tight.append(("AdvDiff var_form 0, 16x16 elements of 20x20 points",
+              (lambda s=s: advdiff.build_model(s, L, var_form=0, init_params=xavier_init(L, 1234, extra=[1.0])))))
+cases = tight if os.environ.get("SOAK_TIGHT_ONLY") else cases + tight
 for name, mk in cases:
     a, b = build(mk, None), build(mk, "n")
     t0 = time.perf_counter()

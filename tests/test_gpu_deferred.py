@@ -72,8 +72,10 @@ CALLS = [("record", 19), ("step", 1), ("step", 1), ("step", 8), ("record", 3), (
     (16, 16, L4, {"Q": "16", "VF": "0"}, True),      # round 6: the general forms -- Poisson-2D var_form 0 (four channels) on 16x16 points, one workgroup per element
     (8, 4, L3, {"Q": "12", "VF": "0"}, True),        # ... and a shared-element shard of it
     (24, 23, L4, None, True),                 # round 6: two full rounds + a 40-element tail in split mode: two launches, the update applied in front
+    (16, 16, L4, {"Q": "20", "VF": "0"}, True),      # round 6, the tight plan (four channels, three hidden layers, 20x20 points): the prologue forms the parameters in its parking area
+    (8, 4, L4, {"Q": "20", "VF": "0"}, True),        # ... and its SPLIT instantiation
 ], ids=["config4", "shared-element", "two-layers", "eager", "two-rounds", "separate-ragged", "separate-forced", "general-form", "general-form-shard",
-        "ragged-tail"])
+        "ragged-tail", "tight-plan", "tight-plan-shard"])
 def test_deferred_update_reproduces_the_per_iteration_update(nx, ny, layers, env, rides):
     env = dict(env or {})
     kw = {}
