@@ -1374,13 +1374,7 @@ __global__ void __launch_bounds__(FZ_BLOCK, 1) k_iter_fused(MfmaArgs g) {
         double acc = 0.0;
 #pragma unroll
         for (int w = 0; w < FZ_WAVES; ++w) acc += W0[(long)w * g.P + idx];
-#if defined(HPV_ROW_STORE) && HPV_ROW_STORE == 1        // A/B (scripts/build_variant.sh): streaming stores of the gradient row
-        __builtin_nontemporal_store(acc, &row[idx]);
-#elif defined(HPV_ROW_STORE) && HPV_ROW_STORE == 2      // A/B: write-through stores
-        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(&row[idx]), "v"(acc) : "memory");
-#else
-        row[idx] = acc;
-#endif
+        row[idx] = acc;      // (streaming / write-through stores measured: no gain, profiles/r06_notes.md 12)
     }
 #ifdef HPV_FZ_TIMING
     if (lane == 0 && pa.GBAR) {   // phase durations in shader cycles: [block][wave][8], into the (otherwise unused) adjoint buffer

@@ -62,14 +62,25 @@ if mode.startswith("t"):   # k_iter_tile (kernels_tile.hip): t1 / t2 = Poisson-1
         s = advdiff.setup(N_el_x=8, N_quad=10, with_test_grid=False)
         m = advdiff.build_model(s, LAYERS, init_params=xavier_init(LAYERS, 1234, extra=[1.0]))
         NB, NW = 8, 8
+elif mode in ("g0", "g1"):    # the general forms on the config-4 grid: g0 = Poisson-2D var_form 0 (four channels, the tight plan), g1 = AdvDiff var_form 1
+    if mode == "g0":
+        s = poisson2d.setup(N_el_x=16, N_el_y=16, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
+        m = poisson2d.build_model(s, LAYERS, var_form=0, init_params=xavier_init(LAYERS, 1234))
+    else:
+        from hp_vpinns_amd.drivers import advdiff
+        s = advdiff.setup(N_el_x=16, N_el_t=16, N_test_x=10, N_test_t=10, N_quad=20, with_test_grid=False)
+        m = advdiff.build_model(s, LAYERS, var_form=1, init_params=xavier_init(LAYERS, 1234, extra=[1.0]))
+    NB, NW = 256, 4
 else:
     if small:
         s = poisson2d.setup(N_el_x=8, N_el_y=8, with_test_grid=False)
     else:
         s = poisson2d.setup(N_el_x=16, N_el_y=16 // shard, N_test_x=10, N_test_y=10, N_quad=20, with_test_grid=False)
     m = poisson2d.build_model(s, LAYERS, var_form=1, init_params=xavier_init(LAYERS, 1234))
-    NB, NW = (64, 8) if small else (256, 4)      # (a shard of 256 / n elements runs 256 workgroups too: n per element)
+    NB, NW = (64, 8) if small else (256, 4)
+# (a shard of 256 / n elements runs 256 workgroups too: n per element)
 m.h.step(50, False)
+print(m.h.kernel_variant())
 out = np.empty(NB * NW * 10)
 m.h.lib.hpv_debug_read_out.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t]
 m.h.lib.hpv_debug_read_out(m.h._h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size)
