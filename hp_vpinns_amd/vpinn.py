@@ -739,8 +739,9 @@ class VPINN2D(_VPINNBase):
                 hidden = self.layers[1:-1]
                 if backend != "generic" and var_form in (0, 1) and max(hidden) <= 20 and 2 <= len(hidden) <= 3:
                     eb, ee = shard_range(self.Nelementx * self.Nelementy, self.rank, self.world)
-                    # (var_form 0 runs on the FOUR-channel instantiations of the whole-iteration kernel: 12x12 and 16x16 points, 20x20 with
-                    #  two hidden layers only; the 10x10 kernel takes the two one-hot terms of var_form 1 alone)
+                    # (var_form 0 runs on the FOUR-channel instantiations of the whole-iteration kernel: 12x12 and 16x16 points, 20x20; with
+                    #  three hidden layers 20x20 is the tight plan, 84.8 us on the config-4 grid -- a 17..19-point rule padded onto it would
+                    #  not beat its own separate launches; the 10x10 kernel takes the two one-hot terms of var_form 1 alone)
                     rej = () if var_form == 1 else ((10, 20) if len(hidden) == 3 else (10,))
                     xi, wx, yi, wy = _device_rule_2d(xi, wx, yi, wy, self.Ntestx, self.Ntesty, ee - eb, self.device, n_hidden=len(hidden), reject=rej)
                 self.h.set_quadrature(xi, wx, yi, wy)
@@ -818,7 +819,7 @@ class VPINNAdvDiff(_VPINNBase):
                 xi, wx, ti, wt = _device_rule_2d(xi, wx, ti, wt, self.Ntestx, self.Ntestt, ee - eb, self.device, exact_counts=True, only=10)
             elif backend != "generic" and max(hidden) <= 20 and 2 <= len(hidden) <= 3 and 10 < xi.size < 20:
                 # rules between the instantiated ones onto the whole-iteration kernel's general forms (round 6): var_form 1 has three
-                # channels (every shape), var_form 0 four (12x12, 16x16; 20x20 with two hidden layers)
+                # channels (every shape), var_form 0 four (12x12, 16x16; 20x20 -- with three hidden layers its tight plan is no target for padding)
                 eb, ee = shard_range(self.Nelementx * self.Nelementt, self.rank, self.world)
                 rej = (10,) if (var_form == 1 or len(hidden) == 2) else (10, 20)
                 xi, wx, ti, wt = _device_rule_2d(xi, wx, ti, wt, self.Ntestx, self.Ntestt, ee - eb, self.device, n_hidden=len(hidden), reject=rej)
