@@ -95,6 +95,15 @@ def _device_rule_2d(xi, wx, yi, wy, ntx, nty, n_elem_shard, device=0, exact_coun
     return xi, wx, yi, wy
 
 
+def _n_cus(device):
+    """Compute units of the device (the tight plan of the whole-iteration kernel is dispatched up to five rounds of elements)."""
+    try:
+        import torch
+        return int(torch.cuda.get_device_properties(device).multi_processor_count)
+    except Exception:      # pragma: no cover - no device: the constructors fail later, loudly
+        return 256
+
+
 def _caller_globals(depth=2):
     """Module globals of whoever called the public method `depth - 1` frames above this function -- the IMPLICIT half of the binding
     (what makes the one-line import swap enough).  The explicit, documented half is `module_globals=globals()` in the constructor
@@ -739,10 +748,11 @@ class VPINN2D(_VPINNBase):
                 hidden = self.layers[1:-1]
                 if backend != "generic" and var_form in (0, 1) and max(hidden) <= 20 and 2 <= len(hidden) <= 3:
                     eb, ee = shard_range(self.Nelementx * self.Nelementy, self.rank, self.world)
-                    # (var_form 0 runs on the FOUR-channel instantiations of the whole-iteration kernel: 12x12 and 16x16 points, 20x20; with
-                    #  three hidden layers 20x20 is the tight plan, 84.8 us on the config-4 grid -- a 17..19-point rule padded onto it would
-                    #  not beat its own separate launches; the 10x10 kernel takes the two one-hot terms of var_form 1 alone)
-                    rej = () if var_form == 1 else ((10, 20) if len(hidden) == 3 else (10,))
+                    # (var_form 0 runs on the FOUR-channel instantiations of the whole-iteration kernel: 12x12, 16x16 and 20x20 points; with
+                    #  three hidden layers 20x20 is the tight plan, dispatched up to five rounds of elements -- 18 / 19-point rules padded onto it
+                    #  95.2 / 96.1 -> 84.8 / 85.2 us, 17 points level: scripts/pad_probe.py; the 10x10 kernel takes the two one-hot terms of
+                    #  var_form 1 alone)
+                    rej = () if var_form == 1 else ((10, 20) if (len(hidden) == 3 and ee - eb > 5 * _n_cus(self.device)) else (10,))
                     xi, wx, yi, wy = _device_rule_2d(xi, wx, yi, wy, self.Ntestx, self.Ntesty, ee - eb, self.device, n_hidden=len(hidden), reject=rej)
                 self.h.set_quadrature(xi, wx, yi, wy)
                 self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntesty, yi))
@@ -819,9 +829,9 @@ class VPINNAdvDiff(_VPINNBase):
                 xi, wx, ti, wt = _device_rule_2d(xi, wx, ti, wt, self.Ntestx, self.Ntestt, ee - eb, self.device, exact_counts=True, only=10)
             elif backend != "generic" and max(hidden) <= 20 and 2 <= len(hidden) <= 3 and 10 < xi.size < 20:
                 # rules between the instantiated ones onto the whole-iteration kernel's general forms (round 6): var_form 1 has three
-                # channels (every shape), var_form 0 four (12x12, 16x16; 20x20 -- with three hidden layers its tight plan is no target for padding)
+                # channels (every shape), var_form 0 four (12x12, 16x16, 20x20 -- with three hidden layers the tight plan, up to five rounds of elements)
                 eb, ee = shard_range(self.Nelementx * self.Nelementt, self.rank, self.world)
-                rej = (10,) if (var_form == 1 or len(hidden) == 2) else (10, 20)
+                rej = (10,) if (var_form == 1 or len(hidden) == 2 or ee - eb <= 5 * _n_cus(self.device)) else (10, 20)
                 xi, wx, ti, wt = _device_rule_2d(xi, wx, ti, wt, self.Ntestx, self.Ntestt, ee - eb, self.device, n_hidden=len(hidden), reject=rej)
             self.h.set_quadrature(xi, wx, ti, wt)
             self.h.set_tables(tables_1d(self.Ntestx, xi), tables_1d(self.Ntestt, ti))

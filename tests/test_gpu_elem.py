@@ -252,11 +252,12 @@ def test_hand_tuned_whole_iteration_kernel_general_forms(prob, q, nt, nhid, grid
 
 @pytest.mark.parametrize("prob,q,nt,nhid,want", [("p2vf0", 14, 7, 3, "16x16/7x7,NT2=1,GEN"), ("advf0", 11, 5, 3, "12x12/5x5,NT2=1,GEN"),
                                                   ("advf1", 18, 9, 3, "20x20/9x9,GEN"), ("advf0", 18, 6, 2, "20x20/6x6,NT2=1,GEN"),
-                                                  ("p2vf0", 18, 9, 3, None)])
+                                                  ("p2vf0", 18, 9, 3, "20x20/9x9,NT2=1,GEN"), ("advf0", 19, 9, 3, "20x20/9x9,NT2=1,GEN")])
 def test_hand_tuned_general_forms_with_smaller_quadrature_rules_than_instantiated(prob, q, nt, nhid, want):
     """The zero-weight padding of a rule onto an instantiated one (vpinn._pad_rule) for the general forms too: Poisson-2D var_form 0 and
-    both AdvDiff forms with N_quad between the instantiated rules run on k_iter_fused<.., GEN>; four channels with three hidden layers
-    have no 20x20 instantiation -- an 18-point rule stays as it is there (want = None).  Against the oracle on the UNPADDED problem."""
+    both AdvDiff forms with N_quad between the instantiated rules run on k_iter_fused<.., GEN> -- four channels with three hidden layers
+    on the tight plan of the 20x20 instantiation (18 / 19-point rules 95 -> 85 us: scripts/pad_probe.py).  Against the oracle on the
+    UNPADDED problem."""
     from hp_vpinns_amd.vpinn import VPINN2D, VPINNAdvDiff
     from oracle.vpinn_oracle import OracleVPINN2D, OracleVPINNAdvDiff
     assert "HPV_FUSE" not in os.environ
